@@ -1,0 +1,369 @@
+"""ctypes front-end of the CPU oracle (oracle/bevoracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(cameracalibration_amd) never does.  PARITY UNPINNED: see the header of bevoracle.c.
+
+`RefBevGenerator` strings the primitives together in the operation order of the reference's
+SurroundBirdEyeView/surroundBEV.py (file:line cited per method) so that it can be diffed against the HIP path
+and timed as the CPU baseline.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libbevoracle.so")
+CAMERAS = ("front", "back", "left", "right")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "bevoracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        vp, i32, u64, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
+        sig = {
+            "orc_set_threads": (None, [i32]),
+            "orc_max_threads": (i32, []),
+            "orc_newcam_inverse": (None, [vp, vp]),
+            "orc_fisheye_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
+            "orc_invert3x3": (i32, [vp, vp]),
+            "orc_perspective_coords": (None, [vp, i32, i32, vp, vp]),
+            "orc_remap_s16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
+            "orc_remap_u16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
+            "orc_remap_u8": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
+            "orc_fill_poly": (None, [vp, i32, i32, vp, i32, C.c_uint8]),
+            "orc_blend_mask": (None, [vp, vp, i32, i32, vp, vp]),
+            "orc_hsv_tables": (None, [vp, vp]),
+            "orc_bgr2hsv": (None, [vp, sz, vp]),
+            "orc_hsv2bgr": (None, [vp, sz, vp]),
+            "orc_sum_v": (u64, [vp, sz]),
+            "orc_round_delta": (i32, [C.c_double]),
+            "orc_luminance_shift": (None, [vp, sz, i32, vp]),
+            "orc_mask_select": (None, [vp, vp, sz, vp]),
+            "orc_weight_mul": (None, [vp, vp, sz, vp]),
+            "orc_add_sat": (None, [vp, vp, sz, vp]),
+            "orc_channel_sums": (None, [vp, sz, vp]),
+            "orc_gain": (None, [vp, sz, vp]),
+            "orc_bev_call": (None, [vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray) -> int:
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def _c(a, dtype) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def set_threads(n: int) -> None:
+    lib().orc_set_threads(int(n))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------------------------------
+def camera_mat_dst(K, frame_w, frame_h, focal_scale, size_scale, offset_h=0.0, offset_v=0.0) -> np.ndarray:
+    """surroundBEV.py:90-96 (twins: intrinsicCalib.py:90-96, Tools/undistort.py:42-46)."""
+    Kd = np.array(K, dtype=np.float64).copy()
+    Kd[0][0] *= focal_scale
+    Kd[1][1] *= focal_scale
+    Kd[0][2] = frame_w / 2 * size_scale + offset_h
+    Kd[1][2] = frame_h / 2 * size_scale + offset_v
+    return Kd
+
+
+def fisheye_init_undistort_rectify_map(K, D, Knew, size):
+    """cv2.fisheye.initUndistortRectifyMap(K, D, eye(3), Knew, size, CV_16SC2)  (surroundBEV.py:98-103)."""
+    w, h = int(size[0]), int(size[1])
+    K = _c(K, np.float64).reshape(9)
+    D = _c(D, np.float64).reshape(-1)[:4].copy()
+    Knew = _c(Knew, np.float64).reshape(9)
+    iR = np.empty(9, np.float64)
+    lib().orc_newcam_inverse(_p(Knew), _p(iR))
+    m1 = np.empty((h, w, 2), np.int16)
+    m2 = np.empty((h, w), np.uint16)
+    lib().orc_fisheye_undistort_map(_p(K), _p(D), _p(iR), w, h, _p(m1), _p(m2))
+    return m1, m2
+
+
+def invert3x3(M) -> np.ndarray:
+    M = _c(M, np.float64).reshape(9)
+    out = np.empty(9, np.float64)
+    lib().orc_invert3x3(_p(M), _p(out))
+    return out.reshape(3, 3)
+
+
+def perspective_coords(Minv, dsize):
+    w, h = int(dsize[0]), int(dsize[1])
+    Minv = _c(Minv, np.float64).reshape(9)
+    xy = np.empty((h, w, 2), np.int16)
+    a = np.empty((h, w), np.uint16)
+    lib().orc_perspective_coords(_p(Minv), w, h, _p(xy), _p(a))
+    return xy, a
+
+
+def remap(src: np.ndarray, map1: np.ndarray, map2: np.ndarray) -> np.ndarray:
+    """cv2.remap(src, map1(16SC2), map2(16UC1), INTER_LINEAR) with BORDER_CONSTANT 0."""
+    src = np.ascontiguousarray(src)
+    sh, sw = src.shape[:2]
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    dh, dw = map2.shape
+    map1, map2 = _c(map1, np.int16), _c(map2, np.uint16)
+    dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), src.dtype)
+    fn = {np.dtype(np.uint8): lib().orc_remap_u8, np.dtype(np.int16): lib().orc_remap_s16_f32,
+          np.dtype(np.uint16): lib().orc_remap_u16_f32}[src.dtype]
+    fn(_p(src), sw, sh, cn, _p(map1), _p(map2), dw, dh, _p(dst))
+    return dst
+
+
+def warp_perspective(src: np.ndarray, H, dsize) -> np.ndarray:
+    """cv2.warpPerspective(src, H, dsize): INTER_LINEAR, BORDER_CONSTANT 0, H inverted internally."""
+    xy, a = perspective_coords(invert3x3(H), dsize)
+    return remap(src, xy, a)
+
+
+def fill_poly(mask: np.ndarray, pts, color=255) -> np.ndarray:
+    pts = _c(pts, np.int32).reshape(-1, 2)
+    h, w = mask.shape
+    lib().orc_fill_poly(_p(mask), w, h, _p(pts), len(pts), int(color))
+    return mask
+
+
+def blend_mask(maskA: np.ndarray, maskB: np.ndarray, lineA, lineB) -> np.ndarray:
+    h, w = maskA.shape
+    lineA, lineB = _c(lineA, np.int32).reshape(4), _c(lineB, np.int32).reshape(4)
+    lib().orc_blend_mask(_p(maskA), _p(_c(maskB, np.uint8)), w, h, _p(lineA), _p(lineB))
+    return maskA
+
+
+def bgr2hsv(img):
+    img = _c(img, np.uint8)
+    out = np.empty_like(img)
+    lib().orc_bgr2hsv(_p(img), img.size // 3, _p(out))
+    return out
+
+
+def hsv2bgr(img):
+    img = _c(img, np.uint8)
+    out = np.empty_like(img)
+    lib().orc_hsv2bgr(_p(img), img.size // 3, _p(out))
+    return out
+
+
+def sum_v(img) -> int:
+    img = _c(img, np.uint8)
+    return int(lib().orc_sum_v(_p(img), img.size // 3))
+
+
+def luminance_balance(images):
+    """surroundBEV.py:57-79."""
+    images = [_c(i, np.uint8) for i in images]
+    means = [sum_v(i) / (i.size // 3) for i in images]
+    v_mean = (means[0] + means[1] + means[2] + means[3]) / 4
+    out = []
+    for img, m in zip(images, means):
+        d = np.empty_like(img)
+        lib().orc_luminance_shift(_p(img), img.size // 3, lib().orc_round_delta(v_mean - m), _p(d))
+        out.append(d)
+    return out
+
+
+def color_balance(image):
+    """surroundBEV.py:43-55."""
+    img = _c(image, np.uint8).copy()
+    npx = img.size // 3
+    sums = np.zeros(3, np.uint64)
+    lib().orc_channel_sums(_p(img), npx, _p(sums))
+    B, G, R = (float(s) / npx for s in sums)
+    K = (R + G + B) / 3
+    with np.errstate(divide="ignore", invalid="ignore"):
+        gains = np.array([np.float64(K) / np.float64(B), np.float64(K) / np.float64(G),
+                          np.float64(K) / np.float64(R)], np.float64)
+    lib().orc_gain(_p(img), npx, _p(gains))
+    return img
+
+
+def add_sat(a, b):
+    a, b = _c(a, np.uint8), _c(b, np.uint8)
+    out = np.empty_like(a)
+    lib().orc_add_sat(_p(a), _p(b), a.size, _p(out))
+    return out
+
+
+def padding(img, width, height):
+    """surroundBEV.py:28-41: centre the sprite on a zero canvas (extra row/column goes bottom/right)."""
+    h, w = img.shape[:2]
+    top, left = (height - h) // 2, (width - w) // 2
+    out = np.zeros((height, width, 3), np.uint8)
+    out[top:top + h, left:left + w] = img
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+# geometry of the masks (surroundBEV.py:123-154, 190-229, 236-268); values truncate like .astype(np.int32)
+# ----------------------------------------------------------------------------------------------------------
+def _anchors(bw, bh, cw, ch):
+    return {
+        "O": (0, 0), "X": (bw, 0), "Y": (0, bh), "XY": (bw, bh),
+        "cTL": ((bw - cw) / 2, (bh - ch) / 2), "cTR": ((bw + cw) / 2, (bh - ch) / 2),
+        "cBL": ((bw - cw) / 2, (bh + ch) / 2), "cBR": ((bw + cw) / 2, (bh + ch) / 2),
+        "lT": (0, bh / 5), "rT": (bw, bh / 5), "lB": (0, bh - bh / 5), "rB": (bw, bh - bh / 5),
+        "tL": (bw / 5, 0), "bL": (bw / 5, bh), "tR": (bw - bw / 5, 0), "bR": (bw - bw / 5, bh),
+    }
+
+
+_DIRECT = {"front": "O X cTR cTL", "back": "Y XY cBR cBL", "left": "O Y cBL cTL", "right": "X XY cBR cTR"}
+_BLEND = {"front": "O X rT cTR cTL lT", "back": "Y XY rB cBR cBL lB",
+          "left": "O Y bL cBL cTL tL", "right": "X XY bR cBR cTR tR"}
+_SEAMS = {"FL": "lT cTL", "FR": "rT cTR", "BL": "lB cBL", "BR": "rB cBR",
+          "LF": "tL cTL", "LB": "bL cBL", "RF": "tR cTR", "RB": "bR cBR"}
+# BlendMask.__init__ (surroundBEV.py:165-186): (other mask, own seam, other seam), applied in this order
+_BLEND_STEPS = {"front": (("left", "FL", "LF"), ("right", "FR", "RF")),
+                "back": (("left", "BL", "LB"), ("right", "BR", "RB")),
+                "left": (("front", "LF", "FL"), ("back", "LB", "BL")),
+                "right": (("front", "RF", "FR"), ("back", "RB", "BR"))}
+
+
+def polygon(name, bw, bh, cw, ch, blend):
+    table = _BLEND if blend else _DIRECT
+    if name not in table:
+        raise Exception("name should be front/back/left/right")
+    a = _anchors(bw, bh, cw, ch)
+    return np.array([a[k] for k in table[name].split()]).astype(np.int32)
+
+
+def seam(name, bw, bh, cw, ch):
+    a = _anchors(bw, bh, cw, ch)
+    return np.array([a[k] for k in _SEAMS[name].split()]).astype(np.int32)
+
+
+def direct_mask(name, bw, bh, cw, ch):
+    return fill_poly(np.zeros((bh, bw), np.uint8), polygon(name, bw, bh, cw, ch, False))
+
+
+def blend_mask_for(name, bw, bh, cw, ch):
+    fresh = {n: fill_poly(np.zeros((bh, bw), np.uint8), polygon(n, bw, bh, cw, ch, True)) for n in CAMERAS}
+    m = fresh[name]
+    for other, own_seam, other_seam in _BLEND_STEPS[name]:
+        blend_mask(m, fresh[other], seam(own_seam, bw, bh, cw, ch), seam(other_seam, bw, bh, cw, ch))
+    return m
+
+
+def blend_weight(mask_u8):
+    """surroundBEV.py:187-188: np.repeat(mask[:, :, None], 3, 2) / 255.0 -> float32."""
+    return (np.repeat(mask_u8[:, :, np.newaxis], 3, axis=2) / 255.0).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# the generator, in the reference's order of operations
+# ----------------------------------------------------------------------------------------------------------
+class RefCamera:
+    """surroundBEV.py:81-117."""
+
+    def __init__(self, K, D, H, cfg):
+        self.K, self.D, self.H = (np.array(x, np.float64) for x in (K, D, H))
+        fw, fh, ss = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["SIZE_SCALE"]
+        self.bev_size = (cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"])
+        self.K_dst = camera_mat_dst(self.K, fw, fh, cfg["FOCAL_SCALE"], ss)
+        self.undistort_maps = fisheye_init_undistort_rectify_map(self.K, self.D, self.K_dst,
+                                                                 (int(fw * ss), int(fh * ss)))
+        self.bev_maps = (self.warp_homography(self.undistort_maps[0]), self.warp_homography(self.undistort_maps[1]))
+
+    def undistort(self, img):
+        return remap(img, *self.undistort_maps)
+
+    def warp_homography(self, img):
+        return warp_perspective(img, self.H, self.bev_size)
+
+    def raw2bev(self, img):
+        return remap(img, *self.bev_maps)
+
+
+DEFAULT_CFG = dict(FRAME_WIDTH=1280, FRAME_HEIGHT=1024, BEV_WIDTH=1000, BEV_HEIGHT=1000, CAR_WIDTH=250,
+                   CAR_HEIGHT=400, FOCAL_SCALE=1.0, SIZE_SCALE=2.0)
+
+
+class RefBevGenerator:
+    """BevGenerator restated (surroundBEV.py:282-325). `rig` maps camera name -> (K, D, H)."""
+
+    def __init__(self, rig, cfg=None, blend=False, balance=False):
+        self.cfg = dict(DEFAULT_CFG)
+        self.cfg.update(cfg or {})
+        c = self.cfg
+        self.blend, self.balance = bool(blend), bool(balance)
+        self.cameras = [RefCamera(*rig[n], c) for n in CAMERAS]
+        geo = (c["BEV_WIDTH"], c["BEV_HEIGHT"], c["CAR_WIDTH"], c["CAR_HEIGHT"])
+        if self.blend:
+            self.masks = [blend_mask_for(n, *geo) for n in CAMERAS]
+            self.weights = [blend_weight(m) for m in self.masks]
+        else:
+            self.masks = [direct_mask(n, *geo) for n in CAMERAS]
+            self.weights = [None] * 4
+
+    def apply_mask(self, i, img):
+        img = _c(img, np.uint8)
+        out = np.empty_like(img)
+        if self.blend:
+            lib().orc_weight_mul(_p(img), _p(self.weights[i]), img.size, _p(out))
+        else:
+            lib().orc_mask_select(_p(img), _p(self.masks[i]), img.size // 3, _p(out))
+        return out
+
+    def __call__(self, front, back, left, right, car=None):
+        images = [front, back, left, right]
+        if self.balance:
+            images = luminance_balance(images)
+        images = [self.apply_mask(i, cam.raw2bev(img)) for i, (img, cam) in enumerate(zip(images, self.cameras))]
+        surround = add_sat(images[0], images[1])
+        surround = add_sat(surround, images[2])
+        surround = add_sat(surround, images[3])
+        if self.balance:
+            surround = color_balance(surround)
+        if car is not None:
+            surround = add_sat(surround, car)
+        return surround
+
+    # ---- single fused C call in the same op order: used for the timed CPU baseline ----
+    def make_fast_call(self):
+        c = self.cfg
+        fw, fh, bw, bh = c["FRAME_WIDTH"], c["FRAME_HEIGHT"], c["BEV_WIDTH"], c["BEV_HEIGHT"]
+        P4 = C.c_void_p * 4
+        xy = P4(*[_p(cam.bev_maps[0]) for cam in self.cameras])
+        al = P4(*[_p(cam.bev_maps[1]) for cam in self.cameras])
+        mk = P4(*[_p(m) for m in self.masks])
+        wt = P4(*[(_p(w) if w is not None else None) for w in self.weights])
+        scratch = np.empty(5 * bw * bh * 3 + 4 * fw * fh * 3, np.uint8)
+        out = np.empty((bh, bw, 3), np.uint8)
+        L = lib()
+
+        def call(frames4, car=None):
+            fr = P4(*[_p(f) for f in frames4])
+            L.orc_bev_call(fr, fw, fh, xy, al, bw, bh, mk, wt, int(self.blend), int(self.balance),
+                           _p(car) if car is not None else None, _p(scratch), _p(out))
+            return out
+
+        return call
