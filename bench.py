@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py -- stitched-BEV throughput of the HIP engine on N MI355X GPUs (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--batch B] [--schedule auto|pixel|plan]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path (BevGenerator.__call__ for a whole batch, surroundBEV.py:312-325) over one
+batch of synthetic frames that is ALREADY RESIDENT IN HBM (bevw_run_device).  Frames shard across ranks with no
+data-path collective (each rank owns its own batch and a full copy of the static tables): weak scaling.  Rank 0
+prints ONE JSON line.  Workloads = BASELINE.json configs:
+
+    direct_stitch_b256   4-cam direct stitch 1280x960 -> 1080x1080, batch 256 per GPU   (default: the metric's config)
+    blend_balance_b256   same sizes, BevGenerator(blend=True, balance=True)
+    undistort_b64        single fisheye undistort remap 1280x960, batch 64
+    blend_4k             4-cam 3840x2160 -> 1080x1080 blend, batch 32
+
+`roofline.achieved` = algorithmic bytes of the workload (cameracalibration_amd/workloads.py) x units
+per launch / the launch's average duration measured with HIP events on the engine's own stream.
+`cpu_baseline` = the CPU oracle (oracle/, reference operation order, OpenMP over all host cores) timed on a bounded
+sample of the same workload on rank 0 at N=1 -- a reported baseline, not the thing measured.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    "direct_stitch_b256": dict(kind="bev", cfg="S", blend=False, balance=False, batch=256, unit="frames/s",
+                               metric="stitched BEV frames/sec (4-cam 1280x960->1080x1080)"),
+    "blend_balance_b256": dict(kind="bev", cfg="S", blend=True, balance=True, batch=256, unit="frames/s",
+                               metric="stitched BEV frames/sec (4-cam 1280x960->1080x1080, blend+balance)"),
+    "undistort_b64": dict(kind="undistort", batch=64, unit="images/s",
+                          metric="fisheye undistort remap images/sec (1280x960 u8)"),
+    "blend_4k": dict(kind="bev", cfg="4K", blend=True, balance=False, batch=32, unit="frames/s",
+                     metric="stitched BEV frames/sec (4-cam 3840x2160->1080x1080, blend)"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="direct_stitch_b256", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="frames (4-camera sets) per GPU per step; 0 = workload default")
+    ap.add_argument("--schedule", default="auto", choices=["auto", "pixel", "plan"])
+    ap.add_argument("--unique-sets", type=int, default=2, help="distinct synthetic frame sets replicated over the batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+class Dist:
+    """Barrier / max over ranks.  torch.distributed (backend nccl == RCCL) only when WORLD_SIZE > 1."""
+
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.t = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            use_gpu = torch.cuda.is_available()
+            if use_gpu:
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl" if use_gpu else "gloo")
+            self.torch, self.dist = torch, dist
+            self.dev = torch.device("cuda", self.local_rank) if use_gpu else torch.device("cpu")
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def max(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+
+def shard_sizes(total_units: int, world: int):
+    """Units (frames) per rank when a fixed total is split (strong scaling helper; also used by the gloo test)."""
+    base, rem = divmod(total_units, world)
+    return [base + (1 if r < rem else 0) for r in range(world)]
+
+
+def upload_replicated(buf, unique: np.ndarray, batch: int):
+    per = unique[0].nbytes
+    for b in range(batch):
+        buf.upload(unique[b % unique.shape[0]], offset=b * per)
+
+
+def cpu_baseline_bev(w, cfg, rig, unique, seconds):
+    """Oracle in the reference's operation order (oracle.RefBevGenerator.make_fast_call), all host cores."""
+    from oracle import oracle as O
+
+    O.build()
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    ref = O.RefBevGenerator(rig, cfg, blend=w["blend"], balance=w["balance"])
+    call = ref.make_fast_call()
+    frames = [np.ascontiguousarray(unique[0][c]) for c in range(4)]
+    call(frames)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        call([np.ascontiguousarray(unique[n % unique.shape[0]][c]) for c in range(4)] if unique.shape[0] > 1 else frames)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 2000:
+            break
+    return {"value": n / dt, "unit": w["unit"], "cores": cores, "kind": "port",
+            "sample": f"{n} stitched frames in {dt:.1f} s (oracle/bevoracle.c orc_bev_call, OpenMP {cores} threads, "
+                      f"reference op order: remap x4 -> mask -> 3 sat-adds)"}
+
+
+def cpu_baseline_undistort(w, K, D, ucfg, unique, seconds):
+    from oracle import oracle as O
+
+    O.build()
+    cores = os.cpu_count() or 1
+    O.set_threads(cores)
+    fw, fh = ucfg["FRAME_WIDTH"], ucfg["FRAME_HEIGHT"]
+    Kd = O.camera_mat_dst(K, fw, fh, ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"])
+    m1, m2 = O.fisheye_init_undistort_rectify_map(K, D, Kd, (int(fw * ucfg["SIZE_SCALE"]), int(fh * ucfg["SIZE_SCALE"])))
+    img = np.ascontiguousarray(unique[0][0])
+    O.remap(img, m1, m2)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.remap(img, m1, m2)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 5000:
+            break
+    return {"value": n / dt, "unit": w["unit"], "cores": cores, "kind": "port",
+            "sample": f"{n} images in {dt:.1f} s (oracle orc_remap_u8, OpenMP {cores} threads)"}
+
+
+def main():
+    a = parse_args()
+    d = Dist()
+    if d.world != a.gpus and d.world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={d.world}")
+    from cameracalibration_amd import _ffi, workloads as W
+
+    _ffi.require_device()  # loud: this bench has no CPU path
+    dev = d.local_rank if _ffi.device_count() > d.local_rank else 0
+    w = WORKLOADS[a.workload]
+    batch = a.batch or w["batch"]
+    sched = {"auto": _ffi.SCHED_AUTO, "pixel": _ffi.SCHED_PER_PIXEL, "plan": _ffi.SCHED_TILE_PLAN}[a.schedule]
+    alg_bytes = W.ALGORITHMIC_BYTES[a.workload]
+    cpu = None
+
+    if w["kind"] == "bev":
+        cfg = {"S": W.CONFIG_S, "4K": W.CONFIG_4K}[w["cfg"]]
+        rig = {"S": W.rig_s, "4K": W.rig_4k}[w["cfg"]]()
+        from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+
+        ns = SB.BevGenerator.get_args()
+        for k, v in cfg.items():
+            setattr(ns, k, v)
+        t_build = time.perf_counter()
+        bev = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=rig, device=dev, schedule=sched)
+        t_build = time.perf_counter() - t_build
+        fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+        unique = W.synthetic_frames(a.unique_sets, fw, fh, seed=W.SEED + d.rank)
+        d_in = _ffi.DeviceBuffer(batch * unique[0].nbytes, dev)
+        d_out = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
+        upload_replicated(d_in, unique, batch)
+        step = lambda: bev.run_device(d_in.ptr, batch, None, d_out.ptr)
+        sync, tstart, tstop = bev.sync, bev.timer_start, bev.timer_stop
+        info = bev.plan_info()
+        extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
+                 "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3)}
+        if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
+    else:
+        import ctypes as C
+        ucfg = W.CONFIG_UNDISTORT
+        K, D = W.undistort_calibration()
+        fw, fh = ucfg["FRAME_WIDTH"], ucfg["FRAME_HEIGHT"]
+        r = C.c_void_p()
+        _ffi.check(_ffi.lib().bevw_fisheye_remapper_create(dev, fw, fh, _ffi.ptr(_ffi.f64(K, 9)), _ffi.ptr(_ffi.f64(D, 4)),
+                                                           ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"], 0.0, 0.0, C.byref(r)))
+        unique = W.synthetic_frames(max(1, a.unique_sets // 2), fw, fh, seed=W.SEED + d.rank)
+        imgs = unique.reshape(-1, fh, fw, 3)
+        d_in = _ffi.DeviceBuffer(batch * imgs[0].nbytes, dev)
+        d_out = _ffi.DeviceBuffer(batch * imgs[0].nbytes, dev)
+        upload_replicated(d_in, imgs, batch)
+        L = _ffi.lib()
+        step = lambda: _ffi.check(L.bevw_remap_device(r, d_in.ptr, batch, d_out.ptr))
+        sync = lambda: _ffi.check(L.bevw_remapper_sync(r))
+        tstart = lambda: _ffi.check(L.bevw_remapper_timer_start(r))
+
+        def tstop():
+            ms = C.c_float()
+            _ffi.check(L.bevw_remapper_timer_stop(r, C.byref(ms)))
+            return float(ms.value)
+        extra = {"frame": [fw, fh], "schedule": "per_pixel"}
+        if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline_undistort(w, K, D, ucfg, unique, a.cpu_seconds)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    d.barrier()
+    t0 = time.perf_counter()
+    tstart()
+    for _ in range(a.steps):
+        step()
+    ev_ms = tstop()  # records the stop event on the engine's stream and waits for it
+    sync()
+    d.barrier()
+    wall = time.perf_counter() - t0
+    wall = d.max(wall)
+    ev_ms = d.max(ev_ms)
+
+    total_units = batch * a.steps * d.world
+    value = total_units / wall
+    launch_ms = ev_ms / a.steps
+    achieved = alg_bytes * batch / (launch_ms * 1e-3) / 1e9
+    out = {
+        "metric": w["metric"], "value": value, "unit": w["unit"], "n_gpus": d.world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": dict({"workload": a.workload, "batch_per_gpu": batch, "global_batch": batch * d.world,
+                        "sharding": "frames across ranks, no data-path collective", "device": _ffi.device_name(dev),
+                        "unique_frame_sets": int(a.unique_sets)}, **extra),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": launch_ms, "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
+        "cpu_baseline": cpu,
+    }
+    if d.rank == 0:
+        print(json.dumps(out), flush=True)
+    d.close()
+
+
+if __name__ == "__main__":
+    main()

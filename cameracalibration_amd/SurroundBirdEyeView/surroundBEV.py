@@ -1,0 +1,359 @@
+"""Host-side mirror of the reference's SurroundBirdEyeView/surroundBEV.py on top of libbevwarp (HIP, gfx950).
+
+Same names, same argument meaning, same error behaviour as the reference module (file:line cited per symbol), so
+``main.py``'s ``runBEV`` body (main.py:79-84) runs unchanged::
+
+    from SurroundBirdEyeView import BevGenerator
+    args = BevGenerator.get_args(); args.CAR_WIDTH = 200; args.CAR_HEIGHT = 350
+    bev = BevGenerator(blend=True, balance=True)
+    surround = bev(front, back, left, right)
+
+Every pixel is produced on the GPU through the C-ABI (include/bevwarp.h); there is no cv2 and no NumPy compute path.
+Additive API (not in the reference): ``BevGenerator(..., rig=..., device=..., schedule=...)``, ``bev.batch(frames)``,
+``bev.run_device(...)``.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _ffi
+from .._ffi import check, f64, lib, ptr
+
+# surroundBEV.py:6-17 -- identical flags and defaults.  parse_known_args: importing this module must never abort
+# because some other program's flags are on sys.argv (the reference's parse_args() does).
+parser = argparse.ArgumentParser(description="Generate Surrounding Camera Bird Eye View")
+parser.add_argument('-fw', '--FRAME_WIDTH', default=1280, type=int, help='Camera Frame Width')
+parser.add_argument('-fh', '--FRAME_HEIGHT', default=1024, type=int, help='Camera Frame Height')
+parser.add_argument('-bw', '--BEV_WIDTH', default=1000, type=int, help='BEV Frame Width')
+parser.add_argument('-bh', '--BEV_HEIGHT', default=1000, type=int, help='BEV Frame Height')
+parser.add_argument('-cw', '--CAR_WIDTH', default=250, type=int, help='Car Frame Width')
+parser.add_argument('-ch', '--CAR_HEIGHT', default=400, type=int, help='Car Frame Height')
+parser.add_argument('-fs', '--FOCAL_SCALE', default=1, type=float, help='Camera Undistort Focal Scale')
+parser.add_argument('-ss', '--SIZE_SCALE', default=2, type=float, help='Camera Undistort Size Scale')
+parser.add_argument('-blend', '--BLEND_FLAG', default=False, type=bool, help='Blend BEV Image (Ture/False)')
+parser.add_argument('-balance', '--BALANCE_FLAG', default=False, type=bool, help='Balance BEV Image (Ture/False)')
+args, _unknown = parser.parse_known_args()
+
+FRAME_WIDTH = args.FRAME_WIDTH
+FRAME_HEIGHT = args.FRAME_HEIGHT
+BEV_WIDTH = args.BEV_WIDTH
+BEV_HEIGHT = args.BEV_HEIGHT
+CAR_WIDTH = args.CAR_WIDTH
+CAR_HEIGHT = args.CAR_HEIGHT
+FOCAL_SCALE = args.FOCAL_SCALE
+SIZE_SCALE = args.SIZE_SCALE
+
+CAMERA_NAMES = ('front', 'back', 'left', 'right')
+
+
+def _data_dir() -> str:
+    """Where camera_<name>_{K,D,H}.npy live (surroundBEV.py:83-85 uses dirname(__file__) + '/data')."""
+    return os.environ.get("BEVW_DATA_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def padding(img, width, height):
+    """surroundBEV.py:28-41 -- centre the car sprite on a zero canvas (cv2.copyMakeBorder, constant 0).
+    A one-off copy of a 250x400 sprite outside the per-frame path (surroundBEV.py:332-333)."""
+    img = np.asarray(img)
+    H, W = img.shape[0], img.shape[1]
+    top = (height - H) // 2
+    left = (width - W) // 2
+    out = np.zeros((height, width) + img.shape[2:], dtype=img.dtype)
+    out[top:top + H, left:left + W] = img
+    return out
+
+
+def color_balance(image, device: int = 0):
+    """surroundBEV.py:43-55 on the GPU (k_channel_sums + k_gain)."""
+    img = _ffi.as_u8_image(image)
+    out = np.empty_like(img)
+    check(lib().bevw_color_balance(device, ptr(img), 1, img.shape[1], img.shape[0], ptr(out)))
+    return out
+
+
+def luminance_balance(images, device: int = 0):
+    """surroundBEV.py:57-79 on the GPU (k_vsum + k_lum_delta + k_lum_shift)."""
+    imgs = [_ffi.as_u8_image(i) for i in images]
+    if len(imgs) != 4 or any(i.shape != imgs[0].shape for i in imgs):
+        raise Exception("luminance_balance expects [front, back, left, right] of one size")
+    stack = np.stack(imgs)
+    out = np.empty_like(stack)
+    check(lib().bevw_luminance_balance(device, ptr(stack), 1, imgs[0].shape[1], imgs[0].shape[0], ptr(out)))
+    return [out[i] for i in range(4)]
+
+
+def _snapshot_config(blend=False, balance=False, device=0, schedule=_ffi.SCHED_AUTO) -> _ffi.bevw_config:
+    return _ffi.bevw_config(int(FRAME_WIDTH), int(FRAME_HEIGHT), int(BEV_WIDTH), int(BEV_HEIGHT), int(CAR_WIDTH),
+                            int(CAR_HEIGHT), float(FOCAL_SCALE), float(SIZE_SCALE), int(bool(blend)),
+                            int(bool(balance)), int(device), int(schedule))
+
+
+class _Engine:
+    """Owns one bevw_handle (4 cameras + masks on the device)."""
+
+    def __init__(self, rig, blend, balance, device, schedule):
+        _ffi.require_device()
+        self.cfg = _snapshot_config(blend, balance, device, schedule)
+        h = C.c_void_p()
+        check(lib().bevw_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        try:
+            for i, (K, D, H) in enumerate(rig):
+                check(lib().bevw_set_camera(self.h, i, ptr(f64(K, 9)), ptr(f64(D, 4)), ptr(f64(H, 9))))
+            check(lib().bevw_build(self.h))
+        except Exception:
+            self.close()
+            raise
+        self.und_size = (int(self.cfg.frame_width * self.cfg.size_scale), int(self.cfg.frame_height * self.cfg.size_scale))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().bevw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Camera:
+    """surroundBEV.py:81-117.  Inside a BevGenerator the four cameras share the generator's device tables; a
+    stand-alone Camera(name) builds a private table set on first use."""
+
+    def __init__(self, name, K=None, D=None, H=None):
+        if name not in CAMERA_NAMES:
+            raise Exception("name should be front/back/left/right")
+        self.name = name
+        if K is None:
+            base = _data_dir()
+            self.camera_mat = np.load(base + '/{}/camera_{}_K.npy'.format(name, name))
+            self.dist_coeff = np.load(base + '/{}/camera_{}_D.npy'.format(name, name))
+            self.homography = np.load(base + '/{}/camera_{}_H.npy'.format(name, name))
+        else:
+            self.camera_mat = np.array(K, dtype=np.float64).reshape(3, 3)
+            self.dist_coeff = np.array(D, dtype=np.float64).reshape(-1, 1)
+            self.homography = np.array(H, dtype=np.float64).reshape(3, 3)
+        self.camera_mat_dst = self.get_camera_mat_dst()
+        self._engine = None
+        self._index = 0
+        self._device = 0
+
+    def _attach(self, engine, index):
+        self._engine, self._index = engine, index
+
+    def _eng(self) -> _Engine:
+        if self._engine is None:
+            trip = (self.camera_mat, self.dist_coeff, self.homography)
+            self._engine = _Engine([trip] * 4, False, False, self._device, _ffi.SCHED_PER_PIXEL)
+            self._index = 0
+        return self._engine
+
+    def get_camera_mat_dst(self):
+        camera_mat_dst = self.camera_mat.copy()
+        camera_mat_dst[0][0] *= FOCAL_SCALE
+        camera_mat_dst[1][1] *= FOCAL_SCALE
+        camera_mat_dst[0][2] = FRAME_WIDTH / 2 * SIZE_SCALE
+        camera_mat_dst[1][2] = FRAME_HEIGHT / 2 * SIZE_SCALE
+        return camera_mat_dst
+
+    def get_undistort_maps(self):
+        e = self._eng()
+        w, h = e.und_size
+        m1, m2 = np.empty((h, w, 2), np.int16), np.empty((h, w), np.uint16)
+        check(lib().bevw_get_undistort_map(e.h, self._index, ptr(m1), ptr(m2)))
+        return (m1, m2)
+
+    def get_bev_maps(self):
+        e = self._eng()
+        w, h = e.cfg.bev_width, e.cfg.bev_height
+        m1, m2 = np.empty((h, w, 2), np.int16), np.empty((h, w), np.uint16)
+        check(lib().bevw_get_lut(e.h, self._index, ptr(m1), ptr(m2)))
+        return (m1, m2)
+
+    @property
+    def undistort_maps(self):
+        return self.get_undistort_maps()
+
+    @property
+    def bev_maps(self):
+        return self.get_bev_maps()
+
+    def undistort(self, img):
+        e = self._eng()
+        img = _ffi.as_u8_image(img)
+        if img.shape[:2] != (e.cfg.frame_height, e.cfg.frame_width):
+            raise Exception("image is {}x{}, FRAME is {}x{}".format(img.shape[1], img.shape[0], e.cfg.frame_width, e.cfg.frame_height))
+        out = np.empty((e.und_size[1], e.und_size[0], 3), np.uint8)
+        check(lib().bevw_camera_undistort(e.h, self._index, ptr(img), 1, ptr(out)))
+        return out
+
+    def warp_homography(self, img):
+        e = self._eng()
+        img = _ffi.as_u8_image(img)
+        out = np.empty((e.cfg.bev_height, e.cfg.bev_width, 3), np.uint8)
+        check(lib().bevw_camera_warp_homography(e.h, self._index, ptr(img), img.shape[1], img.shape[0], 1, ptr(out)))
+        return out
+
+    def raw2bev(self, img):
+        e = self._eng()
+        img = _ffi.as_u8_image(img)
+        if img.shape[:2] != (e.cfg.frame_height, e.cfg.frame_width):
+            raise Exception("image is {}x{}, FRAME is {}x{}".format(img.shape[1], img.shape[0], e.cfg.frame_width, e.cfg.frame_height))
+        out = np.empty((e.cfg.bev_height, e.cfg.bev_width, 3), np.uint8)
+        check(lib().bevw_camera_raw2bev(e.h, self._index, ptr(img), 1, ptr(out)))
+        return out
+
+
+class Mask:
+    """surroundBEV.py:119-162.  `.mask` is the uint8 fillPoly mask, rasterised on the GPU (k_poly_outline/k_poly_fill).
+    In BevGenerator.__call__ the mask is applied inside the fused stitch kernel, not by this object."""
+    _blend = False
+
+    def __init__(self, name, _engine=None, _index=None):
+        if name not in CAMERA_NAMES:
+            raise Exception("name should be front/back/left/right")
+        self.name = name
+        self._engine, self._index = _engine, (CAMERA_NAMES.index(name) if _index is None else _index)
+        self._mask = None
+
+    def _eng(self):
+        if self._engine is None:
+            ident = (np.eye(3), np.zeros(4), np.eye(3))
+            self._engine = _Engine([ident] * 4, self._blend, False, 0, _ffi.SCHED_PER_PIXEL)
+        return self._engine
+
+    def get_mask(self, name=None):
+        e = self._eng()
+        idx = self._index if name is None else CAMERA_NAMES.index(name)
+        m = np.empty((e.cfg.bev_height, e.cfg.bev_width), np.uint8)
+        check(lib().bevw_get_mask(e.h, idx, ptr(m)))
+        return m
+
+    @property
+    def mask(self):
+        if self._mask is None:
+            self._mask = self.get_mask()
+        return self._mask
+
+
+class BlendMask(Mask):
+    """surroundBEV.py:164-280.  `.mask` holds the uint8 alpha codes, `.weight` = float32(mask / 255.0) x 3 channels."""
+    _blend = True
+
+    @property
+    def weight(self):
+        return (np.repeat(self.mask[:, :, np.newaxis], 3, axis=2) / 255.0).astype(np.float32)
+
+
+class BevGenerator:
+    """surroundBEV.py:282-325.
+
+    BevGenerator(blend, balance) reads the module-level `args` (get_args()) at construction exactly like the
+    reference's init_args(), loads the four cameras' K/D/H and builds every table on the GPU.
+    """
+
+    def __init__(self, blend=args.BLEND_FLAG, balance=args.BALANCE_FLAG, *, rig=None, device=0,
+                 schedule=_ffi.SCHED_AUTO):
+        self.init_args()
+        if rig is None:
+            self.cameras = [Camera('front'), Camera('back'), Camera('left'), Camera('right')]
+        else:
+            self.cameras = [Camera(n, *rig[n]) for n in CAMERA_NAMES]
+        self.blend = blend
+        self.balance = balance
+        self.device = device
+        self._engine = _Engine([(c.camera_mat, c.dist_coeff, c.homography) for c in self.cameras], blend, balance,
+                               device, schedule)
+        for i, cam in enumerate(self.cameras):
+            cam._attach(self._engine, i)
+        cls = BlendMask if self.blend else Mask
+        self.masks = [cls(n, self._engine, i) for i, n in enumerate(CAMERA_NAMES)]
+
+    @staticmethod
+    def get_args():
+        return args
+
+    def init_args(self):
+        global FRAME_WIDTH, FRAME_HEIGHT, BEV_WIDTH, BEV_HEIGHT
+        global CAR_WIDTH, CAR_HEIGHT, FOCAL_SCALE, SIZE_SCALE
+        FRAME_WIDTH = args.FRAME_WIDTH
+        FRAME_HEIGHT = args.FRAME_HEIGHT
+        BEV_WIDTH = args.BEV_WIDTH
+        BEV_HEIGHT = args.BEV_HEIGHT
+        CAR_WIDTH = args.CAR_WIDTH
+        CAR_HEIGHT = args.CAR_HEIGHT
+        FOCAL_SCALE = args.FOCAL_SCALE
+        SIZE_SCALE = args.SIZE_SCALE
+
+    # ---- reference call ------------------------------------------------------------------------------------
+    def __call__(self, front, back, left, right, car=None):
+        c = self._engine.cfg
+        images = [_ffi.as_u8_image(i, "camera frame") for i in (front, back, left, right)]
+        for img in images:
+            if img.shape[:2] != (c.frame_height, c.frame_width):
+                raise Exception("camera frame is {}x{}, FRAME is {}x{}".format(img.shape[1], img.shape[0],
+                                                                               c.frame_width, c.frame_height))
+        return self.batch(np.stack(images)[np.newaxis], car)[0]
+
+    # ---- additive: batches ---------------------------------------------------------------------------------
+    def batch(self, frames, car=None):
+        """frames uint8 [B, 4, FH, FW, 3] (front, back, left, right) -> uint8 [B, BH, BW, 3]."""
+        c = self._engine.cfg
+        frames = np.ascontiguousarray(frames)
+        if frames.dtype != np.uint8 or frames.ndim != 5 or frames.shape[1:] != (4, c.frame_height, c.frame_width, 3):
+            raise Exception("frames must be uint8 [B, 4, {}, {}, 3]".format(c.frame_height, c.frame_width))
+        car_p = None
+        if car is not None:
+            car = _ffi.as_u8_image(car, "car")
+            if car.shape[:2] != (c.bev_height, c.bev_width):
+                raise Exception("car must be padded to the BEV size (padding())")
+            car_p = ptr(car)
+        out = np.empty((frames.shape[0], c.bev_height, c.bev_width, 3), np.uint8)
+        check(lib().bevw_run(self._engine.h, ptr(frames), frames.shape[0], car_p, ptr(out)))
+        return out
+
+    def run_device(self, d_frames: int, batch: int, d_car, d_out: int) -> None:
+        """Asynchronous launch on device-resident buffers (raw pointers from DeviceBuffer)."""
+        check(lib().bevw_run_device(self._engine.h, d_frames, batch, d_car, d_out))
+
+    def sync(self) -> None:
+        check(lib().bevw_sync(self._engine.h))
+
+    def timer_start(self) -> None:
+        check(lib().bevw_timer_start(self._engine.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        check(lib().bevw_timer_stop(self._engine.h, C.byref(ms)))
+        return float(ms.value)
+
+    def plan_info(self) -> dict:
+        info = np.zeros(8, np.int32)
+        check(lib().bevw_plan_info(self._engine.h, ptr(info)))
+        return {"max_contributors": int(info[0]), "plan_usable": bool(info[1]), "schedule": int(info[2]),
+                "tiles_x": int(info[3]), "tiles_y": int(info[4])}
+
+
+def main():
+    """surroundBEV.py:327-345 without the GUI: reads ./data like the reference and writes ./surround.png."""
+    from PIL import Image
+
+    def imread(p):
+        return np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1])
+
+    base = _data_dir()
+    front, back, left, right = (imread(base + '/{0}/{0}.jpg'.format(n)) for n in CAMERA_NAMES)
+    car = padding(imread(base + '/car.jpg'), BEV_WIDTH, BEV_HEIGHT)
+    bev = BevGenerator()
+    surround = bev(front, back, left, right, car)
+    Image.fromarray(np.ascontiguousarray(surround[:, :, ::-1])).save('./surround.png')
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,44 @@
+"""Build recipe of libbevwarp.so (hipcc, gfx950 only).  Used by __graft_entry__.build() and by hand:
+
+    python -m cameracalibration_amd.build [--force]
+
+The shared object is written next to this file (in-tree: it travels to the GPU box with the repo snapshot and is
+git-ignored).  -ffp-contract=off is REQUIRED: the arithmetic being reproduced has no fused multiply-add.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libbevwarp.so")
+SOURCES = ["bevwarp.hip"]
+HEADERS = ["bevw_device.h", "bevw_kernels.h", "bevw_plan.h", os.path.join("..", "..", "include", "bevwarp.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+         "-Wno-pass-failed"]
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

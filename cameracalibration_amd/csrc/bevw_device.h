@@ -1,0 +1,205 @@
+// bevw_device.h -- device-side arithmetic shared by every kernel of libbevwarp (gfx950 only).
+//
+// Everything here restates, for one output element, what the reference obtains from cv2 at the call sites cited
+// per function (paths are relative to the reference tree).  The translation unit is compiled with
+// -ffp-contract=off: OpenCV's x86-64 baseline code has no fused multiply-add, so neither may we.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bevw {
+
+constexpr int kQBits = 5;          // INTER_BITS
+constexpr int kQOne = 32;          // INTER_TAB_SIZE
+constexpr int kQTab2 = 1024;       // INTER_TAB_SIZE2
+
+// ---- rounding / saturation (cvRound = round-half-even, saturate_cast<>) -----------------------------------
+__device__ __forceinline__ int rne_d(double v)
+{
+    // cvtsd2si semantics: out-of-range and NaN give INT_MIN
+    if (!(v > -2147483648.5 && v < 2147483647.5)) return INT_MIN;
+    return __double2int_rn(v);
+}
+__device__ __forceinline__ int rne_f(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483520.0f)) return INT_MIN;
+    return __float2int_rn(v);
+}
+__device__ __forceinline__ int sat_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int sat_s16(int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); }
+__device__ __forceinline__ int sat_u16(int v) { return v < 0 ? 0 : (v > 65535 ? 65535 : v); }
+
+// ---- cvtColor BGR<->HSV 8-bit + V shift: luminance_balance (SurroundBirdEyeView/surroundBEV.py:57-79) ------
+struct HsvTables {
+    int sdiv[256];  // cvRound((255 << 12) / (1.0 * i))
+    int hdiv[256];  // cvRound((180 << 12) / (6.0 * i))
+};
+
+// One texel through BGR2HSV -> V = sat_u8(V + delta) -> HSV2BGR.  The round trip is lossy, so it is applied even
+// when delta == 0, exactly as the reference does.
+__device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int delta, const int *__restrict__ sdiv,
+                                                   const int *__restrict__ hdiv)
+{
+    int v = max(b, max(g, r));
+    int vmin = min(b, min(g, r));
+    int diff = v - vmin;
+    int vr = (v == r) ? -1 : 0, vg = (v == g) ? -1 : 0;
+    int s = (diff * sdiv[v] + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv[diff] + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+    h = sat_u8(h);
+    s = s & 255;  // (uint8_t) store of the oracle / OpenCV
+    v = sat_u8(v + delta);
+    // HSV -> BGR, float path
+    const float hscale = 6.f / 180.f;
+    float fh = (float)h, fs = (float)s * (1.f / 255.f), fv = (float)v * (1.f / 255.f);
+    float fb, fg, fr;
+    if (fs == 0.f) {
+        fb = fg = fr = fv;
+    } else {
+        fh *= hscale;
+        fh = fmodf(fh, 6.f);
+        int sector = (int)floorf(fh);
+        fh -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; fh = 0.f; }
+        float t0 = fv;
+        float t1 = fv * (1.f - fs);
+        float t2 = fv * (1.f - fs * fh);
+        float t3 = fv * (1.f - fs * (1.f - fh));
+        // sector table {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} -> (b,g,r)
+        switch (sector) {
+            case 0: fb = t1; fg = t3; fr = t0; break;
+            case 1: fb = t1; fg = t0; fr = t2; break;
+            case 2: fb = t3; fg = t0; fr = t1; break;
+            case 3: fb = t0; fg = t2; fr = t1; break;
+            case 4: fb = t0; fg = t1; fr = t3; break;
+            default: fb = t2; fg = t1; fr = t0; break;
+        }
+    }
+    b = sat_u8(rne_f(fb * 255.f));
+    g = sat_u8(rne_f(fg * 255.f));
+    r = sat_u8(rne_f(fr * 255.f));
+}
+
+// ---- cv2.remap u8c3, INTER_LINEAR fixed point, BORDER_CONSTANT 0 -------------------------------------------
+// call sites: surroundBEV.py:110-111,116-117; intrinsicCalib.py:193-195; Tools/undistort.py:66
+// out = (sum p * w15 + 2^14) >> 15 with w15 = 32 * w10  ==  (sum p * w10 + 512) >> 10, w10 = 5-bit x 5-bit products.
+template <bool LUM>
+__device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, int sw, int sh, int sx, int sy,
+                                              unsigned code, int out[3], int delta, const int *sdiv, const int *hdiv)
+{
+    const int fx = code & 31, fy = (code >> 5) & 31;
+    const int ax = kQOne - fx, ay = kQOne - fy;
+    const int w00 = ax * ay, w01 = fx * ay, w10 = ax * fy, w11 = fx * fy;
+    const unsigned xlim = sw > 1 ? sw - 1 : 0, ylim = sh > 1 ? sh - 1 : 0;
+    if ((unsigned)sx < xlim && (unsigned)sy < ylim) {
+        const uint8_t *p0 = src + ((size_t)sy * sw + sx) * 3;
+        const uint8_t *p1 = p0 + (size_t)sw * 3;
+        int t[4][3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t[0][k] = p0[k]; t[1][k] = p0[3 + k]; t[2][k] = p1[k]; t[3][k] = p1[3 + k]; }
+        if (LUM) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, sdiv, hdiv);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            out[k] = (t[0][k] * w00 + t[1][k] * w01 + t[2][k] * w10 + t[3][k] * w11 + 512) >> 10;
+    } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+        out[0] = out[1] = out[2] = 0;
+    } else {
+        const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw;
+        const bool y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+        int t[4][3];
+        const bool ok[4] = {x0 && y0, x1 && y0, x0 && y1, x1 && y1};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ok[q]) {
+                const uint8_t *p = src + ((size_t)(sy + (q >> 1)) * sw + (sx + (q & 1))) * 3;
+                t[q][0] = p[0]; t[q][1] = p[1]; t[q][2] = p[2];
+                if (LUM) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, sdiv, hdiv);
+            } else {
+                t[q][0] = t[q][1] = t[q][2] = 0;  // border value enters after the balance step
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            out[k] = (t[0][k] * w00 + t[1][k] * w01 + t[2][k] * w10 + t[3][k] * w11 + 512) >> 10;
+    }
+}
+
+// ---- cv2.warpPerspective coordinate generation (surroundBEV.py:113-114, extrinsicCalib.py:166-169) ---------
+// M is the INVERSE homography; the destination is walked in column blocks of bw0 pixels whose origin x0 enters the
+// fp64 expression, so the association (X0 + M0*x1) is kept.
+__device__ __forceinline__ void perspective_coord(const double *__restrict__ M, int x, int y, int bw0, int &sx,
+                                                  int &sy, unsigned &code)
+{
+    const int x0 = (x / bw0) * bw0, x1 = x - x0;
+    const double X0 = M[0] * x0 + M[1] * y + M[2];
+    const double Y0 = M[3] * x0 + M[4] * y + M[5];
+    const double W0 = M[6] * x0 + M[7] * y + M[8];
+    double W = W0 + M[6] * x1;
+    W = (W != 0.0) ? (double)kQOne / W : 0.0;
+    double fX = (X0 + M[0] * x1) * W, fY = (Y0 + M[3] * x1) * W;
+    const double lo = (double)INT_MIN, hi = (double)INT_MAX;
+    // std::max(lo, std::min(hi, v)) with the operand order of the reference implementation (NaN -> hi)
+    fX = (fX < hi) ? fX : hi; fX = (lo < fX) ? fX : lo;
+    fY = (fY < hi) ? fY : hi; fY = (lo < fY) ? fY : lo;
+    const int X = rne_d(fX), Y = rne_d(fY);
+    sx = sat_s16(X >> kQBits);
+    sy = sat_s16(Y >> kQBits);
+    code = (unsigned)((Y & (kQOne - 1)) * kQOne + (X & (kQOne - 1)));
+}
+
+// ---- float-weight bilinear of 16-bit sources: the LUT quirk, Camera.get_bev_maps (surroundBEV.py:105-108) ---
+template <typename T, int CN>
+__device__ __forceinline__ void remap_f32_px(const T *__restrict__ src, int sw, int sh, int sx, int sy, unsigned code,
+                                             int out[CN])
+{
+    const float fx = (float)(code & 31) * (1.f / 32), fy = (float)((code >> 5) & 31) * (1.f / 32);
+    const float ax = 1.f - fx, ay = 1.f - fy;
+    const float w0 = ay * ax, w1 = ay * fx, w2 = fy * ax, w3 = fy * fx;
+    const unsigned xlim = sw > 1 ? sw - 1 : 0, ylim = sh > 1 ? sh - 1 : 0;
+    if ((unsigned)sx < xlim && (unsigned)sy < ylim) {
+        const T *S = src + ((size_t)sy * sw + sx) * CN;
+        const size_t st = (size_t)sw * CN;
+#pragma unroll
+        for (int k = 0; k < CN; ++k)
+            out[k] = rne_f((float)S[k] * w0 + (float)S[k + CN] * w1 + (float)S[k + st] * w2 + (float)S[k + st + CN] * w3);
+    } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+#pragma unroll
+        for (int k = 0; k < CN; ++k) out[k] = 0;
+    } else {
+        const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw;
+        const bool y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+#pragma unroll
+        for (int k = 0; k < CN; ++k) {
+            float v0 = (x0 && y0) ? (float)src[((size_t)sy * sw + sx) * CN + k] : 0.f;
+            float v1 = (x1 && y0) ? (float)src[((size_t)sy * sw + sx + 1) * CN + k] : 0.f;
+            float v2 = (x0 && y1) ? (float)src[((size_t)(sy + 1) * sw + sx) * CN + k] : 0.f;
+            float v3 = (x1 && y1) ? (float)src[((size_t)(sy + 1) * sw + sx + 1) * CN + k] : 0.f;
+            out[k] = rne_f(v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3);
+        }
+    }
+}
+
+// ---- BlendMask weight: (img * float32(mask / 255.0)).astype(uint8)  (surroundBEV.py:187-188, 279-280) -------
+__device__ __forceinline__ float blend_weight_f32(int mask_u8) { return (float)((double)mask_u8 / 255.0); }
+__device__ __forceinline__ int blend_mul(int v, float w) { return (int)((float)v * w); }  // truncation
+
+// ---- wave64 / block reductions for the balance statistics --------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+}  // namespace bevw

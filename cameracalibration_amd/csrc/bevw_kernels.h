@@ -1,0 +1,431 @@
+// bevw_kernels.h -- HIP kernels of libbevwarp (gfx950).  Table builders (run once per calibration) and the
+// per-frame kernels of the first, always-valid schedule (BEVW_SCHED_PER_PIXEL).  The tile-plan schedule lives in
+// bevw_plan.h.
+#pragma once
+#include "bevw_device.h"
+
+namespace bevw {
+
+// =============================================================================================================
+// Table builders
+// =============================================================================================================
+
+// cv2.fisheye.initUndistortRectifyMap(K, D, I, K', size, CV_16SC2)
+// reference: surroundBEV.py:98-103, intrinsicCalib.py:98-103, Tools/undistort.py:50-52
+//
+// OpenCV walks a row accumulating _x += iR[0] per column (an fp64 chain, not j*iR[0]).  With R = I and the skew-free
+// K' the reference always builds, iR = [[1/fx',0,-cx'/fx'],[0,1/fy',-cy'/fy'],[0,0,1]], so the chain of _x is the
+// same for every row (xs[], produced once by the host in the same serial order), _y is constant along a row
+// (it accumulates iR[3] = 0) and _w == 1.  That makes the per-pixel work independent: one thread per map entry.
+struct FisheyeParams {
+    double fx, fy, cx, cy;  // K
+    double k0, k1, k2, k3;  // D
+    double iR4, iR5;        // 1/fy', -cy'/fy'
+};
+
+__global__ void k_fisheye_map(FisheyeParams p, const double *__restrict__ xs, int width, int height,
+                              int16_t *__restrict__ map1, uint16_t *__restrict__ map2)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= width || i >= height) return;
+    const double _w = 1.0;
+    const double x = xs[j] / _w;
+    const double y = ((double)i * p.iR4 + p.iR5) / _w;
+    const double r = sqrt(x * x + y * y);
+    const double theta = atan(r);
+    const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double theta_d = theta * (1 + p.k0 * t2 + p.k1 * t4 + p.k2 * t6 + p.k3 * t8);
+    const double scale = (r == 0) ? 1.0 : theta_d / r;
+    const double u = p.fx * x * scale + p.cx;
+    const double v = p.fy * y * scale + p.cy;
+    const int iu = rne_d(u * kQOne), iv = rne_d(v * kQOne);
+    const size_t o = (size_t)i * width + j;
+    map1[o * 2 + 0] = (int16_t)(iu >> kQBits);
+    map1[o * 2 + 1] = (int16_t)(iv >> kQBits);
+    map2[o] = (uint16_t)((iv & (kQOne - 1)) * kQOne + (iu & (kQOne - 1)));
+}
+
+// Camera.get_bev_maps (surroundBEV.py:105-108): cv2.warpPerspective over the CV_16SC2 and CV_16UC1 undistort maps.
+struct Mat3 { double m[9]; };
+
+__global__ void k_bev_lut(Mat3 Minv, const int16_t *__restrict__ und1, const uint16_t *__restrict__ und2, int uw,
+                          int uh, int bw, int bh, int bw0, int16_t *__restrict__ lut1, uint16_t *__restrict__ lut2)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= bw || y >= bh) return;
+    int sx, sy;
+    unsigned code;
+    perspective_coord(Minv.m, x, y, bw0, sx, sy, code);
+    int o1[2], o2[1];
+    remap_f32_px<int16_t, 2>(und1, uw, uh, sx, sy, code, o1);
+    remap_f32_px<uint16_t, 1>(und2, uw, uh, sx, sy, code, o2);
+    const size_t o = (size_t)y * bw + x;
+    lut1[o * 2 + 0] = (int16_t)sat_s16(o1[0]);
+    lut1[o * 2 + 1] = (int16_t)sat_s16(o1[1]);
+    lut2[o] = (uint16_t)sat_u16(o2[0]);
+}
+
+// cv2.fillPoly(mask, [pts], 255), LINE_8, shift 0  (surroundBEV.py:156-159, 231-234)
+// = Bresenham boundary of every edge  UNION  even-odd scanline spans between XY_SHIFT=16 fixed-point edges.
+struct PolyEdge { int y0, y1; long long x, dx; };
+struct PolyJob {
+    int npts;
+    int pts[8][2];       // integer vertices (after .astype(np.int32))
+    int nedges;
+    PolyEdge edges[8];   // non-horizontal edges, unsorted
+};
+
+__device__ inline bool clip_segment(int w, int h, long long &x1, long long &y1, long long &x2, long long &y2)
+{
+    const long long right = w - 1, bottom = h - 1;
+    if (w <= 0 || h <= 0) return false;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+// One thread per polygon edge: 8-connected Bresenham, left-to-right, after clipping to the image.
+__global__ void k_poly_outline(PolyJob job, uint8_t *__restrict__ img, int w, int h, uint8_t color)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= job.npts) return;
+    const int p = (e + job.npts - 1) % job.npts;
+    long long x1 = job.pts[p][0], y1 = job.pts[p][1], x2 = job.pts[e][0], y2 = job.pts[e][1];
+    if ((unsigned long long)x1 >= (unsigned long long)w || (unsigned long long)x2 >= (unsigned long long)w ||
+        (unsigned long long)y1 >= (unsigned long long)h || (unsigned long long)y2 >= (unsigned long long)h) {
+        if (!clip_segment(w, h, x1, y1, x2, y2)) return;
+    }
+    long long dx = x2 - x1, dy = y2 - y1, x = x1, y = y1;
+    if (dx < 0) { dx = -dx; dy = -dy; x = x2; y = y2; }
+    const int ystep = dy < 0 ? -1 : 1;
+    if (dy < 0) dy = -dy;
+    const bool steep = dy > dx;
+    const long long major = steep ? dy : dx, minor = steep ? dx : dy;
+    long long err = major - 2 * minor;
+    for (long long i = 0; i <= major; ++i) {
+        img[(size_t)y * w + x] = color;
+        const bool neg = err < 0;
+        err += -2 * minor + (neg ? 2 * major : 0);
+        if (steep) { y += ystep; if (neg) x += 1; }
+        else       { x += 1;     if (neg) y += ystep; }
+    }
+}
+
+// One thread per scanline.  An edge alive on row y (y0 <= y < y1) sits at x + (y - y0) * dx: the reference advances
+// every paired edge by dx once per row, which is this closed form.  Spans are [xa >> 16, xb >> 16] between
+// x-sorted pairs.
+__global__ void k_poly_fill(PolyJob job, uint8_t *__restrict__ img, int w, int h, uint8_t color)
+{
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y >= h || job.nedges < 2) return;
+    long long xs[8];
+    int n = 0;
+    for (int e = 0; e < job.nedges; ++e) {
+        const PolyEdge &E = job.edges[e];
+        if (E.y0 <= y && y < E.y1) {
+            const long long xv = E.x + (long long)(y - E.y0) * E.dx;
+            int k = n++;
+            while (k > 0 && xs[k - 1] > xv) { xs[k] = xs[k - 1]; --k; }
+            xs[k] = xv;
+        }
+    }
+    for (int i = 0; i + 1 < n; i += 2) {
+        int xa = (int)(xs[i] >> 16), xb = (int)(xs[i + 1] >> 16);
+        if (xa < w && xb >= 0) {
+            if (xa < 0) xa = 0;
+            if (xb >= w) xb = w - 1;
+            for (int x = xa; x <= xb; ++x) img[(size_t)y * w + x] = color;
+        }
+    }
+}
+
+// BlendMask.get_blend_mask (surroundBEV.py:270-277): weight = uint8(dA**2 / (dA**2 + dB**2 + 1e-6) * 255) with
+// d = |cv2.pointPolygonTest(2-point contour, (x, y), True)| = distance to the seam segment.
+struct Seam { int p[4]; };
+
+__device__ inline double segment_distance(const Seam &s, double px, double py)
+{
+    double min_num = 3.402823466e+38, min_den = 1;
+    float vx = (float)s.p[2], vy = (float)s.p[3];
+    const float ptx = (float)px, pty = (float)py;
+    for (int i = 0; i < 2; ++i) {
+        const float v0x = vx, v0y = vy;
+        vx = (float)s.p[i * 2]; vy = (float)s.p[i * 2 + 1];
+        const double dx = vx - v0x, dy = vy - v0y;
+        const double dx1 = ptx - v0x, dy1 = pty - v0y;
+        const double dx2 = ptx - vx, dy2 = pty - vy;
+        double num, den = 1;
+        if (dx1 * dx + dy1 * dy <= 0) num = dx1 * dx1 + dy1 * dy1;
+        else if (dx2 * dx + dy2 * dy >= 0) num = dx2 * dx2 + dy2 * dy2;
+        else { num = dy1 * dx - dx1 * dy; num *= num; den = dx * dx + dy * dy; }
+        if (num * min_den < min_num * den) {
+            min_num = num; min_den = den;
+            if (min_num == 0) break;
+        }
+    }
+    return sqrt(min_num / min_den);
+}
+
+__global__ void k_blend_weights(uint8_t *__restrict__ maskA, const uint8_t *__restrict__ maskB, int w, int h, Seam lineA,
+                                Seam lineB)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const size_t o = (size_t)y * w + x;
+    if ((maskA[o] & maskB[o]) == 0) return;
+    const double dA = segment_distance(lineA, x, y), dB = segment_distance(lineB, x, y);
+    const double a2 = dA * dA, b2 = dB * dB;  // Python's d**2
+    const double v = a2 / (a2 + b2 + 1e-6) * 255;
+    maskA[o] = (uint8_t)v;  // float64 -> uint8 store: truncation
+}
+
+// =============================================================================================================
+// Per-frame kernels
+// =============================================================================================================
+
+// cv2.remap(src, map1, map2, INTER_LINEAR) for a batch: one thread per destination pixel.
+// grid = (ceil(dw / 256), dh, batch)
+__global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int sh, const int16_t *__restrict__ map1,
+                            const uint16_t *__restrict__ map2, int dw, int dh, uint8_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dw) return;
+    const size_t o = (size_t)y * dw + x;
+    const uint8_t *s = src + (size_t)blockIdx.z * sw * sh * 3;
+    uint8_t *d = dst + ((size_t)blockIdx.z * dw * dh + o) * 3;
+    const int sx = map1[o * 2], sy = map1[o * 2 + 1];
+    int out[3];
+    remap_u8c3_px<false>(s, sw, sh, sx, sy, map2[o] & (kQTab2 - 1), out, 0, nullptr, nullptr);
+    d[0] = (uint8_t)out[0]; d[1] = (uint8_t)out[1]; d[2] = (uint8_t)out[2];
+}
+
+// cv2.warpPerspective(src_8UC3, H, dsize): coordinates made on the fly (extrinsicCalib.py:166-169).
+__global__ void k_warp_perspective(const uint8_t *__restrict__ src, int sw, int sh, Mat3 Minv, int bw0, int dw, int dh,
+                                   uint8_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dw) return;
+    const size_t o = (size_t)y * dw + x;
+    const uint8_t *s = src + (size_t)blockIdx.z * sw * sh * 3;
+    uint8_t *d = dst + ((size_t)blockIdx.z * dw * dh + o) * 3;
+    int sx, sy, out[3];
+    unsigned code;
+    perspective_coord(Minv.m, x, y, bw0, sx, sy, code);
+    remap_u8c3_px<false>(s, sw, sh, sx, sy, code, out, 0, nullptr, nullptr);
+    d[0] = (uint8_t)out[0]; d[1] = (uint8_t)out[1]; d[2] = (uint8_t)out[2];
+}
+
+// sum of V = max(B,G,R) over one frame; np.mean(v) = sum / N exactly in fp64 (surroundBEV.py:64-67).
+// grid = (blocks_per_frame, n_frames); each lane eats 16-byte vectors (16 B = 5.33 texels, so work on 48-byte groups).
+__global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, int vec_ok,
+                       unsigned long long *__restrict__ sums)
+{
+    const uint8_t *f = frames + (size_t)blockIdx.y * frame_bytes;
+    const size_t ngroups = vec_ok ? frame_bytes / 48 : 0;  // 16 texels per 48-byte group (needs 16-byte aligned frames)
+    const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
+    unsigned acc = 0;
+    for (size_t gidx = tid; gidx < ngroups; gidx += nthreads) {
+        uint4 a = f4[gidx * 3], b = f4[gidx * 3 + 1], c = f4[gidx * 3 + 2];
+        const unsigned wds[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int b0 = t * 3;
+            unsigned v0 = (wds[b0 >> 2] >> ((b0 & 3) * 8)) & 255;
+            unsigned v1 = (wds[(b0 + 1) >> 2] >> (((b0 + 1) & 3) * 8)) & 255;
+            unsigned v2 = (wds[(b0 + 2) >> 2] >> (((b0 + 2) & 3) * 8)) & 255;
+            acc += max(v0, max(v1, v2));
+        }
+    }
+    // texels not covered by whole groups
+    for (size_t t = ngroups * 16 + tid; t * 3 + 2 < frame_bytes; t += nthreads)
+        acc += max((unsigned)f[t * 3], max((unsigned)f[t * 3 + 1], (unsigned)f[t * 3 + 2]));
+    __shared__ unsigned long long part[16];
+    unsigned long long s = wave_sum_u64(acc);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) part[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+        atomicAdd(&sums[blockIdx.y], t);
+    }
+}
+
+// luminance_balance scalars (surroundBEV.py:64-72): delta_c = cvRound(V_mean - V_c), V_mean = (Vf+Vb+Vl+Vr)/4.
+// one thread per 4-camera frame set.
+__global__ void k_lum_delta(const unsigned long long *__restrict__ vsums, double npx, int nsets, int *__restrict__ deltas)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nsets) return;
+    double m[4];
+    for (int c = 0; c < 4; ++c) m[c] = (double)vsums[b * 4 + c] / npx;
+    const double vmean = (m[0] + m[1] + m[2] + m[3]) / 4;
+    for (int c = 0; c < 4; ++c) deltas[b * 4 + c] = rne_d(vmean - m[c]);
+}
+
+// luminance_balance applied to whole frames (the exported helper; the stitch kernels apply it per fetched texel).
+// grid = (blocks, n_frames)
+__global__ void k_lum_shift(const uint8_t *__restrict__ frames, size_t frame_px, const int *__restrict__ deltas,
+                            const HsvTables *__restrict__ tab, uint8_t *__restrict__ out)
+{
+    __shared__ int sdiv[256], hdiv[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.y * frame_px * 3;
+    const int delta = deltas[blockIdx.y];
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < frame_px; p += (size_t)gridDim.x * blockDim.x) {
+        int b = frames[base + p * 3], g = frames[base + p * 3 + 1], r = frames[base + p * 3 + 2];
+        luminance_shift_px(b, g, r, delta, sdiv, hdiv);
+        out[base + p * 3] = (uint8_t)b; out[base + p * 3 + 1] = (uint8_t)g; out[base + p * 3 + 2] = (uint8_t)r;
+    }
+}
+
+// Static tables of one BevGenerator as the per-pixel schedule reads them.
+struct StitchTables {
+    const int16_t *lut1[4];
+    const uint16_t *lut2[4];
+    const uint8_t *mask[4];
+};
+
+// BevGenerator.__call__ (surroundBEV.py:312-325), schedule BEVW_SCHED_PER_PIXEL: one thread per BEV pixel loops the
+// four cameras: mask test -> LUT fetch -> fixed-point bilinear gather (with the luminance round trip on the fetched
+// texels when BAL) -> Mask select or BlendMask truncating multiply -> saturating sum.  Without balance the car
+// sprite is added here; with balance the pre-gain value is stored and per-frame channel sums are accumulated
+// (integer, so the result does not depend on the order of the atomics).
+// grid = (ceil(bw / 256), bh, batch)
+template <bool BLEND, bool BAL>
+__global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, int fh, StitchTables T, int bw, int bh,
+                            const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
+                            const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
+                            uint8_t *__restrict__ out)
+{
+    __shared__ int sdiv[256], hdiv[256];
+    __shared__ unsigned long long part[3][4];
+    if (BAL) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+        __syncthreads();
+    }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int b = blockIdx.z;
+    const size_t frame_bytes = (size_t)fw * fh * 3;
+    int acc[3] = {0, 0, 0};
+    if (x < bw) {
+        const size_t o = (size_t)y * bw + x;
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            const int m = T.mask[c][o];
+            if (m == 0) continue;
+            const uint8_t *src = frames + ((size_t)b * 4 + c) * frame_bytes;
+            const int sx = T.lut1[c][o * 2], sy = T.lut1[c][o * 2 + 1];
+            int v[3];
+            remap_u8c3_px<BAL>(src, fw, fh, sx, sy, T.lut2[c][o] & (kQTab2 - 1), v, BAL ? deltas[b * 4 + c] : 0, sdiv, hdiv);
+            if (BLEND) {
+                const float wgt = blend_weight_f32(m);
+                v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
+            }
+            acc[0] = min(255, acc[0] + v[0]); acc[1] = min(255, acc[1] + v[1]); acc[2] = min(255, acc[2] + v[2]);
+        }
+        uint8_t *d = out + ((size_t)b * bw * bh + o) * 3;
+        if (!BAL && car != nullptr) {
+            acc[0] = min(255, acc[0] + car[o * 3]); acc[1] = min(255, acc[1] + car[o * 3 + 1]);
+            acc[2] = min(255, acc[2] + car[o * 3 + 2]);
+        }
+        d[0] = (uint8_t)acc[0]; d[1] = (uint8_t)acc[1]; d[2] = (uint8_t)acc[2];
+    }
+    if (BAL) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned s = wave_sum_u32((unsigned)acc[k]);
+            if (lane == 0) part[k][wv] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            unsigned long long t = 0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[threadIdx.x][i];
+            atomicAdd(&chsums[b * 3 + threadIdx.x], t);
+        }
+    }
+}
+
+// per-channel sums of a batch of images (color_balance as an exported helper). grid = (blocks, batch)
+__global__ void k_channel_sums(const uint8_t *__restrict__ img, size_t npx, unsigned long long *__restrict__ chsums)
+{
+    const uint8_t *p = img + (size_t)blockIdx.y * npx * 3;
+    unsigned acc[3] = {0, 0, 0};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        acc[0] += p[i * 3]; acc[1] += p[i * 3 + 1]; acc[2] += p[i * 3 + 2];
+    }
+    __shared__ unsigned long long part[3][16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        unsigned long long s = wave_sum_u64(acc[k]);
+        if (lane == 0) part[k][wv] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        unsigned long long t = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[threadIdx.x][i];
+        atomicAdd(&chsums[blockIdx.y * 3 + threadIdx.x], t);
+    }
+}
+
+// color_balance (surroundBEV.py:43-55) gain step + the trailing cv2.add(surround, car) (:323-324).
+// B,G,R means in fp64 from the integer sums; K = (R + G + B) / 3; gain_c = K / mean_c;
+// cv2.addWeighted(ch, gain, 0, 0, 0, ch) = sat_u8(cvRound(double(ch) * gain + 0*0 + 0)).
+// grid = (blocks, batch); in place when in == out.
+__global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
+                       const uint8_t *__restrict__ car, uint8_t *out)
+{
+    const double n = (double)npx;
+    const double B = (double)chsums[blockIdx.y * 3 + 0] / n, G = (double)chsums[blockIdx.y * 3 + 1] / n,
+                 R = (double)chsums[blockIdx.y * 3 + 2] / n;
+    const double K = (R + G + B) / 3;
+    const double gain[3] = {K / B, K / G, K / R};
+    const size_t base = (size_t)blockIdx.y * npx * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx * 3; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        int v = sat_u8(rne_d((double)in[base + i] * gain[c] + 0.0 * 0.0 + 0.0));
+        if (car != nullptr) v = min(255, v + car[i]);
+        out[base + i] = (uint8_t)v;
+    }
+}
+
+}  // namespace bevw

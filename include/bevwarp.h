@@ -1,0 +1,147 @@
+/*
+ * bevwarp.h -- C-ABI of libbevwarp.so, the MI355X (gfx950) surround-BEV warping engine.
+ *
+ * The reference (dyfcalid/CameraCalibration) is pure Python on top of cv2; it has no FFI of its own, so this header
+ * DEFINES the boundary a maintainer binds with ctypes (INTEGRATION.md shows the stub).  Every entry point names
+ * the reference call it replaces (file:line under the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only; no exceptions cross the boundary.
+ *   - every function returns 0 on success or a negative bevw_status; bevw_last_error() returns a thread-local text.
+ *   - images are uint8, HWC interleaved BGR, C-contiguous (what cv2.imread hands the reference).
+ *   - camera order is front, back, left, right (surroundBEV.py:285-286).
+ *   - an opaque handle owns one HIP stream and all device tables; calls on one handle are serialised, distinct
+ *     handles may be used from distinct threads.
+ *   - "_device" variants take device pointers (frames already resident in HBM); the others copy host buffers.
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails with BEVW_E_NO_DEVICE.
+ */
+#ifndef BEVWARP_H
+#define BEVWARP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BEVW_ABI_VERSION 1
+
+typedef enum bevw_status {
+    BEVW_OK = 0,
+    BEVW_E_INVALID = -1,    /* bad argument / bad state (e.g. run before build) */
+    BEVW_E_NO_DEVICE = -2,  /* no HIP device, or the requested ordinal does not exist */
+    BEVW_E_HIP = -3,        /* a HIP runtime call failed; text in bevw_last_error() */
+    BEVW_E_NOMEM = -4
+} bevw_status;
+
+typedef enum bevw_camera_id { BEVW_FRONT = 0, BEVW_BACK = 1, BEVW_LEFT = 2, BEVW_RIGHT = 3 } bevw_camera_id;
+
+/* Which device schedule bevw_run* uses.  All schedules produce identical bytes. */
+typedef enum bevw_schedule {
+    BEVW_SCHED_AUTO = 0,     /* tile-plan kernel when the plan fits (<= 2 contributing cameras per BEV pixel) */
+    BEVW_SCHED_PER_PIXEL = 1,/* one thread per BEV pixel, loops the 4 cameras through LUT + mask (always valid) */
+    BEVW_SCHED_TILE_PLAN = 2 /* register-resident contributor plan, batch loop inside the block */
+} bevw_schedule;
+
+/* The ten fields of the reference's argparse Namespace (surroundBEV.py:6-17) that shape the tables, plus placement. */
+typedef struct bevw_config {
+    int32_t frame_width;   /* FRAME_WIDTH  */
+    int32_t frame_height;  /* FRAME_HEIGHT */
+    int32_t bev_width;     /* BEV_WIDTH    */
+    int32_t bev_height;    /* BEV_HEIGHT   */
+    int32_t car_width;     /* CAR_WIDTH    */
+    int32_t car_height;    /* CAR_HEIGHT   */
+    double focal_scale;    /* FOCAL_SCALE  */
+    double size_scale;     /* SIZE_SCALE   */
+    int32_t blend;         /* BevGenerator(blend=...)   surroundBEV.py:283 */
+    int32_t balance;       /* BevGenerator(balance=...) surroundBEV.py:283 */
+    int32_t device;        /* HIP device ordinal */
+    int32_t schedule;      /* bevw_schedule */
+} bevw_config;
+
+typedef struct bevw_handle bevw_handle;   /* a BevGenerator: 4 cameras + masks        (surroundBEV.py:282-325) */
+typedef struct bevw_remapper bevw_remapper; /* one fixed-point remap table on the device (cv2.remap call sites)   */
+
+/* ---- library / device ------------------------------------------------------------------------------------ */
+int bevw_abi_version(void);
+int bevw_device_count(void);               /* 0 when no GPU is visible (never negative) */
+const char *bevw_last_error(void);
+int bevw_device_name(int device, char *buf, size_t buflen);
+
+/* Raw device memory for callers that keep batches resident in HBM without any GPU framework (bench.py, tests). */
+int bevw_malloc(int device, size_t nbytes, void **dptr);
+int bevw_free(int device, void *dptr);
+int bevw_memcpy_h2d(int device, void *dst, const void *src, size_t nbytes);
+int bevw_memcpy_d2h(int device, void *dst, const void *src, size_t nbytes);
+int bevw_memset(int device, void *dst, int value, size_t nbytes);
+
+/* ---- BevGenerator: construction = table build (surroundBEV.py:283-294) ----------------------------------- */
+int bevw_create(const bevw_config *cfg, bevw_handle **out);
+/* Camera.__init__ loads K (3x3), D (4), H (3x3) float64 (surroundBEV.py:83-85). */
+int bevw_set_camera(bevw_handle *h, int cam, const double K[9], const double D[4], const double H[9]);
+/* Camera.get_undistort_maps + get_bev_maps (surroundBEV.py:98-108), Mask.get_mask (:156-159) or
+ * BlendMask.__init__ (:165-188): every table is built by HIP kernels and stays on the device. */
+int bevw_build(bevw_handle *h);
+void bevw_destroy(bevw_handle *h);
+
+/* Table read-back (tests, inspection).  Shapes: undistort maps [int(FH*SS)][int(FW*SS)], BEV tables [BH][BW]. */
+int bevw_get_undistort_map(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2); /* Camera.undistort_maps */
+int bevw_get_lut(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2);           /* Camera.bev_maps       */
+int bevw_get_mask(bevw_handle *h, int cam, uint8_t *mask);  /* Mask.mask / BlendMask.mask (u8, before /255.0)   */
+int bevw_plan_info(bevw_handle *h, int32_t info[8]);        /* [0] max contributors/pixel, [1] plan usable, [2] schedule in use */
+
+/* ---- BevGenerator.__call__ (surroundBEV.py:312-325) ------------------------------------------------------ */
+/* frames: [batch][4][FH][FW][3]; car: [BH][BW][3] or NULL (already padded, surroundBEV.py:28-41); out: [batch][BH][BW][3] */
+int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *car, uint8_t *out);
+int bevw_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_car, void *d_out);
+
+/* Camera.undistort / Camera.warp_homography / Camera.raw2bev (surroundBEV.py:110-117) on host images.
+ * undistort: src [batch][FH][FW][3] -> dst [batch][int(FH*SS)][int(FW*SS)][3]
+ * warp_homography: src [batch][src_h][src_w][3] -> dst [batch][BH][BW][3]
+ * raw2bev: src [batch][FH][FW][3] -> dst [batch][BH][BW][3] */
+int bevw_camera_undistort(bevw_handle *h, int cam, const uint8_t *src, int batch, uint8_t *dst);
+int bevw_camera_warp_homography(bevw_handle *h, int cam, const uint8_t *src, int src_w, int src_h, int batch,
+                                uint8_t *dst);
+int bevw_camera_raw2bev(bevw_handle *h, int cam, const uint8_t *src, int batch, uint8_t *dst);
+
+/* Module-level helpers of surroundBEV.py, exposed because the reference exports them:
+ * luminance_balance(images) (:57-79): frames [batch][4][H][W][3] -> same shape;
+ * color_balance(image) (:43-55): image [batch][H][W][3] -> same shape. */
+int bevw_luminance_balance(int device, const uint8_t *frames, int batch, int width, int height, uint8_t *out);
+int bevw_color_balance(int device, const uint8_t *images, int batch, int width, int height, uint8_t *out);
+
+/* Stream timing for bench.py: HIP events recorded on the handle's own stream. */
+int bevw_sync(bevw_handle *h);
+int bevw_timer_start(bevw_handle *h);
+int bevw_timer_stop(bevw_handle *h, float *elapsed_ms); /* records + synchronises the stop event */
+
+/* ---- cv2.remap with fixed-point maps: InCalibrator.undistort (intrinsicCalib.py:193-195), ----------------- */
+/* ---- Tools/undistort.py:50-52,66, Camera.undistort (surroundBEV.py:110-111) ------------------------------- */
+/* Builds cv2.fisheye.initUndistortRectifyMap(K, D, I, K', (int(fw*size_scale), int(fh*size_scale)), CV_16SC2) with
+ * K' = K, f *= focal_scale, c = (fw/2*size_scale + offset_h, fh/2*size_scale + offset_v)
+ * (intrinsicCalib.py:90-103; offsets: Tools/undistort.py:45-46). */
+int bevw_fisheye_remapper_create(int device, int frame_width, int frame_height, const double K[9], const double D[4],
+                                 double focal_scale, double size_scale, double offset_h, double offset_v,
+                                 bevw_remapper **out);
+/* Wraps caller-made maps (map1 CV_16SC2 [dh][dw][2], map2 CV_16UC1 [dh][dw]) for sources of size src_w x src_h. */
+int bevw_remapper_from_maps(int device, int src_w, int src_h, const int16_t *map1, const uint16_t *map2, int dst_w,
+                            int dst_h, bevw_remapper **out);
+int bevw_remapper_dims(bevw_remapper *r, int32_t dims[4]); /* src_w, src_h, dst_w, dst_h */
+int bevw_remapper_get_maps(bevw_remapper *r, int16_t *map1, uint16_t *map2);
+/* src [batch][src_h][src_w][3] -> dst [batch][dst_h][dst_w][3]; INTER_LINEAR, BORDER_CONSTANT 0 */
+int bevw_remap(bevw_remapper *r, const uint8_t *src, int batch, uint8_t *dst);
+int bevw_remap_device(bevw_remapper *r, const void *d_src, int batch, void *d_dst);
+int bevw_remapper_sync(bevw_remapper *r);
+int bevw_remapper_timer_start(bevw_remapper *r);
+int bevw_remapper_timer_stop(bevw_remapper *r, float *elapsed_ms);
+void bevw_remapper_destroy(bevw_remapper *r);
+
+/* ---- cv2.warpPerspective(src_8UC3, H, (dst_w, dst_h)): ExCalibrator.warp (extrinsicCalib.py:166-169) ------ */
+int bevw_warp_perspective_u8c3(int device, const uint8_t *src, int src_w, int src_h, const double H[9], int dst_w,
+                               int dst_h, int batch, uint8_t *dst);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BEVWARP_H */

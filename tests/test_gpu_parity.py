@@ -1,0 +1,313 @@
+"""GPU parity: the HIP engine (through the C-ABI / the reference-API mirror) against the CPU oracle on the same seeded
+inputs.  Integer / byte / index work -> the bar is BIT-EXACT (tolerance 0), which is inside BASELINE.json's
+"+-1 LSB per channel" for the images.  Run with `-m gpu` on an MI355X.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from cameracalibration_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+CAMS = W.CAMERA_NAMES
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from cameracalibration_amd import _ffi
+
+    _ffi.require_device()
+    return _ffi
+
+
+@pytest.fixture(scope="module")
+def SB():
+    from cameracalibration_amd.SurroundBirdEyeView import surroundBEV
+
+    return surroundBEV
+
+
+def set_args(SB, cfg):
+    ns = SB.BevGenerator.get_args()
+    for k, v in cfg.items():
+        setattr(ns, k, v)
+
+
+def make_pair(SB, oracle, rig, cfg, blend, balance, schedule=0):
+    set_args(SB, cfg)
+    bev = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=schedule)
+    ref = oracle.RefBevGenerator(rig, cfg, blend=blend, balance=balance)
+    return bev, ref
+
+
+def maxdiff(a, b):
+    return int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max())
+
+
+# A small rig whose geometry exercises every path quickly: the repo rig scaled to 320x256 frames -> 250x250 BEV.
+SMALL_CFG = dict(FRAME_WIDTH=320, FRAME_HEIGHT=256, BEV_WIDTH=248, BEV_HEIGHT=250, CAR_WIDTH=62, CAR_HEIGHT=100,
+                 FOCAL_SCALE=1.0, SIZE_SCALE=2.0)
+
+
+def small_rig():
+    out = {}
+    A = np.diag([0.25, 0.25, 1.0])  # raw frame scaled by 1/4
+    for n, (K, D, H) in W.repo_rig().items():
+        Ks = A @ K
+        # undistorted grid also scales by 1/4; BEV by 1/4: H_s = A . H . A^-1
+        out[n] = (Ks, D.copy(), A @ H @ np.linalg.inv(A))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# tables
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["R", "S"])
+def test_tables_bit_exact(ffi, SB, oracle, which):
+    cfg, rig = (W.CONFIG_R, W.repo_rig()) if which == "R" else (W.CONFIG_S, W.rig_s())
+    bev, ref = make_pair(SB, oracle, rig, cfg, blend=False, balance=False)
+    for i, n in enumerate(CAMS):
+        u1, u2 = bev.cameras[i].undistort_maps
+        assert np.array_equal(u1, ref.cameras[i].undistort_maps[0]), f"{n} undistort map1"
+        assert np.array_equal(u2, ref.cameras[i].undistort_maps[1]), f"{n} undistort map2"
+        b1, b2 = bev.cameras[i].bev_maps
+        assert np.array_equal(b1, ref.cameras[i].bev_maps[0]), f"{n} bev map1"
+        assert np.array_equal(b2, ref.cameras[i].bev_maps[1]), f"{n} bev map2"
+        assert np.array_equal(bev.masks[i].mask, ref.masks[i]), f"{n} direct mask"
+    info = bev.plan_info()
+    assert info["max_contributors"] <= 2 and info["plan_usable"]
+
+
+@pytest.mark.parametrize("cfg_name", ["R", "R_main", "S", "small"])
+def test_blend_masks_bit_exact(ffi, SB, oracle, cfg_name):
+    cfg = {"R": W.CONFIG_R, "R_main": dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350), "S": W.CONFIG_S,
+           "small": SMALL_CFG}[cfg_name]
+    set_args(SB, cfg)
+    ident = {n: (np.eye(3) * [100, 100, 1], np.zeros(4), np.eye(3)) for n in CAMS}
+    bev = SB.BevGenerator(blend=True, balance=False, rig=ident)
+    geo = (cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"], cfg["CAR_WIDTH"], cfg["CAR_HEIGHT"])
+    for i, n in enumerate(CAMS):
+        want = oracle.blend_mask_for(n, *geo)
+        got = bev.masks[i].mask
+        assert np.array_equal(got, want), f"{n}: {np.count_nonzero(got != want)} px differ"
+        assert np.array_equal(bev.masks[i].weight, oracle.blend_weight(want))
+
+
+@pytest.mark.parametrize("geo", [(250, 251, 60, 100), (97, 64, 20, 30), (1000, 1000, 250, 400), (40, 40, 0, 0)])
+def test_direct_masks_odd_sizes(ffi, SB, oracle, geo):
+    cfg = dict(SMALL_CFG, BEV_WIDTH=geo[0], BEV_HEIGHT=geo[1], CAR_WIDTH=geo[2], CAR_HEIGHT=geo[3])
+    set_args(SB, cfg)
+    ident = {n: (np.eye(3) * [100, 100, 1], np.zeros(4), np.eye(3)) for n in CAMS}
+    bev = SB.BevGenerator(blend=False, balance=False, rig=ident)
+    for i, n in enumerate(CAMS):
+        assert np.array_equal(bev.masks[i].mask, oracle.direct_mask(n, *geo)), n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BevGenerator.__call__ on the reference's own sample data (config 1)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("blend,balance", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("schedule", [1, 2])
+def test_repo_data_bit_exact(ffi, SB, oracle, repo_rig, blend, balance, schedule):
+    cfg = dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350) if blend else W.CONFIG_R  # main.py:80-81 for the blend demo
+    bev, ref = make_pair(SB, oracle, repo_rig.rig, cfg, blend, balance, schedule)
+    frames = repo_rig.frames()
+    car = SB.padding(repo_rig.image("car"), cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"])
+    assert bev.plan_info()["schedule"] == schedule
+    for c in (None, car):
+        got, want = bev(*frames, c), ref(*frames, c)
+        assert got.dtype == np.uint8 and got.shape == want.shape
+        assert maxdiff(got, want) == 0, f"{np.count_nonzero(got != want)} bytes differ"
+
+
+def test_camera_methods_bit_exact(ffi, SB, oracle, repo_rig):
+    bev, ref = make_pair(SB, oracle, repo_rig.rig, W.CONFIG_R, False, False)
+    frames = repo_rig.frames()
+    for i in range(4):
+        assert np.array_equal(bev.cameras[i].raw2bev(frames[i]), ref.cameras[i].raw2bev(frames[i]))
+    und = bev.cameras[0].undistort(frames[0])
+    want = ref.cameras[0].undistort(frames[0])
+    assert np.array_equal(und, want)
+    assert np.array_equal(bev.cameras[0].warp_homography(und), ref.cameras[0].warp_homography(want))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# seeded synthetic batches, both schedules, all modes (small rig -> seconds on the oracle)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("blend,balance", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("kind", ["random", "smooth"])
+def test_small_rig_batches(ffi, SB, oracle, blend, balance, kind):
+    rig = small_rig()
+    frames = W.synthetic_frames(5, SMALL_CFG["FRAME_WIDTH"], SMALL_CFG["FRAME_HEIGHT"], seed=7, kind=kind)
+    rng = np.random.default_rng(3)
+    car = np.zeros((SMALL_CFG["BEV_HEIGHT"], SMALL_CFG["BEV_WIDTH"], 3), np.uint8)
+    car[60:190, 80:170] = rng.integers(0, 256, (130, 90, 3), dtype=np.uint8)
+    outs = {}
+    for schedule in (1, 2):
+        bev, ref = make_pair(SB, oracle, rig, SMALL_CFG, blend, balance, schedule)
+        assert bev.plan_info()["schedule"] == schedule
+        got = bev.batch(frames, car)
+        for b in range(frames.shape[0]):
+            want = ref(*frames[b], car)
+            assert maxdiff(got[b], want) == 0, (schedule, b, np.count_nonzero(got[b] != want))
+        outs[schedule] = got
+    assert np.array_equal(outs[1], outs[2])
+
+
+def test_odd_bev_width_falls_back_to_per_pixel(ffi, SB, oracle):
+    cfg = dict(SMALL_CFG, BEV_WIDTH=250, BEV_HEIGHT=251)
+    rig = small_rig()
+    bev, ref = make_pair(SB, oracle, rig, cfg, True, False, 0)
+    assert bev.plan_info()["schedule"] == 1 and not bev.plan_info()["plan_usable"]
+    frames = W.synthetic_frames(2, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=11, kind="random")
+    got = bev.batch(frames)
+    for b in range(2):
+        assert maxdiff(got[b], ref(*frames[b])) == 0
+    with pytest.raises(Exception, match="tile plan unusable"):
+        SB.BevGenerator(blend=True, rig=rig, schedule=2)
+
+
+def test_edge_cases(ffi, SB, oracle):
+    rig = small_rig()
+    bev, ref = make_pair(SB, oracle, rig, SMALL_CFG, False, False)
+    fh, fw = SMALL_CFG["FRAME_HEIGHT"], SMALL_CFG["FRAME_WIDTH"]
+    assert bev.batch(np.empty((0, 4, fh, fw, 3), np.uint8)).shape == (0, SMALL_CFG["BEV_HEIGHT"], SMALL_CFG["BEV_WIDTH"], 3)
+    with pytest.raises(Exception, match="frames must be uint8"):
+        bev.batch(np.zeros((1, 4, fh, fw + 1, 3), np.uint8))
+    with pytest.raises(Exception, match="car must be padded"):
+        bev.batch(np.zeros((1, 4, fh, fw, 3), np.uint8), np.zeros((3, 3, 3), np.uint8))
+    # constant frames: every interior BEV pixel of a single-camera region reproduces the colour exactly
+    frames = W.synthetic_frames(1, fw, fh, seed=5, kind="constant")
+    got = bev.batch(frames)[0]
+    assert maxdiff(got, ref(*frames[0])) == 0
+    # maximum values saturate identically
+    full = np.full((1, 4, fh, fw, 3), 255, np.uint8)
+    for blend, balance in [(True, True), (False, False)]:
+        b2, r2 = make_pair(SB, oracle, rig, SMALL_CFG, blend, balance)
+        assert maxdiff(b2.batch(full)[0], r2(*full[0])) == 0
+        zero = np.zeros_like(full)
+        assert maxdiff(b2.batch(zero)[0], r2(*zero[0])) == 0  # balance with 0/0 gains
+
+
+def test_lut_border_entries_are_exercised(ffi, SB, oracle):
+    """A homography that pushes part of the BEV outside the undistort grid and the raw frame: partial footprints,
+    whole-footprint misses and the (0,0)+code 0 'quirk' entries all appear, on both schedules."""
+    rig = small_rig()
+    shift = np.array([[1.0, 0, -90.0], [0, 1.0, 60.0], [0, 0, 1.0]])
+    rig2 = {n: (K * [[1.0, 1, 0.55], [1, 1.0, 0.55], [1, 1, 1]], D, shift @ H) for n, (K, D, H) in rig.items()}
+    frames = W.synthetic_frames(2, SMALL_CFG["FRAME_WIDTH"], SMALL_CFG["FRAME_HEIGHT"], seed=13, kind="random")
+    for schedule in (1, 2):
+        bev, ref = make_pair(SB, oracle, rig2, SMALL_CFG, True, True, schedule)
+        lut1 = ref.cameras[0].bev_maps[0]
+        assert (lut1[..., 0] < 0).any() or (lut1[..., 0] >= SMALL_CFG["FRAME_WIDTH"] - 1).any()
+        got = bev.batch(frames)
+        for b in range(2):
+            assert maxdiff(got[b], ref(*frames[b])) == 0, schedule
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# exported helpers, InCalibrator.undistort (config 2), ExCalibrator.warp
+# ---------------------------------------------------------------------------------------------------------------
+def test_balance_helpers(ffi, SB, oracle, repo_rig):
+    frames = repo_rig.frames()
+    got = SB.luminance_balance(frames)
+    want = oracle.luminance_balance(frames)
+    for g, w_ in zip(got, want):
+        assert np.array_equal(g, w_)
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 200, (123, 77, 3), dtype=np.uint8)
+    assert np.array_equal(SB.color_balance(img), oracle.color_balance(img))
+    odd = [rng.integers(0, 256, (37, 53, 3), dtype=np.uint8) for _ in range(4)]  # frame bytes not a multiple of 16/48
+    for g, w_ in zip(SB.luminance_balance(odd), oracle.luminance_balance(odd)):
+        assert np.array_equal(g, w_)
+
+
+def test_incalibrator_undistort_config2(ffi, oracle):
+    from cameracalibration_amd.IntrinsicCalibration import InCalibrator
+
+    ucfg = W.CONFIG_UNDISTORT
+    a = InCalibrator.get_args()
+    a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE = (ucfg["FRAME_WIDTH"], ucfg["FRAME_HEIGHT"],
+                                                                  ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"])
+    K, D = W.undistort_calibration()
+    cal = InCalibrator("fisheye")
+    data = cal.set_calibration(K, D)
+    Kd = oracle.camera_mat_dst(K, a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE)
+    m1, m2 = oracle.fisheye_init_undistort_rectify_map(K, D, Kd, (a.FRAME_WIDTH, a.FRAME_HEIGHT))
+    assert np.array_equal(data.map1, m1) and np.array_equal(data.map2, m2)
+    imgs = W.synthetic_frames(1, a.FRAME_WIDTH, a.FRAME_HEIGHT, seed=21, kind="random").reshape(4, a.FRAME_HEIGHT, a.FRAME_WIDTH, 3)
+    got = cal.undistort_batch(imgs)
+    for i in range(4):
+        assert np.array_equal(got[i], oracle.remap(imgs[i], m1, m2))
+    assert np.array_equal(cal.undistort(imgs[0]), got[0])
+    a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE = 1280, 1024, 0.5, 1
+
+
+def test_incalibrator_on_reference_image(ffi, oracle, repo_rig):
+    from cameracalibration_amd.IntrinsicCalibration import InCalibrator
+
+    img = repo_rig.image("incalib")
+    K, D, _ = repo_rig.rig["front"]
+    cal = InCalibrator("fisheye")
+    cal.set_calibration(K, D)
+    Kd = oracle.camera_mat_dst(K, 1280, 1024, 0.5, 1)
+    m1, m2 = oracle.fisheye_init_undistort_rectify_map(K, D, Kd, (1280, 1024))
+    assert np.array_equal(cal.undistort(img), oracle.remap(img, m1, m2))
+
+
+def test_excalibrator_warp(ffi, oracle, repo_rig):
+    from cameracalibration_amd.ExtrinsicCalibration import ExCalibrator
+
+    src = repo_rig.image("excalib_src")  # 2560x2048
+    H = repo_rig.rig["back"][2]
+    ex = ExCalibrator()
+    ex.set_homography(H, src, (1000, 1000))
+    assert np.array_equal(ex.warp(), oracle.warp_perspective(src, H, (1000, 1000)))
+    rng = np.random.default_rng(4)
+    small = rng.integers(0, 256, (40, 90, 3), dtype=np.uint8)
+    for Hm, size in [(np.eye(3), (90, 40)), (np.array([[1, 0, 5.0], [0, 1, 3.0], [0, 0, 1]]), (90, 40)),
+                     (np.array([[0.9, 0.2, -3.0], [-0.1, 1.1, 2.0], [1e-3, -2e-3, 1.0]]), (131, 67)),
+                     (np.array([[1, 2, 3.0], [2, 4, 6.0], [1, 1, 1.0]]), (20, 10))]:  # last one is singular
+        ex.set_homography(Hm, small, (size[1], size[0]))
+        assert np.array_equal(ex.warp(), oracle.warp_perspective(small, Hm, size))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties + spot parity
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("blend,balance", [(False, False), (True, True)])
+def test_full_size_batch_properties(ffi, SB, oracle, blend, balance):
+    cfg, rig = W.CONFIG_S, W.rig_s()
+    batch, uniq = 64, 2
+    frames = W.synthetic_frames(uniq, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=W.SEED)
+    bev, ref = make_pair(SB, oracle, rig, cfg, blend, balance)
+    assert bev.plan_info()["schedule"] == 2
+    d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
+    d_out = ffi.DeviceBuffer(batch * 1080 * 1080 * 3)
+    d_out.fill(0xA5)
+    for b in range(batch):
+        d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
+    bev.run_device(d_in.ptr, batch, None, d_out.ptr)
+    bev.sync()
+    out = d_out.download((batch, 1080, 1080, 3))
+    # a frame's BEV does not depend on its position in the batch (XCD / chunk mapping, batch loop)
+    for b in range(uniq, batch):
+        assert np.array_equal(out[b], out[b % uniq]), b
+    # and equals the oracle
+    for b in range(uniq):
+        assert maxdiff(out[b], ref(*frames[b])) == 0
+    # the per-pixel schedule gives the same bytes
+    bev1 = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=1)
+    assert np.array_equal(bev1.batch(frames), out[:uniq])
+    # ragged batch sizes through the host-buffer entry point
+    rag = bev.batch(np.concatenate([frames, frames, frames[:1]]))
+    assert np.array_equal(rag[:2], out[:2]) and np.array_equal(rag[4], out[0])
+
+
+def test_4k_rig_spot(ffi, SB, oracle):
+    cfg, rig = W.CONFIG_4K, W.rig_4k()
+    frames = W.synthetic_frames(1, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=9, kind="random")
+    bev, ref = make_pair(SB, oracle, rig, cfg, True, False)
+    assert maxdiff(bev.batch(frames)[0], ref(*frames[0])) == 0
