@@ -17,6 +17,8 @@
 // index is mapped so that all tiles of one batch chunk run on the same XCD (block id % 8), which keeps a frame's
 // source rows in one L2 while neighbouring tiles consume them.
 #pragma once
+#include <vector>
+
 #include "bevw_kernels.h"
 
 namespace bevw {
@@ -26,7 +28,9 @@ constexpr uint32_t kMetaSlow = 1u << 21;   // footprint touches the frame border
 constexpr uint32_t kHdrSecond = 1u;        // some lane of the tile has a second contributor
 constexpr uint32_t kHdrSlow = 2u;          // some entry of the tile needs the per-tap border path
 constexpr uint32_t kHdrEmpty = 4u;         // no contributor at all (car rectangle): tile is zero + car
-constexpr int kPlanLX = 4;                 // lanes along x -> 16 x 16 pixel tiles
+constexpr uint32_t kHdrTransposed = 16u;   // lanes of a quad run along BEV y (see lane_xy)
+constexpr uint32_t kHdrInterleaved = 32u;  // x-major tile whose lanes COMPUTE interleaved pixels (see pixel ownership)
+constexpr int kPlanLXDefault = 4;          // lanes along x -> 16 x 16 pixel tiles
 
 struct Plan {
     void *entries = nullptr;     // uint2[ntiles][8][64]
@@ -36,8 +40,12 @@ struct Plan {
     int *d_max = nullptr;
     int fw = 0, fh = 0, bw = 0, bh = 0;
     int tiles_x = 0, tiles_y = 0, ntiles = 0;
+    int lx = kPlanLXDefault;     // lanes of a wave along x; tile = (4 * lx) x (64 / lx) pixels
     int max_contrib = 0;
     bool usable = false;
+    // tile classes (lists of tile indices, row-major order kept): each class has its own lean kernel
+    void *list_single = nullptr, *list_double = nullptr, *list_slow = nullptr, *list_empty = nullptr;
+    int n_single = 0, n_double = 0, n_slow = 0, n_empty = 0;
 };
 
 struct __attribute__((packed, aligned(1))) PackedU2 { uint32_t x, y; };
@@ -47,24 +55,134 @@ __device__ __forceinline__ uint2 load_u2_unaligned(const uint8_t *p)
     return make_uint2(v.x, v.y);
 }
 
+// 12 bytes from a 4-byte aligned address: one global_load_dwordx3.  On gfx950 a dword-aligned gather of up to 16 B per
+// lane costs ~14 clk per wave instruction in the texture addresser, a byte-misaligned dwordx2 twice that
+// (tools/microbench.hip), so footprints are fetched as the aligned 12-byte window around them and realigned with
+// v_alignbyte_b32.
+struct __attribute__((packed, aligned(4))) AlignedU3 { uint32_t x, y, z; };
+__device__ __forceinline__ uint2 load_footprint_row(const uint8_t *p_aligned, uint32_t mis)
+{
+    const AlignedU3 v = *reinterpret_cast<const AlignedU3 *>(p_aligned);
+    return make_uint2(__builtin_amdgcn_alignbyte(v.y, v.x, mis), __builtin_amdgcn_alignbyte(v.z, v.y, mis));
+}
+
+// Lane -> pixel-quad position inside a (4*LX) x LY tile.  The vector memory pipe works on quads of 4 consecutive lanes
+// and pays one cache access per distinct line a quad touches (measured: ~1.2 accesses/clk/CU, tools/microbench.hip and
+// TCP_TOTAL_CACHE_ACCESSES), so the 4 lanes of a quad should sample neighbouring texels of ONE source row.  Where the
+// BEV x axis runs along source rows (front/back cameras) that is the natural x-major order; where the BEV y axis does
+// (left/right cameras: the image is rotated by ~90 degrees) the lanes of a quad are stacked along y instead.  The
+// plan compiler picks per tile whichever order touches fewer lines.
+__device__ __forceinline__ void lane_xy(int lane, int LX, bool transposed, int &lx, int &ly)
+{
+    const int LY = 64 / LX;
+    if (transposed) { ly = lane % LY; lx = lane / LY; }
+    else { lx = lane % LX; ly = lane / LX; }
+}
+
+// Pixel ownership.  A lane STORES 4 horizontally adjacent pixels (one 12-byte piece of a BEV row).  In x-major tiles
+// it COMPUTES an interleaved set instead: lane l of a quad (a 16-pixel row segment) computes pixels {l, l+4, l+8, l+12},
+// so that load instruction j of the quad fetches the footprints of the ADJACENT pixels 4j..4j+3, which sit in one or
+// two 64-byte lines (a quad of non-interleaved lanes spreads over 16 pixels = ~50 source bytes and pays ~1.9 lines).
+// The 4x4 exchange back to store order goes through a wave-private 1 KB LDS patch (4 ds_write_b32 + 1 ds_read_b128;
+// the LDS pipe is otherwise idle in this kernel).  In y-major (transposed) tiles the quad's lanes are already adjacent
+// along the source row, so compute order == store order.
+__device__ __forceinline__ void quad_exchange(uint32_t P[4], uint32_t *xp_wave, int lane)
+{
+    const int base = (lane >> 2) * 16 + (lane & 3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xp_wave[base + 4 * j] = P[j];
+    __builtin_amdgcn_wave_barrier();
+    const uint4 v = *reinterpret_cast<const uint4 *>(xp_wave + lane * 4);
+    __builtin_amdgcn_wave_barrier();
+    P[0] = v.x; P[1] = v.y; P[2] = v.z; P[3] = v.w;
+}
+
+// 4 pixel dwords (B | G << 8 | R << 16) -> the 12 output bytes
+__device__ __forceinline__ void pack_pixels(const uint32_t P[4], uint32_t &d0, uint32_t &d1, uint32_t &d2)
+{
+    d0 = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
+    d1 = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
+    d2 = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
+}
+
+// saturating add of the car sprite (12 bytes c0 c1 c2 at the lane's store position) onto 4 pixel dwords
+__device__ __forceinline__ void add_car(uint32_t P[4], uint32_t c0, uint32_t c1, uint32_t c2)
+{
+    const uint32_t C[4] = {c0 & 0xffffffu, __builtin_amdgcn_alignbyte(c1, c0, 3) & 0xffffffu,
+                           __builtin_amdgcn_alignbyte(c2, c1, 2) & 0xffffffu, c2 >> 8};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t b = min(255u, (P[j] & 255u) + (C[j] & 255u));
+        const uint32_t g = min(255u, ((P[j] >> 8) & 255u) + ((C[j] >> 8) & 255u));
+        const uint32_t r = min(255u, ((P[j] >> 16) & 255u) + ((C[j] >> 16) & 255u));
+        P[j] = b | (g << 8) | (r << 16);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // plan compiler: one wave per tile
 // ---------------------------------------------------------------------------------------------------------------
-__global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int tiles_x, int ntiles,
-                             uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int *__restrict__ max_contrib)
+// 64-byte line id of the top footprint row of the first contributor of BEV pixel (x, y); ~0 when there is none
+__device__ inline uint32_t plan_line_id(const StitchTables &T, int fw, int fh, int bw, int bh, int x, int y)
 {
-    constexpr int LX = kPlanLX, LY = 64 / LX;
+    if (x >= bw || y >= bh) return 0xffffffffu;
+    const size_t o = (size_t)y * bw + x;
+    for (int c = 0; c < 4; ++c) {
+        if (T.mask[c][o] == 0) continue;
+        const int sx = T.lut1[c][o * 2], sy = T.lut1[c][o * 2 + 1];
+        if ((unsigned)sx >= (unsigned)fw || (unsigned)sy >= (unsigned)fh) continue;
+        return (((uint32_t)c * fh + sy) * fw + sx) * 3 >> 6;
+    }
+    return 0xffffffffu;
+}
+
+// number of distinct line ids over the 4 lanes of every quad, summed over the wave
+__device__ inline int quad_distinct_lines(uint32_t id, int lane)
+{
+    const int q0 = lane & ~3;
+    int first = 1;
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t other = __shfl(id, q0 + k, 64);
+        if (q0 + k < lane && other == id) first = 0;
+    }
+    int n = first;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    return n;
+}
+
+__global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int tiles_x, int ntiles, int LX, int orient,
+                             int interleave, uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int *__restrict__ max_contrib)
+{
+    const int LY = 64 / LX;
     const int tile = blockIdx.x, lane = threadIdx.x;
     if (tile >= ntiles) return;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
-    const int x0 = (tx * LX + lane % LX) * 4, y = ty * LY + lane / LX;
+    // choose the lane order that touches fewer 64-byte lines per quad (orient: 0 auto, 1 x-major, 2 y-major)
+    bool transposed = orient == 2;
+    if (orient == 0) {
+        int cost[2] = {0, 0};
+        for (int t = 0; t < 2; ++t) {
+            int lx, ly;
+            lane_xy(lane, LX, t != 0, lx, ly);
+            for (int j = 0; j < 4; ++j) {
+                const int xq = (t == 0 && interleave) ? (tx * LX + (lx & ~3)) * 4 + 4 * j + (lx & 3) : (tx * LX + lx) * 4 + j;
+                cost[t] += quad_distinct_lines(plan_line_id(T, fw, fh, bw, bh, xq, ty * LY + ly), lane);
+            }
+        }
+        transposed = cost[1] < cost[0];
+    }
+    int lx_, ly_;
+    lane_xy(lane, LX, transposed, lx_, ly_);
+    const bool inter = interleave && !transposed;
+    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const uint32_t frame_bytes = (uint32_t)fw * fh * 3;
     uint32_t flags = 0;
     int worst = 0;
     for (int j = 0; j < 4; ++j) {
         uint2 e[2] = {make_uint2(0, 0), make_uint2(0, 0)};
         int count = 0;
-        const int x = x0 + j;
+        // compute pixel of slot j: store order x0 + j, or the interleaved one inside the quad's 16-pixel segment
+        const int x = inter ? (tx * LX + (lx_ & ~3)) * 4 + 4 * j + (lx_ & 3) : x0 + j;
         if (x < bw && y < bh) {
             const size_t o = (size_t)y * bw + x;
             for (int c = 0; c < 4; ++c) {
@@ -76,7 +194,7 @@ __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int
                 uint32_t meta = code | (m << 10) | ((uint32_t)c << 18) | kMetaValid, off;
                 const bool interior = (unsigned)sx < (unsigned)(fw > 1 ? fw - 1 : 0) && (unsigned)sy < (unsigned)(fh > 1 ? fh - 1 : 0);
                 const uint32_t toff = ((uint32_t)sy * fw + sx) * 3;
-                if (interior && toff + (uint32_t)fw * 3 + 8 <= frame_bytes) {
+                if (interior && (toff & ~3u) + (uint32_t)fw * 3 + 12 <= frame_bytes) {  // aligned 12-byte row reads stay inside
                     off = (uint32_t)c * frame_bytes + toff;
                 } else {
                     meta |= kMetaSlow;
@@ -101,6 +219,8 @@ __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int
     if (lane == 0) {
         uint32_t hflags = flags & (kHdrSecond | kHdrSlow);
         if (!(flags & 8u)) hflags |= kHdrEmpty;
+        if (transposed) hflags |= kHdrTransposed;
+        if (inter) hflags |= kHdrInterleaved;
         hdr[tile] = hflags;
         atomicMax(max_contrib, worst);
     }
@@ -149,6 +269,24 @@ __device__ __forceinline__ void bilinear_rows(uint2 r0, uint2 r1, uint32_t wx, u
     v[2] = (int)(__builtin_amdgcn_udot2(pr.v, w.v, 512u, false) >> 10);
 }
 
+// Same arithmetic with the y weights pre-scaled by 64: (S * 64 + 512 * 64) >> 16 == (S + 512) >> 10, so the result
+// byte sits in bits 16..23 of each accumulator and the 12 output bytes of a lane are assembled with v_perm_b32
+// instead of 12 shifts.  wy64 = (32-fy)*64 | (fy*64) << 16 (<= 2048 each; H <= 8160, so the sum stays < 2^32).
+__device__ __forceinline__ void bilinear_rows_b2(uint2 r0, uint2 r1, uint32_t wx, uint32_t wy64, uint32_t acc[3])
+{
+    const uint32_t g0 = __builtin_amdgcn_alignbyte(r0.y, r0.x, 1), q0 = __builtin_amdgcn_alignbyte(r0.y, r0.x, 2);
+    const uint32_t g1 = __builtin_amdgcn_alignbyte(r1.y, r1.x, 1), q1 = __builtin_amdgcn_alignbyte(r1.y, r1.x, 2);
+    const uint32_t hb0 = __builtin_amdgcn_udot4(r0.x, wx, 0u, false), hb1 = __builtin_amdgcn_udot4(r1.x, wx, 0u, false);
+    const uint32_t hg0 = __builtin_amdgcn_udot4(g0, wx, 0u, false), hg1 = __builtin_amdgcn_udot4(g1, wx, 0u, false);
+    const uint32_t hr0 = __builtin_amdgcn_udot4(q0, wx, 0u, false), hr1 = __builtin_amdgcn_udot4(q1, wx, 0u, false);
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    union { uint32_t u; us2 v; } pb, pg, pr, w;
+    pb.u = hb0 | (hb1 << 16); pg.u = hg0 | (hg1 << 16); pr.u = hr0 | (hr1 << 16); w.u = wy64;
+    acc[0] = __builtin_amdgcn_udot2(pb.v, w.v, 32768u, false);
+    acc[1] = __builtin_amdgcn_udot2(pg.v, w.v, 32768u, false);
+    acc[2] = __builtin_amdgcn_udot2(pr.v, w.v, 32768u, false);
+}
+
 template <bool BLEND, bool BAL>
 __device__ __forceinline__ void eval_entry(const uint8_t *__restrict__ fb, const EntryRegs &e, uint32_t row_bytes, int fw,
                                            int fh, uint32_t frame_bytes, bool tile_slow, const int *__restrict__ fdeltas,
@@ -190,14 +328,17 @@ struct PlanArgs {
     int fw, fh, bw, bh;
     int tiles_x, ntiles, ngroups;
     int batch, nb, nchunks, xcd_affine;
+    const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
+    int nlist;
 };
 
 // grid = ngroups * (nchunks rounded up to a multiple of 8 when xcd_affine), block = 256 (4 tiles)
-template <bool BLEND, bool BAL>
+template <int LX, bool BLEND, bool BAL>
 __global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
 {
-    constexpr int LX = kPlanLX, LY = 64 / LX;
+    constexpr int LY = 64 / LX;
     __shared__ int sdiv[BAL ? 256 : 1], hdiv[BAL ? 256 : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
     if (BAL) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = a.tab->sdiv[i]; hdiv[i] = a.tab->hdiv[i]; }
         __syncthreads();
@@ -214,13 +355,16 @@ __global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
     }
     if ((int)chunk >= a.nchunks) return;
     const int lane = threadIdx.x & 63;
-    const int tile = (int)group * 4 + (threadIdx.x >> 6);
-    if (tile >= a.ntiles) return;
+    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    if (slot >= a.nlist) return;
+    const int tile = a.tile_list ? (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]) : slot;
 
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
     const bool second = hdr & kHdrSecond, tile_slow = hdr & kHdrSlow;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int x0 = (tx * LX + lane % LX) * 4, y = ty * LY + lane / LX;
+    int lx_, ly_;
+    lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
+    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const bool inimg = x0 < a.bw && y < a.bh;
     const uint32_t frame_bytes = (uint32_t)a.fw * a.fh * 3, row_bytes = (uint32_t)a.fw * 3;
     const size_t set_bytes = (size_t)frame_bytes * 4, img_bytes = (size_t)a.bw * a.bh * 3;
@@ -263,34 +407,185 @@ __global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
             }
         }
         if (BAL) {
-            // per-tile channel sums of the pre-gain BEV (color_balance means, surroundBEV.py:44-47)
+            // per-tile channel sums of the pre-gain BEV (color_balance means, surroundBEV.py:44-47); pixels outside
+            // the image have no plan entry and contribute 0
             unsigned s0 = 0, s1 = 0, s2 = 0;
-            if (inimg) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { s0 += px[j][0]; s1 += px[j][1]; s2 += px[j][2]; }
-            }
+            for (int j = 0; j < 4; ++j) { s0 += px[j][0]; s1 += px[j][1]; s2 += px[j][2]; }
             s0 = wave_sum_u32(s0); s1 = wave_sum_u32(s1); s2 = wave_sum_u32(s2);
             if (lane == 0) {
                 uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
                 ps[0] = s0; ps[1] = s1; ps[2] = s2;
             }
-        } else if (car_any) {
-            const uint32_t cw[3] = {car0, car1, car2};
+        }
+        uint32_t P[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
+        if (hdr & kHdrInterleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
+        if (!BAL && car_any) add_car(P, car0, car1, car2);
+        if (inimg) {
+            uint32_t d0, d1, d2;
+            pack_pixels(P, d0, d1, d2);
+            uint32_t *op = reinterpret_cast<uint32_t *>(a.out + (size_t)b * img_bytes + ooff);
+            op[0] = d0; op[1] = d1; op[2] = d2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// lean class kernels (no balance): every contributor of the tile is an interior footprint.
+//   NSLOT = 1: exactly <= 1 contributor per pixel (inside a trapezoid)        -> list_single
+//   NSLOT = 2: some pixel has two (direct-stitch seams, blend overlaps)       -> list_double
+// Register diet: per pixel and slot only {offset, wx, wy (, wf)} live across the batch loop, so 8 waves/SIMD fit and
+// the gathers of many tiles overlap.  Same block -> (chunk, tile) mapping as k_stitch_plan.
+// ---------------------------------------------------------------------------------------------------------------
+// ABL (experiments only, BEVW_ABL): 0 = product kernel, 1 = no stores, 2 = no loads (synthetic texels),
+// 3 = loads confined to a 4 KB window (all L1 hits), 4 = every frame of the batch reads frame set 0 (cache-resident
+// source with the real address pattern)
+template <int LX, int NSLOT, bool BLEND, int ABL = 0>
+__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
+{
+    constexpr int LY = 64 / LX;
+    const uint32_t id = blockIdx.x;
+    uint32_t chunk, group;
+    if (a.xcd_affine) {
+        const uint32_t xcd = id & 7u, k = id >> 3;
+        chunk = xcd + 8u * (k / (uint32_t)a.ngroups);
+        group = k % (uint32_t)a.ngroups;
+    } else {
+        chunk = id / (uint32_t)a.ngroups;
+        group = id % (uint32_t)a.ngroups;
+    }
+    if ((int)chunk >= a.nchunks) return;
+    const int lane = threadIdx.x & 63;
+    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    if (slot >= a.nlist) return;
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
+    const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
+    const bool interleaved = (hdr & kHdrInterleaved) != 0;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
+    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
+    const bool inimg = x0 < a.bw && y < a.bh;
+    const uint32_t row_bytes = (uint32_t)a.fw * 3;
+    const size_t set_bytes = (size_t)a.fw * a.fh * 12, img_bytes = (size_t)a.bw * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+
+    uint32_t off[NSLOT][4], mis[NSLOT][4], wx[NSLOT][4], wy[NSLOT][4];
+    float wf[NSLOT][4];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint2 e = a.plan[((size_t)tile * 8 + s * 4 + j) * 64 + lane];
+            const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
+            const bool valid = e.y & kMetaValid;
+            const uint32_t o = valid ? (ABL == 3 ? (e.x & 0xfffu) : e.x) : 0u;
+            off[s][j] = o & ~3u;   // frames are 4-byte aligned (checked by the host), so this is an aligned address
+            mis[s][j] = o & 3u;
+            wx[s][j] = valid ? ((32 - fx) | (fx << 24)) : 0u;  // zero x-weights: an absent entry contributes exactly 0
+            wy[s][j] = ((32 - fy) << 6) | (fy << 22);          // y weights x 64 (bilinear_rows_b2)
+            wf[s][j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
+        }
+    uint32_t car0 = 0, car1 = 0, car2 = 0;
+    if (a.car != nullptr && inimg) {
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
+        car0 = cp[0]; car1 = cp[1]; car2 = cp[2];
+    }
+    const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
+
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    const uint8_t *fb = a.frames + (ABL == 4 ? 0 : (size_t)b_begin * set_bytes);
+    uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
+#pragma unroll 1
+    for (int b = b_begin; b < b_end; ++b, fb += (ABL == 4 ? 0 : set_bytes), ob += img_bytes) {
+        const uint8_t *fb1 = fb + row_bytes;
+        uint32_t acc[4][3];
+        {
+            uint2 r0[4], r1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ABL == 2) { r0[j] = make_uint2(off[0][j] ^ (uint32_t)b, wx[0][j]); r1[j] = make_uint2(off[0][j] + (uint32_t)b, wy[0][j]); }
+                else { r0[j] = load_footprint_row(fb + off[0][j], mis[0][j]); r1[j] = load_footprint_row(fb1 + off[0][j], mis[0][j]); }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bilinear_rows_b2(r0[j], r1[j], wx[0][j], wy[0][j], acc[j]);
+        }
+        uint32_t P[4];
+        if (!BLEND && NSLOT == 1) {
+            // result bytes sit in bits 16..23 of the accumulators: gather them into pixel dwords B | G << 8 | R << 16
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                P[j] = __builtin_amdgcn_perm(acc[j][2], __builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x0c0c0602u), 0x0c060100u);
+        } else {
+            int px[4][3];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const int bi = j * 3 + k;
-                    px[j][k] = min(255, px[j][k] + (int)((cw[bi >> 2] >> ((bi & 3) * 8)) & 255));
+                    const uint32_t v = (acc[j][k] >> 16) & 255u;
+                    px[j][k] = BLEND ? (int)((float)v * wf[0][j]) : (int)v;
                 }
+            if (NSLOT == 2) {
+                uint2 r0[4], r1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r0[j] = load_footprint_row(fb + off[NSLOT - 1][j], mis[NSLOT - 1][j]);
+                    r1[j] = load_footprint_row(fb1 + off[NSLOT - 1][j], mis[NSLOT - 1][j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t w[3];
+                    bilinear_rows_b2(r0[j], r1[j], wx[NSLOT - 1][j], wy[NSLOT - 1][j], w);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const uint32_t v = (w[k] >> 16) & 255u;
+                        px[j][k] = min(255, px[j][k] + (BLEND ? (int)((float)v * wf[NSLOT - 1][j]) : (int)v));
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
         }
-        if (inimg) {
-            const uint32_t d0 = (uint32_t)px[0][0] | ((uint32_t)px[0][1] << 8) | ((uint32_t)px[0][2] << 16) | ((uint32_t)px[1][0] << 24);
-            const uint32_t d1 = (uint32_t)px[1][1] | ((uint32_t)px[1][2] << 8) | ((uint32_t)px[2][0] << 16) | ((uint32_t)px[2][1] << 24);
-            const uint32_t d2 = (uint32_t)px[2][2] | ((uint32_t)px[3][0] << 8) | ((uint32_t)px[3][1] << 16) | ((uint32_t)px[3][2] << 24);
-            uint32_t *op = reinterpret_cast<uint32_t *>(a.out + (size_t)b * img_bytes + ooff);
+        if (interleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
+        if (car_any) add_car(P, car0, car1, car2);
+        if (inimg && (ABL != 1 || (P[0] == 0xdeadbeefu && P[1] == 0x12345678u))) {
+            uint32_t d0, d1, d2;
+            pack_pixels(P, d0, d1, d2);
+            uint32_t *op = reinterpret_cast<uint32_t *>(ob);
             op[0] = d0; op[1] = d1; op[2] = d2;
         }
+    }
+}
+
+// tiles without any contributor (under the car): out = car (or 0) for every frame of the chunk
+template <int LX>
+__global__ void __launch_bounds__(256) k_plan_empty(PlanArgs a)
+{
+    constexpr int LY = 64 / LX;
+    const uint32_t chunk = blockIdx.x / (uint32_t)a.ngroups, group = blockIdx.x % (uint32_t)a.ngroups;
+    const int lane = threadIdx.x & 63;
+    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    if (slot >= a.nlist) return;
+    const int tile = (int)a.tile_list[slot];
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_xy(lane, LX, false, lx_, ly_);
+    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
+    if (!(x0 < a.bw && y < a.bh)) return;
+    const size_t img_bytes = (size_t)a.bw * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if (a.car != nullptr) {
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
+        c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+    }
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    for (int b = b_begin; b < b_end; ++b) {
+        uint32_t *op = reinterpret_cast<uint32_t *>(a.out + (size_t)b * img_bytes + ooff);
+        op[0] = c0; op[1] = c1; op[2] = c2;
     }
 }
 
@@ -320,39 +615,119 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    if (p.entries) (void)hipFree(p.entries);
-    if (p.hdr) (void)hipFree(p.hdr);
-    if (p.psums) (void)hipFree(p.psums);
-    if (p.d_max) (void)hipFree(p.d_max);
+    void *ptrs[] = {p.entries, p.hdr, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
     p = Plan();
 }
 
-// returns 0 or a hipError_t cast to a negative-free int; the caller turns it into a bevw_status
-static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh)
+static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void **dptr)
+{
+    *dptr = nullptr;
+    if (v.empty()) return hipSuccess;
+    hipError_t e = hipMalloc(dptr, v.size() * sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dptr, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+}
+
+static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
+                                         int orient = 0, int interleave = 1)
 {
     plan_release(p);
+    if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
+    p.lx = lx;
     p.fw = fw; p.fh = fh; p.bw = bw; p.bh = bh;
-    p.tiles_x = (bw + 4 * kPlanLX - 1) / (4 * kPlanLX);
-    p.tiles_y = (bh + (64 / kPlanLX) - 1) / (64 / kPlanLX);
+    p.tiles_x = (bw + 4 * lx - 1) / (4 * lx);
+    p.tiles_y = (bh + (64 / lx) - 1) / (64 / lx);
     p.ntiles = p.tiles_x * p.tiles_y;
     hipError_t e;
     if ((e = hipMalloc(&p.entries, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
     if ((e = hipMalloc(&p.hdr, (size_t)p.ntiles * sizeof(uint32_t))) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&p.d_max, sizeof(int))) != hipSuccess) return e;
     if ((e = hipMemsetAsync(p.d_max, 0, sizeof(int), st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_plan_build, dim3(p.ntiles), dim3(64), 0, st, T, fw, fh, bw, bh, p.tiles_x, p.ntiles,
+    hipLaunchKernelGGL(k_plan_build, dim3(p.ntiles), dim3(64), 0, st, T, fw, fh, bw, bh, p.tiles_x, p.ntiles, lx, orient, interleave,
                        static_cast<uint2 *>(p.entries), static_cast<uint32_t *>(p.hdr), p.d_max);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&p.max_contrib, p.d_max, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    std::vector<uint32_t> hdr((size_t)p.ntiles);
+    if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    // classify tiles (order kept): slow > empty > double > single
+    std::vector<uint32_t> ls, ld, lw, le;
+    for (int t = 0; t < p.ntiles; ++t) {
+        const uint32_t h = hdr[(size_t)t];
+        if (h & kHdrSlow) lw.push_back((uint32_t)t);
+        else if (h & kHdrEmpty) le.push_back((uint32_t)t);
+        else if (h & kHdrSecond) ld.push_back((uint32_t)t);
+        else ls.push_back((uint32_t)t);
+    }
+    p.n_single = (int)ls.size(); p.n_double = (int)ld.size(); p.n_slow = (int)lw.size(); p.n_empty = (int)le.size();
+    if ((e = plan_upload_list(ls, &p.list_single)) != hipSuccess) return e;
+    if ((e = plan_upload_list(ld, &p.list_double)) != hipSuccess) return e;
+    if ((e = plan_upload_list(lw, &p.list_slow)) != hipSuccess) return e;
+    if ((e = plan_upload_list(le, &p.list_empty)) != hipSuccess) return e;
     // 12-byte stores need 4-byte aligned pixel quads: bw % 4 == 0 makes every row and every image start aligned
-    p.usable = p.max_contrib <= 2 && (bw % 4 == 0);
+    // and the aligned 12-byte footprint reads need every frame of a set to start on a 4-byte boundary
+    p.usable = p.max_contrib <= 2 && (bw % 4 == 0) && (((size_t)fw * fh * 3) % 4 == 0);
+    return hipSuccess;
+}
+
+struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; };
+
+template <int LX>
+static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0)
+{
+    hipError_t e;
+    const dim3 block(256);
+    const int chunks_padded = a.xcd_affine ? ((a.nchunks + 7) / 8) * 8 : a.nchunks;
+    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; };
+    if (balance || !lean) {
+        // generic kernel over every tile (luminance round trip per tap, per-tile channel sums)
+        set_list(nullptr, p.ntiles);
+        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        if (blend && balance) hipLaunchKernelGGL((k_stitch_plan<LX, true, true>), grid, block, 0, st, a);
+        else if (balance) hipLaunchKernelGGL((k_stitch_plan<LX, false, true>), grid, block, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
+        return hipGetLastError();
+    }
+    if (p.n_single) {
+        set_list(p.list_single, p.n_single);
+        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 1) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 1>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 2) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 2>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 3) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 3>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 4) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 4>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_plan_lean<LX, 1, false>), grid, block, 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (p.n_double) {
+        set_list(p.list_double, p.n_double);
+        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_plan_lean<LX, 2, false>), grid, block, 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (p.n_slow) {
+        set_list(p.list_slow, p.n_slow);
+        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (p.n_empty) {
+        set_list(p.list_empty, p.n_empty);
+        const dim3 grid((unsigned)(a.ngroups * a.nchunks));
+        hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     return hipSuccess;
 }
 
 static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
                                           const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car,
-                                          unsigned long long *d_chsums, uint8_t *d_out, int nb_override)
+                                          unsigned long long *d_chsums, uint8_t *d_out, const PlanTuning &tune)
 {
     hipError_t e;
     PlanArgs a;
@@ -360,14 +735,14 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.deltas = d_deltas; a.tab = d_tab; a.car = d_car; a.out = d_out;
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
+    a.tile_list = nullptr; a.nlist = p.ntiles;
     a.batch = batch;
     // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk
-    int nb = nb_override > 0 ? nb_override : 16;
+    int nb = tune.nb > 0 ? tune.nb : 8;
     if (batch < 8 * nb) nb = batch >= 8 ? batch / 8 : 1;
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
     a.xcd_affine = a.nchunks >= 8 ? 1 : 0;
-    const int chunks_padded = a.xcd_affine ? ((a.nchunks + 7) / 8) * 8 : a.nchunks;
     if (balance) {
         const size_t need = (size_t)batch * p.ntiles * 3 * sizeof(uint32_t);
         if (need > p.psums_cap) {
@@ -378,12 +753,12 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         }
     }
     a.psums = static_cast<uint32_t *>(p.psums);
-    const dim3 grid((unsigned)(a.ngroups * chunks_padded)), block(256);
-    if (blend && balance) hipLaunchKernelGGL((k_stitch_plan<true, true>), grid, block, 0, st, a);
-    else if (blend) hipLaunchKernelGGL((k_stitch_plan<true, false>), grid, block, 0, st, a);
-    else if (balance) hipLaunchKernelGGL((k_stitch_plan<false, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_stitch_plan<false, false>), grid, block, 0, st, a);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    switch (p.lx) {
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl); break;
+    }
+    if (e != hipSuccess) return e;
     if (balance) {
         hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, p.ntiles, d_chsums);
         if ((e = hipGetLastError()) != hipSuccess) return e;

@@ -63,7 +63,10 @@ static int use_device(int device)
 
 static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh)
 {
-    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh);
+    static const int lx_env = [] { const char *s = getenv("BEVW_PLAN_LX"); return s ? atoi(s) : 0; }();
+    static const int orient_env = [] { const char *s = getenv("BEVW_PLAN_ORIENT"); return s ? atoi(s) : 0; }();
+    static const int inter_env = [] { const char *s = getenv("BEVW_PLAN_INTERLEAVE"); return s ? atoi(s) : 1; }();
+    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -72,8 +75,15 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
                        const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car, unsigned long long *d_chsums,
                        uint8_t *d_out)
 {
-    static const int nb_env = [] { const char *s = getenv("BEVW_PLAN_NB"); return s ? atoi(s) : 0; }();
-    hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, nb_env);
+    // tuning knobs for experiments (defaults are the shipped configuration)
+    static const PlanTuning tune = [] {
+        PlanTuning t;
+        if (const char *s = getenv("BEVW_PLAN_NB")) t.nb = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_LEAN")) t.lean = atoi(s);
+        if (const char *s = getenv("BEVW_ABL")) t.abl = atoi(s);
+        return t;
+    }();
+    hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "tile-plan stitch launch failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -642,7 +652,7 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
                                  h->vsums.as<unsigned long long>(), h->deltas.as<int>()));
         HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
     }
-    const bool aligned4 = (((uintptr_t)d_out | (uintptr_t)d_car) & 3u) == 0;
+    const bool aligned4 = (((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) == 0;
     if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4) {
         BEVW_TRY(plan_stitch(h->plan, h->stream, d_frames, batch, c.blend != 0, c.balance != 0, h->deltas.as<int>(),
                              h->hsv.as<HsvTables>(), d_car, h->chsums.as<unsigned long long>(), d_out));
@@ -851,6 +861,9 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[2] = h->schedule_in_use;
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
+    info[5] = h->plan.n_single;
+    info[6] = h->plan.n_double;
+    info[7] = h->plan.n_slow;
     return BEVW_OK;
 }
 

@@ -124,6 +124,7 @@ ALGORITHMIC_BYTES = {
     "repo_direct": 4_949_148,          # config 1: touched 1,949,148 + out 3,000,000
     "undistort_b64": 5_421_912,        # config 2: touched 1,735,512 + out 3,686,400
     "direct_stitch_b256": 5_532_357,   # config 3: touched 2,033,157 + out 3,499,200
+    "blend_b256": 5_669_538,           # S blend only: touched 2,170,338 + out 3,499,200
     "blend_balance_b256": 22_585_476,  # config 4: V-mean pass 14,745,600 + 2 x touched 2,170,338 + out 3,499,200
     "blend_4k": 11_810_991,            # config 5 (blend only): touched 8,311,791 + out 3,499,200
 }

@@ -31,6 +31,28 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def usable_cores(cap: int = 64) -> int:
+    """Host cores this process may really use: affinity mask, clipped by the cgroup CPU quota and by `cap` (OpenMP over
+    every *visible* core of a quota-limited container thrashes)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
@@ -66,6 +88,7 @@ def lib() -> C.CDLL:
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
+        L.orc_set_threads(usable_cores(16))
         _lib = L
     return _lib
 
