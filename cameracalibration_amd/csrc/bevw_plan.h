@@ -17,6 +17,7 @@
 // index is mapped so that all tiles of one batch chunk run on the same XCD (block id % 8), which keeps a frame's
 // source rows in one L2 while neighbouring tiles consume them.
 #pragma once
+#include <algorithm>
 #include <vector>
 
 #include "bevw_kernels.h"
@@ -35,6 +36,7 @@ constexpr int kPlanLXDefault = 4;          // lanes along x -> 16 x 16 pixel til
 struct Plan {
     void *entries = nullptr;     // uint2[ntiles][8][64]
     void *hdr = nullptr;         // uint32[ntiles]
+    void *pf = nullptr;          // uint32[ntiles][2][64]: per-lane byte offsets of the tile's source sectors (prefetch)
     void *psums = nullptr;       // uint32[batch][ntiles][3]  (balance: per-tile channel sums)
     size_t psums_cap = 0;
     int *d_max = nullptr;
@@ -226,6 +228,46 @@ __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int
     }
 }
 
+// Prefetch list of a tile: the distinct 64-byte sectors its footprints touch, one (or two) per lane, as byte offsets
+// inside the 4-camera frame set.  The stitch kernels read one dword from each, one frame AHEAD of the gathers: the
+// ~25 sector misses a tile-frame needs are then started by a single wave instruction while the previous frame is
+// still being interpolated, instead of trickling out of the 8 gather instructions (whose every miss otherwise holds
+// an in-order vector-memory slot for a full HBM round trip).  Rows are tracked relative to the tile's first source
+// row; a tile spanning more than 64 source rows prefetches only the first 64.
+__global__ void k_plan_prefetch(const uint2 *__restrict__ plan, int ntiles, uint32_t row_bytes, uint32_t *__restrict__ pf)
+{
+    __shared__ uint32_t rmin[64], rmax[64];
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (tile >= ntiles) return;
+    rmin[lane] = 0xffffffffu; rmax[lane] = 0;
+    uint2 e[8];
+    uint32_t r0 = 0xffffffffu;
+    for (int k = 0; k < 8; ++k) {
+        e[k] = plan[((size_t)tile * 8 + k) * 64 + lane];
+        if ((e[k].y & kMetaValid) && !(e[k].y & kMetaSlow)) r0 = min(r0, e[k].x / row_bytes);
+    }
+    for (int off = 32; off > 0; off >>= 1) r0 = min(r0, (uint32_t)__shfl_xor((int)r0, off, 64));
+    __syncthreads();
+    if (r0 != 0xffffffffu) {
+        for (int k = 0; k < 8; ++k) {
+            if (!((e[k].y & kMetaValid) && !(e[k].y & kMetaSlow))) continue;
+            const uint32_t r = e[k].x / row_bytes - r0, x = (e[k].x % row_bytes) & ~3u;
+            for (uint32_t d = 0; d < 2; ++d)
+                if (r + d < 64) { atomicMin(&rmin[r + d], x); atomicMax(&rmax[r + d], x + 11); }
+        }
+    }
+    __syncthreads();
+    uint32_t p0 = 0xffffffffu, p1 = 0xffffffffu;
+    if (r0 != 0xffffffffu && rmin[lane] != 0xffffffffu) {
+        const uint32_t base = (r0 + lane) * row_bytes;
+        p0 = (base + rmin[lane]) & ~63u;
+        const uint32_t last = (base + rmax[lane]) & ~63u;
+        if (last > p0) p1 = last;   // rows of a 16-pixel tile span at most two sectors; wider tiles get first + last
+    }
+    pf[((size_t)tile * 2 + 0) * 64 + lane] = p0;
+    pf[((size_t)tile * 2 + 1) * 64 + lane] = p1;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // per-entry evaluation
 // ---------------------------------------------------------------------------------------------------------------
@@ -328,17 +370,20 @@ struct PlanArgs {
     int fw, fh, bw, bh;
     int tiles_x, ntiles, ngroups;
     int batch, nb, nchunks, xcd_affine;
+    const uint32_t *pf;          // prefetch offsets [ntiles][2][64] or nullptr
+    int *sink;                   // scratch word that absorbs the prefetched values
+    int nt_store;                // experiments: 1 = nontemporal stores
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
     int nlist;
 };
 
 // grid = ngroups * (nchunks rounded up to a multiple of 8 when xcd_affine), block = 256 (4 tiles)
 template <int LX, bool BLEND, bool BAL>
-__global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
+__global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
     __shared__ int sdiv[BAL ? 256 : 1], hdiv[BAL ? 256 : 1];
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[16 * 256];
     if (BAL) {
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = a.tab->sdiv[i]; hdiv[i] = a.tab->hdiv[i]; }
         __syncthreads();
@@ -355,7 +400,7 @@ __global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
     }
     if ((int)chunk >= a.nchunks) return;
     const int lane = threadIdx.x & 63;
-    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
     const int tile = a.tile_list ? (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]) : slot;
 
@@ -441,9 +486,10 @@ __global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // ABL (experiments only, BEVW_ABL): 0 = product kernel, 1 = no stores, 2 = no loads (synthetic texels),
 // 3 = loads confined to a 4 KB window (all L1 hits), 4 = every frame of the batch reads frame set 0 (cache-resident
-// source with the real address pattern)
-template <int LX, int NSLOT, bool BLEND, int ABL = 0>
-__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
+// source with the real address pattern), 5/6/7 = loads only (12 / 8 / 16 bytes per lane, real addresses, no
+// arithmetic, no stores), 8 = 5 on a cache-resident source
+template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true>
+__global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
     const uint32_t id = blockIdx.x;
@@ -458,9 +504,9 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
     }
     if ((int)chunk >= a.nchunks) return;
     const int lane = threadIdx.x & 63;
-    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[16 * 256];
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
     const bool interleaved = (hdr & kHdrInterleaved) != 0;
@@ -496,9 +542,37 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
     }
     const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
 
+    // prefetch offsets; lanes without a sector re-touch offset 0 of the set (always mapped, one extra hot line)
+    uint32_t pf0 = 0, pf1 = 0, pfa_prev = 0, pfb_prev = 0, pf_acc = 0;
+    constexpr bool do_pf = PF;   // compile-time: the vmcnt bookkeeping must not depend on a runtime branch
+    if (do_pf) {
+        pf0 = a.pf[((size_t)tile * 2 + 0) * 64 + lane]; pf1 = a.pf[((size_t)tile * 2 + 1) * 64 + lane];
+        pf0 = pf0 == 0xffffffffu ? 0u : pf0; pf1 = pf1 == 0xffffffffu ? pf0 : pf1;
+    }
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
     const uint8_t *fb = a.frames + (ABL == 4 ? 0 : (size_t)b_begin * set_bytes);
     uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
+    if (ABL >= 5) {
+        uint32_t x = 0;
+        for (int b = b_begin; b < b_end; ++b, fb += (ABL == 8 ? 0 : set_bytes)) {
+            const uint8_t *fb1 = fb + row_bytes;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ABL == 6) {
+                    const uint2 u = *reinterpret_cast<const uint2 *>(fb + (off[0][j] & ~7u)), v = *reinterpret_cast<const uint2 *>(fb1 + (off[0][j] & ~7u));
+                    x ^= u.x + u.y + v.x + v.y;
+                } else if (ABL == 7) {
+                    const uint4 u = *reinterpret_cast<const uint4 *>(fb + (off[0][j] & ~15u)), v = *reinterpret_cast<const uint4 *>(fb1 + (off[0][j] & ~15u));
+                    x ^= u.x + u.y + u.z + u.w + v.x + v.y + v.z + v.w;
+                } else {
+                    const uint2 u = load_footprint_row(fb + off[0][j], mis[0][j]), v = load_footprint_row(fb1 + off[0][j], mis[0][j]);
+                    x ^= u.x + u.y + v.x + v.y;
+                }
+            }
+        }
+        if (x == 0x12345678u && inimg) *reinterpret_cast<uint32_t *>(ob) = x;
+        return;
+    }
 #pragma unroll 1
     for (int b = b_begin; b < b_end; ++b, fb += (ABL == 4 ? 0 : set_bytes), ob += img_bytes) {
         const uint8_t *fb1 = fb + row_bytes;
@@ -510,8 +584,17 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
                 if (ABL == 2) { r0[j] = make_uint2(off[0][j] ^ (uint32_t)b, wx[0][j]); r1[j] = make_uint2(off[0][j] + (uint32_t)b, wy[0][j]); }
                 else { r0[j] = load_footprint_row(fb + off[0][j], mis[0][j]); r1[j] = load_footprint_row(fb1 + off[0][j], mis[0][j]); }
             }
+            // touch the sectors of the NEXT frame (issued after this frame's gathers: vector loads return in order)
+            uint32_t pfa_now = 0, pfb_now = 0;
+            if (do_pf) {
+                const uint8_t *fn = (b + 1 < b_end) ? fb + set_bytes : fb;   // wave-uniform select, no branch
+                pfa_now = *reinterpret_cast<const uint32_t *>(fn + pf0);
+                pfb_now = *reinterpret_cast<const uint32_t *>(fn + pf1);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) bilinear_rows_b2(r0[j], r1[j], wx[0][j], wy[0][j], acc[j]);
+            pf_acc ^= pfa_prev ^ pfb_prev;   // consumed one iteration late, so the wait for it never stalls the pipeline
+            pfa_prev = pfa_now; pfb_prev = pfb_now;
         }
         uint32_t P[4];
         if (!BLEND && NSLOT == 1) {
@@ -555,19 +638,24 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
             uint32_t d0, d1, d2;
             pack_pixels(P, d0, d1, d2);
             uint32_t *op = reinterpret_cast<uint32_t *>(ob);
-            op[0] = d0; op[1] = d1; op[2] = d2;
+            if (a.nt_store) {
+                __builtin_nontemporal_store(d0, op); __builtin_nontemporal_store(d1, op + 1); __builtin_nontemporal_store(d2, op + 2);
+            } else {
+                op[0] = d0; op[1] = d1; op[2] = d2;
+            }
         }
     }
+    if ((pf_acc ^ pfa_prev ^ pfb_prev) == 0x9e3779b9u) *a.sink = 1;   // keeps the prefetch loads alive (scratch word, not the output)
 }
 
 // tiles without any contributor (under the car): out = car (or 0) for every frame of the chunk
 template <int LX>
-__global__ void __launch_bounds__(256) k_plan_empty(PlanArgs a)
+__global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
     const uint32_t chunk = blockIdx.x / (uint32_t)a.ngroups, group = blockIdx.x % (uint32_t)a.ngroups;
     const int lane = threadIdx.x & 63;
-    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
     const int tile = (int)a.tile_list[slot];
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -615,7 +703,7 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries, p.hdr, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
+    void *ptrs[] = {p.entries, p.hdr, p.pf, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = Plan();
@@ -631,7 +719,7 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 }
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
-                                         int orient = 0, int interleave = 1)
+                                         int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -649,6 +737,10 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
                        static_cast<uint2 *>(p.entries), static_cast<uint32_t *>(p.hdr), p.d_max);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&p.max_contrib, p.d_max, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+    if ((e = hipMalloc(&p.pf, (size_t)p.ntiles * 2 * 64 * sizeof(uint32_t))) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_plan_prefetch, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries), p.ntiles,
+                       (uint32_t)fw * 3, static_cast<uint32_t *>(p.pf));
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     std::vector<uint32_t> hdr((size_t)p.ntiles);
     if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -661,6 +753,32 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         else if (h & kHdrSecond) ld.push_back((uint32_t)t);
         else ls.push_back((uint32_t)t);
     }
+    // HBM serves 128-byte lines (a 64-byte sector request costs as much, tools/hbm_gather.hip), so the 4 waves of a
+    // block -- which share one L1 -- should cover ONE contiguous stretch of source rows: consecutive list entries are
+    // x-neighbours for x-major tiles (BEV x runs along source rows) and y-neighbours for y-major (transposed) tiles.
+    auto order = [&](std::vector<uint32_t> &v) {
+        if (super_tile > 1) {
+            // blocks of super_tile x super_tile tiles are contiguous in the list: the waves of one workgroup (one L1)
+            // then share source rows in both directions
+            const uint32_t tx = (uint32_t)p.tiles_x, S = (uint32_t)super_tile;
+            auto key = [tx, S](uint32_t t) {
+                const uint32_t x = t % tx, y = t / tx;
+                return (((uint64_t)(y / S) * 4096 + (x / S)) * S + (y % S)) * S + (x % S);
+            };
+            std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+            return;
+        }
+        if (!column_major_transposed) return;
+        std::vector<uint32_t> xm, ym;
+        for (uint32_t t : v) ((hdr[t] & kHdrTransposed) ? ym : xm).push_back(t);
+        const uint32_t tx = (uint32_t)p.tiles_x;
+        std::stable_sort(ym.begin(), ym.end(), [tx](uint32_t a, uint32_t b) {
+            return (a % tx) != (b % tx) ? (a % tx) < (b % tx) : (a / tx) < (b / tx);
+        });
+        v = xm;
+        v.insert(v.end(), ym.begin(), ym.end());
+    };
+    order(ls); order(ld); order(lw);
     p.n_single = (int)ls.size(); p.n_double = (int)ld.size(); p.n_slow = (int)lw.size(); p.n_empty = (int)le.size();
     if ((e = plan_upload_list(ls, &p.list_single)) != hipSuccess) return e;
     if ((e = plan_upload_list(ld, &p.list_double)) != hipSuccess) return e;
@@ -672,15 +790,17 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     return hipSuccess;
 }
 
-struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; };
+struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; };
 
 template <int LX>
-static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0)
+static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
+                                        int wpb = 4, int lds_pad = 0)
 {
     hipError_t e;
-    const dim3 block(256);
+    if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
+    const dim3 block(64 * wpb);
     const int chunks_padded = a.xcd_affine ? ((a.nchunks + 7) / 8) * 8 : a.nchunks;
-    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; };
+    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + wpb - 1) / wpb; };
     if (balance || !lean) {
         // generic kernel over every tile (luminance round trip per tap, per-tile channel sums)
         set_list(nullptr, p.ntiles);
@@ -694,19 +814,27 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     if (p.n_single) {
         set_list(p.list_single, p.n_single);
         const dim3 grid((unsigned)(a.ngroups * chunks_padded));
-        if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 1) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 1>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 2) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 2>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 3) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 3>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 4) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 4>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_plan_lean<LX, 1, false>), grid, block, 0, st, a);
+        if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, true>), grid, block, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 1) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 1, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 2) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 2, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 3) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 3, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 4) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 4, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 5) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 5, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 6) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 6, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 7) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 7, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 8) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 8, false>), grid, block, 0, st, a);
+        else if (a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, true>), grid, block, lds_pad, st, a);
+        else hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false>), grid, block, lds_pad, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (p.n_double) {
         set_list(p.list_double, p.n_double);
         const dim3 grid((unsigned)(a.ngroups * chunks_padded));
-        if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_plan_lean<LX, 2, false>), grid, block, 0, st, a);
+        if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, true>), grid, block, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false>), grid, block, 0, st, a);
+        else if (a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, false>), grid, block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (p.n_slow) {
@@ -736,6 +864,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
     a.tile_list = nullptr; a.nlist = p.ntiles;
+    a.pf = tune.prefetch ? static_cast<const uint32_t *>(p.pf) : nullptr;
+    a.sink = p.d_max;
+    a.nt_store = tune.nt;
     a.batch = batch;
     // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk
     int nb = tune.nb > 0 ? tune.nb : 8;
@@ -754,9 +885,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     }
     a.psums = static_cast<uint32_t *>(p.psums);
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad); break;
     }
     if (e != hipSuccess) return e;
     if (balance) {

@@ -66,7 +66,9 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     static const int lx_env = [] { const char *s = getenv("BEVW_PLAN_LX"); return s ? atoi(s) : 0; }();
     static const int orient_env = [] { const char *s = getenv("BEVW_PLAN_ORIENT"); return s ? atoi(s) : 0; }();
     static const int inter_env = [] { const char *s = getenv("BEVW_PLAN_INTERLEAVE"); return s ? atoi(s) : 1; }();
-    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env);
+    static const int colmajor_env = [] { const char *s = getenv("BEVW_PLAN_COLMAJOR"); return s ? atoi(s) : 1; }();
+    static const int super_env = [] { const char *s = getenv("BEVW_PLAN_SUPER"); return s ? atoi(s) : 1; }();
+    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -81,6 +83,10 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         if (const char *s = getenv("BEVW_PLAN_NB")) t.nb = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LEAN")) t.lean = atoi(s);
         if (const char *s = getenv("BEVW_ABL")) t.abl = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_WPB")) t.wpb = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_PREFETCH")) t.prefetch = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_NT")) t.nt = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         return t;
     }();
     hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune);
