@@ -12,8 +12,17 @@ import ctypes as C
 
 import numpy as np
 
-from .. import _ffi
-from .._ffi import check, f64, lib, ptr
+try:
+    from .. import _ffi
+except ImportError:
+    # imported as a TOP-LEVEL package (sys.path points inside cameracalibration_amd/, the drop-in layout of main.py:5-7)
+    import importlib
+    import os as _os
+    import sys as _sys
+
+    _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))))
+    _ffi = importlib.import_module("cameracalibration_amd._ffi")
+check, f64, lib, ptr = _ffi.check, _ffi.f64, _ffi.lib, _ffi.ptr
 
 # the flags of intrinsicCalib.py:6-29 that shape the undistort maps (same names / defaults)
 parser = argparse.ArgumentParser(description="Camera Intrinsic Calibration")

@@ -377,7 +377,31 @@ struct PlanArgs {
     int nlist;
 };
 
-// grid = ngroups * (nchunks rounded up to a multiple of 8 when xcd_affine), block = 256 (4 tiles)
+// Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
+// its own L2, so the map decides what an L2 sees:
+//   xcd_affine 1: an XCD owns whole batch chunks (all tiles of frames b0..b0+nb), neighbouring tiles share its L2
+//   xcd_affine 2: an XCD owns a contiguous BAND of tile groups for every chunk (spatial partition)
+//   xcd_affine 0: plain chunk-major order (few chunks)
+__device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, uint32_t &chunk, uint32_t &group)
+{
+    const uint32_t ng = (uint32_t)a.ngroups;
+    if (a.xcd_affine == 1) {
+        const uint32_t xcd = id & 7u, k = id >> 3;
+        chunk = xcd + 8u * (k / ng);
+        group = k % ng;
+    } else if (a.xcd_affine == 2) {
+        const uint32_t xcd = id & 7u, k = id >> 3, gpb = (ng + 7u) / 8u;   // groups per band
+        chunk = k / gpb;
+        group = xcd * gpb + k % gpb;
+        if (group >= ng) return false;
+    } else {
+        chunk = id / ng;
+        group = id % ng;
+    }
+    return (int)chunk < a.nchunks;
+}
+
+// grid: see plan_grid_blocks(); block = 64 * waves-per-block threads (one tile per wave)
 template <int LX, bool BLEND, bool BAL>
 __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 {
@@ -388,17 +412,8 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = a.tab->sdiv[i]; hdiv[i] = a.tab->hdiv[i]; }
         __syncthreads();
     }
-    const uint32_t id = blockIdx.x;
     uint32_t chunk, group;
-    if (a.xcd_affine) {
-        const uint32_t xcd = id & 7u, k = id >> 3;
-        chunk = xcd + 8u * (k / (uint32_t)a.ngroups);
-        group = k % (uint32_t)a.ngroups;
-    } else {
-        chunk = id / (uint32_t)a.ngroups;
-        group = id % (uint32_t)a.ngroups;
-    }
-    if ((int)chunk >= a.nchunks) return;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
     const int lane = threadIdx.x & 63;
     const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
@@ -492,17 +507,8 @@ template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true>
 __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
-    const uint32_t id = blockIdx.x;
     uint32_t chunk, group;
-    if (a.xcd_affine) {
-        const uint32_t xcd = id & 7u, k = id >> 3;
-        chunk = xcd + 8u * (k / (uint32_t)a.ngroups);
-        group = k % (uint32_t)a.ngroups;
-    } else {
-        chunk = id / (uint32_t)a.ngroups;
-        group = id % (uint32_t)a.ngroups;
-    }
-    if ((int)chunk >= a.nchunks) return;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
     const int lane = threadIdx.x & 63;
     const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
@@ -790,7 +796,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     return hipSuccess;
 }
 
-struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; };
+struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
@@ -799,12 +805,16 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     hipError_t e;
     if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
     const dim3 block(64 * wpb);
-    const int chunks_padded = a.xcd_affine ? ((a.nchunks + 7) / 8) * 8 : a.nchunks;
+    auto grid_blocks = [&]() -> unsigned {
+        if (a.xcd_affine == 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
+        if (a.xcd_affine == 2) return (unsigned)(((a.ngroups + 7) / 8) * 8 * a.nchunks);
+        return (unsigned)(a.ngroups * a.nchunks);
+    };
     auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + wpb - 1) / wpb; };
     if (balance || !lean) {
         // generic kernel over every tile (luminance round trip per tap, per-tile channel sums)
         set_list(nullptr, p.ntiles);
-        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        const dim3 grid(grid_blocks());
         if (blend && balance) hipLaunchKernelGGL((k_stitch_plan<LX, true, true>), grid, block, 0, st, a);
         else if (balance) hipLaunchKernelGGL((k_stitch_plan<LX, false, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
@@ -813,7 +823,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     }
     if (p.n_single) {
         set_list(p.list_single, p.n_single);
-        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        const dim3 grid(grid_blocks());
         if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false>), grid, block, 0, st, a);
         else if (LX == 4 && abl == 1) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 1, false>), grid, block, 0, st, a);
@@ -830,7 +840,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     }
     if (p.n_double) {
         set_list(p.list_double, p.n_double);
-        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        const dim3 grid(grid_blocks());
         if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false>), grid, block, 0, st, a);
         else if (a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, true>), grid, block, 0, st, a);
@@ -839,7 +849,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     }
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
-        const dim3 grid((unsigned)(a.ngroups * chunks_padded));
+        const dim3 grid(grid_blocks());
         if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -873,7 +883,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     if (batch < 8 * nb) nb = batch >= 8 ? batch / 8 : 1;
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
-    a.xcd_affine = a.nchunks >= 8 ? 1 : 0;
+    a.xcd_affine = tune.xcd_map == 2 ? 2 : (a.nchunks >= 8 ? tune.xcd_map : 0);
     if (balance) {
         const size_t need = (size_t)batch * p.ntiles * 3 * sizeof(uint32_t);
         if (need > p.psums_cap) {

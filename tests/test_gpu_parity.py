@@ -311,3 +311,36 @@ def test_4k_rig_spot(ffi, SB, oracle):
     frames = W.synthetic_frames(1, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=9, kind="random")
     bev, ref = make_pair(SB, oracle, rig, cfg, True, False)
     assert maxdiff(bev.batch(frames)[0], ref(*frames[0])) == 0
+
+
+def test_main_py_runbev_body_drop_in(ffi, oracle, repo_rig, tmp_path):
+    """main.py:72-89 (runBEV) with the package on sys.path the way the reference lays it out, K/D/H read from .npy files."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    import os
+
+    for n in CAMS:
+        os.makedirs(tmp_path / "data" / n)
+        for kind, arr in zip("KDH", repo_rig.rig[n]):
+            np.save(tmp_path / "data" / n / f"camera_{n}_{kind}.npy", arr)
+        np.save(tmp_path / f"{n}.npy", repo_rig.image(n))
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {os.path.join(ROOT, 'cameracalibration_amd')!r})
+from SurroundBirdEyeView import BevGenerator
+front, back, left, right = (np.load({str(tmp_path)!r} + '/%s.npy' % n) for n in ('front', 'back', 'left', 'right'))
+args = BevGenerator.get_args()
+args.CAR_WIDTH = 200
+args.CAR_HEIGHT = 350
+bev = BevGenerator(blend=True, balance=True)
+surround = bev(front, back, left, right)
+np.save({str(tmp_path)!r} + '/surround.npy', surround)
+"""
+    env = dict(os.environ, BEVW_DATA_DIR=str(tmp_path / "data"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    cfg = dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350)
+    want = oracle.RefBevGenerator(repo_rig.rig, cfg, blend=True, balance=True)(*repo_rig.frames())
+    assert np.array_equal(np.load(tmp_path / "surround.npy"), want)

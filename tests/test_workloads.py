@@ -89,3 +89,20 @@ def test_bench_shard_sizes():
 
     assert bench.shard_sizes(256, 8) == [32] * 8
     assert bench.shard_sizes(10, 4) == [3, 3, 2, 2] and sum(bench.shard_sizes(257, 8)) == 257
+
+
+def test_drop_in_top_level_import(tmp_path):
+    """main.py:5-7 imports `SurroundBirdEyeView`, `IntrinsicCalibration`, `ExtrinsicCalibration` as top-level packages."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    code = ("import sys; sys.path.insert(0, %r); "
+            "from SurroundBirdEyeView import BevGenerator; from IntrinsicCalibration import InCalibrator; "
+            "from ExtrinsicCalibration import ExCalibrator; a = BevGenerator.get_args(); a.CAR_WIDTH = 200; "
+            "print(a.CAR_WIDTH, InCalibrator.get_args().FOCAL_SCALE, ExCalibrator.get_args().CAMERA_ID)"
+            % os.path.join(ROOT, "cameracalibration_amd"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["200", "0.5", "1"]
