@@ -114,6 +114,14 @@ def shard_sizes(total_units: int, world: int):
     return [base + (1 if r < rem else 0) for r in range(world)]
 
 
+def aggregate(world: int, batch: int, steps: int, wall: float, ev_ms: float, alg_bytes: int) -> dict:
+    """Whole-job numbers from the max-over-ranks wall time (s) and HIP-event time (ms) of `steps` steps."""
+    total_units = batch * steps * world
+    launch_ms = ev_ms / steps
+    return {"total_units": total_units, "value": total_units / wall, "launch_ms": launch_ms,
+            "achieved_gbs": alg_bytes * batch / (launch_ms * 1e-3) / 1e9}
+
+
 def upload_replicated(buf, unique: np.ndarray, batch: int):
     per = unique[0].nbytes
     for b in range(batch):
@@ -260,10 +268,8 @@ def main():
     wall = d.max(wall)
     ev_ms = d.max(ev_ms)
 
-    total_units = batch * a.steps * d.world
-    value = total_units / wall
-    launch_ms = ev_ms / a.steps
-    achieved = alg_bytes * batch / (launch_ms * 1e-3) / 1e9
+    agg = aggregate(d.world, batch, a.steps, wall, ev_ms, alg_bytes)
+    value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
         "metric": w["metric"], "value": value, "unit": w["unit"], "n_gpus": d.world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
