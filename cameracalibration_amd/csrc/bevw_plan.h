@@ -43,6 +43,7 @@ struct Plan {
     int fw = 0, fh = 0, bw = 0, bh = 0;
     int tiles_x = 0, tiles_y = 0, ntiles = 0;
     int lx = kPlanLXDefault;     // lanes of a wave along x; tile = (4 * lx) x (64 / lx) pixels
+    int ncams = 4;
     int max_contrib = 0;
     bool usable = false;
     // tile classes (lists of tile indices, row-major order kept): each class has its own lean kernel
@@ -125,11 +126,11 @@ __device__ __forceinline__ void add_car(uint32_t P[4], uint32_t c0, uint32_t c1,
 // plan compiler: one wave per tile
 // ---------------------------------------------------------------------------------------------------------------
 // 64-byte line id of the top footprint row of the first contributor of BEV pixel (x, y); ~0 when there is none
-__device__ inline uint32_t plan_line_id(const StitchTables &T, int fw, int fh, int bw, int bh, int x, int y)
+__device__ inline uint32_t plan_line_id(const StitchTables &T, int ncams, int fw, int fh, int bw, int bh, int x, int y)
 {
     if (x >= bw || y >= bh) return 0xffffffffu;
     const size_t o = (size_t)y * bw + x;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < ncams; ++c) {
         if (T.mask[c][o] == 0) continue;
         const int sx = T.lut1[c][o * 2], sy = T.lut1[c][o * 2 + 1];
         if ((unsigned)sx >= (unsigned)fw || (unsigned)sy >= (unsigned)fh) continue;
@@ -153,7 +154,7 @@ __device__ inline int quad_distinct_lines(uint32_t id, int lane)
 }
 
 __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int tiles_x, int ntiles, int LX, int orient,
-                             int interleave, uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int *__restrict__ max_contrib)
+                             int interleave, int ncams, uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int *__restrict__ max_contrib)
 {
     const int LY = 64 / LX;
     const int tile = blockIdx.x, lane = threadIdx.x;
@@ -168,7 +169,7 @@ __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int
             lane_xy(lane, LX, t != 0, lx, ly);
             for (int j = 0; j < 4; ++j) {
                 const int xq = (t == 0 && interleave) ? (tx * LX + (lx & ~3)) * 4 + 4 * j + (lx & 3) : (tx * LX + lx) * 4 + j;
-                cost[t] += quad_distinct_lines(plan_line_id(T, fw, fh, bw, bh, xq, ty * LY + ly), lane);
+                cost[t] += quad_distinct_lines(plan_line_id(T, ncams, fw, fh, bw, bh, xq, ty * LY + ly), lane);
             }
         }
         transposed = cost[1] < cost[0];
@@ -187,7 +188,7 @@ __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int
         const int x = inter ? (tx * LX + (lx_ & ~3)) * 4 + 4 * j + (lx_ & 3) : x0 + j;
         if (x < bw && y < bh) {
             const size_t o = (size_t)y * bw + x;
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < ncams; ++c) {
                 const uint32_t m = T.mask[c][o];
                 if (m == 0) continue;
                 const int sx = T.lut1[c][o * 2], sy = T.lut1[c][o * 2 + 1];
@@ -369,6 +370,7 @@ struct PlanArgs {
     uint8_t *out;
     int fw, fh, bw, bh;
     int tiles_x, ntiles, ngroups;
+    int ncams;                   // images per frame set: 4 for BevGenerator, 1 for a plain cv2.remap
     int batch, nb, nchunks, xcd_affine;
     const uint32_t *pf;          // prefetch offsets [ntiles][2][64] or nullptr
     int *sink;                   // scratch word that absorbs the prefetched values
@@ -427,7 +429,7 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
     const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const bool inimg = x0 < a.bw && y < a.bh;
     const uint32_t frame_bytes = (uint32_t)a.fw * a.fh * 3, row_bytes = (uint32_t)a.fw * 3;
-    const size_t set_bytes = (size_t)frame_bytes * 4, img_bytes = (size_t)a.bw * a.bh * 3;
+    const size_t set_bytes = (size_t)frame_bytes * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
     const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
 
     EntryRegs e0[4], e1[4];
@@ -522,7 +524,7 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
     const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const bool inimg = x0 < a.bw && y < a.bh;
     const uint32_t row_bytes = (uint32_t)a.fw * 3;
-    const size_t set_bytes = (size_t)a.fw * a.fh * 12, img_bytes = (size_t)a.bw * a.bh * 3;
+    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
     const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
 
     uint32_t off[NSLOT][4], mis[NSLOT][4], wx[NSLOT][4], wy[NSLOT][4];
@@ -725,11 +727,13 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 }
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
-                                         int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1)
+                                         int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
+                                         int ncams = 4)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
     p.lx = lx;
+    p.ncams = ncams;
     p.fw = fw; p.fh = fh; p.bw = bw; p.bh = bh;
     p.tiles_x = (bw + 4 * lx - 1) / (4 * lx);
     p.tiles_y = (bh + (64 / lx) - 1) / (64 / lx);
@@ -739,7 +743,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     if ((e = hipMalloc(&p.hdr, (size_t)p.ntiles * sizeof(uint32_t))) != hipSuccess) return e;
     if ((e = hipMalloc((void **)&p.d_max, sizeof(int))) != hipSuccess) return e;
     if ((e = hipMemsetAsync(p.d_max, 0, sizeof(int), st)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_plan_build, dim3(p.ntiles), dim3(64), 0, st, T, fw, fh, bw, bh, p.tiles_x, p.ntiles, lx, orient, interleave,
+    hipLaunchKernelGGL(k_plan_build, dim3(p.ntiles), dim3(64), 0, st, T, fw, fh, bw, bh, p.tiles_x, p.ntiles, lx, orient, interleave, ncams,
                        static_cast<uint2 *>(p.entries), static_cast<uint32_t *>(p.hdr), p.d_max);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&p.max_contrib, p.d_max, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
@@ -792,7 +796,8 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     if ((e = plan_upload_list(le, &p.list_empty)) != hipSuccess) return e;
     // 12-byte stores need 4-byte aligned pixel quads: bw % 4 == 0 makes every row and every image start aligned
     // and the aligned 12-byte footprint reads need every frame of a set to start on a 4-byte boundary
-    p.usable = p.max_contrib <= 2 && (bw % 4 == 0) && (((size_t)fw * fh * 3) % 4 == 0);
+    p.usable = p.max_contrib <= 2 && (bw % 4 == 0) && (((size_t)fw * fh * 3) % 4 == 0) &&
+               (size_t)fw * fh * 3 * ncams < (1ull << 31);
     return hipSuccess;
 }
 
@@ -873,6 +878,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.deltas = d_deltas; a.tab = d_tab; a.car = d_car; a.out = d_out;
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
+    a.ncams = p.ncams;
     a.tile_list = nullptr; a.nlist = p.ntiles;
     a.pf = tune.prefetch ? static_cast<const uint32_t *>(p.pf) : nullptr;
     a.sink = p.d_max;

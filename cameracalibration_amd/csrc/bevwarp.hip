@@ -61,14 +61,14 @@ static int use_device(int device)
     return BEVW_OK;
 }
 
-static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh)
+static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int ncams = 4)
 {
     static const int lx_env = [] { const char *s = getenv("BEVW_PLAN_LX"); return s ? atoi(s) : 0; }();
     static const int orient_env = [] { const char *s = getenv("BEVW_PLAN_ORIENT"); return s ? atoi(s) : 0; }();
     static const int inter_env = [] { const char *s = getenv("BEVW_PLAN_INTERLEAVE"); return s ? atoi(s) : 1; }();
     static const int colmajor_env = [] { const char *s = getenv("BEVW_PLAN_COLMAJOR"); return s ? atoi(s) : 1; }();
     static const int super_env = [] { const char *s = getenv("BEVW_PLAN_SUPER"); return s ? atoi(s) : 1; }();
-    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env);
+    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -327,8 +327,27 @@ struct bevw_remapper {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int sw = 0, sh = 0, dw = 0, dh = 0;
-    DevBuf map1, map2, in, out;
+    DevBuf map1, map2, in, out, ones;
+    Plan plan;            // single-image contributor plan (same kernels as the BEV stitch, ncams = 1)
+    bool plan_ready = false;
 };
+
+// cv2.remap as a 1-camera stitch: every destination pixel has exactly one contributor with mask 255.
+static int remapper_build_plan(bevw_remapper *r)
+{
+    static const int use_plan = [] { const char *s = getenv("BEVW_REMAP_PLAN"); return s ? atoi(s) : 1; }();
+    r->plan_ready = false;
+    if (!use_plan) return BEVW_OK;
+    const size_t npx = (size_t)r->dw * r->dh;
+    BEVW_TRY(r->ones.reserve(npx));
+    HIP_TRY(hipMemsetAsync(r->ones.p, 0xff, npx, r->stream));
+    StitchTables T;
+    for (int i = 0; i < 4; ++i) { T.lut1[i] = r->map1.as<int16_t>(); T.lut2[i] = r->map2.as<uint16_t>(); T.mask[i] = r->ones.as<uint8_t>(); }
+    BEVW_TRY(plan_build(r->plan, r->stream, T, r->sw, r->sh, r->dw, r->dh, 1));
+    r->ones.release();
+    r->plan_ready = r->plan.usable;
+    return BEVW_OK;
+}
 
 static int remapper_alloc(int device, int sw, int sh, int dw, int dh, bevw_remapper **out)
 {
@@ -433,6 +452,7 @@ int bevw_fisheye_remapper_create(int device, int frame_width, int frame_height, 
     double Kd[9];
     camera_mat_dst(K, frame_width, frame_height, focal_scale, size_scale, offset_h, offset_v, Kd);
     int s = build_fisheye_maps(r->stream, K, D, Kd, dw, dh, r->map1.as<int16_t>(), r->map2.as<uint16_t>());
+    if (s == BEVW_OK) s = remapper_build_plan(r);
     if (s != BEVW_OK) { bevw_remapper_destroy(r); return s; }
     *out = r;
     return BEVW_OK;
@@ -447,6 +467,8 @@ int bevw_remapper_from_maps(int device, int src_w, int src_h, const int16_t *map
     hipError_t e = hipMemcpy(r->map1.p, map1, (size_t)dst_w * dst_h * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(r->map2.p, map2, (size_t)dst_w * dst_h * 2, hipMemcpyHostToDevice);
     if (e != hipSuccess) { bevw_remapper_destroy(r); return fail(BEVW_E_HIP, "map upload failed: %s", hipGetErrorString(e)); }
+    int s = remapper_build_plan(r);
+    if (s != BEVW_OK) { bevw_remapper_destroy(r); return s; }
     *out = r;
     return BEVW_OK;
 }
@@ -473,6 +495,9 @@ int bevw_remap_device(bevw_remapper *r, const void *d_src, int batch, void *d_ds
     if (!r || !d_src || !d_dst || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
     if (batch == 0) return BEVW_OK;
     BEVW_TRY(use_device(r->device));
+    if (r->plan_ready && ((((uintptr_t)d_src) | ((uintptr_t)d_dst)) & 3u) == 0)
+        return plan_stitch(r->plan, r->stream, (const uint8_t *)d_src, batch, false, false, nullptr, nullptr, nullptr, nullptr,
+                           (uint8_t *)d_dst);
     return remap_launch(r->stream, (const uint8_t *)d_src, r->sw, r->sh, r->map1.as<int16_t>(), r->map2.as<uint16_t>(),
                         r->dw, r->dh, batch, (uint8_t *)d_dst);
 }
@@ -521,7 +546,8 @@ void bevw_remapper_destroy(bevw_remapper *r)
     if (!r) return;
     if (hipSetDevice(r->device) == hipSuccess) {
         if (r->stream) (void)hipStreamSynchronize(r->stream);
-        r->map1.release(); r->map2.release(); r->in.release(); r->out.release();
+        r->map1.release(); r->map2.release(); r->in.release(); r->out.release(); r->ones.release();
+        plan_release(r->plan);
         if (r->ev0) (void)hipEventDestroy(r->ev0);
         if (r->ev1) (void)hipEventDestroy(r->ev1);
         if (r->stream) (void)hipStreamDestroy(r->stream);
