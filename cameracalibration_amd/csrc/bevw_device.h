@@ -59,7 +59,7 @@ __device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int d
         fb = fg = fr = fv;
     } else {
         fh *= hscale;
-        fh = fmodf(fh, 6.f);
+        if (fh >= 6.f) fh = fmodf(fh, 6.f);  // H < 180 makes this the identity (fmod is exact); kept for out-of-range H
         int sector = (int)floorf(fh);
         fh -= (float)sector;
         if ((unsigned)sector >= 6u) { sector = 0; fh = 0.f; }

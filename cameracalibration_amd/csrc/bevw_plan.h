@@ -44,6 +44,9 @@ struct Plan {
     int tiles_x = 0, tiles_y = 0, ntiles = 0;
     int lx = kPlanLXDefault;     // lanes of a wave along x; tile = (4 * lx) x (64 / lx) pixels
     int ncams = 4;
+    void *groups = nullptr;      // uint32[n_groups]: byte offsets (inside the frame set) of the sampled 4-texel groups
+    int n_groups = 0;
+    bool band_ok = false;        // the sampled-group list exists (balance schedule 1)
     int max_contrib = 0;
     bool usable = false;
     // tile classes (lists of tile indices, row-major order kept): each class has its own lean kernel
@@ -269,6 +272,66 @@ __global__ void k_plan_prefetch(const uint2 *__restrict__ plan, int ntiles, uint
     pf[((size_t)tile * 2 + 1) * 64 + lane] = p1;
 }
 
+// Bitmap of the 4-texel groups (12 bytes, 4-byte aligned because fw % 4 == 0) that the plan samples, over the 4-camera
+// frame set: bit index = (cam * fh + y) * (fw / 4) + x / 4.  The balance schedule converts exactly these groups of every
+// raw frame (luminance round trip) instead of whole frames or bounding boxes (the LUT quirk makes the right camera's
+// bounding box start at texel (0,0)).
+__global__ void k_plan_touch(const uint2 *__restrict__ plan, int ntiles, int fw, int fh, uint32_t *__restrict__ bitmap)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)ntiles * 8 * 64) return;
+    const uint2 e = plan[i];
+    if (!(e.y & kMetaValid)) return;
+    const int cam = (e.y >> 18) & 3;
+    int sx, sy;
+    if (e.y & kMetaSlow) { sx = (int)(int16_t)(e.x & 0xffffu); sy = (int)(int16_t)(e.x >> 16); }
+    else {
+        const uint32_t t = e.x - (uint32_t)cam * (uint32_t)fw * fh * 3;
+        sy = (int)(t / ((uint32_t)fw * 3)); sx = (int)((t % ((uint32_t)fw * 3)) / 3);
+    }
+    const int gw = fw / 4;
+    for (int dy = 0; dy < 2; ++dy)
+        for (int dx = 0; dx < 2; ++dx) {
+            const int x = sx + dx, y = sy + dy;
+            if ((unsigned)x >= (unsigned)fw || (unsigned)y >= (unsigned)fh) continue;
+            const uint32_t bit = ((uint32_t)cam * fh + y) * gw + x / 4;
+            atomicOr(&bitmap[bit >> 5], 1u << (bit & 31));
+        }
+}
+
+// luminance_balance (surroundBEV.py:57-79) applied to the sampled texel groups of every raw frame:
+// scratch = HSV2BGR(sat(V + delta)).  One lane = one group = 4 texels (12 bytes, one dwordx3 each way); groups[] holds
+// byte offsets inside the frame set in ascending order, so neighbouring lanes touch neighbouring memory.
+// grid = (ceil(ngroups / 256), batch); block = 256.
+__global__ void __launch_bounds__(256) k_lum_groups(const uint8_t *__restrict__ frames, uint8_t *__restrict__ scratch, size_t set_bytes,
+                                                     uint32_t frame_bytes, const uint32_t *__restrict__ groups, int ngroups,
+                                                     const int *__restrict__ deltas, const HsvTables *__restrict__ tab)
+{
+    __shared__ int sdiv[256], hdiv[256];
+    for (int i = threadIdx.x; i < 256; i += 256) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+    __syncthreads();
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const int b = blockIdx.y;
+    const uint32_t goff = groups[gi];
+    const size_t off = (size_t)b * set_bytes + goff;
+    const AlignedU3 v = *reinterpret_cast<const AlignedU3 *>(frames + off);
+    const uint32_t w[3] = {v.x, v.y, v.z};
+    const int delta = deltas[b * 4 + (int)(goff / frame_bytes)];
+    uint32_t o[3] = {0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int c3[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int bi = t * 3 + k; c3[k] = (int)((w[bi >> 2] >> ((bi & 3) * 8)) & 255u); }
+        luminance_shift_px(c3[0], c3[1], c3[2], delta, sdiv, hdiv);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { const int bi = t * 3 + k; o[bi >> 2] |= (uint32_t)c3[k] << ((bi & 3) * 8); }
+    }
+    AlignedU3 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2];
+    *reinterpret_cast<AlignedU3 *>(scratch + off) = ov;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // per-entry evaluation
 // ---------------------------------------------------------------------------------------------------------------
@@ -404,9 +467,11 @@ __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, u
 }
 
 // grid: see plan_grid_blocks(); block = 64 * waves-per-block threads (one tile per wave)
-template <int LX, bool BLEND, bool BAL>
+// LUM: luminance round trip per fetched texel (raw frames); SUMS: emit per-tile channel sums and leave the car to k_gain
+template <int LX, bool BLEND, bool LUM, bool SUMS = LUM>
 __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 {
+    constexpr bool BAL = LUM;
     constexpr int LY = 64 / LX;
     __shared__ int sdiv[BAL ? 256 : 1], hdiv[BAL ? 256 : 1];
     __shared__ __attribute__((aligned(16))) uint32_t xpose[16 * 256];
@@ -439,7 +504,7 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
         e1[j] = decode_entry(second ? a.plan[((size_t)tile * 8 + 4 + j) * 64 + lane] : make_uint2(0, 0), BLEND);
     }
     uint32_t car0 = 0, car1 = 0, car2 = 0;
-    if (!BAL && a.car != nullptr && inimg) {
+    if (!SUMS && a.car != nullptr && inimg) {
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
         car0 = cp[0]; car1 = cp[1]; car2 = cp[2];
     }
@@ -468,7 +533,7 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
                 }
             }
         }
-        if (BAL) {
+        if (SUMS) {
             // per-tile channel sums of the pre-gain BEV (color_balance means, surroundBEV.py:44-47); pixels outside
             // the image have no plan entry and contribute 0
             unsigned s0 = 0, s1 = 0, s2 = 0;
@@ -484,7 +549,7 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
         if (hdr & kHdrInterleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
-        if (!BAL && car_any) add_car(P, car0, car1, car2);
+        if (!SUMS && car_any) add_car(P, car0, car1, car2);
         if (inimg) {
             uint32_t d0, d1, d2;
             pack_pixels(P, d0, d1, d2);
@@ -505,7 +570,7 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 // 3 = loads confined to a 4 KB window (all L1 hits), 4 = every frame of the batch reads frame set 0 (cache-resident
 // source with the real address pattern), 5/6/7 = loads only (12 / 8 / 16 bytes per lane, real addresses, no
 // arithmetic, no stores), 8 = 5 on a cache-resident source
-template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true>
+template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false>
 __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
@@ -544,7 +609,7 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
             wf[s][j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
         }
     uint32_t car0 = 0, car1 = 0, car2 = 0;
-    if (a.car != nullptr && inimg) {
+    if (!SUMS && a.car != nullptr && inimg) {
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
         car0 = cp[0]; car1 = cp[1]; car2 = cp[2];
     }
@@ -640,6 +705,24 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
 #pragma unroll
             for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
         }
+        if (SUMS) {
+            // channel sums of the tile for color_balance: a lane's 4 pixels sum to <= 1020 per channel and a wave to
+            // <= 65280, so B and G travel packed in one dword through the butterfly
+            uint32_t sb = 0, sg = 0, sr = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
+                sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
+                sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
+            }
+            uint32_t bg = sb | (sg << 16);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
+            if (lane == 0) {
+                uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
+                ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
+            }
+        }
         if (interleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
         if (car_any) add_car(P, car0, car1, car2);
         if (inimg && (ABL != 1 || (P[0] == 0xdeadbeefu && P[1] == 0x12345678u))) {
@@ -711,7 +794,7 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries, p.hdr, p.pf, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
+    void *ptrs[] = {p.entries, p.hdr, p.pf, p.groups, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = Plan();
@@ -751,6 +834,33 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     hipLaunchKernelGGL(k_plan_prefetch, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries), p.ntiles,
                        (uint32_t)fw * 3, static_cast<uint32_t *>(p.pf));
     if ((e = hipGetLastError()) != hipSuccess) return e;
+    p.band_ok = false;
+    if (ncams == 4 && fw % 4 == 0) {
+        const size_t nbits = (size_t)4 * fh * (fw / 4), nwords = (nbits + 31) / 32;
+        uint32_t *d_bits = nullptr;
+        if ((e = hipMalloc((void **)&d_bits, nwords * 4)) != hipSuccess) return e;
+        if ((e = hipMemsetAsync(d_bits, 0, nwords * 4, st)) != hipSuccess) return e;
+        const size_t nent = (size_t)p.ntiles * 8 * 64;
+        hipLaunchKernelGGL(k_plan_touch, dim3((unsigned)((nent + 255) / 256)), dim3(256), 0, st, static_cast<const uint2 *>(p.entries),
+                           p.ntiles, fw, fh, d_bits);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        std::vector<uint32_t> bits(nwords), list;
+        if ((e = hipMemcpyAsync(bits.data(), d_bits, nwords * 4, hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+        (void)hipFree(d_bits);
+        const uint32_t gw = (uint32_t)fw / 4, row_bytes = (uint32_t)fw * 3;
+        for (size_t wi = 0; wi < nwords; ++wi) {
+            uint32_t m = bits[wi];
+            while (m) {
+                const uint32_t bit = (uint32_t)wi * 32 + (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                list.push_back((bit / gw) * row_bytes + (bit % gw) * 12);   // (cam * fh + y) rows of the set, 12 B per group
+            }
+        }
+        p.n_groups = (int)list.size();
+        if ((e = plan_upload_list(list, &p.groups)) != hipSuccess) return e;
+        p.band_ok = true;
+    }
     std::vector<uint32_t> hdr((size_t)p.ntiles);
     if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -805,7 +915,7 @@ struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int pref
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
-                                        int wpb = 4, int lds_pad = 0)
+                                        int wpb = 4, int lds_pad = 0, bool sums = false)
 {
     hipError_t e;
     if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
@@ -825,6 +935,38 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
         return hipGetLastError();
+    }
+    if (sums) {
+        // balance on pre-shifted frames: lean kernels + per-tile channel sums; the car is added by k_gain
+        a.car = nullptr;
+        if (p.n_single) {
+            set_list(p.list_single, p.n_single);
+            const dim3 grid(grid_blocks());
+            if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false, true>), grid, block, lds_pad, st, a);
+            else hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false, true>), grid, block, lds_pad, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (p.n_double) {
+            set_list(p.list_double, p.n_double);
+            const dim3 grid(grid_blocks());
+            if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, false, true>), grid, block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (p.n_slow) {
+            set_list(p.list_slow, p.n_slow);
+            const dim3 grid(grid_blocks());
+            if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_stitch_plan<LX, false, false, true>), grid, block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (p.n_empty) {
+            set_list(p.list_empty, p.n_empty);
+            const dim3 grid((unsigned)(a.ngroups * a.nchunks));
+            hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     if (p.n_single) {
         set_list(p.list_single, p.n_single);
@@ -868,9 +1010,11 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     return hipSuccess;
 }
 
+// balance = per-tap luminance round trip on RAW frames (generic kernel); sums = frames are already luminance-shifted
+// (k_lum_band), run the lean kernels and emit per-tile channel sums.  Both end with k_reduce_psums.
 static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
                                           const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car,
-                                          unsigned long long *d_chsums, uint8_t *d_out, const PlanTuning &tune)
+                                          unsigned long long *d_chsums, uint8_t *d_out, const PlanTuning &tune, bool sums = false)
 {
     hipError_t e;
     PlanArgs a;
@@ -890,7 +1034,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
     a.xcd_affine = tune.xcd_map == 2 ? 2 : (a.nchunks >= 8 ? tune.xcd_map : 0);
-    if (balance) {
+    if (balance || sums) {
         const size_t need = (size_t)batch * p.ntiles * 3 * sizeof(uint32_t);
         if (need > p.psums_cap) {
             if (p.psums) (void)hipFree(p.psums);
@@ -900,17 +1044,33 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         }
     }
     a.psums = static_cast<uint32_t *>(p.psums);
+    if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums); break;
     }
     if (e != hipSuccess) return e;
-    if (balance) {
+    if (balance || sums) {
         hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, p.ntiles, d_chsums);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// luminance-shift the sampled texel groups of every raw frame of the batch into `scratch` (same layout as `frames`)
+static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch,
+                                       const int *d_deltas, const HsvTables *d_tab)
+{
+    if (p.n_groups == 0) return hipSuccess;
+    const size_t set_bytes = (size_t)p.fw * p.fh * 12;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(k_lum_groups, dim3((p.n_groups + 255) / 256, nb), dim3(256), 0, st, d_frames + (size_t)b0 * set_bytes,
+                           d_scratch + (size_t)b0 * set_bytes, set_bytes, (uint32_t)p.fw * p.fh * 3,
+                           static_cast<const uint32_t *>(p.groups), p.n_groups, d_deltas + (size_t)b0 * 4, d_tab);
+    }
+    return hipGetLastError();
 }
 
 }  // namespace bevw

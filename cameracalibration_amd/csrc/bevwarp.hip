@@ -75,7 +75,7 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
 
 static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
                        const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car, unsigned long long *d_chsums,
-                       uint8_t *d_out)
+                       uint8_t *d_out, bool sums = false)
 {
     // tuning knobs for experiments (defaults are the shipped configuration)
     static const PlanTuning tune = [] {
@@ -90,7 +90,7 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         return t;
     }();
-    hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune);
+    hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune, sums);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "tile-plan stitch launch failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -686,7 +686,18 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
     }
     const bool aligned4 = (((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) == 0;
-    if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4) {
+    // balance schedule of the tile plan: 1 = shift the sampled band of the raw frames once (k_lum_band), then the lean
+    // kernels; 0 = luminance round trip per fetched texel inside the generic kernel
+    static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
+    if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok) {
+        const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
+        BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
+        hipError_t e = plan_lum_band(h->plan, h->stream, d_frames, h->tmp.as<uint8_t>(), batch, h->deltas.as<int>(),
+                                     h->hsv.as<HsvTables>());
+        if (e != hipSuccess) return fail(BEVW_E_HIP, "k_lum_band launch failed: %s", hipGetErrorString(e));
+        BEVW_TRY(plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr,
+                             h->chsums.as<unsigned long long>(), d_out, true));
+    } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4) {
         BEVW_TRY(plan_stitch(h->plan, h->stream, d_frames, batch, c.blend != 0, c.balance != 0, h->deltas.as<int>(),
                              h->hsv.as<HsvTables>(), d_car, h->chsums.as<unsigned long long>(), d_out));
     } else {
@@ -695,8 +706,12 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
     if (c.balance) {
         for (int b0 = 0; b0 < batch; b0 += 65535) {
             const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-            hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
-                               h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3);
+            if (npx % 4 == 0 && aligned4)
+                hipLaunchKernelGGL(k_gain_lut, dim3(32, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
+                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3);
+            else
+                hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
+                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3);
         }
         BEVW_TRY(launch_check("k_gain"));
     }
