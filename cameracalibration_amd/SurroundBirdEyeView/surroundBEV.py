@@ -346,7 +346,8 @@ class BevGenerator:
         info = np.zeros(8, np.int32)
         check(lib().bevw_plan_info(self._engine.h, ptr(info)))
         return {"max_contributors": int(info[0]), "plan_usable": bool(info[1]), "schedule": int(info[2]),
-                "tiles_x": int(info[3]), "tiles_y": int(info[4])}
+                "tiles_x": int(info[3]), "tiles_y": int(info[4]), "tiles_staged": int(info[5]),
+                "tiles_gather": int(info[6]), "tiles_border": int(info[7])}
 
 
 def main():

@@ -31,7 +31,11 @@ constexpr uint32_t kHdrSlow = 2u;          // some entry of the tile needs the p
 constexpr uint32_t kHdrEmpty = 4u;         // no contributor at all (car rectangle): tile is zero + car
 constexpr uint32_t kHdrTransposed = 16u;   // lanes of a quad run along BEV y (see lane_xy)
 constexpr uint32_t kHdrInterleaved = 32u;  // x-major tile whose lanes COMPUTE interleaved pixels (see pixel ownership)
-constexpr int kPlanLXDefault = 4;          // lanes along x -> 16 x 16 pixel tiles
+constexpr uint32_t kHdrStaged = 64u;       // tile has an LDS staging plan (<= kStageSectors source sectors)
+constexpr int kStageInstr = 2;             // LDS-DMA instructions per tile-frame (1 KB = 16 sectors each)
+constexpr int kStageSectors = 16 * kStageInstr;
+constexpr int kStageBytes = 1024 * kStageInstr + 64;   // per wave and buffer (64 B slack for the 12-byte read windows)
+constexpr int kPlanLXDefault = 8;          // lanes along x -> 32 x 8 pixel tiles (best of 4 / 8 / 16 on config 3)
 
 struct Plan {
     void *entries = nullptr;     // uint2[ntiles][8][64]
@@ -52,6 +56,13 @@ struct Plan {
     // tile classes (lists of tile indices, row-major order kept): each class has its own lean kernel
     void *list_single = nullptr, *list_double = nullptr, *list_slow = nullptr, *list_empty = nullptr;
     int n_single = 0, n_double = 0, n_slow = 0, n_empty = 0;
+    // LDS-staged variant: tiles whose footprints fit kStageSectors sectors get a second entry table (LDS addresses) and a
+    // DMA list; st_* lists hold them, rs_* the single/double tiles that stay on the L1-gather kernels
+    void *entries_st = nullptr;  // uint2[ntiles][8][64]: x = LDS byte address of footprint row 0 | row 1 << 16, y = meta
+    void *dma = nullptr;         // uint32[ntiles][kStageInstr][64]: per-lane source offset of each LDS-DMA instruction
+    void *list_st_single = nullptr, *list_st_double = nullptr, *list_rs_single = nullptr, *list_rs_double = nullptr;
+    int n_st_single = 0, n_st_double = 0, n_rs_single = 0, n_rs_double = 0;
+    bool staged_ok = false;
 };
 
 struct __attribute__((packed, aligned(1))) PackedU2 { uint32_t x, y; };
@@ -422,6 +433,8 @@ __device__ __forceinline__ void eval_entry(const uint8_t *__restrict__ fb, const
     if (BLEND) { v[0] = blend_mul(v[0], e.wf); v[1] = blend_mul(v[1], e.wf); v[2] = blend_mul(v[2], e.wf); }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct PlanArgs {
     const uint8_t *frames;
     const uint2 *plan;
@@ -435,6 +448,8 @@ struct PlanArgs {
     int tiles_x, ntiles, ngroups;
     int ncams;                   // images per frame set: 4 for BevGenerator, 1 for a plain cv2.remap
     int batch, nb, nchunks, xcd_affine;
+    const uint2 *plan_st;        // LDS-staged entries (k_plan_staged)
+    const uint32_t *dma;         // LDS-DMA source offsets [ntiles][kStageInstr][64]
     const uint32_t *pf;          // prefetch offsets [ntiles][2][64] or nullptr
     int *sink;                   // scratch word that absorbs the prefetched values
     int nt_store;                // experiments: 1 = nontemporal stores
@@ -570,7 +585,8 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 // 3 = loads confined to a 4 KB window (all L1 hits), 4 = every frame of the batch reads frame set 0 (cache-resident
 // source with the real address pattern), 5/6/7 = loads only (12 / 8 / 16 bytes per lane, real addresses, no
 // arithmetic, no stores), 8 = 5 on a cache-resident source
-template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false>
+// PFW (experiment): touch THIS frame's sectors with one instruction and wait for them before the gathers (all-hit gathers)
+template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false, bool PFW = false>
 __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
@@ -618,7 +634,7 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
     // prefetch offsets; lanes without a sector re-touch offset 0 of the set (always mapped, one extra hot line)
     uint32_t pf0 = 0, pf1 = 0, pfa_prev = 0, pfb_prev = 0, pf_acc = 0;
     constexpr bool do_pf = PF;   // compile-time: the vmcnt bookkeeping must not depend on a runtime branch
-    if (do_pf) {
+    if (do_pf || PFW) {
         pf0 = a.pf[((size_t)tile * 2 + 0) * 64 + lane]; pf1 = a.pf[((size_t)tile * 2 + 1) * 64 + lane];
         pf0 = pf0 == 0xffffffffu ? 0u : pf0; pf1 = pf1 == 0xffffffffu ? pf0 : pf1;
     }
@@ -646,15 +662,46 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
         if (x == 0x12345678u && inimg) *reinterpret_cast<uint32_t *>(ob) = x;
         return;
     }
+    // ABL 9 (cost model of an LDS-staged variant, results are NOT valid): two LDS-DMA instructions fetch the tile's
+    // sectors, the footprints are read back with ds_read2_b32 + ds_read_b32 at addresses derived from the real offsets
+    __shared__ __attribute__((aligned(16))) uint8_t stage[ABL == 9 ? 16 * 2 * 2112 : 16];
+    uint32_t dma0 = 0, dma1 = 0;
+    if (ABL == 9) {
+        const uint32_t s0 = a.pf ? a.pf[((size_t)tile * 2 + 0) * 64 + (lane >> 2)] : 0u, s1 = a.pf ? a.pf[((size_t)tile * 2 + 1) * 64 + (lane >> 2)] : 0u;
+        dma0 = (s0 == 0xffffffffu ? 0u : s0) + (lane & 3) * 16;
+        dma1 = (s1 == 0xffffffffu ? dma0 : s1 + (lane & 3) * 16);
+    }
 #pragma unroll 1
     for (int b = b_begin; b < b_end; ++b, fb += (ABL == 4 ? 0 : set_bytes), ob += img_bytes) {
         const uint8_t *fb1 = fb + row_bytes;
         uint32_t acc[4][3];
-        {
+        if (ABL == 9) {
+            uint8_t *buf = stage + ((threadIdx.x >> 6) * 2 + (b & 1)) * 2112;
+            auto l3 = (__attribute__((address_space(3))) uint8_t *)buf;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + dma0), (__attribute__((address_space(3))) void *)l3, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + dma1), (__attribute__((address_space(3))) void *)(l3 + 1024), 16, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(buf);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t i0 = (off[0][j] >> 2) & 0x1ffu, i1 = ((off[0][j] + row_bytes) >> 2) & 0x1ffu;
+                const uint2 r0 = make_uint2(__builtin_amdgcn_alignbyte(w[i0 + 1], w[i0], mis[0][j]), __builtin_amdgcn_alignbyte(w[i0 + 2], w[i0 + 1], mis[0][j]));
+                const uint2 r1 = make_uint2(__builtin_amdgcn_alignbyte(w[i1 + 1], w[i1], mis[0][j]), __builtin_amdgcn_alignbyte(w[i1 + 2], w[i1 + 1], mis[0][j]));
+                bilinear_rows_b2(r0, r1, wx[0][j], wy[0][j], acc[j]);
+            }
+        } else
+        if (PFW) {
+            const uint32_t t0 = *reinterpret_cast<const uint32_t *>(fb + pf0), t1 = *reinterpret_cast<const uint32_t *>(fb + pf1);
+            pf_acc ^= t0 ^ t1;
+            // the XOR above makes the compiler wait for both loads; keep the gathers behind it
+            asm volatile("" : "+v"(pf_acc));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ABL != 9) {
             uint2 r0[4], r1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (ABL == 2) { r0[j] = make_uint2(off[0][j] ^ (uint32_t)b, wx[0][j]); r1[j] = make_uint2(off[0][j] + (uint32_t)b, wy[0][j]); }
+                if (ABL == 2 || ABL == 10) { r0[j] = make_uint2(off[0][j] ^ (uint32_t)b, wx[0][j]); r1[j] = make_uint2(off[0][j] + (uint32_t)b, wy[0][j]); }
                 else { r0[j] = load_footprint_row(fb + off[0][j], mis[0][j]); r1[j] = load_footprint_row(fb1 + off[0][j], mis[0][j]); }
             }
             // touch the sectors of the NEXT frame (issued after this frame's gathers: vector loads return in order)
@@ -725,7 +772,7 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
         }
         if (interleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
         if (car_any) add_car(P, car0, car1, car2);
-        if (inimg && (ABL != 1 || (P[0] == 0xdeadbeefu && P[1] == 0x12345678u))) {
+        if (inimg && ((ABL != 1 && ABL != 10) || (P[0] == 0xdeadbeefu && P[1] == 0x12345678u))) {
             uint32_t d0, d1, d2;
             pack_pixels(P, d0, d1, d2);
             uint32_t *op = reinterpret_cast<uint32_t *>(ob);
@@ -768,6 +815,223 @@ __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-staged schedule.  The gathers of k_plan_lean are bound by the per-instruction cost of the vector-memory pipe
+// (8 gather instructions per tile-frame, each carrying ~3 sector misses: DESIGN.md section 4).  Here the ~27 distinct
+// 64-byte source sectors of a tile-frame are fetched by TWO LDS-DMA instructions (global_load_lds_dwordx4: every lane
+// brings 16 bytes, 4 lanes = one sector, the data lands in LDS in lane order) into a wave-private, double-buffered
+// 2 KB patch, one frame ahead of its use; the 2x2 footprints are then read back from LDS (4-byte aligned 12-byte
+// windows, same v_alignbyte realignment as the global path).  The plan compiler assigns every distinct sector of the
+// tile a slot (ascending address order, so a footprint that straddles two sectors of a row finds them adjacent) and
+// rewrites the entries to LDS byte addresses.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) k_plan_stage_build(const uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int ntiles,
+                                                          uint32_t row_bytes, uint32_t set_bytes, uint2 *__restrict__ plan_st,
+                                                          uint32_t *__restrict__ dma)
+{
+    __shared__ uint32_t cand[64 * 32];
+    __shared__ uint32_t list[kStageSectors + 1];
+    __shared__ int s_count;
+    const int tile = blockIdx.x, lane = threadIdx.x;
+    if (tile >= ntiles) return;
+    const uint32_t h = hdr[tile];
+    if (h & (kHdrSlow | kHdrEmpty)) return;
+    uint2 e[8];
+    bool overrun = false;
+    for (int k = 0; k < 8; ++k) {
+        e[k] = plan[((size_t)tile * 8 + k) * 64 + lane];
+        uint32_t c[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (e[k].y & kMetaValid) {
+            const uint32_t o0 = e[k].x, o1 = o0 + row_bytes;
+            c[0] = o0 >> 6; c[1] = (o0 + 5) >> 6; c[2] = o1 >> 6; c[3] = (o1 + 5) >> 6;
+            if (((o1 + 5) >> 6) * 64 + 64 > set_bytes) overrun = true;   // DMA moves whole sectors
+        }
+        for (int i = 0; i < 4; ++i) cand[lane * 32 + k * 4 + i] = c[i];
+    }
+    if (lane == 0) s_count = 0;
+    __syncthreads();
+    // distinct sectors in ascending order: repeated extraction of the smallest candidate above the last one taken
+    uint32_t last = 0;
+    bool first = true, fits = !__any(overrun);
+    for (int it = 0; it <= kStageSectors && fits; ++it) {
+        uint32_t m = 0xffffffffu;
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t v = cand[lane * 32 + i];
+            if (v != 0xffffffffu && (first || v > last)) m = min(m, v);
+        }
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if (m == 0xffffffffu) break;
+        if (it == kStageSectors) { fits = false; break; }
+        if (lane == 0) { list[it] = m; s_count = it + 1; }
+        last = m; first = false;
+    }
+    __syncthreads();
+    const int count = s_count;
+    if (!fits || count == 0) return;
+    for (int k = 0; k < 8; ++k) {
+        uint2 o = make_uint2(0u, e[k].y & ~kMetaValid);
+        if (e[k].y & kMetaValid) {
+            const uint32_t o0 = e[k].x, o1 = o0 + row_bytes;
+            uint32_t s0 = 0, s1 = 0;
+            for (int i = 0; i < count; ++i) { if (list[i] == (o0 >> 6)) s0 = i; if (list[i] == (o1 >> 6)) s1 = i; }
+            o = make_uint2((s0 * 64 + (o0 & 63u)) | ((s1 * 64 + (o1 & 63u)) << 16), e[k].y);
+        }
+        plan_st[((size_t)tile * 8 + k) * 64 + lane] = o;
+    }
+    for (int k = 0; k < kStageInstr; ++k) {
+        const int slot = k * 16 + lane / 4;
+        dma[((size_t)tile * kStageInstr + k) * 64 + lane] = slot < count ? list[slot] * 64u + (uint32_t)(lane % 4) * 16u : 0u;
+    }
+    if (lane == 0) hdr[tile] = h | kHdrStaged;
+}
+
+template <int LX, int NSLOT, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
+{
+    constexpr int LY = 64 / LX;
+    __shared__ __attribute__((aligned(16))) uint8_t stage_a[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_b[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    uint32_t chunk, group;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = (int)group * 4 + wave;
+    if (slot >= a.nlist) return;
+    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
+    const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
+    const bool interleaved = (hdr & kHdrInterleaved) != 0;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
+    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
+    const bool inimg = x0 < a.bw && y < a.bh;
+    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+
+    // per entry: qword index of the 16-byte window (two 8-byte aligned LDS words, one ds_read2_b64) of each footprint
+    // row inside the wave's patch, byte offset 0..7 of the footprint inside it, x / y weights (as in k_plan_lean)
+    uint32_t i0[NSLOT][4], i1[NSLOT][4], mis[NSLOT][4], wx[NSLOT][4], wy[NSLOT][4];
+    float wf[NSLOT][4];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint2 e = a.plan_st[((size_t)tile * 8 + s * 4 + j) * 64 + lane];
+            const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
+            const bool valid = e.y & kMetaValid;
+            const uint32_t a0 = e.x & 0xffffu, a1 = e.x >> 16;
+            i0[s][j] = a0 >> 3; i1[s][j] = a1 >> 3; mis[s][j] = a0 & 7u;   // rows are a multiple of 64 bytes apart: same offset
+            wx[s][j] = valid ? ((32 - fx) | (fx << 24)) : 0u;
+            wy[s][j] = ((32 - fy) << 6) | (fy << 22);
+            wf[s][j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
+        }
+    uint32_t dsrc[kStageInstr];
+#pragma unroll
+    for (int k = 0; k < kStageInstr; ++k) dsrc[k] = a.dma[((size_t)tile * kStageInstr + k) * 64 + lane];
+    uint32_t car0 = 0, car1 = 0, car2 = 0;
+    if (!SUMS && a.car != nullptr && inimg) {
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
+        car0 = cp[0]; car1 = cp[1]; car2 = cp[2];
+    }
+    const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
+
+    typedef __attribute__((address_space(3))) uint8_t lds_u8;
+    typedef const __attribute__((address_space(1))) void gvoid;
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    const uint8_t *fb = a.frames + (size_t)b_begin * set_bytes;
+    uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
+
+    // Two SEPARATE LDS arrays (ping / pong) and a 2x unrolled frame loop: the compiler tracks LDS-DMA writes per
+    // destination object, so reads of one array need not wait for the DMA that is filling the other.
+    // The LDS-DMA is issued through inline asm: the compiler orders every later LDS read behind ALL pending LDS-DMA it
+    // knows about (vmcnt(0)), which would serialise the double buffer.  Hidden from it, only the explicit vmcnt below
+    // governs the patches.  (Unknown vector loads can only make compiler-placed vmcnt waits longer, never shorter:
+    // loads retire in issue order.)
+    auto stage_frame = [&](const uint8_t *src, uint8_t *dst_generic) {
+        const uint32_t dst = (uint32_t)(uintptr_t)(lds_u8 *)dst_generic;
+#pragma unroll
+        for (int k = 0; k < kStageInstr; ++k) {
+            const uint8_t *g = src + dsrc[k];
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst + k * 1024), "v"(g) : "memory", "m0");
+        }
+    };
+    auto one_frame = [&](const uint8_t *patch_cur, uint8_t *patch_next, int b) {
+        // start the next frame's sectors (the last iteration re-stages its own frame: uniform instruction count)
+        stage_frame(b + 1 < b_end ? fb + set_bytes : fb, patch_next);
+        // the kStageInstr DMAs just issued may stay in flight; everything older (this frame's patch) must have landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStageInstr) : "memory");
+        const uint2 *w = reinterpret_cast<const uint2 *>(patch_cur);
+        uint32_t P[4];
+        {
+            int px[4][3];
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t k0 = i0[s][j], k1 = i1[s][j], m = mis[s][j];
+                    // 16-byte window = LDS qwords k, k+1 (one ds_read2_b64); the footprint starts at byte m (0..7) of it:
+                    // pick the three dwords that hold bytes m..m+5, then realign by m & 3 as on the global path
+                    const uint2 q00 = w[k0], q01 = w[k0 + 1], q10 = w[k1], q11 = w[k1 + 1];
+                    const bool up = m >= 4;
+                    const uint32_t a0 = up ? q00.y : q00.x, b0 = up ? q01.x : q00.y, c0 = up ? q01.y : q01.x;
+                    const uint32_t a1 = up ? q10.y : q10.x, b1 = up ? q11.x : q10.y, c1 = up ? q11.y : q11.x;
+                    const uint2 r0 = make_uint2(__builtin_amdgcn_alignbyte(b0, a0, m), __builtin_amdgcn_alignbyte(c0, b0, m));
+                    const uint2 r1 = make_uint2(__builtin_amdgcn_alignbyte(b1, a1, m), __builtin_amdgcn_alignbyte(c1, b1, m));
+                    uint32_t acc[3];
+                    bilinear_rows_b2(r0, r1, wx[s][j], wy[s][j], acc);
+                    if (!BLEND && NSLOT == 1) {
+                        P[j] = __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const uint32_t v = (acc[k] >> 16) & 255u;
+                            const int c = BLEND ? (int)((float)v * wf[s][j]) : (int)v;
+                            px[j][k] = s == 0 ? c : min(255, px[j][k] + c);
+                        }
+                    }
+                }
+            if (BLEND || NSLOT == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
+            }
+        }
+        if (SUMS) {
+            uint32_t sb = 0, sg = 0, sr = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
+                sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
+                sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
+            }
+            uint32_t bg = sb | (sg << 16);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
+            if (lane == 0) {
+                uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
+                ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
+            }
+        }
+        if (interleaved) quad_exchange(P, xpose + wave * 256, lane);
+        if (car_any) add_car(P, car0, car1, car2);
+        if (inimg) {
+            uint32_t d0, d1, d2;
+            pack_pixels(P, d0, d1, d2);
+            uint32_t *op = reinterpret_cast<uint32_t *>(ob);
+            op[0] = d0; op[1] = d1; op[2] = d2;
+        }
+        fb += set_bytes;
+        ob += img_bytes;
+    };
+    uint8_t *const ping = stage_a + wave * kStageBytes, *const pong = stage_b + wave * kStageBytes;
+    stage_frame(fb, ping);
+#pragma unroll 1
+    for (int b = b_begin; b < b_end; b += 2) {
+        one_frame(ping, pong, b);
+        if (b + 1 < b_end) one_frame(pong, ping, b + 1);
+    }
+}
+
 // psums[b][tile][3] -> chsums[b][3] ; grid = batch, block = 256
 __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, unsigned long long *__restrict__ chsums)
 {
@@ -794,7 +1058,8 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries, p.hdr, p.pf, p.groups, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
+    void *ptrs[] = {p.entries, p.hdr, p.pf, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
+                    p.list_st_double, p.list_rs_single, p.list_rs_double, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = Plan();
@@ -861,6 +1126,16 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = plan_upload_list(list, &p.groups)) != hipSuccess) return e;
         p.band_ok = true;
     }
+    p.staged_ok = false;
+    if (fw % 8 == 0 && ((size_t)fw * fh * 3 * ncams) % 16 == 0) {   // row pitch % 8 == 0: both footprint rows share the offset
+        if ((e = hipMalloc(&p.entries_st, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
+        if ((e = hipMalloc(&p.dma, (size_t)p.ntiles * kStageInstr * 64 * sizeof(uint32_t))) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_plan_stage_build, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries),
+                           static_cast<uint32_t *>(p.hdr), p.ntiles, (uint32_t)fw * 3, (uint32_t)((size_t)fw * fh * 3 * ncams),
+                           static_cast<uint2 *>(p.entries_st), static_cast<uint32_t *>(p.dma));
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        p.staged_ok = true;
+    }
     std::vector<uint32_t> hdr((size_t)p.ntiles);
     if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -899,6 +1174,16 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         v.insert(v.end(), ym.begin(), ym.end());
     };
     order(ls); order(ld); order(lw);
+    {
+        std::vector<uint32_t> ss, sd, rs, rd;
+        for (uint32_t t : ls) ((hdr[t] & kHdrStaged) ? ss : rs).push_back(t);
+        for (uint32_t t : ld) ((hdr[t] & kHdrStaged) ? sd : rd).push_back(t);
+        p.n_st_single = (int)ss.size(); p.n_st_double = (int)sd.size(); p.n_rs_single = (int)rs.size(); p.n_rs_double = (int)rd.size();
+        if ((e = plan_upload_list(ss, &p.list_st_single)) != hipSuccess) return e;
+        if ((e = plan_upload_list(sd, &p.list_st_double)) != hipSuccess) return e;
+        if ((e = plan_upload_list(rs, &p.list_rs_single)) != hipSuccess) return e;
+        if ((e = plan_upload_list(rd, &p.list_rs_double)) != hipSuccess) return e;
+    }
     p.n_single = (int)ls.size(); p.n_double = (int)ld.size(); p.n_slow = (int)lw.size(); p.n_empty = (int)le.size();
     if ((e = plan_upload_list(ls, &p.list_single)) != hipSuccess) return e;
     if ((e = plan_upload_list(ld, &p.list_double)) != hipSuccess) return e;
@@ -911,11 +1196,11 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     return hipSuccess;
 }
 
-struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; };
+struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; int staged = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
-                                        int wpb = 4, int lds_pad = 0, bool sums = false)
+                                        int wpb = 4, int lds_pad = 0, bool sums = false, bool pfw = false, bool staged = false)
 {
     hipError_t e;
     if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
@@ -936,18 +1221,47 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
         return hipGetLastError();
     }
+    // class lists: with the LDS-staged schedule the single / double classes split into staged tiles (k_plan_staged, always
+    // 4 waves per block) and the rest (k_plan_lean)
+    void *l_single = staged ? p.list_rs_single : p.list_single, *l_double = staged ? p.list_rs_double : p.list_double;
+    const int n_single = staged ? p.n_rs_single : p.n_single, n_double = staged ? p.n_rs_double : p.n_double;
+    if (staged) {
+        if (sums) a.car = nullptr;
+        const int wpb_keep = wpb;
+        wpb = 4;
+        const dim3 block4(256);
+        if (p.n_st_single) {
+            set_list(p.list_st_single, p.n_st_single);
+            const dim3 grid(grid_blocks());
+            if (blend && sums) hipLaunchKernelGGL((k_plan_staged<LX, 1, true, true>), grid, block4, 0, st, a);
+            else if (blend) hipLaunchKernelGGL((k_plan_staged<LX, 1, true, false>), grid, block4, 0, st, a);
+            else if (sums) hipLaunchKernelGGL((k_plan_staged<LX, 1, false, true>), grid, block4, 0, st, a);
+            else hipLaunchKernelGGL((k_plan_staged<LX, 1, false, false>), grid, block4, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (p.n_st_double) {
+            set_list(p.list_st_double, p.n_st_double);
+            const dim3 grid(grid_blocks());
+            if (blend && sums) hipLaunchKernelGGL((k_plan_staged<LX, 2, true, true>), grid, block4, 0, st, a);
+            else if (blend) hipLaunchKernelGGL((k_plan_staged<LX, 2, true, false>), grid, block4, 0, st, a);
+            else if (sums) hipLaunchKernelGGL((k_plan_staged<LX, 2, false, true>), grid, block4, 0, st, a);
+            else hipLaunchKernelGGL((k_plan_staged<LX, 2, false, false>), grid, block4, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        wpb = wpb_keep;
+    }
     if (sums) {
         // balance on pre-shifted frames: lean kernels + per-tile channel sums; the car is added by k_gain
         a.car = nullptr;
-        if (p.n_single) {
-            set_list(p.list_single, p.n_single);
+        if (n_single) {
+            set_list(l_single, n_single);
             const dim3 grid(grid_blocks());
             if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false, true>), grid, block, lds_pad, st, a);
             else hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false, true>), grid, block, lds_pad, st, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        if (p.n_double) {
-            set_list(p.list_double, p.n_double);
+        if (n_double) {
+            set_list(l_double, n_double);
             const dim3 grid(grid_blocks());
             if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, false, true>), grid, block, 0, st, a);
@@ -968,8 +1282,8 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         }
         return hipSuccess;
     }
-    if (p.n_single) {
-        set_list(p.list_single, p.n_single);
+    if (n_single) {
+        set_list(l_single, n_single);
         const dim3 grid(grid_blocks());
         if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false>), grid, block, 0, st, a);
@@ -981,12 +1295,15 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else if (LX == 4 && abl == 6) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 6, false>), grid, block, 0, st, a);
         else if (LX == 4 && abl == 7) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 7, false>), grid, block, 0, st, a);
         else if (LX == 4 && abl == 8) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 8, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 9) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 9, false>), grid, block, 0, st, a);
+        else if (LX == 4 && abl == 10) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 10, false>), grid, block, 0, st, a);
+        else if (a.pf && pfw) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false, false, true>), grid, block, lds_pad, st, a);
         else if (a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, true>), grid, block, lds_pad, st, a);
         else hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false>), grid, block, lds_pad, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (p.n_double) {
-        set_list(p.list_double, p.n_double);
+    if (n_double) {
+        set_list(l_double, n_double);
         const dim3 grid(grid_blocks());
         if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false>), grid, block, 0, st, a);
@@ -1025,6 +1342,11 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.ncams = p.ncams;
     a.tile_list = nullptr; a.nlist = p.ntiles;
     a.pf = tune.prefetch ? static_cast<const uint32_t *>(p.pf) : nullptr;
+    a.plan_st = static_cast<const uint2 *>(p.entries_st);
+    a.dma = static_cast<const uint32_t *>(p.dma);
+    // LDS-staged schedule: needs 16-byte aligned frame sets (whole-sector DMA) and is not combined with the per-tap
+    // luminance kernel or the ablation modes
+    const bool use_staged = tune.staged && p.staged_ok && !balance && tune.abl == 0 && tune.lean && (((uintptr_t)d_frames) & 15u) == 0;
     a.sink = p.d_max;
     a.nt_store = tune.nt;
     a.batch = batch;
@@ -1046,9 +1368,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, tune.prefetch == 2, use_staged); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

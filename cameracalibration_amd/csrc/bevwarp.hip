@@ -87,6 +87,7 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         if (const char *s = getenv("BEVW_PLAN_PREFETCH")) t.prefetch = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_NT")) t.nt = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_XCDMAP")) t.xcd_map = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         return t;
     }();
@@ -909,8 +910,8 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[2] = h->schedule_in_use;
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
-    info[5] = h->plan.n_single;
-    info[6] = h->plan.n_double;
+    info[5] = h->plan.n_st_single + h->plan.n_st_double;   // tiles on the LDS-staged schedule
+    info[6] = h->plan.n_rs_single + h->plan.n_rs_double;   // single/double tiles left on the L1-gather kernels
     info[7] = h->plan.n_slow;
     return BEVW_OK;
 }
