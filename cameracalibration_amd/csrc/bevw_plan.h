@@ -63,6 +63,9 @@ struct Plan {
     void *list_st_single = nullptr, *list_st_double = nullptr, *list_rs_single = nullptr, *list_rs_double = nullptr;
     int n_st_single = 0, n_st_double = 0, n_rs_single = 0, n_rs_double = 0;
     bool staged_ok = false;
+    // second stream for the tile classes that stay on the gather kernels: they overlap with the staged kernels
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct __attribute__((packed, aligned(1))) PackedU2 { uint32_t x, y; };
@@ -1062,6 +1065,9 @@ static inline void plan_release(Plan &p)
                     p.list_st_double, p.list_rs_single, p.list_rs_double, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p.ev_fork) (void)hipEventDestroy(p.ev_fork);
+    if (p.ev_join) (void)hipEventDestroy(p.ev_join);
+    if (p.side) (void)hipStreamDestroy(p.side);
     p = Plan();
 }
 
@@ -1126,6 +1132,9 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = plan_upload_list(list, &p.groups)) != hipSuccess) return e;
         p.band_ok = true;
     }
+    if ((e = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
     p.staged_ok = false;
     if (fw % 8 == 0 && ((size_t)fw * fh * 3 * ncams) % 16 == 0) {   // row pitch % 8 == 0: both footprint rows share the offset
         if ((e = hipMalloc(&p.entries_st, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
@@ -1196,11 +1205,12 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     return hipSuccess;
 }
 
-struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; int staged = 1; };
+struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int two_streams = 0; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
-                                        int wpb = 4, int lds_pad = 0, bool sums = false, bool pfw = false, bool staged = false)
+                                        int wpb = 4, int lds_pad = 0, bool sums = false, bool pfw = false, bool staged = false,
+                                        bool two_streams = true)
 {
     hipError_t e;
     if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
@@ -1225,6 +1235,8 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     // 4 waves per block) and the rest (k_plan_lean)
     void *l_single = staged ? p.list_rs_single : p.list_single, *l_double = staged ? p.list_rs_double : p.list_double;
     const int n_single = staged ? p.n_rs_single : p.n_single, n_double = staged ? p.n_rs_double : p.n_double;
+    hipStream_t st_main = st;
+    const bool fork = staged && two_streams && p.side != nullptr;
     if (staged) {
         if (sums) a.car = nullptr;
         const int wpb_keep = wpb;
@@ -1249,7 +1261,26 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         wpb = wpb_keep;
+        if (p.n_empty) {
+            set_list(p.list_empty, p.n_empty);
+            const dim3 grid((unsigned)(a.ngroups * a.nchunks));
+            hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (fork) {
+            // everything below (gather-class tiles) goes to the side stream and is joined at the end
+            if ((e = hipEventRecord(p.ev_fork, st_main)) != hipSuccess) return e;   // orders it after earlier work of the call
+            if ((e = hipStreamWaitEvent(p.side, p.ev_fork, 0)) != hipSuccess) return e;
+            st = p.side;
+        }
     }
+    auto join = [&]() -> hipError_t {
+        if (!fork) return hipSuccess;
+        hipError_t je = hipEventRecord(p.ev_join, p.side);
+        if (je != hipSuccess) return je;
+        return hipStreamWaitEvent(st_main, p.ev_join, 0);
+    };
+    const bool skip_empty = staged;
     if (sums) {
         // balance on pre-shifted frames: lean kernels + per-tile channel sums; the car is added by k_gain
         a.car = nullptr;
@@ -1274,13 +1305,13 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
             else hipLaunchKernelGGL((k_stitch_plan<LX, false, false, true>), grid, block, 0, st, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        if (p.n_empty) {
+        if (p.n_empty && !skip_empty) {
             set_list(p.list_empty, p.n_empty);
             const dim3 grid((unsigned)(a.ngroups * a.nchunks));
             hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        return hipSuccess;
+        return join();
     }
     if (n_single) {
         set_list(l_single, n_single);
@@ -1318,13 +1349,13 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (p.n_empty) {
+    if (p.n_empty && !skip_empty) {
         set_list(p.list_empty, p.n_empty);
         const dim3 grid((unsigned)(a.ngroups * a.nchunks));
         hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    return hipSuccess;
+    return join();
 }
 
 // balance = per-tap luminance round trip on RAW frames (generic kernel); sums = frames are already luminance-shifted
@@ -1368,9 +1399,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, tune.prefetch == 2, use_staged); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, tune.prefetch == 2, use_staged, tune.two_streams != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {
