@@ -92,6 +92,32 @@ class Fisheye:
             pass
 
 
+class Normal(Fisheye):
+    """intrinsicCalib.py:108-163 -- pinhole model: cv2.initUndistortRectifyMap with D = k1 k2 p1 p2 k3 (k_pinhole_map)."""
+
+    def __init__(self):
+        super().__init__()
+        self.data.type = "NORMAL"
+
+    def _get_undistort_maps(self):
+        """intrinsicCalib.py:158-163"""
+        _ffi.require_device()
+        self._release()
+        d = self.data
+        dist = np.ascontiguousarray(np.asarray(d.dist_coeff, np.float64).reshape(-1))
+        r = C.c_void_p()
+        check(lib().bevw_pinhole_remapper_create(self._device, int(args.FRAME_WIDTH), int(args.FRAME_HEIGHT),
+                                                 ptr(f64(d.camera_mat, 9)), ptr(dist), int(dist.size),
+                                                 float(args.FOCAL_SCALE), float(args.SIZE_SCALE), 0.0, 0.0, C.byref(r)))
+        self._remapper = r
+        dims = np.zeros(4, np.int32)
+        check(lib().bevw_remapper_dims(r, ptr(dims)))
+        d.map1 = np.empty((dims[3], dims[2], 2), np.int16)
+        d.map2 = np.empty((dims[3], dims[2]), np.uint16)
+        check(lib().bevw_remapper_get_maps(r, ptr(d.map1), ptr(d.map2)))
+        d.ok = True
+
+
 class InCalibrator:
     """intrinsicCalib.py:165-224 -- construction, get_args() and undistort() keep the reference's behaviour."""
 
@@ -99,8 +125,7 @@ class InCalibrator:
         if camera == 'fisheye':
             self.camera = Fisheye()
         elif camera == 'normal':
-            raise Exception("camera type 'normal' (pinhole cv2.initUndistortRectifyMap) is not built yet: "
-                            "SURVEY.md 8(f) item 1")
+            self.camera = Normal()
         else:
             raise Exception("camera should be fisheye/normal")
         self.corners = []

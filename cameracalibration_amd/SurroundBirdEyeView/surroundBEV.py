@@ -250,6 +250,16 @@ class Mask:
             self._mask = self.get_mask()
         return self._mask
 
+    def __call__(self, img):
+        """surroundBEV.py:161-162 (Mask) / :279-280 (BlendMask) as a stand-alone GPU operation."""
+        e = self._eng()
+        img = _ffi.as_u8_image(img)
+        if img.shape[:2] != (e.cfg.bev_height, e.cfg.bev_width):
+            raise Exception("image is {}x{}, BEV is {}x{}".format(img.shape[1], img.shape[0], e.cfg.bev_width, e.cfg.bev_height))
+        out = np.empty_like(img)
+        check(lib().bevw_apply_mask(e.h, self._index, ptr(img), 1, ptr(out)))
+        return out
+
 
 class BlendMask(Mask):
     """surroundBEV.py:164-280.  `.mask` holds the uint8 alpha codes, `.weight` = float32(mask / 255.0) x 3 channels."""

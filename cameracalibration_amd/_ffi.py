@@ -54,12 +54,14 @@ SIGNATURES = {
     "bevw_camera_undistort": (_i, [_vp, _i, _vp, _i, _vp]),
     "bevw_camera_warp_homography": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "bevw_camera_raw2bev": (_i, [_vp, _i, _vp, _i, _vp]),
+    "bevw_apply_mask": (_i, [_vp, _i, _vp, _i, _vp]),
     "bevw_luminance_balance": (_i, [_i, _vp, _i, _i, _i, _vp]),
     "bevw_color_balance": (_i, [_i, _vp, _i, _i, _i, _vp]),
     "bevw_sync": (_i, [_vp]),
     "bevw_timer_start": (_i, [_vp]),
     "bevw_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "bevw_fisheye_remapper_create": (_i, [_i, _i, _i, _vp, _vp, _d, _d, _d, _d, _pvp]),
+    "bevw_pinhole_remapper_create": (_i, [_i, _i, _i, _vp, _vp, _i, _d, _d, _d, _d, _pvp]),
     "bevw_remapper_from_maps": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _pvp]),
     "bevw_remapper_dims": (_i, [_vp, _vp]),
     "bevw_remapper_get_maps": (_i, [_vp, _vp, _vp]),

@@ -46,6 +46,37 @@ __global__ void k_fisheye_map(FisheyeParams p, const double *__restrict__ xs, in
     map2[o] = (uint16_t)((iv & (kQOne - 1)) * kQOne + (iu & (kQOne - 1)));
 }
 
+// cv2.initUndistortRectifyMap(K, D, I, K', size, CV_16SC2) -- pinhole model of Normal._get_undistort_maps
+// (intrinsicCalib.py:158-163).  iR = inv(K') by cofactors (cv::invert, DECOMP_LU, 3x3); for the skew-free K' its
+// off-diagonal terms iR[1], iR[3], iR[6], iR[7] are exactly 0, so the per-column accumulation _x += iR[0] is the same
+// chain for every row (xs[], made by the host in the same serial order) and _y, _w are constant along a row.
+struct PinholeParams {
+    double fx, fy, u0, v0;
+    double k1, k2, p1, p2, k3, k4, k5, k6;
+    double iR4, iR5, iR8;
+};
+
+__global__ void k_pinhole_map(PinholeParams p, const double *__restrict__ xs, int width, int height,
+                              int16_t *__restrict__ map1, uint16_t *__restrict__ map2)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= width || i >= height) return;
+    const double _x = xs[j], _y = (double)i * p.iR4 + p.iR5, _w = (double)i * 0.0 + p.iR8;
+    const double w = 1. / _w, x = _x * w, y = _y * w;
+    const double x2 = x * x, y2 = y * y;
+    const double r2 = x2 + y2, _2xy = 2 * x * y;
+    const double kr = (1 + ((p.k3 * r2 + p.k2) * r2 + p.k1) * r2) / (1 + ((p.k6 * r2 + p.k5) * r2 + p.k4) * r2);
+    const double xd = (x * kr + p.p1 * _2xy + p.p2 * (r2 + 2 * x2));
+    const double yd = (y * kr + p.p1 * (r2 + 2 * y2) + p.p2 * _2xy);
+    const double u = p.fx * xd + p.u0, v = p.fy * yd + p.v0;
+    const int iu = rne_d(u * kQOne), iv = rne_d(v * kQOne);
+    const size_t o = (size_t)i * width + j;
+    map1[o * 2 + 0] = (int16_t)(iu >> kQBits);
+    map1[o * 2 + 1] = (int16_t)(iv >> kQBits);
+    map2[o] = (uint16_t)((iv & (kQOne - 1)) * kQOne + (iu & (kQOne - 1)));
+}
+
 // Camera.get_bev_maps (surroundBEV.py:105-108): cv2.warpPerspective over the CV_16SC2 and CV_16UC1 undistort maps.
 struct Mat3 { double m[9]; };
 
@@ -425,6 +456,24 @@ __global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *
         int v = sat_u8(rne_d((double)in[base + i] * gain[c] + 0.0 * 0.0 + 0.0));
         if (car != nullptr) v = min(255, v + car[i]);
         out[base + i] = (uint8_t)v;
+    }
+}
+
+// Mask.__call__ = cv2.bitwise_and(img, img, mask=mask) (surroundBEV.py:161-162) and
+// BlendMask.__call__ = (img * float32(mask / 255.0)).astype(uint8) (surroundBEV.py:279-280) as stand-alone operations
+// (inside BevGenerator.__call__ they are fused into the stitch kernels).  grid = (blocks, batch)
+__global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask, size_t npx, int blend,
+                             uint8_t *__restrict__ out)
+{
+    const size_t base = (size_t)blockIdx.y * npx * 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += (size_t)gridDim.x * blockDim.x) {
+        const int m = mask[i];
+        const float w = blend_weight_f32(m);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int v = img[base + i * 3 + k];
+            out[base + i * 3 + k] = (uint8_t)(blend ? blend_mul(v, w) : (m != 0 ? v : 0));
+        }
     }
 }
 

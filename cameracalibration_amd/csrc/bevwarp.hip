@@ -311,6 +311,32 @@ static int build_fisheye_maps(hipStream_t st, const double K[9], const double D[
     return BEVW_OK;
 }
 
+// cv2.initUndistortRectifyMap (pinhole) on the device; returns BEVW_E_INVALID when K' has skew (the reference never
+// builds one: intrinsicCalib.py:150-156)
+static int build_pinhole_maps(hipStream_t st, const double K[9], const double D[8], const double Knew[9], int w, int h,
+                              int16_t *d_map1, uint16_t *d_map2)
+{
+    double iR[9];
+    if (!invert3x3(Knew, iR)) return fail(BEVW_E_INVALID, "new camera matrix is singular");
+    if (iR[1] != 0.0 || iR[3] != 0.0 || iR[6] != 0.0 || iR[7] != 0.0)
+        return fail(BEVW_E_INVALID, "new camera matrix with skew / perspective terms is not supported");
+    PinholeParams p;
+    p.fx = K[0]; p.fy = K[4]; p.u0 = K[2]; p.v0 = K[5];
+    p.k1 = D[0]; p.k2 = D[1]; p.p1 = D[2]; p.p2 = D[3]; p.k3 = D[4]; p.k4 = D[5]; p.k5 = D[6]; p.k6 = D[7];
+    p.iR4 = iR[4]; p.iR5 = iR[5]; p.iR8 = iR[8];
+    std::vector<double> xs((size_t)w);
+    double x = 0 * iR[1] + iR[2];
+    for (int j = 0; j < w; ++j) { xs[j] = x; x += iR[0]; }
+    DevBuf dxs;
+    BEVW_TRY(dxs.reserve(sizeof(double) * (size_t)w));
+    HIP_TRY(hipMemcpyAsync(dxs.p, xs.data(), sizeof(double) * (size_t)w, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_pinhole_map, dim3((w + 255) / 256, h), dim3(256), 0, st, p, dxs.as<double>(), w, h, d_map1, d_map2);
+    BEVW_TRY(launch_check("k_pinhole_map"));
+    HIP_TRY(hipStreamSynchronize(st));
+    dxs.release();
+    return BEVW_OK;
+}
+
 static void camera_mat_dst(const double K[9], int fw, int fh, double fs, double ss, double off_h, double off_v,
                            double Kd[9])
 {
@@ -454,6 +480,24 @@ int bevw_fisheye_remapper_create(int device, int frame_width, int frame_height, 
     double Kd[9];
     camera_mat_dst(K, frame_width, frame_height, focal_scale, size_scale, offset_h, offset_v, Kd);
     int s = build_fisheye_maps(r->stream, K, D, Kd, dw, dh, r->map1.as<int16_t>(), r->map2.as<uint16_t>());
+    if (s == BEVW_OK) s = remapper_build_plan(r);
+    if (s != BEVW_OK) { bevw_remapper_destroy(r); return s; }
+    *out = r;
+    return BEVW_OK;
+}
+
+int bevw_pinhole_remapper_create(int device, int frame_width, int frame_height, const double K[9], const double *D, int n_dist,
+                                 double focal_scale, double size_scale, double offset_h, double offset_v, bevw_remapper **out)
+{
+    if (!K || (!D && n_dist > 0) || n_dist < 0) return fail(BEVW_E_INVALID, "null K/D");
+    if (n_dist > 8) return fail(BEVW_E_INVALID, "thin-prism / tilt distortion terms (more than 8 coefficients) are not supported");
+    const int dw = (int)(frame_width * size_scale), dh = (int)(frame_height * size_scale);
+    bevw_remapper *r = nullptr;
+    BEVW_TRY(remapper_alloc(device, frame_width, frame_height, dw, dh, &r));
+    double Kd[9], d8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n_dist; ++i) d8[i] = D[i];
+    camera_mat_dst(K, frame_width, frame_height, focal_scale, size_scale, offset_h, offset_v, Kd);
+    int s = build_pinhole_maps(r->stream, K, d8, Kd, dw, dh, r->map1.as<int16_t>(), r->map2.as<uint16_t>());
     if (s == BEVW_OK) s = remapper_build_plan(r);
     if (s != BEVW_OK) { bevw_remapper_destroy(r); return s; }
     *out = r;
@@ -985,6 +1029,27 @@ int bevw_camera_warp_homography(bevw_handle *h, int cam, const uint8_t *src, int
     if (cam < 0 || cam > 3) return fail(BEVW_E_INVALID, "name should be front/back/left/right");
     return bevw_warp_perspective_u8c3(h->cfg.device, src, src_w, src_h, h->H[cam], h->cfg.bev_width, h->cfg.bev_height,
                                       batch, dst);
+}
+
+int bevw_apply_mask(bevw_handle *h, int cam, const uint8_t *img, int batch, uint8_t *out)
+{
+    BEVW_TRY(need_built(h));
+    if (cam < 0 || cam > 3) return fail(BEVW_E_INVALID, "name should be front/back/left/right");
+    if (!img || !out || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (batch == 0) return BEVW_OK;
+    const size_t npx = (size_t)h->cfg.bev_width * h->cfg.bev_height, n = npx * 3 * (size_t)batch;
+    BEVW_TRY(h->in.reserve(n));
+    BEVW_TRY(h->out.reserve(n));
+    HIP_TRY(hipMemcpyAsync(h->in.p, img, n, hipMemcpyHostToDevice, h->stream));
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        hipLaunchKernelGGL(k_apply_mask, dim3(256, nb), dim3(256), 0, h->stream, h->in.as<uint8_t>() + (size_t)b0 * npx * 3,
+                           h->mask[cam].as<uint8_t>(), npx, h->cfg.blend, h->out.as<uint8_t>() + (size_t)b0 * npx * 3);
+    }
+    BEVW_TRY(launch_check("k_apply_mask"));
+    HIP_TRY(hipMemcpyAsync(out, h->out.p, n, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BEVW_OK;
 }
 
 int bevw_luminance_balance(int device, const uint8_t *frames, int batch, int width, int height, uint8_t *out)

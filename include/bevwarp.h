@@ -105,6 +105,11 @@ int bevw_camera_warp_homography(bevw_handle *h, int cam, const uint8_t *src, int
                                 uint8_t *dst);
 int bevw_camera_raw2bev(bevw_handle *h, int cam, const uint8_t *src, int batch, uint8_t *dst);
 
+/* Mask.__call__ (surroundBEV.py:161-162, blend = 0: cv2.bitwise_and(img, img, mask=mask)) and BlendMask.__call__
+ * (surroundBEV.py:279-280, blend = 1: (img * float32(mask / 255.0)).astype(uint8)) with the handle's mask of `cam`.
+ * img / out: [batch][BH][BW][3].  Inside bevw_run the same arithmetic is fused into the stitch kernels. */
+int bevw_apply_mask(bevw_handle *h, int cam, const uint8_t *img, int batch, uint8_t *out);
+
 /* Module-level helpers of surroundBEV.py, exposed because the reference exports them:
  * luminance_balance(images) (:57-79): frames [batch][4][H][W][3] -> same shape;
  * color_balance(image) (:43-55): image [batch][H][W][3] -> same shape. */
@@ -122,6 +127,11 @@ int bevw_timer_stop(bevw_handle *h, float *elapsed_ms); /* records + synchronise
  * K' = K, f *= focal_scale, c = (fw/2*size_scale + offset_h, fh/2*size_scale + offset_v)
  * (intrinsicCalib.py:90-103; offsets: Tools/undistort.py:45-46). */
 int bevw_fisheye_remapper_create(int device, int frame_width, int frame_height, const double K[9], const double D[4],
+                                 double focal_scale, double size_scale, double offset_h, double offset_v,
+                                 bevw_remapper **out);
+/* Same for the pinhole ("normal") model: cv2.initUndistortRectifyMap(K, D, I, K', size, CV_16SC2) with
+ * D = k1 k2 p1 p2 [k3 [k4 k5 k6]] (n_dist = 4, 5 or 8)  (Normal._get_undistort_maps, intrinsicCalib.py:150-163). */
+int bevw_pinhole_remapper_create(int device, int frame_width, int frame_height, const double K[9], const double *D, int n_dist,
                                  double focal_scale, double size_scale, double offset_h, double offset_v,
                                  bevw_remapper **out);
 /* Wraps caller-made maps (map1 CV_16SC2 [dh][dw][2], map2 CV_16UC1 [dh][dw]) for sources of size src_w x src_h. */

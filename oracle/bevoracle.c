@@ -113,6 +113,41 @@ ORC_API void orc_fisheye_undistort_map(const double K[9], const double D[4], con
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* A.1b cv2.initUndistortRectifyMap(K, D, I, K', size, CV_16SC2)  -- the pinhole ("normal") camera model   */
+/*      reference: Normal._get_undistort_maps intrinsicCalib.py:158-163                                    */
+/* ------------------------------------------------------------------------------------------------ */
+/* iR = inv(K' * I) with DECOMP_LU, which for a 3x3 matrix is the cofactor formula (orc_invert3x3, defined below).
+ * D holds k1 k2 p1 p2 k3 [k4 k5 k6]; thin-prism and tilt terms are zero in the reference's calibration output
+ * (the tilt matrix is the identity, so xd, yd pass through unchanged).  Scalar C++ path of OpenCV (no FMA);
+ * builds with an AVX2/FMA dispatch of this loop may differ in the last ulp (version-sensitive, see header). */
+ORC_API int orc_invert3x3(const double m[9], double t[9]);
+ORC_API void orc_pinhole_undistort_map(const double K[9], const double D[8], const double iR[9], int width, int height,
+                                       int16_t *map1, uint16_t *map2)
+{
+    const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
+    const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4], k4 = D[5], k5 = D[6], k6 = D[7];
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < height; ++i) {
+        double _x = i * iR[1] + iR[2], _y = i * iR[4] + iR[5], _w = i * iR[7] + iR[8];
+        int16_t *m1 = map1 + (size_t)i * width * 2;
+        uint16_t *m2 = map2 + (size_t)i * width;
+        for (int j = 0; j < width; ++j, _x += iR[0], _y += iR[3], _w += iR[6]) {
+            double w = 1. / _w, x = _x * w, y = _y * w;
+            double x2 = x * x, y2 = y * y;
+            double r2 = x2 + y2, _2xy = 2 * x * y;
+            double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+            double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2));
+            double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy);
+            double u = fx * xd + u0, v = fy * yd + v0;
+            int iu = rne_d(u * Q_ONE), iv = rne_d(v * Q_ONE);
+            m1[j * 2 + 0] = (int16_t)(iu >> Q_BITS);
+            m1[j * 2 + 1] = (int16_t)(iv >> Q_BITS);
+            m2[j] = (uint16_t)((iv & (Q_ONE - 1)) * Q_ONE + (iu & (Q_ONE - 1)));
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* A.2  cv2.warpPerspective coordinate generation (inverse map, Q5 quantisation)                      */
 /*      reference: surroundBEV.py:113-114, extrinsicCalib.py:166-169                                  */
 /* ------------------------------------------------------------------------------------------------ */

@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
             "orc_newcam_inverse": (None, [vp, vp]),
             "orc_fisheye_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
             "orc_invert3x3": (i32, [vp, vp]),
+            "orc_pinhole_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
             "orc_perspective_coords": (None, [vp, i32, i32, vp, vp]),
             "orc_remap_s16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
             "orc_remap_u16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
@@ -130,6 +131,20 @@ def fisheye_init_undistort_rectify_map(K, D, Knew, size):
     m1 = np.empty((h, w, 2), np.int16)
     m2 = np.empty((h, w), np.uint16)
     lib().orc_fisheye_undistort_map(_p(K), _p(D), _p(iR), w, h, _p(m1), _p(m2))
+    return m1, m2
+
+
+def init_undistort_rectify_map(K, D, Knew, size):
+    """cv2.initUndistortRectifyMap(K, D, eye(3), Knew, size, CV_16SC2)  (intrinsicCalib.py:158-163, pinhole model)."""
+    w, h = int(size[0]), int(size[1])
+    K = _c(K, np.float64).reshape(9)
+    d = np.zeros(8, np.float64)
+    dv = _c(D, np.float64).reshape(-1)
+    d[:min(8, dv.size)] = dv[:8]
+    iR = invert3x3(np.asarray(Knew, np.float64)).reshape(9).copy()
+    m1 = np.empty((h, w, 2), np.int16)
+    m2 = np.empty((h, w), np.uint16)
+    lib().orc_pinhole_undistort_map(_p(K), _p(d), _p(iR), w, h, _p(m1), _p(m2))
     return m1, m2
 
 

@@ -344,3 +344,29 @@ np.save({str(tmp_path)!r} + '/surround.npy', surround)
     cfg = dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350)
     want = oracle.RefBevGenerator(repo_rig.rig, cfg, blend=True, balance=True)(*repo_rig.frames())
     assert np.array_equal(np.load(tmp_path / "surround.npy"), want)
+
+
+@pytest.mark.parametrize("blend", [False, True])
+def test_mask_call_standalone(ffi, SB, oracle, blend):
+    """Mask.__call__ / BlendMask.__call__ (surroundBEV.py:161-162, 279-280) outside the fused stitch."""
+    rig = small_rig()
+    bev, ref = make_pair(SB, oracle, rig, SMALL_CFG, blend, False)
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (SMALL_CFG["BEV_HEIGHT"], SMALL_CFG["BEV_WIDTH"], 3), dtype=np.uint8)
+    for i in range(4):
+        assert np.array_equal(bev.masks[i](img), ref.apply_mask(i, img)), i
+
+
+def test_incalibrator_normal_pinhole(ffi, oracle, repo_rig):
+    """InCalibrator('normal') (intrinsicCalib.py:150-163, 193-195): pinhole undistort maps + remap, 5 and 8 coefficients."""
+    from cameracalibration_amd.IntrinsicCalibration import InCalibrator
+
+    img = repo_rig.image("incalib")  # 1280 x 1024
+    K = np.array([[820.0, 0, 655.3], [0, 815.5, 500.7], [0, 0, 1]])
+    for D in ([-0.31, 0.12, 0.0011, -0.0007, -0.02], [-0.2, 0.05, 0.001, 0.002, 0.01, 0.02, -0.01, 0.003], [0.05, -0.01, 0, 0]):
+        cal = InCalibrator("normal")
+        data = cal.set_calibration(K, D)
+        Kd = oracle.camera_mat_dst(K, 1280, 1024, 0.5, 1)
+        m1, m2 = oracle.init_undistort_rectify_map(K, D, Kd, (1280, 1024))
+        assert np.array_equal(data.map1, m1) and np.array_equal(data.map2, m2)
+        assert np.array_equal(cal.undistort(img), oracle.remap(img, m1, m2))

@@ -224,3 +224,29 @@ def test_weight_mul_truncates_all_pairs(oracle):
     lib().orc_weight_mul(_p(img), _p(w), img.size, _p(out))
     assert np.array_equal(out, (img * w).astype(np.uint8))
     assert out[255 * 256 + 255] == 255 and out[128 * 256 + 255] == 128
+
+
+def test_pinhole_map_identity_and_radial(oracle):
+    """cv2.initUndistortRectifyMap known answers: D = 0 and K' = K is the identity map; a pure k1 term moves a pixel
+    radially by x * k1 * r^2 (hand-computed), and the fixed-point split is the same Q5 packing as the fisheye map."""
+    K = np.array([[400.0, 0, 320.0], [0, 410.0, 240.0], [0, 0, 1]])
+    m1, m2 = oracle.init_undistort_rectify_map(K, np.zeros(5), K, (640, 480))
+    xs, ys = np.meshgrid(np.arange(640), np.arange(480))
+    # iR = cofactor inverse of K: u = fx * ((j - cx) / fx) + cx may be off by an ulp, far below 1/32 px
+    assert np.array_equal(m1[..., 0], xs) and np.array_equal(m1[..., 1], ys) and (m2 == 0).all()
+    k1 = 0.1
+    m1, m2 = oracle.init_undistort_rectify_map(K, [k1, 0, 0, 0, 0], K, (640, 480))
+    j, i = 600, 100
+    x, y = (j - 320.0) / 400.0, (i - 240.0) / 410.0
+    r2 = x * x + y * y
+    u, v = 400.0 * x * (1 + k1 * r2) + 320.0, 410.0 * y * (1 + k1 * r2) + 240.0
+    iu, iv = int(np.rint(u * 32)), int(np.rint(v * 32))
+    assert (m1[i, j, 0], m1[i, j, 1]) == (iu >> 5, iv >> 5)
+    assert m2[i, j] == (iv & 31) * 32 + (iu & 31)
+    # tangential terms: p1 shifts x by 2 p1 x y and y by p1 (r2 + 2 y2)
+    p1 = 0.01
+    m1, m2 = oracle.init_undistort_rectify_map(K, [0, 0, p1, 0, 0], K, (640, 480))
+    u = 400.0 * (x + p1 * 2 * x * y) + 320.0
+    v = 410.0 * (y + p1 * (r2 + 2 * y * y)) + 240.0
+    iu, iv = int(np.rint(u * 32)), int(np.rint(v * 32))
+    assert (m1[i, j, 0], m1[i, j, 1]) == (iu >> 5, iv >> 5)
