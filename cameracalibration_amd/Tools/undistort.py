@@ -1,0 +1,128 @@
+"""Batch fisheye undistortion of a directory of images -- the reference's Tools/undistort.py (:25-77) on the GPU.
+
+Same flags and defaults (Tools/undistort.py:7-23); the maps come from bevw_fisheye_remapper_create (k_fisheye_map) with the
+optical-axis offsets of :45-46, the pixels from bevw_remap (all images of the directory in one batch).  File decode / encode
+uses Pillow instead of cv2.imread / cv2.imwrite (same codecs: libjpeg-turbo, libpng).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _ffi
+from .._ffi import check, f64, lib, ptr
+
+parser = argparse.ArgumentParser(description="Fisheye Camera Undistortion")
+parser.add_argument('-width', default=1280, type=int, help='Camera Frame Width')
+parser.add_argument('-height', default=1024, type=int, help='Camera Frame Height')
+parser.add_argument('-load', default=True, type=bool, help='Load New Camera K/D Data (True/False)')
+parser.add_argument('-path_read', default='./data/', type=str, help='Original Image Read Path')
+parser.add_argument('-path_save', default='./', type=str, help='Undistortion Image Save Path')
+parser.add_argument('-path_k', default='./data/camera_0_K.npy', type=str, help='Camera K File Path')
+parser.add_argument('-path_d', default='./data/camera_0_D.npy', type=str, help='Camera D File Path')
+parser.add_argument('-focalscale', default=1, type=float, help='Camera Undistortion Focal Scale')
+parser.add_argument('-sizescale', default=1, type=float, help='Camera Undistortion Size Scale')
+parser.add_argument('-offset_h', default=0, type=float, help='Horizontal Offset of Optical Axis')
+parser.add_argument('-offset_v', default=0, type=float, help='Vertical Offset of Optical Axis')
+parser.add_argument('-srcformat', default='jpg', type=str, help='Original Image Format (jpg/png)')
+parser.add_argument('-dstformat', default='jpg', type=str, help='Final Image Format (jpg/png)')
+parser.add_argument('-quality', default=100, type=int, help='Save Image Quality (jpg:0-100, png:9-0 (low-high))')
+parser.add_argument('-name', default=None, type=str, help='Save Image Name')
+
+# Tools/undistort.py:28-32: the built-in calibration used with -load False (identical to data/front's K and D)
+DEFAULT_K = np.array([[350.4931893001142, 0.0, 647.6297467576265],
+                      [0.0, 352.43072872484805, 513.5196785119657],
+                      [0.0, 0.0, 1.0]])
+DEFAULT_D = np.array([[-0.03367245449576437], [0.015380779195912842], [-0.018654590946883556], [0.0058128945633924185]])
+
+
+class Undistorter:
+    """The map set of one (K, D, size, scales, offsets) on the device."""
+
+    def __init__(self, K, D, width, height, focalscale=1.0, sizescale=1.0, offset_h=0.0, offset_v=0.0, device=0):
+        _ffi.require_device()
+        self.width, self.height = int(width), int(height)
+        r = C.c_void_p()
+        check(lib().bevw_fisheye_remapper_create(device, self.width, self.height, ptr(f64(K, 9)), ptr(f64(D, 4)),
+                                                 float(focalscale), float(sizescale), float(offset_h), float(offset_v),
+                                                 C.byref(r)))
+        self._r = r
+        dims = np.zeros(4, np.int32)
+        check(lib().bevw_remapper_dims(r, ptr(dims)))
+        self.out_w, self.out_h = int(dims[2]), int(dims[3])
+
+    def maps(self):
+        m1 = np.empty((self.out_h, self.out_w, 2), np.int16)
+        m2 = np.empty((self.out_h, self.out_w), np.uint16)
+        check(lib().bevw_remapper_get_maps(self._r, ptr(m1), ptr(m2)))
+        return m1, m2
+
+    def __call__(self, images):
+        """uint8 [B, height, width, 3] (or one [height, width, 3]) -> undistorted images of the map size."""
+        imgs = np.ascontiguousarray(images)
+        single = imgs.ndim == 3
+        if single:
+            imgs = imgs[np.newaxis]
+        if imgs.dtype != np.uint8 or imgs.shape[1:] != (self.height, self.width, 3):
+            raise Exception("images must be uint8 [B, {}, {}, 3]".format(self.height, self.width))
+        out = np.empty((imgs.shape[0], self.out_h, self.out_w, 3), np.uint8)
+        check(lib().bevw_remap(self._r, ptr(imgs), imgs.shape[0], ptr(out)))
+        return out[0] if single else out
+
+    def close(self):
+        if self._r:
+            lib().bevw_remapper_destroy(self._r)
+            self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def main(argv=None):
+    from PIL import Image
+
+    args = parser.parse_args(argv)
+    if not args.load:
+        camera_mat, dist_coeff = DEFAULT_K, DEFAULT_D
+    else:
+        if not os.path.exists(args.path_k):
+            raise Exception("Camera K File Path not exist")
+        if not os.path.exists(args.path_d):
+            raise Exception("Camera D File Path not exist")
+        camera_mat, dist_coeff = np.load(args.path_k), np.load(args.path_d)
+    if not os.path.exists(args.path_read):
+        raise Exception("Original Image Read Path not exist")
+    if not os.path.exists(args.path_save):
+        raise Exception("Undistortion Image Save Path not exist")
+    und = Undistorter(camera_mat, dist_coeff, args.width, args.height, args.focalscale, args.sizescale, args.offset_h,
+                      args.offset_v)
+    names = [f for f in os.listdir(args.path_read) if f[-4:] == '.' + args.srcformat]
+    if not names:
+        return 0
+    batch = np.stack([np.ascontiguousarray(np.asarray(Image.open(os.path.join(args.path_read, f)).convert("RGB"))[:, :, ::-1])
+                      for f in names])
+    out = und(batch)
+    index = 1
+    for filename, img in zip(names, out):
+        print(filename)
+        if args.name is not None:
+            filename = args.name + '_{:04d}.'.format(index) + args.srcformat
+            index += 1
+        pil = Image.fromarray(np.ascontiguousarray(img[:, :, ::-1]))
+        if args.dstformat == 'jpg':
+            pil.save(os.path.join(args.path_save, filename[:-4] + '.jpg'), quality=args.quality, subsampling=0 if args.quality >= 100 else -1)
+        elif args.dstformat == 'png':
+            pil.save(os.path.join(args.path_save, filename[:-4] + '.png'), compress_level=min(9, max(0, args.quality)))
+        else:
+            pil.save(filename[:-4] + '.' + args.dstformat)
+    return len(names)
+
+
+if __name__ == '__main__':
+    main()
