@@ -871,6 +871,9 @@ __global__ void __launch_bounds__(64) k_plan_stage_build(const uint2 *__restrict
     __syncthreads();
     const int count = s_count;
     if (!fits || count == 0) return;
+    // The staged kernel needs no quad coalescing, so interleaved tiles are rewritten to store order here: compute pixel
+    // (slot j of lane l) -> the lane that STORES it (lane (l & ~3) + j, slot l & 3) -- and the LDS exchange disappears.
+    const bool inter = (h & kHdrInterleaved) != 0;
     for (int k = 0; k < 8; ++k) {
         uint2 o = make_uint2(0u, e[k].y & ~kMetaValid);
         if (e[k].y & kMetaValid) {
@@ -879,7 +882,9 @@ __global__ void __launch_bounds__(64) k_plan_stage_build(const uint2 *__restrict
             for (int i = 0; i < count; ++i) { if (list[i] == (o0 >> 6)) s0 = i; if (list[i] == (o1 >> 6)) s1 = i; }
             o = make_uint2((s0 * 64 + (o0 & 63u)) | ((s1 * 64 + (o1 & 63u)) << 16), e[k].y);
         }
-        plan_st[((size_t)tile * 8 + k) * 64 + lane] = o;
+        const int j = k & 3, sl = k & 4;
+        const int dst_lane = inter ? (lane & ~3) + j : lane, dst_slot = inter ? sl + (lane & 3) : k;
+        plan_st[((size_t)tile * 8 + dst_slot) * 64 + dst_lane] = o;
     }
     for (int k = 0; k < kStageInstr; ++k) {
         const int slot = k * 16 + lane / 4;
@@ -892,9 +897,11 @@ template <int LX, int NSLOT, bool BLEND, bool SUMS>
 __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
-    __shared__ __attribute__((aligned(16))) uint8_t stage_a[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_b[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    // three LDS patches per wave: frame b is read while b+1 and b+2 are in flight (one HBM round trip is longer than one
+    // frame of work of all the waves of a SIMD, so a plain double buffer still stalls on every frame)
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
     uint32_t chunk, group;
     if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
     const int lane = threadIdx.x & 63;
@@ -903,7 +910,6 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
     if (slot >= a.nlist) return;
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
-    const bool interleaved = (hdr & kHdrInterleaved) != 0;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     int lx_, ly_;
     lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
@@ -912,8 +918,9 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
     const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
 
-    // per entry: qword index of the 16-byte window (two 8-byte aligned LDS words, one ds_read2_b64) of each footprint
-    // row inside the wave's patch, byte offset 0..7 of the footprint inside it, x / y weights (as in k_plan_lean)
+    // per entry (already in store order: k_plan_stage_build): qword index of the 16-byte window (two 8-byte aligned LDS
+    // words, one ds_read2_b64) of each footprint row inside the wave's patch, byte offset 0..7 of the footprint inside
+    // it, x / y weights (as in k_plan_lean)
     uint32_t i0[NSLOT][4], i1[NSLOT][4], mis[NSLOT][4], wx[NSLOT][4], wy[NSLOT][4];
     float wf[NSLOT][4];
 #pragma unroll
@@ -940,17 +947,14 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
     const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
 
     typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    typedef const __attribute__((address_space(1))) void gvoid;
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
     const uint8_t *fb = a.frames + (size_t)b_begin * set_bytes;
     uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
 
-    // Two SEPARATE LDS arrays (ping / pong) and a 2x unrolled frame loop: the compiler tracks LDS-DMA writes per
-    // destination object, so reads of one array need not wait for the DMA that is filling the other.
     // The LDS-DMA is issued through inline asm: the compiler orders every later LDS read behind ALL pending LDS-DMA it
-    // knows about (vmcnt(0)), which would serialise the double buffer.  Hidden from it, only the explicit vmcnt below
-    // governs the patches.  (Unknown vector loads can only make compiler-placed vmcnt waits longer, never shorter:
-    // loads retire in issue order.)
+    // knows about (vmcnt(0)), which would serialise the ring.  Hidden from it, only the explicit vmcnt below governs
+    // the patches.  (Unknown vector loads can only make compiler-placed vmcnt waits longer, never shorter: loads retire
+    // in issue order.)
     auto stage_frame = [&](const uint8_t *src, uint8_t *dst_generic) {
         const uint32_t dst = (uint32_t)(uintptr_t)(lds_u8 *)dst_generic;
 #pragma unroll
@@ -959,11 +963,14 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst + k * 1024), "v"(g) : "memory", "m0");
         }
     };
-    auto one_frame = [&](const uint8_t *patch_cur, uint8_t *patch_next, int b) {
-        // start the next frame's sectors (the last iteration re-stages its own frame: uniform instruction count)
-        stage_frame(b + 1 < b_end ? fb + set_bytes : fb, patch_next);
-        // the kStageInstr DMAs just issued may stay in flight; everything older (this frame's patch) must have landed
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStageInstr) : "memory");
+    auto one_frame = [&](const uint8_t *patch_cur, uint8_t *patch_fill, int b) {
+        // refill the patch that frame b-1 used with frame b+2 (past the end of the chunk: the last frame again, so the
+        // instruction count per iteration is uniform)
+        const int ahead = min(b + 2, b_end - 1) - b;
+        stage_frame(fb + (size_t)ahead * set_bytes, patch_fill);
+        // at most the 2 * kStageInstr youngest vector-memory operations may still be in flight: frame b's patch (issued
+        // two iterations ago) has landed, whether or not the store of frame b-1 is among the youngest
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr) : "memory");
         const uint2 *w = reinterpret_cast<const uint2 *>(patch_cur);
         uint32_t P[4];
         {
@@ -1015,7 +1022,6 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
                 ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
             }
         }
-        if (interleaved) quad_exchange(P, xpose + wave * 256, lane);
         if (car_any) add_car(P, car0, car1, car2);
         if (inimg) {
             uint32_t d0, d1, d2;
@@ -1026,12 +1032,14 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
         fb += set_bytes;
         ob += img_bytes;
     };
-    uint8_t *const ping = stage_a + wave * kStageBytes, *const pong = stage_b + wave * kStageBytes;
-    stage_frame(fb, ping);
+    uint8_t *const p0 = stage_0 + wave * kStageBytes, *const p1 = stage_1 + wave * kStageBytes, *const p2 = stage_2 + wave * kStageBytes;
+    stage_frame(fb, p0);
+    stage_frame(b_begin + 1 < b_end ? fb + set_bytes : fb, p1);
 #pragma unroll 1
-    for (int b = b_begin; b < b_end; b += 2) {
-        one_frame(ping, pong, b);
-        if (b + 1 < b_end) one_frame(pong, ping, b + 1);
+    for (int b = b_begin; b < b_end; b += 3) {
+        one_frame(p0, p2, b);
+        if (b + 1 < b_end) one_frame(p1, p0, b + 1);
+        if (b + 2 < b_end) one_frame(p2, p1, b + 2);
     }
 }
 
