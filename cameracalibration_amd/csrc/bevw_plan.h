@@ -590,15 +590,14 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 // arithmetic, no stores), 8 = 5 on a cache-resident source
 // PFW (experiment): touch THIS frame's sectors with one instruction and wait for them before the gathers (all-hit gathers)
 template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false, bool PFW = false>
-__global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
+__device__ __forceinline__ void plan_lean_body(const PlanArgs &a, uint32_t block_id, int waves_per_block, uint32_t *xpose)
 {
     constexpr int LY = 64 / LX;
     uint32_t chunk, group;
-    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    if (!plan_block_map(a, block_id, chunk, group)) return;
     const int lane = threadIdx.x & 63;
-    const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int slot = (int)group * waves_per_block + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[16 * 256];
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
     const bool interleaved = (hdr & kHdrInterleaved) != 0;
@@ -789,6 +788,13 @@ __global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
     if ((pf_acc ^ pfa_prev ^ pfb_prev) == 0x9e3779b9u) *a.sink = 1;   // keeps the prefetch loads alive (scratch word, not the output)
 }
 
+template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false, bool PFW = false>
+__global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[16 * 256];
+    plan_lean_body<LX, NSLOT, BLEND, ABL, PF, SUMS, PFW>(a, blockIdx.x, (int)(blockDim.x >> 6), xpose);
+}
+
 // tiles without any contributor (under the car): out = car (or 0) for every frame of the chunk
 template <int LX>
 __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a)
@@ -893,17 +899,15 @@ __global__ void __launch_bounds__(64) k_plan_stage_build(const uint2 *__restrict
     if (lane == 0) hdr[tile] = h | kHdrStaged;
 }
 
+// three LDS patches per wave (stage_0/1/2, 4 waves x kStageBytes each): frame b is read while b+1 and b+2 are in flight (one
+// HBM round trip is longer than one frame of work of all the waves of a SIMD, so a plain double buffer still stalls)
 template <int LX, int NSLOT, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
+__device__ __forceinline__ void plan_staged_body(const PlanArgs &a, uint32_t block_id, uint8_t *stage_0, uint8_t *stage_1,
+                                                 uint8_t *stage_2)
 {
     constexpr int LY = 64 / LX;
-    // three LDS patches per wave: frame b is read while b+1 and b+2 are in flight (one HBM round trip is longer than one
-    // frame of work of all the waves of a SIMD, so a plain double buffer still stalls on every frame)
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
     uint32_t chunk, group;
-    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    if (!plan_block_map(a, block_id, chunk, group)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = (int)group * 4 + wave;
@@ -1041,6 +1045,32 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
         if (b + 1 < b_end) one_frame(p1, p0, b + 1);
         if (b + 2 < b_end) one_frame(p2, p1, b + 2);
     }
+}
+
+template <int LX, int NSLOT, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
+    plan_staged_body<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, stage_0, stage_1, stage_2);
+}
+
+// Staged (VALU / LDS bound) and gather (vector-memory bound) single-contributor tiles in ONE launch: blocks of the two
+// kinds are interleaved in groups of 8 (a group keeps block id % 8, i.e. its XCD), so both kinds are resident on every
+// CU at the same time and their different bottlenecks overlap.  Gather blocks use the first 4 KB of the staging memory
+// as their quad-exchange patch.
+template <int LX, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_fused(PlanArgs a_st, PlanArgs a_ga, uint32_t nsuper_st, uint32_t nsuper_ga)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
+    const uint32_t super = blockIdx.x >> 3, l8 = blockIdx.x & 7u, total = nsuper_st + nsuper_ga;
+    const uint32_t g_before = (uint32_t)(((uint64_t)super * nsuper_ga) / total);
+    const bool is_ga = (uint32_t)(((uint64_t)(super + 1) * nsuper_ga) / total) > g_before;
+    if (is_ga) plan_lean_body<LX, 1, BLEND, 0, false, SUMS, false>(a_ga, (g_before << 3) | l8, 4, reinterpret_cast<uint32_t *>(stage_0));
+    else plan_staged_body<LX, 1, BLEND, SUMS>(a_st, ((super - g_before) << 3) | l8, stage_0, stage_1, stage_2);
 }
 
 // psums[b][tile][3] -> chsums[b][3] ; grid = batch, block = 256
@@ -1213,12 +1243,12 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     return hipSuccess;
 }
 
-struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int two_streams = 0; };
+struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int two_streams = 0; int fuse = 0; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
                                         int wpb = 4, int lds_pad = 0, bool sums = false, bool pfw = false, bool staged = false,
-                                        bool two_streams = true)
+                                        bool two_streams = true, bool fuse = true)
 {
     hipError_t e;
     if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
@@ -1242,7 +1272,8 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     // class lists: with the LDS-staged schedule the single / double classes split into staged tiles (k_plan_staged, always
     // 4 waves per block) and the rest (k_plan_lean)
     void *l_single = staged ? p.list_rs_single : p.list_single, *l_double = staged ? p.list_rs_double : p.list_double;
-    const int n_single = staged ? p.n_rs_single : p.n_single, n_double = staged ? p.n_rs_double : p.n_double;
+    int n_single = staged ? p.n_rs_single : p.n_single;
+    const int n_double = staged ? p.n_rs_double : p.n_double;
     hipStream_t st_main = st;
     const bool fork = staged && two_streams && p.side != nullptr;
     if (staged) {
@@ -1250,7 +1281,28 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         const int wpb_keep = wpb;
         wpb = 4;
         const dim3 block4(256);
-        if (p.n_st_single) {
+        bool fused_singles = false;
+        if (fuse && p.n_st_single && p.n_rs_single) {
+            // one launch for both single-contributor classes (k_plan_fused)
+            PlanArgs a_st = a, a_ga = a;
+            a_st.tile_list = static_cast<const uint32_t *>(p.list_st_single); a_st.nlist = p.n_st_single; a_st.ngroups = (p.n_st_single + 3) / 4;
+            a_ga.tile_list = static_cast<const uint32_t *>(p.list_rs_single); a_ga.nlist = p.n_rs_single; a_ga.ngroups = (p.n_rs_single + 3) / 4;
+            auto blocks_of = [&](const PlanArgs &q) -> unsigned {
+                if (q.xcd_affine == 1) return (unsigned)(q.ngroups * (((q.nchunks + 7) / 8) * 8));
+                if (q.xcd_affine == 2) return (unsigned)(((q.ngroups + 7) / 8) * 8 * q.nchunks);
+                return (unsigned)(q.ngroups * q.nchunks);
+            };
+            const unsigned ns_st = (blocks_of(a_st) + 7) / 8, ns_ga = (blocks_of(a_ga) + 7) / 8;
+            const dim3 grid((ns_st + ns_ga) * 8);
+            if (blend && sums) hipLaunchKernelGGL((k_plan_fused<LX, true, true>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
+            else if (blend) hipLaunchKernelGGL((k_plan_fused<LX, true, false>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
+            else if (sums) hipLaunchKernelGGL((k_plan_fused<LX, false, true>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
+            else hipLaunchKernelGGL((k_plan_fused<LX, false, false>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            fused_singles = true;
+            n_single = 0;   // the gather singles ran inside the fused launch
+        }
+        if (p.n_st_single && !fused_singles) {
             set_list(p.list_st_single, p.n_st_single);
             const dim3 grid(grid_blocks());
             if (blend && sums) hipLaunchKernelGGL((k_plan_staged<LX, 1, true, true>), grid, block4, 0, st, a);
@@ -1407,9 +1459,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, tune.prefetch == 2, use_staged, tune.two_streams != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0, tune.fuse != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, 0, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0, tune.fuse != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, tune.prefetch == 2, use_staged, tune.two_streams != 0, tune.fuse != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

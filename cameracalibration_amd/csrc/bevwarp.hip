@@ -89,6 +89,7 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         if (const char *s = getenv("BEVW_PLAN_XCDMAP")) t.xcd_map = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_TWOSTREAMS")) t.two_streams = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_FUSE")) t.fuse = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         return t;
     }();
