@@ -122,6 +122,17 @@ def aggregate(world: int, batch: int, steps: int, wall: float, ev_ms: float, alg
             "achieved_gbs": alg_bytes * batch / (launch_ms * 1e-3) / 1e9}
 
 
+def measured_traffic(workload: str, batch: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(workload)
+        if rec and rec.get("units_per_launch") == batch:
+            return rec["fetch_bytes"] + rec["write_bytes"]
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def upload_replicated(buf, unique: np.ndarray, batch: int):
     per = unique[0].nbytes
     for b in range(batch):
@@ -278,7 +289,7 @@ def main():
                         "sharding": "frames across ranks, no data-path collective", "device": _ffi.device_name(dev),
                         "unique_frame_sets": int(a.unique_sets)}, **extra),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload, batch),
                      "kernel_ms": launch_ms, "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
         "cpu_baseline": cpu,
     }
