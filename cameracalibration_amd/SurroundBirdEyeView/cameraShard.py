@@ -1,0 +1,398 @@
+"""Camera-per-GPU surround BEV: every rank stitches the cameras it owns, one exchange, the stitch rank adds the parts.
+
+The reference has no multi-GPU code; this module is the scale-out form of ``BevGenerator.__call__``
+(surroundBEV.py:312-325) for BASELINE config 5.  It leans on one arithmetic fact: the reference
+combines the four masked images and the car with ``cv2.add`` (surroundBEV.py:318-320, 323-324), which saturates, so the
+result is ``min(255, sum)`` however the terms are grouped.  A rank therefore adds its own cameras first
+(``bevw_shard_run_device``), sends the bounding box of its masks, and the stitch rank adds the boxes
+(``bevw_combine_device``) -- never a summing collective, u8 sums would wrap.
+
+    ranks 4g .. 4g+3 form camera group g: rank 4g+c owns camera c (front, back, left, right)      [world 4, 8, 12 ..]
+    world 2: rank 0 owns front+back, rank 1 owns left+right;  world 1: one rank owns all four (no exchange)
+    groups are replicas: each works on its own frame sets, as in batch sharding.
+
+With balance=True there is one more (tiny) exchange before the warp: the per-frame V sums of every camera
+(luminance_balance needs the mean over all four, surroundBEV.py:60-66) are all-gathered inside the group; the white
+balance (color_balance, :321-322) and the car run on the stitch rank after the add.
+
+``torch.distributed`` is the transport (backend "nccl" = RCCL over xGMI: device buffers are torch tensors handed to the
+library by pointer; any other backend, e.g. "gloo": host-staged numpy).  The compute is libbevwarp only.
+Import torch BEFORE the first libbevwarp call in a process that uses both (bench.py and the test workers do): the
+wheel carries its own HIP runtime, and the first one loaded must serve both.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+try:
+    from .. import _ffi
+except ImportError:  # imported as a top-level package (main.py drop-in layout)
+    from cameracalibration_amd import _ffi
+from . import surroundBEV as _sb
+
+lib, check, ptr, f64 = _ffi.lib, _ffi.check, _ffi.ptr, _ffi.f64
+
+CAMERA_NAMES = ('front', 'back', 'left', 'right')
+
+
+def camera_assignment(world_size: int):
+    """-> [(group, cams)] per rank.  cams: ascending camera ids (0 front, 1 back, 2 left, 3 right)."""
+    if world_size == 1:
+        return [(0, (0, 1, 2, 3))]
+    if world_size == 2:
+        return [(0, (0, 1)), (0, (2, 3))]
+    if world_size % 4 == 0:
+        return [(r // 4, (r % 4,)) for r in range(world_size)]
+    raise Exception("camera-per-GPU mode needs 1, 2 or a multiple of 4 ranks, got {}".format(world_size))
+
+
+def group_ranks(world_size: int, group: int):
+    return [r for r, (g, _) in enumerate(camera_assignment(world_size)) if g == group]
+
+
+class HipShardEngine:
+    """One bevw_handle in camera-shard mode (bevw_set_camera_shard).  Host-array methods for the drop-in path and
+    ``*_device`` methods for callers that keep frames resident in HBM."""
+
+    def __init__(self, rig, cams, blend, balance, device=0):
+        _ffi.require_device()
+        self.cams = tuple(int(c) for c in cams)
+        self.device = int(device)
+        self.cfg = _sb._snapshot_config(blend, balance, device, _ffi.SCHED_TILE_PLAN)
+        self.blend, self.balance = bool(blend), bool(balance)
+        h = C.c_void_p()
+        check(lib().bevw_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        try:
+            ids = np.asarray(self.cams, np.int32)
+            check(lib().bevw_set_camera_shard(self.h, ptr(ids), len(self.cams)))
+            for c in self.cams:
+                K, D, H = rig[c]
+                check(lib().bevw_set_camera(self.h, c, ptr(f64(K, 9)), ptr(f64(D, 4)), ptr(f64(H, 9))))
+            check(lib().bevw_build(self.h))
+            box = np.zeros(4, np.int32)
+            check(lib().bevw_shard_box(self.h, ptr(box)))
+        except Exception:
+            self.close()
+            raise
+        self.box = tuple(int(v) for v in box)
+        self.fw, self.fh = self.cfg.frame_width, self.cfg.frame_height
+        self.bw, self.bh = self.cfg.bev_width, self.cfg.bev_height
+        self._bufs = {}
+
+    # ---- sizes -------------------------------------------------------------------------------------------------
+    @property
+    def frame_set_bytes(self):
+        return len(self.cams) * self.fw * self.fh * 3
+
+    @property
+    def bev_bytes(self):
+        return self.bw * self.bh * 3
+
+    @staticmethod
+    def box_bytes(box):
+        return (box[2] - box[0]) * (box[3] - box[1]) * 3
+
+    def _buf(self, name, nbytes) -> _ffi.DeviceBuffer:
+        b = self._bufs.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self._bufs[name] = _ffi.DeviceBuffer(nbytes, self.device)
+        return b
+
+    # ---- device-resident calls (pointers are ints) ---------------------------------------------------------------
+    def vsums_device(self, d_frames, batch, d_vsums):
+        check(lib().bevw_shard_vsums_device(self.h, d_frames, batch, d_vsums))
+
+    def run_device(self, d_frames, batch, d_all_vsums, d_full):
+        check(lib().bevw_shard_run_device(self.h, d_frames, batch, d_all_vsums, d_full))
+
+    def pack_device(self, d_full, batch, d_packed):
+        check(lib().bevw_shard_pack_device(self.h, d_full, batch, d_packed))
+
+    def combine_device(self, d_parts, boxes, batch, d_car, d_out):
+        n = len(d_parts)
+        arr = (C.c_void_p * n)(*[C.c_void_p(p) for p in d_parts])
+        bx = np.ascontiguousarray(np.asarray(boxes, np.int32).reshape(n, 4))
+        check(lib().bevw_combine_device(self.h, arr, ptr(bx), n, batch, d_car, d_out))
+
+    def sync(self):
+        check(lib().bevw_sync(self.h))
+
+    # ---- host-array calls ---------------------------------------------------------------------------------------
+    def _upload_frames(self, frames):
+        f = np.ascontiguousarray(frames)
+        if f.dtype != np.uint8 or f.ndim != 5 or f.shape[1:] != (len(self.cams), self.fh, self.fw, 3):
+            raise Exception("frames must be uint8 [B, {}, {}, {}, 3], got {} {}".format(
+                len(self.cams), self.fh, self.fw, f.dtype, f.shape))
+        return self._buf("frames", max(f.nbytes, 4)).upload(f), f.shape[0]
+
+    def vsums(self, frames) -> np.ndarray:
+        d, batch = self._upload_frames(frames)
+        v = self._buf("vsums", max(8 * batch * len(self.cams), 8))
+        self.vsums_device(d.ptr, batch, v.ptr)
+        self.sync()
+        return v.download((batch, len(self.cams)), np.uint64)
+
+    def partial(self, frames, all_vsums=None) -> np.ndarray:
+        """-> packed part uint8 [B, y1-y0, x1-x0, 3] of this rank's cameras."""
+        d, batch = self._upload_frames(frames)
+        d_all = None
+        if self.balance:
+            a = np.ascontiguousarray(np.asarray(all_vsums, np.uint64).reshape(batch, 4))
+            d_all = self._buf("all_vsums", max(a.nbytes, 8)).upload(a).ptr
+        full = self._buf("full", max(batch * self.bev_bytes, 4))
+        packed = self._buf("packed", max(batch * self.box_bytes(self.box), 4))
+        self.run_device(d.ptr, batch, d_all, full.ptr)
+        self.pack_device(full.ptr, batch, packed.ptr)
+        self.sync()
+        x0, y0, x1, y1 = self.box
+        return packed.download((batch, y1 - y0, x1 - x0, 3))
+
+    def combine(self, parts, boxes, car=None) -> np.ndarray:
+        batch = parts[0].shape[0]
+        ptrs = []
+        for k, (p, bx) in enumerate(zip(parts, boxes)):
+            p = np.ascontiguousarray(p, np.uint8)
+            assert p.shape == (batch, bx[3] - bx[1], bx[2] - bx[0], 3), (p.shape, bx)
+            ptrs.append(self._buf("part%d" % k, max(p.nbytes, 4)).upload(p).ptr)
+        d_car = None
+        if car is not None:
+            c = _ffi.as_u8_image(car, "car image")
+            if c.shape != (self.bh, self.bw, 3):
+                raise Exception("car image must be padded to the BEV size")
+            d_car = self._buf("car", c.nbytes).upload(c).ptr
+        out = self._buf("out", max(batch * self.bev_bytes, 4))
+        self.combine_device(ptrs, boxes, batch, d_car, out.ptr)
+        self.sync()
+        return out.download((batch, self.bh, self.bw, 3))
+
+    def close(self):
+        for b in getattr(self, "_bufs", {}).values():
+            b.free()
+        self._bufs = {}
+        if getattr(self, "h", None):
+            lib().bevw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Transport:
+    """The two exchanges of the camera-per-GPU mode inside one camera group, on numpy arrays.  Point-to-point
+    send/recv for the parts (boxes differ in size, and on xGMI every peer -> root transfer rides its own link)."""
+
+    def __init__(self, rank, ranks):
+        self.rank, self.ranks = rank, list(ranks)
+        self.pg = None
+        if len(self.ranks) > 1:
+            import torch.distributed as dist
+            world = dist.get_world_size()
+            # every rank creates every group, in the same order (torch.distributed requirement)
+            ngroups = len({g for g, _ in camera_assignment(world)})
+            for g in range(ngroups):
+                rs = group_ranks(world, g)
+                pg = dist.new_group(rs)
+                if rs == self.ranks:
+                    self.pg = pg
+            self.device_tensors = dist.get_backend() == "nccl"
+
+    def _tensor(self, a: np.ndarray):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+        return t.cuda() if self.device_tensors else t
+
+    def all_gather(self, a: np.ndarray):
+        """-> list of every group member's array (same shape / dtype everywhere), in group order."""
+        if len(self.ranks) == 1:
+            return [a]
+        import torch
+        import torch.distributed as dist
+        mine = self._tensor(a)
+        outs = [torch.empty_like(mine) for _ in self.ranks]
+        dist.all_gather(outs, mine, group=self.pg)
+        return [o.cpu().numpy().view(a.dtype).reshape(a.shape) for o in outs]
+
+    def gather_parts(self, part: np.ndarray, shapes, root: int):
+        """-> on `root`: list of the parts in group order; elsewhere None."""
+        if len(self.ranks) == 1:
+            return [part]
+        import torch
+        import torch.distributed as dist
+        if self.rank != root:
+            dist.send(self._tensor(part), dst=root)
+            return None
+        bufs, reqs = [], []
+        for r, shp in zip(self.ranks, shapes):
+            if r == root:
+                bufs.append(None)
+                continue
+            t = torch.empty(int(np.prod(shp)), dtype=torch.uint8, device="cuda" if self.device_tensors else "cpu")
+            bufs.append(t)
+            reqs.append(dist.irecv(t, src=r))
+        for q in reqs:
+            q.wait()
+        return [part if t is None else t.cpu().numpy().reshape(shp) for t, shp in zip(bufs, shapes)]
+
+
+class CameraShardedBev:
+    """BevGenerator(blend, balance) spread one-camera-per-GPU.
+
+    ``rig``: {'front': (K, D, H), ...} or None for the repo's data/ directory; sizes come from the module arguments of
+    surroundBEV (``BevGenerator.get_args()``), exactly as for BevGenerator.  ``torch.distributed`` must be initialised
+    by the caller when world_size > 1.  ``engine_factory(rig_list, cams, blend, balance, device)`` exists so the
+    exchange logic can be exercised without a GPU (tests); the default is the HIP engine and there is no CPU path.
+    """
+
+    def __init__(self, blend=False, balance=False, *, rig=None, rank=None, world_size=None, device=0, engine_factory=None):
+        if world_size is None:
+            import torch.distributed as dist
+            on = dist.is_available() and dist.is_initialized()
+            world_size = dist.get_world_size() if on else 1
+            rank = dist.get_rank() if on else 0
+        self.rank, self.world_size = int(rank), int(world_size)
+        assign = camera_assignment(self.world_size)
+        self.group, self.cams = assign[self.rank]
+        self.ranks = group_ranks(self.world_size, self.group)
+        self.blend, self.balance = bool(blend), bool(balance)
+        _sb.BevGenerator.init_args(None)   # args -> module sizes, as BevGenerator.__init__ does (surroundBEV.py:284)
+        if rig is None:
+            cams = [_sb.Camera(n) for n in CAMERA_NAMES]
+            rig_list = [(c.camera_mat, c.dist_coeff, c.homography) for c in cams]
+        else:
+            rig_list = [rig[n] for n in CAMERA_NAMES]
+        factory = engine_factory or HipShardEngine
+        self.engine = factory(rig_list, self.cams, self.blend, self.balance, device)
+        self.transport = _Transport(self.rank, self.ranks)
+        boxes = self.transport.all_gather(np.asarray(self.engine.box, np.int32))
+        self.boxes = [tuple(int(v) for v in b) for b in boxes]
+        self.step = 0
+
+    @property
+    def camera_names(self):
+        return tuple(CAMERA_NAMES[c] for c in self.cams)
+
+    def next_root(self) -> int:
+        """The stitch role rotates over the group so that ingress is spread over the ranks' links."""
+        r = self.ranks[self.step % len(self.ranks)]
+        self.step += 1
+        return r
+
+    def __call__(self, frames, car=None, root=None):
+        """frames: uint8 [B, len(cams), FH, FW, 3] -- this rank's cameras of B frame sets (all ranks of a group pass
+        the same B).  Returns uint8 [B, BH, BW, 3] on the stitch rank and None on the others."""
+        if root is None:
+            root = self.next_root()
+        if root not in self.ranks:
+            raise Exception("stitch rank {} is not in camera group {}".format(root, self.ranks))
+        frames = np.ascontiguousarray(frames)
+        batch = frames.shape[0]
+        all_vsums = None
+        if self.balance:
+            mine = self.engine.vsums(frames)                      # [B, ncams]
+            per_rank = self.transport.all_gather(mine)            # group order == ascending camera order
+            all_vsums = np.concatenate(per_rank, axis=1)
+            assert all_vsums.shape == (batch, 4)
+        part = self.engine.partial(frames, all_vsums)
+        shapes = [(batch, b[3] - b[1], b[2] - b[0], 3) for b in self.boxes]
+        parts = self.transport.gather_parts(part, shapes, root)
+        if self.rank != root:
+            return None
+        return self.engine.combine(parts, self.boxes, car)
+
+
+class _CudaView:
+    """__cuda_array_interface__ over a bevw_malloc allocation, so that RCCL (torch.distributed "nccl") can move it."""
+
+    def __init__(self, ptr_, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr_), False), "version": 2}
+
+
+class ResidentShardPipeline:
+    """The same step with everything resident in HBM (what bench.py times): frames of the owned cameras stay in a
+    device buffer, parts travel device-to-device over RCCL send/recv when the backend is "nccl" (host-staged
+    otherwise), the stitch rank writes the BEV batch into its own device buffer."""
+
+    def __init__(self, gen: CameraShardedBev, batch: int):
+        if not isinstance(gen.engine, HipShardEngine):
+            raise Exception("the resident pipeline needs the HIP engine")
+        self.gen, self.e, self.batch = gen, gen.engine, int(batch)
+        e, dev = self.e, gen.engine.device
+        D = _ffi.DeviceBuffer
+        self.full = D(batch * e.bev_bytes, dev)
+        self.packed = D(batch * e.box_bytes(e.box), dev)
+        self.out = D(batch * e.bev_bytes, dev)
+        self.recv = [None if r == gen.rank else D(batch * e.box_bytes(b), dev) for r, b in zip(gen.ranks, gen.boxes)]
+        n = len(e.cams)
+        self.vs = D(8 * batch * n, dev)
+        self.vs_all = D(8 * batch * 4, dev)
+        self.multi = len(gen.ranks) > 1
+        self.on_device = self.multi and gen.transport.device_tensors
+
+    def _tensor(self, buf, nbytes=None):
+        import torch
+        return torch.as_tensor(_CudaView(buf.ptr, nbytes or buf.nbytes), device="cuda")
+
+    def _all_vsums(self, d_frames):
+        e, g, B, n = self.e, self.gen, self.batch, len(self.e.cams)
+        e.vsums_device(d_frames, B, self.vs.ptr)
+        if not self.multi:
+            return self.vs.ptr                                   # one rank owns all four: already [B][4]
+        e.sync()
+        import torch
+        import torch.distributed as dist
+        if self.on_device:
+            mine = self._tensor(self.vs)
+            outs = [torch.empty_like(mine) for _ in g.ranks]
+            dist.all_gather(outs, mine, group=g.transport.pg)
+            allv = torch.cat([o.view(torch.int64).view(B, n) for o in outs], dim=1).contiguous()
+            self._tensor(self.vs_all).copy_(allv.view(torch.uint8).view(-1))
+            torch.cuda.current_stream().synchronize()
+        else:
+            per_rank = g.transport.all_gather(self.vs.download((B, n), np.uint64))
+            self.vs_all.upload(np.ascontiguousarray(np.concatenate(per_rank, axis=1)))
+        return self.vs_all.ptr
+
+    def step(self, d_frames: int, d_car=None, root=None):
+        """One batch.  Returns the stitch rank (its `out` buffer holds uint8 [batch, BH, BW, 3])."""
+        g, e, B = self.gen, self.e, self.batch
+        if root is None:
+            root = g.next_root()
+        d_all = self._all_vsums(d_frames) if g.balance else None
+        e.run_device(d_frames, B, d_all, self.full.ptr)
+        e.pack_device(self.full.ptr, B, self.packed.ptr)
+        parts = [self.packed.ptr if b is None else b.ptr for b in self.recv]
+        if self.multi:
+            import torch
+            import torch.distributed as dist
+            e.sync()
+            if self.on_device:
+                if g.rank != root:
+                    dist.send(self._tensor(self.packed), dst=root)
+                else:
+                    reqs = [dist.irecv(self._tensor(b), src=r) for r, b in zip(g.ranks, self.recv) if b is not None]
+                    for q in reqs:
+                        q.wait()
+                torch.cuda.current_stream().synchronize()
+            else:
+                shapes = [(B, b[3] - b[1], b[2] - b[0], 3) for b in g.boxes]
+                mine = self.packed.download(shapes[g.ranks.index(g.rank)])
+                got = g.transport.gather_parts(mine, shapes, root)
+                if g.rank == root:
+                    for b, p in zip(self.recv, got):
+                        if b is not None:
+                            b.upload(p)
+        if g.rank == root:
+            e.combine_device(parts, g.boxes, B, d_car, self.out.ptr)
+        return root
+
+    def close(self):
+        for b in [self.full, self.packed, self.out, self.vs, self.vs_all] + [r for r in self.recv if r is not None]:
+            b.free()

@@ -55,6 +55,12 @@ SIGNATURES = {
     "bevw_camera_warp_homography": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "bevw_camera_raw2bev": (_i, [_vp, _i, _vp, _i, _vp]),
     "bevw_apply_mask": (_i, [_vp, _i, _vp, _i, _vp]),
+    "bevw_set_camera_shard": (_i, [_vp, _vp, _i]),
+    "bevw_shard_box": (_i, [_vp, _vp]),
+    "bevw_shard_vsums_device": (_i, [_vp, _vp, _i, _vp]),
+    "bevw_shard_run_device": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "bevw_shard_pack_device": (_i, [_vp, _vp, _i, _vp]),
+    "bevw_combine_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "bevw_luminance_balance": (_i, [_i, _vp, _i, _i, _i, _vp]),
     "bevw_color_balance": (_i, [_i, _vp, _i, _i, _i, _vp]),
     "bevw_sync": (_i, [_vp]),

@@ -516,4 +516,90 @@ __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Camera-per-GPU mode: a rank stitches only the cameras it owns, sends the bounding box of its
+// masks, and the stitch rank adds the parts.  cv2.add saturates, so front + back + left + right (+ car) is
+// min(255, sum) however the terms are grouped (surroundBEV.py:318-320, 323-324).
+// ---------------------------------------------------------------------------------------------------------------
+
+// deltas of the owned cameras in plan order: out[b][k] = deltas[b][cams[k]]
+struct ShardCams { int cam[4]; int n; };
+__global__ void k_delta_select(const int *__restrict__ deltas, ShardCams sc, int nsets, int *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsets * 4) return;
+    const int b = i >> 2, k = i & 3;
+    out[i] = k < sc.n ? deltas[b * 4 + sc.cam[k]] : 0;
+}
+
+// full BEV [batch][bh][bw][3] -> packed box [batch][y1-y0][x1-x0][3].  U = uint32_t when every row start is dword
+// aligned (bw % 4 == 0 and x0 % 4 == 0), else uint8_t.  grid = (ceil(row units / 256), box rows, batch)
+template <typename U>
+__global__ void k_pack_box(const uint8_t *__restrict__ full, int bw, int bh, int x0, int y0, int x1, int y1, uint8_t *__restrict__ packed)
+{
+    const int row_units = (x1 - x0) * 3 / (int)sizeof(U);
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= row_units) return;
+    const int y = blockIdx.y;
+    const size_t b = blockIdx.z;
+    const U *src = reinterpret_cast<const U *>(full + (b * bh + (size_t)(y0 + y)) * bw * 3 + (size_t)x0 * 3);
+    U *dst = reinterpret_cast<U *>(packed + (b * (size_t)(y1 - y0) + y) * (size_t)(x1 - x0) * 3);
+    dst[u] = src[u];
+}
+
+struct CombineParts {
+    const uint8_t *p[8];
+    int box[8][4];   // x0, y0, x1, y1 of each packed part
+    int n;
+};
+
+__device__ inline uint32_t sat_add_u8x4(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = (a & 0x00ff00ffu) + (b & 0x00ff00ffu), hi = ((a >> 8) & 0x00ff00ffu) + ((b >> 8) & 0x00ff00ffu);
+    const uint32_t slo = (lo | (((lo >> 8) & 0x00010001u) * 0xffu)) & 0x00ff00ffu;
+    const uint32_t shi = (hi | (((hi >> 8) & 0x00010001u) * 0xffu)) & 0x00ff00ffu;
+    return slo | (shi << 8);
+}
+
+// out = min(255, sum of the parts covering the pixel (+ car)).  PX = 4: one thread = 4 pixels = 3 dwords (needs
+// bw % 4 == 0 and boxes aligned to 4 pixels in x); PX = 1: one thread = one pixel, byte accesses.
+// grid = (ceil(bw / PX / 256), bh, batch)
+template <int PX>
+__global__ void k_combine(CombineParts parts, int bw, int bh, const uint8_t *__restrict__ car, uint8_t *__restrict__ out)
+{
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * PX, y = blockIdx.y;
+    if (x >= bw) return;
+    const size_t b = blockIdx.z;
+    const size_t o = ((size_t)y * bw + x) * 3;
+    if (PX == 4) {
+        uint32_t acc[3] = {0, 0, 0};
+        for (int k = 0; k < parts.n; ++k) {
+            const int *bx = parts.box[k];
+            if (x < bx[0] || x >= bx[2] || y < bx[1] || y >= bx[3]) continue;
+            const size_t pw = (size_t)(bx[2] - bx[0]), ph = (size_t)(bx[3] - bx[1]);
+            const uint32_t *pp = reinterpret_cast<const uint32_t *>(parts.p[k] + ((b * ph + (size_t)(y - bx[1])) * pw + (size_t)(x - bx[0])) * 3);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = sat_add_u8x4(acc[i], pp[i]);
+        }
+        if (car != nullptr) {
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(car + o);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = sat_add_u8x4(acc[i], cp[i]);
+        }
+        uint32_t *op = reinterpret_cast<uint32_t *>(out + b * (size_t)bw * bh * 3 + o);
+        op[0] = acc[0]; op[1] = acc[1]; op[2] = acc[2];
+    } else {
+        unsigned acc[3] = {0, 0, 0};
+        for (int k = 0; k < parts.n; ++k) {
+            const int *bx = parts.box[k];
+            if (x < bx[0] || x >= bx[2] || y < bx[1] || y >= bx[3]) continue;
+            const size_t pw = (size_t)(bx[2] - bx[0]), ph = (size_t)(bx[3] - bx[1]);
+            const uint8_t *pp = parts.p[k] + ((b * ph + (size_t)(y - bx[1])) * pw + (size_t)(x - bx[0])) * 3;
+            for (int i = 0; i < 3; ++i) acc[i] = min(255u, acc[i] + pp[i]);
+        }
+        uint8_t *op = out + b * (size_t)bw * bh * 3 + o;
+        for (int i = 0; i < 3; ++i) op[i] = (uint8_t)min(255u, acc[i] + (car != nullptr ? car[o + i] : 0u));
+    }
+}
+
 }  // namespace bevw

@@ -1147,8 +1147,8 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
                        (uint32_t)fw * 3, static_cast<uint32_t *>(p.pf));
     if ((e = hipGetLastError()) != hipSuccess) return e;
     p.band_ok = false;
-    if (ncams == 4 && fw % 4 == 0) {
-        const size_t nbits = (size_t)4 * fh * (fw / 4), nwords = (nbits + 31) / 32;
+    if (fw % 4 == 0) {
+        const size_t nbits = (size_t)ncams * fh * (fw / 4), nwords = (nbits + 31) / 32;
         uint32_t *d_bits = nullptr;
         if ((e = hipMalloc((void **)&d_bits, nwords * 4)) != hipSuccess) return e;
         if ((e = hipMemsetAsync(d_bits, 0, nwords * 4, st)) != hipSuccess) return e;
@@ -1480,7 +1480,7 @@ static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint
                                        const int *d_deltas, const HsvTables *d_tab)
 {
     if (p.n_groups == 0) return hipSuccess;
-    const size_t set_bytes = (size_t)p.fw * p.fh * 12;
+    const size_t set_bytes = (size_t)p.fw * p.fh * 3 * p.ncams;
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         hipLaunchKernelGGL(k_lum_groups, dim3((p.n_groups + 255) / 256, nb), dim3(256), 0, st, d_frames + (size_t)b0 * set_bytes,

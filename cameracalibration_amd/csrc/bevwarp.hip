@@ -650,6 +650,17 @@ struct bevw_handle {
     DevBuf in, out, car, tmp;
     Plan plan;
     int schedule_in_use = BEVW_SCHED_PER_PIXEL;
+    // camera-per-GPU mode: the cameras this handle owns (shard_n == 0: all four, the ordinary BevGenerator)
+    int shard_n = 0;
+    int shard_cams[4] = {0, 1, 2, 3};
+    int shard_box[4] = {0, 0, 0, 0};   // x0, y0, x1, y1: bounding box of the owned masks
+    DevBuf sdeltas;
+    bool owns(int cam) const
+    {
+        if (shard_n == 0) return true;
+        for (int k = 0; k < shard_n; ++k) if (shard_cams[k] == cam) return true;
+        return false;
+    }
 };
 
 static int fill_poly_device(hipStream_t st, const MaskGeometry &g, int cam, bool blend, uint8_t *d_mask)
@@ -809,7 +820,7 @@ int bevw_build(bevw_handle *h)
 {
     if (!h) return fail(BEVW_E_INVALID, "null handle");
     for (int c = 0; c < 4; ++c)
-        if (!h->cam_set[c]) return fail(BEVW_E_INVALID, "camera %d has no K/D/H (bevw_set_camera)", c);
+        if (h->owns(c) && !h->cam_set[c]) return fail(BEVW_E_INVALID, "camera %d has no K/D/H (bevw_set_camera)", c);
     const bevw_config &cfg = h->cfg;
     BEVW_TRY(use_device(cfg.device));
     hipStream_t st = h->stream;
@@ -820,11 +831,12 @@ int bevw_build(bevw_handle *h)
 
     // Camera.__init__ (surroundBEV.py:82-88): undistort maps, then the BEV look-up table
     for (int c = 0; c < 4; ++c) {
+        BEVW_TRY(h->mask[c].reserve(bpx));   // masks depend on the BEV geometry only: all four, every handle
+        if (!h->owns(c)) continue;
         BEVW_TRY(h->und1[c].reserve(upx * 4));
         BEVW_TRY(h->und2[c].reserve(upx * 2));
         BEVW_TRY(h->lut1[c].reserve(bpx * 4));
         BEVW_TRY(h->lut2[c].reserve(bpx * 2));
-        BEVW_TRY(h->mask[c].reserve(bpx));
         double Kd[9];
         camera_mat_dst(h->K[c], cfg.frame_width, cfg.frame_height, cfg.focal_scale, cfg.size_scale, 0.0, 0.0, Kd);
         BEVW_TRY(build_fisheye_maps(st, h->K[c], h->D[c], Kd, uw, uh, h->und1[c].as<int16_t>(), h->und2[c].as<uint16_t>()));
@@ -878,12 +890,39 @@ int bevw_build(bevw_handle *h)
 
     // contributor plan for the tile schedule
     StitchTables T;
+    const int ncams = h->shard_n ? h->shard_n : 4;
     for (int i = 0; i < 4; ++i) {
-        T.lut1[i] = h->lut1[i].as<int16_t>();
-        T.lut2[i] = h->lut2[i].as<uint16_t>();
-        T.mask[i] = h->mask[i].as<uint8_t>();
+        const int c = h->shard_cams[i < ncams ? i : 0];
+        T.lut1[i] = h->lut1[c].as<int16_t>();
+        T.lut2[i] = h->lut2[c].as<uint16_t>();
+        T.mask[i] = h->mask[c].as<uint8_t>();
     }
-    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh));
+    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams));
+    if (h->shard_n) {
+        if (!h->plan.usable) return fail(BEVW_E_INVALID, "camera shard needs the tile plan: %d contributors on some pixel", h->plan.max_contrib);
+        // bounding box of the owned masks, widened to multiples of 4 pixels in x so that packed rows stay dword aligned
+        std::vector<uint8_t> m(bpx);
+        int x0 = bw, y0 = bh, x1 = 0, y1 = 0;
+        for (int k = 0; k < h->shard_n; ++k) {
+            HIP_TRY(hipMemcpy(m.data(), h->mask[h->shard_cams[k]].p, bpx, hipMemcpyDeviceToHost));
+            for (int y = 0; y < bh; ++y) {
+                const uint8_t *row = m.data() + (size_t)y * bw;
+                int a = 0, b = bw - 1;
+                while (a < bw && row[a] == 0) ++a;
+                if (a == bw) continue;
+                while (row[b] == 0) --b;
+                if (a < x0) x0 = a;
+                if (b + 1 > x1) x1 = b + 1;
+                if (y < y0) y0 = y;
+                if (y + 1 > y1) y1 = y + 1;
+            }
+        }
+        if (x1 <= x0 || y1 <= y0) { x0 = y0 = 0; x1 = bw < 4 ? bw : 4; y1 = 1; }
+        x0 &= ~3;
+        x1 = (x1 + 3) & ~3;
+        if (x1 > bw) x1 = bw;
+        h->shard_box[0] = x0; h->shard_box[1] = y0; h->shard_box[2] = x1; h->shard_box[3] = y1;
+    }
     h->schedule_in_use = BEVW_SCHED_PER_PIXEL;
     if (cfg.schedule == BEVW_SCHED_TILE_PLAN) {
         if (!h->plan.usable) return fail(BEVW_E_INVALID, "tile plan unusable: %d contributors on some pixel", h->plan.max_contrib);
@@ -904,7 +943,7 @@ void bevw_destroy(bevw_handle *h)
         for (int c = 0; c < 4; ++c) {
             h->und1[c].release(); h->und2[c].release(); h->lut1[c].release(); h->lut2[c].release(); h->mask[c].release();
         }
-        h->hsv.release(); h->vsums.release(); h->deltas.release(); h->chsums.release();
+        h->hsv.release(); h->vsums.release(); h->deltas.release(); h->chsums.release(); h->sdeltas.release();
         h->in.release(); h->out.release(); h->car.release(); h->tmp.release();
         plan_release(h->plan);
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -925,6 +964,7 @@ int bevw_get_undistort_map(bevw_handle *h, int cam, int16_t *map1, uint16_t *map
 {
     BEVW_TRY(need_built(h));
     if (cam < 0 || cam > 3) return fail(BEVW_E_INVALID, "name should be front/back/left/right");
+    if (!h->owns(cam)) return fail(BEVW_E_INVALID, "camera %d is not owned by this shard", cam);
     const size_t n = (size_t)h->uw * h->uh;
     if (map1) HIP_TRY(hipMemcpy(map1, h->und1[cam].p, n * 4, hipMemcpyDeviceToHost));
     if (map2) HIP_TRY(hipMemcpy(map2, h->und2[cam].p, n * 2, hipMemcpyDeviceToHost));
@@ -934,6 +974,7 @@ int bevw_get_lut(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2)
 {
     BEVW_TRY(need_built(h));
     if (cam < 0 || cam > 3) return fail(BEVW_E_INVALID, "name should be front/back/left/right");
+    if (!h->owns(cam)) return fail(BEVW_E_INVALID, "camera %d is not owned by this shard", cam);
     const size_t n = (size_t)h->cfg.bev_width * h->cfg.bev_height;
     if (map1) HIP_TRY(hipMemcpy(map1, h->lut1[cam].p, n * 4, hipMemcpyDeviceToHost));
     if (map2) HIP_TRY(hipMemcpy(map2, h->lut2[cam].p, n * 2, hipMemcpyDeviceToHost));
@@ -965,6 +1006,7 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
 int bevw_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_car, void *d_out)
 {
     BEVW_TRY(need_built(h));
+    if (h->shard_n) return fail(BEVW_E_INVALID, "handle is a camera shard: use bevw_shard_run_device + bevw_combine_device");
     if (!d_frames || !d_out || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
     if (batch == 0) return BEVW_OK;
     return run_device(h, (const uint8_t *)d_frames, batch, (const uint8_t *)d_car, (uint8_t *)d_out);
@@ -973,6 +1015,7 @@ int bevw_run_device(bevw_handle *h, const void *d_frames, int batch, const void 
 int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *car, uint8_t *out)
 {
     BEVW_TRY(need_built(h));
+    if (h->shard_n) return fail(BEVW_E_INVALID, "handle is a camera shard: use bevw_shard_run_device + bevw_combine_device");
     if (!frames || !out || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
     if (batch == 0) return BEVW_OK;
     const bevw_config &c = h->cfg;
@@ -1010,6 +1053,7 @@ int bevw_camera_undistort(bevw_handle *h, int cam, const uint8_t *src, int batch
 {
     BEVW_TRY(need_built(h));
     if (cam < 0 || cam > 3 || !src || !dst || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (!h->owns(cam)) return fail(BEVW_E_INVALID, "camera %d is not owned by this shard", cam);
     if (batch == 0) return BEVW_OK;
     return camera_remap(h, src, h->cfg.frame_width, h->cfg.frame_height, h->und1[cam].as<int16_t>(),
                         h->und2[cam].as<uint16_t>(), h->uw, h->uh, batch, dst);
@@ -1019,6 +1063,7 @@ int bevw_camera_raw2bev(bevw_handle *h, int cam, const uint8_t *src, int batch, 
 {
     BEVW_TRY(need_built(h));
     if (cam < 0 || cam > 3 || !src || !dst || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (!h->owns(cam)) return fail(BEVW_E_INVALID, "camera %d is not owned by this shard", cam);
     if (batch == 0) return BEVW_OK;
     return camera_remap(h, src, h->cfg.frame_width, h->cfg.frame_height, h->lut1[cam].as<int16_t>(),
                         h->lut2[cam].as<uint16_t>(), h->cfg.bev_width, h->cfg.bev_height, batch, dst);
@@ -1028,8 +1073,173 @@ int bevw_camera_warp_homography(bevw_handle *h, int cam, const uint8_t *src, int
 {
     BEVW_TRY(need_built(h));
     if (cam < 0 || cam > 3) return fail(BEVW_E_INVALID, "name should be front/back/left/right");
+    if (!h->owns(cam)) return fail(BEVW_E_INVALID, "camera %d is not owned by this shard", cam);
     return bevw_warp_perspective_u8c3(h->cfg.device, src, src_w, src_h, h->H[cam], h->cfg.bev_width, h->cfg.bev_height,
                                       batch, dst);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// camera-per-GPU mode
+// ---------------------------------------------------------------------------------------------------------------
+int bevw_set_camera_shard(bevw_handle *h, const int32_t *cams, int ncams)
+{
+    if (!h || !cams) return fail(BEVW_E_INVALID, "null argument");
+    if (ncams < 1 || ncams > 4) return fail(BEVW_E_INVALID, "a shard owns 1..4 cameras");
+    for (int k = 0; k < ncams; ++k) {
+        if (cams[k] < 0 || cams[k] > 3) return fail(BEVW_E_INVALID, "name should be front/back/left/right");
+        if (k && cams[k] <= cams[k - 1]) return fail(BEVW_E_INVALID, "shard cameras must be distinct and ascending");
+    }
+    h->shard_n = ncams;
+    for (int k = 0; k < 4; ++k) h->shard_cams[k] = k < ncams ? cams[k] : cams[0];
+    h->built = false;
+    return BEVW_OK;
+}
+
+static int need_shard(bevw_handle *h)
+{
+    BEVW_TRY(need_built(h));
+    if (!h->shard_n) return fail(BEVW_E_INVALID, "handle is not a camera shard (bevw_set_camera_shard before bevw_build)");
+    return BEVW_OK;
+}
+
+int bevw_shard_box(bevw_handle *h, int32_t box[4])
+{
+    BEVW_TRY(need_shard(h));
+    if (!box) return fail(BEVW_E_INVALID, "null argument");
+    for (int i = 0; i < 4; ++i) box[i] = h->shard_box[i];
+    return BEVW_OK;
+}
+
+int bevw_shard_vsums_device(bevw_handle *h, const void *d_frames, int batch, void *d_vsums)
+{
+    BEVW_TRY(need_shard(h));
+    if (!d_frames || !d_vsums || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (batch == 0) return BEVW_OK;
+    const bevw_config &c = h->cfg;
+    const size_t frame_bytes = (size_t)c.frame_width * c.frame_height * 3;
+    const int nframes = batch * h->shard_n;
+    HIP_TRY(hipMemsetAsync(d_vsums, 0, sizeof(unsigned long long) * (size_t)nframes, h->stream));
+    const int vec_ok = (frame_bytes % 16 == 0 && ((uintptr_t)d_frames & 15u) == 0) ? 1 : 0;
+    int bpf = 2048 / nframes;
+    if (bpf < 8) bpf = 8;
+    if (bpf > 256) bpf = 256;
+    for (int f0 = 0; f0 < nframes; f0 += 65535) {
+        const int nf = nframes - f0 < 65535 ? nframes - f0 : 65535;
+        hipLaunchKernelGGL(k_vsum, dim3(bpf, nf), dim3(256), 0, h->stream, (const uint8_t *)d_frames + (size_t)f0 * frame_bytes,
+                           frame_bytes, vec_ok, (unsigned long long *)d_vsums + f0);
+    }
+    return launch_check("k_vsum");
+}
+
+int bevw_shard_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_all_vsums, void *d_out)
+{
+    BEVW_TRY(need_shard(h));
+    if (!d_frames || !d_out || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    const bevw_config &c = h->cfg;
+    if (c.balance && !d_all_vsums) return fail(BEVW_E_INVALID, "balance needs the V sums of all four cameras");
+    if ((((uintptr_t)d_out | (uintptr_t)d_frames) & 3u) != 0) return fail(BEVW_E_INVALID, "device buffers must be 4-byte aligned");
+    if (batch == 0) return BEVW_OK;
+    const uint8_t *frames = (const uint8_t *)d_frames;
+    if (!c.balance) return plan_stitch(h->plan, h->stream, frames, batch, c.blend != 0, false, nullptr, nullptr, nullptr, nullptr,
+                                       (uint8_t *)d_out);
+    // luminance_balance (surroundBEV.py:57-79) with the means of ALL four cameras, applied to the owned ones
+    BEVW_TRY(ensure_stats(h, batch));
+    BEVW_TRY(h->sdeltas.reserve(sizeof(int) * 4 * (size_t)batch));
+    hipLaunchKernelGGL(k_lum_delta, dim3((batch + 63) / 64), dim3(64), 0, h->stream, (const unsigned long long *)d_all_vsums,
+                       (double)c.frame_width * (double)c.frame_height, batch, h->deltas.as<int>());
+    ShardCams sc;
+    sc.n = h->shard_n;
+    for (int k = 0; k < 4; ++k) sc.cam[k] = h->shard_cams[k];
+    hipLaunchKernelGGL(k_delta_select, dim3((batch * 4 + 255) / 256), dim3(256), 0, h->stream, h->deltas.as<int>(), sc, batch,
+                       h->sdeltas.as<int>());
+    BEVW_TRY(launch_check("k_lum_delta/k_delta_select"));
+    static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
+    if (bal_mode == 1 && h->plan.band_ok) {
+        const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 3 * h->shard_n;
+        BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
+        hipError_t e = plan_lum_band(h->plan, h->stream, frames, h->tmp.as<uint8_t>(), batch, h->sdeltas.as<int>(),
+                                     h->hsv.as<HsvTables>());
+        if (e != hipSuccess) return fail(BEVW_E_HIP, "k_lum_groups launch failed: %s", hipGetErrorString(e));
+        return plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr, nullptr,
+                           (uint8_t *)d_out);
+    }
+    HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
+    return plan_stitch(h->plan, h->stream, frames, batch, c.blend != 0, true, h->sdeltas.as<int>(), h->hsv.as<HsvTables>(), nullptr,
+                       h->chsums.as<unsigned long long>(), (uint8_t *)d_out);
+}
+
+int bevw_shard_pack_device(bevw_handle *h, const void *d_full, int batch, void *d_packed)
+{
+    BEVW_TRY(need_shard(h));
+    if (!d_full || !d_packed || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (batch == 0) return BEVW_OK;
+    const bevw_config &c = h->cfg;
+    const int *bx = h->shard_box;
+    const int rows = bx[3] - bx[1], row_bytes = (bx[2] - bx[0]) * 3;
+    const bool dwords = c.bev_width % 4 == 0 && bx[0] % 4 == 0 && (bx[2] - bx[0]) % 4 == 0 &&
+                        (((uintptr_t)d_full | (uintptr_t)d_packed) & 3u) == 0;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        const uint8_t *src = (const uint8_t *)d_full + (size_t)b0 * c.bev_width * c.bev_height * 3;
+        uint8_t *dst = (uint8_t *)d_packed + (size_t)b0 * rows * row_bytes;
+        if (dwords)
+            hipLaunchKernelGGL((k_pack_box<uint32_t>), dim3((row_bytes / 4 + 255) / 256, rows, nb), dim3(256), 0, h->stream, src,
+                               c.bev_width, c.bev_height, bx[0], bx[1], bx[2], bx[3], dst);
+        else
+            hipLaunchKernelGGL((k_pack_box<uint8_t>), dim3((row_bytes + 255) / 256, rows, nb), dim3(256), 0, h->stream, src,
+                               c.bev_width, c.bev_height, bx[0], bx[1], bx[2], bx[3], dst);
+    }
+    return launch_check("k_pack_box");
+}
+
+int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_t *boxes, int nparts, int batch, const void *d_car,
+                        void *d_out)
+{
+    BEVW_TRY(need_built(h));
+    if (!d_parts || !boxes || !d_out || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (nparts < 1 || nparts > 8) return fail(BEVW_E_INVALID, "1..8 parts");
+    const bevw_config &c = h->cfg;
+    const int bw = c.bev_width, bh = c.bev_height;
+    CombineParts parts;
+    memset(&parts, 0, sizeof parts);
+    parts.n = nparts;
+    bool dwords = bw % 4 == 0 && (((uintptr_t)d_out | (uintptr_t)d_car) & 3u) == 0;
+    for (int k = 0; k < nparts; ++k) {
+        const int32_t *bx = boxes + k * 4;
+        if (!d_parts[k] || bx[0] < 0 || bx[1] < 0 || bx[2] > bw || bx[3] > bh || bx[2] <= bx[0] || bx[3] <= bx[1])
+            return fail(BEVW_E_INVALID, "part %d: bad pointer or box", k);
+        parts.p[k] = (const uint8_t *)d_parts[k];
+        for (int i = 0; i < 4; ++i) parts.box[k][i] = bx[i];
+        if (bx[0] % 4 != 0 || (bx[2] - bx[0]) % 4 != 0 || ((uintptr_t)d_parts[k] & 3u) != 0) dwords = false;
+    }
+    if (batch == 0) return BEVW_OK;
+    const size_t npx = (size_t)bw * bh;
+    // balance: the car is added after the white balance (surroundBEV.py:321-324), so the sum goes out bare first
+    const uint8_t *car_now = c.balance ? nullptr : (const uint8_t *)d_car;
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        CombineParts pb = parts;
+        for (int k = 0; k < nparts; ++k)
+            pb.p[k] += (size_t)b0 * (size_t)(pb.box[k][2] - pb.box[k][0]) * (size_t)(pb.box[k][3] - pb.box[k][1]) * 3;
+        uint8_t *o = (uint8_t *)d_out + (size_t)b0 * npx * 3;
+        if (dwords) hipLaunchKernelGGL((k_combine<4>), dim3((bw / 4 + 255) / 256, bh, nb), dim3(256), 0, h->stream, pb, bw, bh, car_now, o);
+        else hipLaunchKernelGGL((k_combine<1>), dim3((bw + 255) / 256, bh, nb), dim3(256), 0, h->stream, pb, bw, bh, car_now, o);
+    }
+    BEVW_TRY(launch_check("k_combine"));
+    if (c.balance) {
+        BEVW_TRY(ensure_stats(h, batch));
+        HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
+        for (int b0 = 0; b0 < batch; b0 += 65535) {
+            const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+            uint8_t *o = (uint8_t *)d_out + (size_t)b0 * npx * 3;
+            unsigned long long *chs = h->chsums.as<unsigned long long>() + (size_t)b0 * 3;
+            hipLaunchKernelGGL(k_channel_sums, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs);
+            if (npx % 4 == 0 && dwords) hipLaunchKernelGGL(k_gain_lut, dim3(32, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o);
+            else hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o);
+        }
+        BEVW_TRY(launch_check("k_channel_sums/k_gain"));
+    }
+    return BEVW_OK;
 }
 
 int bevw_apply_mask(bevw_handle *h, int cam, const uint8_t *img, int batch, uint8_t *out)

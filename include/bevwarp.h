@@ -110,6 +110,31 @@ int bevw_camera_raw2bev(bevw_handle *h, int cam, const uint8_t *src, int batch, 
  * img / out: [batch][BH][BW][3].  Inside bevw_run the same arithmetic is fused into the stitch kernels. */
 int bevw_apply_mask(bevw_handle *h, int cam, const uint8_t *img, int batch, uint8_t *out);
 
+/* ---- camera-per-GPU mode: every rank stitches the cameras it owns, one exchange, the stitch rank adds ---------- */
+/* The reference adds the four masked BEV images with cv2.add (surroundBEV.py:318-320) and the car with another
+ * (:323-324); cv2.add saturates, so the sum is min(255, total) however the terms are grouped -- a rank may add its own
+ * cameras first and the stitch rank the parts.  Never reduce with a wrapping/plain sum collective.
+ *
+ * bevw_set_camera_shard (before bevw_build): the handle owns `cams` (ascending, 1..4 of front/back/left/right); only
+ * those need bevw_set_camera, only their tables are built, and frame sets shrink to [batch][ncams][FH][FW][3]. */
+int bevw_set_camera_shard(bevw_handle *h, const int32_t *cams, int ncams);
+/* x0, y0, x1, y1 of the owned masks (x widened to multiples of 4 pixels): the part a rank sends. */
+int bevw_shard_box(bevw_handle *h, int32_t box[4]);
+/* luminance_balance statistics (surroundBEV.py:60-66): d_vsums[batch][ncams] (uint64) = sum of V over each owned
+ * frame.  The host all-gathers them into [batch][4] (camera order) for bevw_shard_run_device. */
+int bevw_shard_vsums_device(bevw_handle *h, const void *d_frames, int batch, void *d_vsums);
+/* Partial BevGenerator.__call__ (surroundBEV.py:312-320): luminance shift with the global means (balance = 1,
+ * d_all_vsums[batch][4] uint64, else NULL), raw2bev, mask / blend weight and cv2.add over the owned cameras.
+ * d_out: full-size [batch][BH][BW][3], zero outside the owned masks.  No white balance, no car: bevw_combine_device. */
+int bevw_shard_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_all_vsums, void *d_out);
+/* d_full [batch][BH][BW][3] -> d_packed [batch][y1-y0][x1-x0][3] (the bevw_shard_box window). */
+int bevw_shard_pack_device(bevw_handle *h, const void *d_full, int batch, void *d_packed);
+/* Stitch rank: out = cv2.add over the packed parts (boxes[k] = x0,y0,x1,y1), then color_balance when the handle was
+ * created with balance = 1 (surroundBEV.py:321-322), then cv2.add(surround, car) when d_car != NULL (:323-324).
+ * Works on any built handle of the same BEV geometry (shard or not). */
+int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_t *boxes, int nparts, int batch,
+                        const void *d_car, void *d_out);
+
 /* Module-level helpers of surroundBEV.py, exposed because the reference exports them:
  * luminance_balance(images) (:57-79): frames [batch][4][H][W][3] -> same shape;
  * color_balance(image) (:43-55): image [batch][H][W][3] -> same shape. */
