@@ -47,6 +47,10 @@ WORKLOADS = {
                           metric="fisheye undistort remap images/sec (1280x960 u8)"),
     "blend_4k": dict(kind="bev", cfg="4K", blend=True, balance=False, batch=32, unit="frames/s",
                      metric="stitched BEV frames/sec (4-cam 3840x2160->1080x1080, blend)"),
+    # BASELINE config 5 in its camera-per-GPU form: ranks own cameras, parts travel over RCCL
+    # send/recv, the stitch rank rotates.  1, 2 or a multiple of 4 ranks; every group of 4 ranks is a replica.
+    "blend_4k_camera_shard": dict(kind="camera", cfg="4K", blend=True, balance=False, batch=32, unit="frames/s",
+                                  metric="stitched BEV frames/sec (4-cam 3840x2160->1080x1080, blend, camera per GPU)"),
 }
 
 
@@ -78,7 +82,8 @@ class Dist:
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            use_gpu = torch.cuda.is_available()
+            # BEVW_BENCH_BACKEND=gloo: every rank on one GPU with host-staged exchange (validation on a 1-GPU box)
+            use_gpu = torch.cuda.is_available() and os.environ.get("BEVW_BENCH_BACKEND", "nccl") == "nccl"
             if use_gpu:
                 torch.cuda.set_device(self.local_rank)
             dist.init_process_group("nccl" if use_gpu else "gloo")
@@ -215,7 +220,41 @@ def main():
     alg_bytes = W.ALGORITHMIC_BYTES[a.workload]
     cpu = None
 
-    if w["kind"] == "bev":
+    units_world = d.world   # ranks that each contribute `batch` units per step
+    if w["kind"] == "camera":
+        cfg, rig = W.CONFIG_4K, W.rig_4k()
+        from cameracalibration_amd.SurroundBirdEyeView import cameraShard as CS, surroundBEV as SB
+
+        ns = SB.BevGenerator.get_args()
+        for k, v in cfg.items():
+            setattr(ns, k, v)
+        t_build = time.perf_counter()
+        gen = CS.CameraShardedBev(w["blend"], w["balance"], rig=rig, rank=d.rank, world_size=d.world, device=dev)
+        t_build = time.perf_counter() - t_build
+        fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+        unique = W.synthetic_frames(a.unique_sets, fw, fh, seed=W.SEED + gen.group)
+        mine = np.ascontiguousarray(unique[:, list(gen.cams)])
+        d_in = _ffi.DeviceBuffer(batch * mine[0].nbytes, dev)
+        upload_replicated(d_in, mine, batch)
+        pipe = CS.ResidentShardPipeline(gen, batch)
+        step = lambda: pipe.step(d_in.ptr, None)
+        e = gen.engine
+        sync = e.sync
+        tstart = lambda: _ffi.check(_ffi.lib().bevw_timer_start(e.h))
+
+        def tstop():
+            import ctypes as C
+            ms = C.c_float()
+            _ffi.check(_ffi.lib().bevw_timer_stop(e.h, C.byref(ms)))
+            return float(ms.value)
+        units_world = max(1, d.world // 4)
+        extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"], "schedule": "tile_plan",
+                 "table_build_s": round(t_build, 3), "cameras_per_rank": len(gen.cams), "camera_groups": units_world,
+                 "part_boxes": [list(b) for b in gen.boxes],
+                 "transport": "single rank" if d.world == 1 else ("rccl send/recv" if gen.transport.device_tensors else "host staged")}
+        if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
+    elif w["kind"] == "bev":
         cfg = {"S": W.CONFIG_S, "4K": W.CONFIG_4K}[w["cfg"]]
         rig = {"S": W.rig_s, "4K": W.rig_4k}[w["cfg"]]()
         from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
@@ -279,14 +318,16 @@ def main():
     wall = d.max(wall)
     ev_ms = d.max(ev_ms)
 
-    agg = aggregate(d.world, batch, a.steps, wall, ev_ms, alg_bytes)
+    agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
         "metric": w["metric"], "value": value, "unit": w["unit"], "n_gpus": d.world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if (w["kind"] == "camera" and d.world <= 4) else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": dict({"workload": a.workload, "batch_per_gpu": batch, "global_batch": batch * d.world,
-                        "sharding": "frames across ranks, no data-path collective", "device": _ffi.device_name(dev),
+        "config": dict({"workload": a.workload, "batch_per_gpu": batch, "global_batch": batch * units_world,
+                        "sharding": ("cameras across ranks, one send/recv of mask boxes per step" if w["kind"] == "camera"
+                                     else "frames across ranks, no data-path collective"), "device": _ffi.device_name(dev),
                         "unique_frame_sets": int(a.unique_sets)}, **extra),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload, batch),

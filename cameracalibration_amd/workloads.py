@@ -127,4 +127,5 @@ ALGORITHMIC_BYTES = {
     "blend_b256": 5_669_538,           # S blend only: touched 2,170,338 + out 3,499,200
     "blend_balance_b256": 22_585_476,  # config 4: V-mean pass 14,745,600 + 2 x touched 2,170,338 + out 3,499,200
     "blend_4k": 11_810_991,            # config 5 (blend only): touched 8,311,791 + out 3,499,200
+    "blend_4k_camera_shard": 11_810_991,  # same frames, camera per GPU (exchange bytes are overhead, not counted)
 }
