@@ -78,6 +78,9 @@ SIGNATURES = {
     "bevw_remapper_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
     "bevw_remapper_destroy": (None, [_vp]),
     "bevw_warp_perspective_u8c3": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "bevw_translate_u8c3": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp]),
+    "bevw_resize_dsize": (_i, [_i, _i, _d, _d, _vp]),
+    "bevw_resize_linear_u8c3": (_i, [_i, _vp, _i, _i, _d, _d, _i, _vp]),
 }
 
 _lib = None

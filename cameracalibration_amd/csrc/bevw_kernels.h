@@ -602,4 +602,63 @@ __global__ void k_combine(CombineParts parts, int bw, int bh, const uint8_t *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// ExCalibrator pre-processing warps (extrinsicCalib.py:54-59, 122-130)
+// ---------------------------------------------------------------------------------------------------------------
+// CenterImage.translate: cv2.warpAffine with an integer shift = one tap per pixel, zeros outside.
+// grid = (ceil(w / 256), h, batch)
+__global__ void k_translate(const uint8_t *__restrict__ src, int w, int h, int shift_x, int shift_y, uint8_t *__restrict__ dst)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t img = (size_t)blockIdx.z * w * h * 3;
+    const int u = x - shift_x, v = y - shift_y;
+    uint8_t *d = dst + img + ((size_t)y * w + x) * 3;
+    if (u >= 0 && u < w && v >= 0 && v < h) {
+        const uint8_t *p = src + img + ((size_t)v * w + u) * 3;
+        d[0] = p[0]; d[1] = p[1]; d[2] = p[2];
+    } else {
+        d[0] = d[1] = d[2] = 0;
+    }
+}
+
+// One axis of cv2.resize INTER_LINEAR (8U fixed point): source index and the two 11-bit weights of destination
+// index d.  clamp_frac: columns zero the fraction when the tap pair leaves the image, rows clip the pair instead.
+__device__ inline void resize_tap(int d, double scale, int n_src, bool clamp_frac, int &s, int &c0, int &c1)
+{
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp_frac) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    }
+    c0 = rne_f((1.f - f) * 2048.f);
+    c1 = rne_f(f * 2048.f);
+}
+
+// cv2.resize(src, (0,0), fx, fy), INTER_LINEAR, 8UC3 (ScaleImage.__call__, extrinsicCalib.py:125).
+// grid = (ceil(dw / 256), dh, batch)
+__global__ void k_resize_linear(const uint8_t *__restrict__ src, int w, int h, double scale_x, double scale_y,
+                                uint8_t *__restrict__ dst, int dw, int dh)
+{
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    int s0, a0, a1, r0, b0, b1;
+    resize_tap(dx, scale_x, w, true, s0, a0, a1);
+    resize_tap(dy, scale_y, h, false, r0, b0, b1);
+    const int s1 = min(s0 + 1, w - 1);
+    const int r1 = min(max(r0 + 1, 0), h - 1);
+    r0 = min(max(r0, 0), h - 1);
+    const uint8_t *img = src + (size_t)blockIdx.z * w * h * 3;
+    const uint8_t *p0 = img + (size_t)r0 * w * 3, *p1 = img + (size_t)r1 * w * 3;
+    uint8_t *d = dst + ((size_t)blockIdx.z * dh * dw + (size_t)dy * dw + dx) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = p0[s0 * 3 + c] * a0 + p0[s1 * 3 + c] * a1;
+        const int S1 = p1[s0 * 3 + c] * a0 + p1[s1 * 3 + c] * a1;
+        d[c] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
 }  // namespace bevw

@@ -634,6 +634,62 @@ int bevw_warp_perspective_u8c3(int device, const uint8_t *src, int src_w, int sr
 
 }  // extern "C"
 
+// CenterImage.translate (extrinsicCalib.py:54-59)
+int bevw_translate_u8c3(int device, const uint8_t *src, int width, int height, int shift_x, int shift_y, int batch, uint8_t *dst)
+{
+    if (!src || !dst || width <= 0 || height <= 0 || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (batch == 0) return BEVW_OK;
+    if (batch > 65535) return fail(BEVW_E_INVALID, "batch > 65535");
+    BEVW_TRY(use_device(device));
+    const size_t n = (size_t)batch * width * height * 3;
+    DevBuf d_src, d_dst;
+    int s = d_src.reserve(n);
+    if (s == BEVW_OK) s = d_dst.reserve(n);
+    if (s == BEVW_OK && hipMemcpy(d_src.p, src, n, hipMemcpyHostToDevice) != hipSuccess) s = fail(BEVW_E_HIP, "H2D copy failed");
+    if (s == BEVW_OK) {
+        hipLaunchKernelGGL(k_translate, dim3((width + 255) / 256, height, batch), dim3(256), 0, nullptr, d_src.as<uint8_t>(), width,
+                           height, shift_x, shift_y, d_dst.as<uint8_t>());
+        s = launch_check("k_translate");
+    }
+    if (s == BEVW_OK && hipMemcpy(dst, d_dst.p, n, hipMemcpyDeviceToHost) != hipSuccess) s = fail(BEVW_E_HIP, "D2H copy failed");
+    d_src.release(); d_dst.release();
+    return s;
+}
+
+// cv2.resize's output size for dsize = (0, 0): (cvRound(w * fx), cvRound(h * fy))
+int bevw_resize_dsize(int src_w, int src_h, double fx, double fy, int32_t dsize[2])
+{
+    if (!dsize || src_w <= 0 || src_h <= 0 || !(fx > 0) || !(fy > 0)) return fail(BEVW_E_INVALID, "bad argument");
+    dsize[0] = host_rne((double)src_w * fx);
+    dsize[1] = host_rne((double)src_h * fy);
+    if (dsize[0] <= 0 || dsize[1] <= 0) return fail(BEVW_E_INVALID, "empty destination");
+    return BEVW_OK;
+}
+
+// ScaleImage.__call__'s cv2.resize (extrinsicCalib.py:125)
+int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h, double fx, double fy, int batch, uint8_t *dst)
+{
+    int32_t ds[2];
+    BEVW_TRY(bevw_resize_dsize(src_w, src_h, fx, fy, ds));
+    if (!src || !dst || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (batch == 0) return BEVW_OK;
+    if (batch > 65535 || ds[1] > 65535) return fail(BEVW_E_INVALID, "batch or destination height > 65535");
+    BEVW_TRY(use_device(device));
+    const size_t nin = (size_t)batch * src_w * src_h * 3, nout = (size_t)batch * ds[0] * ds[1] * 3;
+    DevBuf d_src, d_dst;
+    int s = d_src.reserve(nin);
+    if (s == BEVW_OK) s = d_dst.reserve(nout);
+    if (s == BEVW_OK && hipMemcpy(d_src.p, src, nin, hipMemcpyHostToDevice) != hipSuccess) s = fail(BEVW_E_HIP, "H2D copy failed");
+    if (s == BEVW_OK) {
+        hipLaunchKernelGGL(k_resize_linear, dim3((ds[0] + 255) / 256, ds[1], batch), dim3(256), 0, nullptr, d_src.as<uint8_t>(), src_w,
+                           src_h, 1.0 / fx, 1.0 / fy, d_dst.as<uint8_t>(), ds[0], ds[1]);
+        s = launch_check("k_resize_linear");
+    }
+    if (s == BEVW_OK && hipMemcpy(dst, d_dst.p, nout, hipMemcpyDeviceToHost) != hipSuccess) s = fail(BEVW_E_HIP, "D2H copy failed");
+    d_src.release(); d_dst.release();
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // bevw_handle
 // ---------------------------------------------------------------------------------------------------------------

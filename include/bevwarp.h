@@ -176,6 +176,18 @@ void bevw_remapper_destroy(bevw_remapper *r);
 int bevw_warp_perspective_u8c3(int device, const uint8_t *src, int src_w, int src_h, const double H[9], int dst_w,
                                int dst_h, int batch, uint8_t *dst);
 
+/* ---- ExCalibrator pre-processing warps --------------------------------------------------------------------- */
+/* CenterImage.translate (extrinsicCalib.py:54-59): cv2.warpAffine(img, [[1,0,shift_x],[0,1,shift_y]], (w, h)) with the
+ * integer shifts the reference builds (image centre minus the picked point): dst(x,y) = src(x-shift_x, y-shift_y) or 0. */
+int bevw_translate_u8c3(int device, const uint8_t *src, int width, int height, int shift_x, int shift_y, int batch,
+                        uint8_t *dst);
+/* cv2.resize(img, (0,0), fx=fx, fy=fy), INTER_LINEAR, 8UC3 (ScaleImage.__call__, extrinsicCalib.py:125).
+ * bevw_resize_dsize gives the output size (cvRound(w*fx), cvRound(h*fy)); dst: [batch][dsize[1]][dsize[0]][3].
+ * The pad / centre-crop back to the input size (extrinsicCalib.py:101-120) is a host-side copy in the mirror. */
+int bevw_resize_dsize(int src_w, int src_h, double fx, double fy, int32_t dsize[2]);
+int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h, double fx, double fy, int batch,
+                            uint8_t *dst);
+
 #ifdef __cplusplus
 }
 #endif

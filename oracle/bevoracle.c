@@ -710,3 +710,80 @@ ORC_API void orc_bev_call(const uint8_t *const frames[4], int fw, int fh, const 
     }
     if (car) orc_add_sat(out, car, bpx * 3, out);
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ExCalibrator pre-processing warps (extrinsicCalib.py:54-59, 122-130)                               */
+/* ------------------------------------------------------------------------------------------------ */
+/* CenterImage.translate (extrinsicCalib.py:54-59): cv2.warpAffine(img, [[1,0,sx],[0,1,sy]], (w,h)), INTER_LINEAR,
+ * BORDER_CONSTANT 0.  warpAffine inverts M and walks fixed-point coordinates (AB_BITS 10, round_delta 16, then >> 5);
+ * with integer shifts every coordinate lands on an integer texel with fraction 0, so all the bilinear weight sits on
+ * one tap: dst(x, y) = src(x - sx, y - sy), 0 where that tap is outside. */
+ORC_API void orc_translate_u8c3(const uint8_t *src, int w, int h, int shift_x, int shift_y, uint8_t *dst)
+{
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const int u = x - shift_x, v = y - shift_y;
+            uint8_t *d = dst + ((size_t)y * w + x) * 3;
+            if (u >= 0 && u < w && v >= 0 && v < h) memcpy(d, src + ((size_t)v * w + u) * 3, 3);
+            else d[0] = d[1] = d[2] = 0;
+        }
+}
+
+/* cv2.resize(src, (0,0), fx, fy) with INTER_LINEAR on 8UC3 (ScaleImage.__call__, extrinsicCalib.py:125).
+ * dsize = (cvRound(w*fx), cvRound(h*fy)); scale = 1/fx (not re-derived from dsize when dsize is empty).
+ * Per destination column: f = (float)((dx+0.5)*scale - 0.5); s = floor(f); f -= s; s < 0 -> (0, 0);
+ * s >= w-1 -> (w-1, 0); alpha = saturate_cast<short>({1-f, f} * 2048).  Rows: same without the clamping of f
+ * (the two source rows are clipped into the image instead).  Horizontal pass in int32 (S[s]*a0 + S[s+1]*a1),
+ * vertical pass of the 8U specialisation: (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2.
+ * (For fx = fy = 0.5 OpenCV switches to its INTER_AREA fast path, (a+b+c+d+2)>>2, which this formula reproduces.) */
+ORC_API void orc_resize_dsize(int w, int h, double fx, double fy, int *dw, int *dh)
+{
+    *dw = rne_d((double)w * fx);
+    *dh = rne_d((double)h * fy);
+}
+static void resize_axis(int n_src, int n_dst, double scale, int clamp_frac, int *ofs, short *coef)
+{
+    for (int d = 0; d < n_dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)floorf(f);
+        f -= (float)s;
+        if (clamp_frac) {
+            if (s < 0) { f = 0.f; s = 0; }
+            if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+        }
+        ofs[d] = s;
+        const float c0 = 1.f - f;
+        int a0 = (int)lrintf(c0 * 2048.f), a1 = (int)lrintf(f * 2048.f);
+        coef[d * 2] = (short)(a0 > 32767 ? 32767 : a0 < -32768 ? -32768 : a0);
+        coef[d * 2 + 1] = (short)(a1 > 32767 ? 32767 : a1 < -32768 ? -32768 : a1);
+    }
+}
+ORC_API void orc_resize_linear_u8c3(const uint8_t *src, int w, int h, double fx, double fy, uint8_t *dst, int dw, int dh)
+{
+    int *xofs = (int *)malloc(sizeof(int) * (size_t)(dw + dh));
+    short *alpha = (short *)malloc(sizeof(short) * 2 * (size_t)(dw + dh));
+    int *yofs = xofs + dw;
+    short *beta = alpha + 2 * (size_t)dw;
+    resize_axis(w, dw, 1.0 / fx, 1, xofs, alpha);
+    resize_axis(h, dh, 1.0 / fy, 0, yofs, beta);
+#pragma omp parallel for schedule(static)
+    for (int dy = 0; dy < dh; ++dy) {
+        int r0 = yofs[dy], r1 = yofs[dy] + 1;
+        r0 = r0 < 0 ? 0 : (r0 < h ? r0 : h - 1);
+        r1 = r1 < 0 ? 0 : (r1 < h ? r1 : h - 1);
+        const int b0 = beta[dy * 2], b1 = beta[dy * 2 + 1];
+        const uint8_t *p0 = src + (size_t)r0 * w * 3, *p1 = src + (size_t)r1 * w * 3;
+        for (int dx = 0; dx < dw; ++dx) {
+            const int s0 = xofs[dx], s1 = s0 + 1 < w ? s0 + 1 : w - 1;
+            const int a0 = alpha[dx * 2], a1 = alpha[dx * 2 + 1];
+            for (int c = 0; c < 3; ++c) {
+                const int S0 = p0[s0 * 3 + c] * a0 + p0[s1 * 3 + c] * a1;
+                const int S1 = p1[s0 * 3 + c] * a0 + p1[s1 * 3 + c] * a1;
+                dst[((size_t)dy * dw + dx) * 3 + c] = (uint8_t)((((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2);
+            }
+        }
+    }
+    free(xofs);
+    free(alpha);
+}

@@ -84,6 +84,9 @@ def lib() -> C.CDLL:
             "orc_add_sat": (None, [vp, vp, sz, vp]),
             "orc_channel_sums": (None, [vp, sz, vp]),
             "orc_gain": (None, [vp, sz, vp]),
+            "orc_translate_u8c3": (None, [vp, i32, i32, i32, i32, vp]),
+            "orc_resize_dsize": (None, [i32, i32, C.c_double, C.c_double, vp, vp]),
+            "orc_resize_linear_u8c3": (None, [vp, i32, i32, C.c_double, C.c_double, vp, i32, i32]),
             "orc_bev_call": (None, [vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
         }
         for name, (res, args) in sig.items():
@@ -182,6 +185,25 @@ def warp_perspective(src: np.ndarray, H, dsize) -> np.ndarray:
     """cv2.warpPerspective(src, H, dsize): INTER_LINEAR, BORDER_CONSTANT 0, H inverted internally."""
     xy, a = perspective_coords(invert3x3(H), dsize)
     return remap(src, xy, a)
+
+
+def translate(img: np.ndarray, shift_x: int, shift_y: int) -> np.ndarray:
+    """cv2.warpAffine(img, [[1,0,shift_x],[0,1,shift_y]], (w,h)) (CenterImage.translate, extrinsicCalib.py:54-59)."""
+    img = _c(img, np.uint8)
+    out = np.empty_like(img)
+    lib().orc_translate_u8c3(_p(img), img.shape[1], img.shape[0], int(shift_x), int(shift_y), _p(out))
+    return out
+
+
+def resize_linear(img: np.ndarray, fx: float, fy: float) -> np.ndarray:
+    """cv2.resize(img, (0,0), fx=fx, fy=fy) with INTER_LINEAR (ScaleImage.__call__, extrinsicCalib.py:125)."""
+    img = _c(img, np.uint8)
+    h, w = img.shape[:2]
+    dw, dh = C.c_int(), C.c_int()
+    lib().orc_resize_dsize(w, h, float(fx), float(fy), C.byref(dw), C.byref(dh))
+    out = np.empty((dh.value, dw.value, 3), np.uint8)
+    lib().orc_resize_linear_u8c3(_p(img), w, h, float(fx), float(fy), _p(out), dw.value, dh.value)
+    return out
 
 
 def fill_poly(mask: np.ndarray, pts, color=255) -> np.ndarray:

@@ -250,3 +250,58 @@ def test_pinhole_map_identity_and_radial(oracle):
     v = 410.0 * (y + p1 * (r2 + 2 * y * y)) + 240.0
     iu, iv = int(np.rint(u * 32)), int(np.rint(v * 32))
     assert (m1[i, j, 0], m1[i, j, 1]) == (iu >> 5, iv >> 5)
+
+
+def test_translate_known_answers(oracle):
+    """cv2.warpAffine with an integer shift (CenterImage.translate, extrinsicCalib.py:54-59): a copy moved by
+    (shift_x, shift_y), zeros where the source tap falls outside."""
+    img = np.arange(5 * 7 * 3, dtype=np.uint8).reshape(5, 7, 3)
+    assert np.array_equal(oracle.translate(img, 0, 0), img)
+    out = oracle.translate(img, 2, 1)
+    assert np.array_equal(out[1:, 2:], img[:-1, :-2]) and not out[0].any() and not out[:, :2].any()
+    out = oracle.translate(img, -3, -2)
+    assert np.array_equal(out[:-2, :-3], img[2:, 3:]) and not out[-2:].any() and not out[:, -3:].any()
+    assert not oracle.translate(img, 7, 0).any() and not oracle.translate(img, 0, -5).any()
+
+
+def test_resize_known_answers(oracle):
+    """cv2.resize INTER_LINEAR on 8U (ScaleImage.__call__, extrinsicCalib.py:125): hand-derived cases."""
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (12, 18, 3), dtype=np.uint8)
+    # scale 1: weights (2048, 0) both ways -> ((2048 * (S*2048 >> 4)) >> 16) = 4 S -> (4 S + 2) >> 2 = S
+    assert np.array_equal(oracle.resize_linear(img, 1.0, 1.0), img)
+    # scale 1/2: every tap pair has weight 1024 -> (a + b + c + d + 2) >> 2, which is also OpenCV's area-fast shortcut
+    half = oracle.resize_linear(img, 0.5, 0.5)
+    i32 = img.astype(np.int32)
+    want = (i32[0::2, 0::2] + i32[0::2, 1::2] + i32[1::2, 0::2] + i32[1::2, 1::2] + 2) >> 2
+    assert half.shape == (6, 9, 3) and np.array_equal(half, want.astype(np.uint8))
+    # dsize = cvRound(size * f): round-half-to-even
+    assert oracle.resize_linear(np.zeros((5, 7, 3), np.uint8), 0.5, 0.5).shape == (2, 4, 3)   # 2.5 -> 2, 3.5 -> 4
+    # 2x upscale of the row [0, 100] (one image row): columns sample at -0.25, 0.25, 0.75, 1.25
+    row = np.zeros((1, 2, 3), np.uint8)
+    row[0, 1] = 100
+    up = oracle.resize_linear(row, 2.0, 2.0)
+    # x=0: s<0 -> 0; x=1: f=.25 -> S=100*512=51200, (51200>>4)=3200, rows both clip to row 0 with b=(512,1536):
+    #   ((512*3200)>>16) + ((1536*3200)>>16) = 25 + 75 = 100 -> (100+2)>>2 = 25;  x=2: f=.75 -> 75;  x=3: s>=w-1 -> 100
+    assert up.shape == (2, 4, 3) and up[0, :, 0].tolist() == [0, 25, 75, 100] and np.array_equal(up[0], up[1])
+    # constant images stay constant up to the fixed-point floor of the two vertical terms (never above the value)
+    for v in (1, 77, 255):
+        c = oracle.resize_linear(np.full((9, 11, 3), v, np.uint8), 1.7, 1.7)
+        assert c.max() <= v and c.min() >= v - 1
+
+
+@pytest.mark.parametrize("f", [0.37, 0.8, 1.3, 2.6])
+def test_resize_close_to_float_bilinear(oracle, f):
+    """Independent check of the geometry (half-pixel centres, edge replication): float bilinear within 1 LSB."""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    got = oracle.resize_linear(img, f, f).astype(np.float64)
+    dh, dw = got.shape[:2]
+    ys = np.clip((np.arange(dh) + 0.5) / f - 0.5, 0, img.shape[0] - 1)
+    xs = np.clip((np.arange(dw) + 0.5) / f - 0.5, 0, img.shape[1] - 1)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, img.shape[0] - 1), np.minimum(x0 + 1, img.shape[1] - 1)
+    wy, wx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    I = img.astype(np.float64)
+    want = (I[y0][:, x0] * (1 - wx) + I[y0][:, x1] * wx) * (1 - wy) + (I[y1][:, x0] * (1 - wx) + I[y1][:, x1] * wx) * wy
+    assert np.abs(got - want).max() <= 1.0
