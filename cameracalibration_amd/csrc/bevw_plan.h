@@ -40,7 +40,6 @@ constexpr int kPlanLXDefault = 8;          // lanes along x -> 32 x 8 pixel tile
 struct Plan {
     void *entries = nullptr;     // uint2[ntiles][8][64]
     void *hdr = nullptr;         // uint32[ntiles]
-    void *pf = nullptr;          // uint32[ntiles][2][64]: per-lane byte offsets of the tile's source sectors (prefetch)
     void *psums = nullptr;       // uint32[batch][ntiles][3]  (balance: per-tile channel sums)
     size_t psums_cap = 0;
     int *d_max = nullptr;
@@ -63,9 +62,6 @@ struct Plan {
     void *list_st_single = nullptr, *list_st_double = nullptr, *list_rs_single = nullptr, *list_rs_double = nullptr;
     int n_st_single = 0, n_st_double = 0, n_rs_single = 0, n_rs_double = 0;
     bool staged_ok = false;
-    // second stream for the tile classes that stay on the gather kernels: they overlap with the staged kernels
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct __attribute__((packed, aligned(1))) PackedU2 { uint32_t x, y; };
@@ -246,46 +242,6 @@ __global__ void k_plan_build(StitchTables T, int fw, int fh, int bw, int bh, int
     }
 }
 
-// Prefetch list of a tile: the distinct 64-byte sectors its footprints touch, one (or two) per lane, as byte offsets
-// inside the 4-camera frame set.  The stitch kernels read one dword from each, one frame AHEAD of the gathers: the
-// ~25 sector misses a tile-frame needs are then started by a single wave instruction while the previous frame is
-// still being interpolated, instead of trickling out of the 8 gather instructions (whose every miss otherwise holds
-// an in-order vector-memory slot for a full HBM round trip).  Rows are tracked relative to the tile's first source
-// row; a tile spanning more than 64 source rows prefetches only the first 64.
-__global__ void k_plan_prefetch(const uint2 *__restrict__ plan, int ntiles, uint32_t row_bytes, uint32_t *__restrict__ pf)
-{
-    __shared__ uint32_t rmin[64], rmax[64];
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    if (tile >= ntiles) return;
-    rmin[lane] = 0xffffffffu; rmax[lane] = 0;
-    uint2 e[8];
-    uint32_t r0 = 0xffffffffu;
-    for (int k = 0; k < 8; ++k) {
-        e[k] = plan[((size_t)tile * 8 + k) * 64 + lane];
-        if ((e[k].y & kMetaValid) && !(e[k].y & kMetaSlow)) r0 = min(r0, e[k].x / row_bytes);
-    }
-    for (int off = 32; off > 0; off >>= 1) r0 = min(r0, (uint32_t)__shfl_xor((int)r0, off, 64));
-    __syncthreads();
-    if (r0 != 0xffffffffu) {
-        for (int k = 0; k < 8; ++k) {
-            if (!((e[k].y & kMetaValid) && !(e[k].y & kMetaSlow))) continue;
-            const uint32_t r = e[k].x / row_bytes - r0, x = (e[k].x % row_bytes) & ~3u;
-            for (uint32_t d = 0; d < 2; ++d)
-                if (r + d < 64) { atomicMin(&rmin[r + d], x); atomicMax(&rmax[r + d], x + 11); }
-        }
-    }
-    __syncthreads();
-    uint32_t p0 = 0xffffffffu, p1 = 0xffffffffu;
-    if (r0 != 0xffffffffu && rmin[lane] != 0xffffffffu) {
-        const uint32_t base = (r0 + lane) * row_bytes;
-        p0 = (base + rmin[lane]) & ~63u;
-        const uint32_t last = (base + rmax[lane]) & ~63u;
-        if (last > p0) p1 = last;   // rows of a 16-pixel tile span at most two sectors; wider tiles get first + last
-    }
-    pf[((size_t)tile * 2 + 0) * 64 + lane] = p0;
-    pf[((size_t)tile * 2 + 1) * 64 + lane] = p1;
-}
-
 // Bitmap of the 4-texel groups (12 bytes, 4-byte aligned because fw % 4 == 0) that the plan samples, over the 4-camera
 // frame set: bit index = (cam * fh + y) * (fw / 4) + x / 4.  The balance schedule converts exactly these groups of every
 // raw frame (luminance round trip) instead of whole frames or bounding boxes (the LUT quirk makes the right camera's
@@ -453,9 +409,6 @@ struct PlanArgs {
     int batch, nb, nchunks, xcd_affine;
     const uint2 *plan_st;        // LDS-staged entries (k_plan_staged)
     const uint32_t *dma;         // LDS-DMA source offsets [ntiles][kStageInstr][64]
-    const uint32_t *pf;          // prefetch offsets [ntiles][2][64] or nullptr
-    int *sink;                   // scratch word that absorbs the prefetched values
-    int nt_store;                // experiments: 1 = nontemporal stores
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
     int nlist;
 };
@@ -463,7 +416,6 @@ struct PlanArgs {
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
 // its own L2, so the map decides what an L2 sees:
 //   xcd_affine 1: an XCD owns whole batch chunks (all tiles of frames b0..b0+nb), neighbouring tiles share its L2
-//   xcd_affine 2: an XCD owns a contiguous BAND of tile groups for every chunk (spatial partition)
 //   xcd_affine 0: plain chunk-major order (few chunks)
 __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, uint32_t &chunk, uint32_t &group)
 {
@@ -472,11 +424,6 @@ __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, u
         const uint32_t xcd = id & 7u, k = id >> 3;
         chunk = xcd + 8u * (k / ng);
         group = k % ng;
-    } else if (a.xcd_affine == 2) {
-        const uint32_t xcd = id & 7u, k = id >> 3, gpb = (ng + 7u) / 8u;   // groups per band
-        chunk = k / gpb;
-        group = xcd * gpb + k % gpb;
-        if (group >= ng) return false;
     } else {
         chunk = id / ng;
         group = id % ng;
@@ -578,25 +525,22 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// lean class kernels (no balance): every contributor of the tile is an interior footprint.
-//   NSLOT = 1: exactly <= 1 contributor per pixel (inside a trapezoid)        -> list_single
-//   NSLOT = 2: some pixel has two (direct-stitch seams, blend overlaps)       -> list_double
-// Register diet: per pixel and slot only {offset, wx, wy (, wf)} live across the batch loop, so 8 waves/SIMD fit and
-// the gathers of many tiles overlap.  Same block -> (chunk, tile) mapping as k_stitch_plan.
+// gather class kernels (no luminance round trip): every contributor of the tile is an interior footprint.
+//   NSLOT = 1: <= 1 contributor per pixel (inside a trapezoid)                -> list_single / list_rs_single
+//   NSLOT = 2: some pixel has two (direct-stitch seams, blend overlaps)       -> list_double / list_rs_double
+// Register diet: per pixel and slot only {offset, misalignment, wx, wy (, wf)} live across the batch loop, so many waves
+// fit a SIMD and the gathers of many tiles overlap.  Same block -> (chunk, tile) mapping as k_stitch_plan.
+// SUMS: emit per-tile channel sums (balance on pre-shifted frames) and leave the car to k_gain.
 // ---------------------------------------------------------------------------------------------------------------
-// ABL (experiments only, BEVW_ABL): 0 = product kernel, 1 = no stores, 2 = no loads (synthetic texels),
-// 3 = loads confined to a 4 KB window (all L1 hits), 4 = every frame of the batch reads frame set 0 (cache-resident
-// source with the real address pattern), 5/6/7 = loads only (12 / 8 / 16 bytes per lane, real addresses, no
-// arithmetic, no stores), 8 = 5 on a cache-resident source
-// PFW (experiment): touch THIS frame's sectors with one instruction and wait for them before the gathers (all-hit gathers)
-template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false, bool PFW = false>
-__device__ __forceinline__ void plan_lean_body(const PlanArgs &a, uint32_t block_id, int waves_per_block, uint32_t *xpose)
+template <int LX, int NSLOT, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
 {
     constexpr int LY = 64 / LX;
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
     uint32_t chunk, group;
-    if (!plan_block_map(a, block_id, chunk, group)) return;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
     const int lane = threadIdx.x & 63;
-    const int slot = (int)group * waves_per_block + (threadIdx.x >> 6);
+    const int slot = (int)group * 4 + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
@@ -619,7 +563,7 @@ __device__ __forceinline__ void plan_lean_body(const PlanArgs &a, uint32_t block
             const uint2 e = a.plan[((size_t)tile * 8 + s * 4 + j) * 64 + lane];
             const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
             const bool valid = e.y & kMetaValid;
-            const uint32_t o = valid ? (ABL == 3 ? (e.x & 0xfffu) : e.x) : 0u;
+            const uint32_t o = valid ? e.x : 0u;
             off[s][j] = o & ~3u;   // frames are 4-byte aligned (checked by the host), so this is an aligned address
             mis[s][j] = o & 3u;
             wx[s][j] = valid ? ((32 - fx) | (fx << 24)) : 0u;  // zero x-weights: an absent entry contributes exactly 0
@@ -633,93 +577,22 @@ __device__ __forceinline__ void plan_lean_body(const PlanArgs &a, uint32_t block
     }
     const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
 
-    // prefetch offsets; lanes without a sector re-touch offset 0 of the set (always mapped, one extra hot line)
-    uint32_t pf0 = 0, pf1 = 0, pfa_prev = 0, pfb_prev = 0, pf_acc = 0;
-    constexpr bool do_pf = PF;   // compile-time: the vmcnt bookkeeping must not depend on a runtime branch
-    if (do_pf || PFW) {
-        pf0 = a.pf[((size_t)tile * 2 + 0) * 64 + lane]; pf1 = a.pf[((size_t)tile * 2 + 1) * 64 + lane];
-        pf0 = pf0 == 0xffffffffu ? 0u : pf0; pf1 = pf1 == 0xffffffffu ? pf0 : pf1;
-    }
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
-    const uint8_t *fb = a.frames + (ABL == 4 ? 0 : (size_t)b_begin * set_bytes);
+    const uint8_t *fb = a.frames + (size_t)b_begin * set_bytes;
     uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
-    if (ABL >= 5 && ABL <= 8) {
-        uint32_t x = 0;
-        for (int b = b_begin; b < b_end; ++b, fb += (ABL == 8 ? 0 : set_bytes)) {
-            const uint8_t *fb1 = fb + row_bytes;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ABL == 6) {
-                    const uint2 u = *reinterpret_cast<const uint2 *>(fb + (off[0][j] & ~7u)), v = *reinterpret_cast<const uint2 *>(fb1 + (off[0][j] & ~7u));
-                    x ^= u.x + u.y + v.x + v.y;
-                } else if (ABL == 7) {
-                    const uint4 u = *reinterpret_cast<const uint4 *>(fb + (off[0][j] & ~15u)), v = *reinterpret_cast<const uint4 *>(fb1 + (off[0][j] & ~15u));
-                    x ^= u.x + u.y + u.z + u.w + v.x + v.y + v.z + v.w;
-                } else {
-                    const uint2 u = load_footprint_row(fb + off[0][j], mis[0][j]), v = load_footprint_row(fb1 + off[0][j], mis[0][j]);
-                    x ^= u.x + u.y + v.x + v.y;
-                }
-            }
-        }
-        if (x == 0x12345678u && inimg) *reinterpret_cast<uint32_t *>(ob) = x;
-        return;
-    }
-    // ABL 9 (cost model of an LDS-staged variant, results are NOT valid): two LDS-DMA instructions fetch the tile's
-    // sectors, the footprints are read back with ds_read2_b32 + ds_read_b32 at addresses derived from the real offsets
-    __shared__ __attribute__((aligned(16))) uint8_t stage[ABL == 9 ? 16 * 2 * 2112 : 16];
-    uint32_t dma0 = 0, dma1 = 0;
-    if (ABL == 9) {
-        const uint32_t s0 = a.pf ? a.pf[((size_t)tile * 2 + 0) * 64 + (lane >> 2)] : 0u, s1 = a.pf ? a.pf[((size_t)tile * 2 + 1) * 64 + (lane >> 2)] : 0u;
-        dma0 = (s0 == 0xffffffffu ? 0u : s0) + (lane & 3) * 16;
-        dma1 = (s1 == 0xffffffffu ? dma0 : s1 + (lane & 3) * 16);
-    }
 #pragma unroll 1
-    for (int b = b_begin; b < b_end; ++b, fb += (ABL == 4 ? 0 : set_bytes), ob += img_bytes) {
+    for (int b = b_begin; b < b_end; ++b, fb += set_bytes, ob += img_bytes) {
         const uint8_t *fb1 = fb + row_bytes;
         uint32_t acc[4][3];
-        if (ABL == 9) {
-            uint8_t *buf = stage + ((threadIdx.x >> 6) * 2 + (b & 1)) * 2112;
-            auto l3 = (__attribute__((address_space(3))) uint8_t *)buf;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + dma0), (__attribute__((address_space(3))) void *)l3, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(fb + dma1), (__attribute__((address_space(3))) void *)(l3 + 1024), 16, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(buf);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t i0 = (off[0][j] >> 2) & 0x1ffu, i1 = ((off[0][j] + row_bytes) >> 2) & 0x1ffu;
-                const uint2 r0 = make_uint2(__builtin_amdgcn_alignbyte(w[i0 + 1], w[i0], mis[0][j]), __builtin_amdgcn_alignbyte(w[i0 + 2], w[i0 + 1], mis[0][j]));
-                const uint2 r1 = make_uint2(__builtin_amdgcn_alignbyte(w[i1 + 1], w[i1], mis[0][j]), __builtin_amdgcn_alignbyte(w[i1 + 2], w[i1 + 1], mis[0][j]));
-                bilinear_rows_b2(r0, r1, wx[0][j], wy[0][j], acc[j]);
-            }
-        } else
-        if (PFW) {
-            const uint32_t t0 = *reinterpret_cast<const uint32_t *>(fb + pf0), t1 = *reinterpret_cast<const uint32_t *>(fb + pf1);
-            pf_acc ^= t0 ^ t1;
-            // the XOR above makes the compiler wait for both loads; keep the gathers behind it
-            asm volatile("" : "+v"(pf_acc));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ABL != 9) {
+        {
             uint2 r0[4], r1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (ABL == 2 || ABL == 10) { r0[j] = make_uint2(off[0][j] ^ (uint32_t)b, wx[0][j]); r1[j] = make_uint2(off[0][j] + (uint32_t)b, wy[0][j]); }
-                else { r0[j] = load_footprint_row(fb + off[0][j], mis[0][j]); r1[j] = load_footprint_row(fb1 + off[0][j], mis[0][j]); }
-            }
-            // touch the sectors of the NEXT frame (issued after this frame's gathers: vector loads return in order)
-            uint32_t pfa_now = 0, pfb_now = 0;
-            if (do_pf) {
-                const uint8_t *fn = (b + 1 < b_end) ? fb + set_bytes : fb;   // wave-uniform select, no branch
-                pfa_now = *reinterpret_cast<const uint32_t *>(fn + pf0);
-                pfb_now = *reinterpret_cast<const uint32_t *>(fn + pf1);
+                r0[j] = load_footprint_row(fb + off[0][j], mis[0][j]);
+                r1[j] = load_footprint_row(fb1 + off[0][j], mis[0][j]);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (ABL == 11) { acc[j][0] = r0[j].x << 16; acc[j][1] = r1[j].x << 8; acc[j][2] = r0[j].y ^ r1[j].y; }  // memory traffic only
-                else bilinear_rows_b2(r0[j], r1[j], wx[0][j], wy[0][j], acc[j]);
-            }
-            pf_acc ^= pfa_prev ^ pfb_prev;   // consumed one iteration late, so the wait for it never stalls the pipeline
-            pfa_prev = pfa_now; pfb_prev = pfb_now;
+            for (int j = 0; j < 4; ++j) bilinear_rows_b2(r0[j], r1[j], wx[0][j], wy[0][j], acc[j]);
         }
         uint32_t P[4];
         if (!BLEND && NSLOT == 1) {
@@ -777,25 +650,13 @@ __device__ __forceinline__ void plan_lean_body(const PlanArgs &a, uint32_t block
         }
         if (interleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
         if (car_any) add_car(P, car0, car1, car2);
-        if (inimg && ((ABL != 1 && ABL != 10) || ((P[0] ^ P[1] ^ P[2] ^ P[3]) == 0xdeadbeefu))) {
+        if (inimg) {
             uint32_t d0, d1, d2;
             pack_pixels(P, d0, d1, d2);
             uint32_t *op = reinterpret_cast<uint32_t *>(ob);
-            if (a.nt_store) {
-                __builtin_nontemporal_store(d0, op); __builtin_nontemporal_store(d1, op + 1); __builtin_nontemporal_store(d2, op + 2);
-            } else {
-                op[0] = d0; op[1] = d1; op[2] = d2;
-            }
+            op[0] = d0; op[1] = d1; op[2] = d2;
         }
     }
-    if ((pf_acc ^ pfa_prev ^ pfb_prev) == 0x9e3779b9u) *a.sink = 1;   // keeps the prefetch loads alive (scratch word, not the output)
-}
-
-template <int LX, int NSLOT, bool BLEND, int ABL = 0, bool PF = true, bool SUMS = false, bool PFW = false>
-__global__ void __launch_bounds__(1024) k_plan_lean(PlanArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[16 * 256];
-    plan_lean_body<LX, NSLOT, BLEND, ABL, PF, SUMS, PFW>(a, blockIdx.x, (int)(blockDim.x >> 6), xpose);
 }
 
 // tiles without any contributor (under the car): out = car (or 0) for every frame of the chunk
@@ -1059,23 +920,6 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
     plan_staged_body<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, stage_0, stage_1, stage_2);
 }
 
-// Staged (VALU / LDS bound) and gather (vector-memory bound) single-contributor tiles in ONE launch: blocks of the two
-// kinds are interleaved in groups of 8 (a group keeps block id % 8, i.e. its XCD), so both kinds are resident on every
-// CU at the same time and their different bottlenecks overlap.  Gather blocks use the first 4 KB of the staging memory
-// as their quad-exchange patch.
-template <int LX, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_fused(PlanArgs a_st, PlanArgs a_ga, uint32_t nsuper_st, uint32_t nsuper_ga)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
-    const uint32_t super = blockIdx.x >> 3, l8 = blockIdx.x & 7u, total = nsuper_st + nsuper_ga;
-    const uint32_t g_before = (uint32_t)(((uint64_t)super * nsuper_ga) / total);
-    const bool is_ga = (uint32_t)(((uint64_t)(super + 1) * nsuper_ga) / total) > g_before;
-    if (is_ga) plan_lean_body<LX, 1, BLEND, 0, false, SUMS, false>(a_ga, (g_before << 3) | l8, 4, reinterpret_cast<uint32_t *>(stage_0));
-    else plan_staged_body<LX, 1, BLEND, SUMS>(a_st, ((super - g_before) << 3) | l8, stage_0, stage_1, stage_2);
-}
-
 // psums[b][tile][3] -> chsums[b][3] ; grid = batch, block = 256
 __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, unsigned long long *__restrict__ chsums)
 {
@@ -1102,13 +946,10 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries, p.hdr, p.pf, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
+    void *ptrs[] = {p.entries, p.hdr, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
                     p.list_st_double, p.list_rs_single, p.list_rs_double, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    if (p.ev_fork) (void)hipEventDestroy(p.ev_fork);
-    if (p.ev_join) (void)hipEventDestroy(p.ev_join);
-    if (p.side) (void)hipStreamDestroy(p.side);
     p = Plan();
 }
 
@@ -1142,10 +983,6 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
                        static_cast<uint2 *>(p.entries), static_cast<uint32_t *>(p.hdr), p.d_max);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&p.max_contrib, p.d_max, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
-    if ((e = hipMalloc(&p.pf, (size_t)p.ntiles * 2 * 64 * sizeof(uint32_t))) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_plan_prefetch, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries), p.ntiles,
-                       (uint32_t)fw * 3, static_cast<uint32_t *>(p.pf));
-    if ((e = hipGetLastError()) != hipSuccess) return e;
     p.band_ok = false;
     if (fw % 4 == 0) {
         const size_t nbits = (size_t)ncams * fh * (fw / 4), nwords = (nbits + 31) / 32;
@@ -1173,9 +1010,6 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = plan_upload_list(list, &p.groups)) != hipSuccess) return e;
         p.band_ok = true;
     }
-    if ((e = hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
     p.staged_ok = false;
     if (fw % 8 == 0 && ((size_t)fw * fh * 3 * ncams) % 16 == 0) {   // row pitch % 8 == 0: both footprint rows share the offset
         if ((e = hipMalloc(&p.entries_st, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
@@ -1246,22 +1080,22 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     return hipSuccess;
 }
 
-struct PlanTuning { int nb = 0; int lean = 1; int abl = 0; int wpb = 4; int prefetch = 0; int nt = 0; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int two_streams = 0; int fuse = 0; };
+// nb: frames per block (0 = default); lean: 0 = one generic kernel over every tile (debug); lds_pad: dynamic LDS added to the
+// single-contributor gather kernel to cap it at 5 waves per SIMD (more resident gather waves thrash the L1);
+// xcd_map: 1 = an XCD owns whole batch chunks; staged: 1 = LDS-staged kernels for the tiles that have a staging plan
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; };
 
 template <int LX>
-static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int abl = 0,
-                                        int wpb = 4, int lds_pad = 0, bool sums = false, bool pfw = false, bool staged = false,
-                                        bool two_streams = true, bool fuse = true)
+static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
+                                        bool sums, bool staged)
 {
     hipError_t e;
-    if (wpb != 4 && wpb != 8 && wpb != 16) wpb = 4;
-    const dim3 block(64 * wpb);
+    const dim3 block(256);   // 4 waves = 4 tiles per workgroup
     auto grid_blocks = [&]() -> unsigned {
         if (a.xcd_affine == 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
-        if (a.xcd_affine == 2) return (unsigned)(((a.ngroups + 7) / 8) * 8 * a.nchunks);
         return (unsigned)(a.ngroups * a.nchunks);
     };
-    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + wpb - 1) / wpb; };
+    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; };
     if (balance || !lean) {
         // generic kernel over every tile (luminance round trip per tap, per-tile channel sums)
         set_list(nullptr, p.ntiles);
@@ -1272,154 +1106,41 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
         return hipGetLastError();
     }
-    // class lists: with the LDS-staged schedule the single / double classes split into staged tiles (k_plan_staged, always
-    // 4 waves per block) and the rest (k_plan_lean)
+    // sums = balance on pre-shifted frames: per-tile channel sums, the car is added by k_gain afterwards
+    if (sums) a.car = nullptr;
+    // class lists: with the LDS-staged schedule the single / double classes split into staged tiles (k_plan_staged) and
+    // the rest (k_plan_lean)
     void *l_single = staged ? p.list_rs_single : p.list_single, *l_double = staged ? p.list_rs_double : p.list_double;
-    int n_single = staged ? p.n_rs_single : p.n_single;
-    const int n_double = staged ? p.n_rs_double : p.n_double;
-    hipStream_t st_main = st;
-    const bool fork = staged && two_streams && p.side != nullptr;
-    if (staged) {
-        if (sums) a.car = nullptr;
-        const int wpb_keep = wpb;
-        wpb = 4;
-        const dim3 block4(256);
-        bool fused_singles = false;
-        if (fuse && p.n_st_single && p.n_rs_single) {
-            // one launch for both single-contributor classes (k_plan_fused)
-            PlanArgs a_st = a, a_ga = a;
-            a_st.tile_list = static_cast<const uint32_t *>(p.list_st_single); a_st.nlist = p.n_st_single; a_st.ngroups = (p.n_st_single + 3) / 4;
-            a_ga.tile_list = static_cast<const uint32_t *>(p.list_rs_single); a_ga.nlist = p.n_rs_single; a_ga.ngroups = (p.n_rs_single + 3) / 4;
-            auto blocks_of = [&](const PlanArgs &q) -> unsigned {
-                if (q.xcd_affine == 1) return (unsigned)(q.ngroups * (((q.nchunks + 7) / 8) * 8));
-                if (q.xcd_affine == 2) return (unsigned)(((q.ngroups + 7) / 8) * 8 * q.nchunks);
-                return (unsigned)(q.ngroups * q.nchunks);
-            };
-            const unsigned ns_st = (blocks_of(a_st) + 7) / 8, ns_ga = (blocks_of(a_ga) + 7) / 8;
-            const dim3 grid((ns_st + ns_ga) * 8);
-            if (blend && sums) hipLaunchKernelGGL((k_plan_fused<LX, true, true>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
-            else if (blend) hipLaunchKernelGGL((k_plan_fused<LX, true, false>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
-            else if (sums) hipLaunchKernelGGL((k_plan_fused<LX, false, true>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
-            else hipLaunchKernelGGL((k_plan_fused<LX, false, false>), grid, block4, 0, st, a_st, a_ga, ns_st, ns_ga);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            fused_singles = true;
-            n_single = 0;   // the gather singles ran inside the fused launch
-        }
-        if (p.n_st_single && !fused_singles) {
-            set_list(p.list_st_single, p.n_st_single);
-            const dim3 grid(grid_blocks());
-            if (blend && sums) hipLaunchKernelGGL((k_plan_staged<LX, 1, true, true>), grid, block4, 0, st, a);
-            else if (blend) hipLaunchKernelGGL((k_plan_staged<LX, 1, true, false>), grid, block4, 0, st, a);
-            else if (sums) hipLaunchKernelGGL((k_plan_staged<LX, 1, false, true>), grid, block4, 0, st, a);
-            else hipLaunchKernelGGL((k_plan_staged<LX, 1, false, false>), grid, block4, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (p.n_st_double) {
-            set_list(p.list_st_double, p.n_st_double);
-            const dim3 grid(grid_blocks());
-            if (blend && sums) hipLaunchKernelGGL((k_plan_staged<LX, 2, true, true>), grid, block4, 0, st, a);
-            else if (blend) hipLaunchKernelGGL((k_plan_staged<LX, 2, true, false>), grid, block4, 0, st, a);
-            else if (sums) hipLaunchKernelGGL((k_plan_staged<LX, 2, false, true>), grid, block4, 0, st, a);
-            else hipLaunchKernelGGL((k_plan_staged<LX, 2, false, false>), grid, block4, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        wpb = wpb_keep;
-        if (p.n_empty) {
-            set_list(p.list_empty, p.n_empty);
-            const dim3 grid((unsigned)(a.ngroups * a.nchunks));
-            hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (fork) {
-            // everything below (gather-class tiles) goes to the side stream and is joined at the end
-            if ((e = hipEventRecord(p.ev_fork, st_main)) != hipSuccess) return e;   // orders it after earlier work of the call
-            if ((e = hipStreamWaitEvent(p.side, p.ev_fork, 0)) != hipSuccess) return e;
-            st = p.side;
-        }
-    }
-    auto join = [&]() -> hipError_t {
-        if (!fork) return hipSuccess;
-        hipError_t je = hipEventRecord(p.ev_join, p.side);
-        if (je != hipSuccess) return je;
-        return hipStreamWaitEvent(st_main, p.ev_join, 0);
-    };
-    const bool skip_empty = staged;
-    if (sums) {
-        // balance on pre-shifted frames: lean kernels + per-tile channel sums; the car is added by k_gain
-        a.car = nullptr;
-        if (n_single) {
-            set_list(l_single, n_single);
-            const dim3 grid(grid_blocks());
-            if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false, true>), grid, block, lds_pad, st, a);
-            else hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false, true>), grid, block, lds_pad, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (n_double) {
-            set_list(l_double, n_double);
-            const dim3 grid(grid_blocks());
-            if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, false, true>), grid, block, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (p.n_slow) {
-            set_list(p.list_slow, p.n_slow);
-            const dim3 grid(grid_blocks());
-            if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_stitch_plan<LX, false, false, true>), grid, block, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (p.n_empty && !skip_empty) {
-            set_list(p.list_empty, p.n_empty);
-            const dim3 grid((unsigned)(a.ngroups * a.nchunks));
-            hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        return join();
-    }
-    if (n_single) {
-        set_list(l_single, n_single);
-        const dim3 grid(grid_blocks());
-        if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, true>), grid, block, 0, st, a);
-        else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 1, true, 0, false>), grid, block, 0, st, a);
-        else if (abl == 1) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 1, false>), grid, block, 0, st, a);
-        else if (abl == 2) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 2, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 3) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 3, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 4) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 4, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 5) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 5, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 6) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 6, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 7) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 7, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 8) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 8, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 9) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 9, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 10) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 10, false>), grid, block, 0, st, a);
-        else if (LX == 4 && abl == 11) hipLaunchKernelGGL((k_plan_lean<4, 1, false, 11, false>), grid, block, 0, st, a);
-        else if (a.pf && pfw) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false, false, true>), grid, block, lds_pad, st, a);
-        else if (a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, true>), grid, block, lds_pad, st, a);
-        else hipLaunchKernelGGL((k_plan_lean<LX, 1, false, 0, false>), grid, block, lds_pad, st, a);
+    const int n_single = staged ? p.n_rs_single : p.n_single, n_double = staged ? p.n_rs_double : p.n_double;
+#define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM)                                                                       \
+    do {                                                                                                            \
+        const dim3 grid(grid_blocks());                                                                             \
+        if (blend && sums) hipLaunchKernelGGL((KERNEL<LX, NS, true, true>), grid, block, SHMEM, st, a);             \
+        else if (blend) hipLaunchKernelGGL((KERNEL<LX, NS, true, false>), grid, block, SHMEM, st, a);               \
+        else if (sums) hipLaunchKernelGGL((KERNEL<LX, NS, false, true>), grid, block, SHMEM, st, a);                \
+        else hipLaunchKernelGGL((KERNEL<LX, NS, false, false>), grid, block, SHMEM, st, a);                         \
+        if ((e = hipGetLastError()) != hipSuccess) return e;                                                        \
+    } while (0)
+    if (staged && p.n_st_single) { set_list(p.list_st_single, p.n_st_single); BEVW_LAUNCH_CLASS(k_plan_staged, 1, 0); }
+    if (staged && p.n_st_double) { set_list(p.list_st_double, p.n_st_double); BEVW_LAUNCH_CLASS(k_plan_staged, 2, 0); }
+    if (p.n_empty) {
+        set_list(p.list_empty, p.n_empty);
+        hipLaunchKernelGGL((k_plan_empty<LX>), dim3((unsigned)(a.ngroups * a.nchunks)), block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (n_double) {
-        set_list(l_double, n_double);
-        const dim3 grid(grid_blocks());
-        if (blend && a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, true>), grid, block, 0, st, a);
-        else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, 0, false>), grid, block, 0, st, a);
-        else if (a.pf) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, 0, false>), grid, block, 0, st, a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
+    if (n_single) { set_list(l_single, n_single); BEVW_LAUNCH_CLASS(k_plan_lean, 1, lds_pad); }
+    if (n_double) { set_list(l_double, n_double); BEVW_LAUNCH_CLASS(k_plan_lean, 2, 0); }
+#undef BEVW_LAUNCH_CLASS
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
         const dim3 grid(grid_blocks());
-        if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
+        if (blend && sums) hipLaunchKernelGGL((k_stitch_plan<LX, true, false, true>), grid, block, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_stitch_plan<LX, true, false>), grid, block, 0, st, a);
+        else if (sums) hipLaunchKernelGGL((k_stitch_plan<LX, false, false, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_stitch_plan<LX, false, false>), grid, block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (p.n_empty && !skip_empty) {
-        set_list(p.list_empty, p.n_empty);
-        const dim3 grid((unsigned)(a.ngroups * a.nchunks));
-        hipLaunchKernelGGL((k_plan_empty<LX>), grid, block, 0, st, a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-    }
-    return join();
+    return hipSuccess;
 }
 
 // balance = per-tap luminance round trip on RAW frames (generic kernel); sums = frames are already luminance-shifted
@@ -1436,21 +1157,18 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
     a.ncams = p.ncams;
     a.tile_list = nullptr; a.nlist = p.ntiles;
-    a.pf = tune.prefetch ? static_cast<const uint32_t *>(p.pf) : nullptr;
     a.plan_st = static_cast<const uint2 *>(p.entries_st);
     a.dma = static_cast<const uint32_t *>(p.dma);
     // LDS-staged schedule: needs 16-byte aligned frame sets (whole-sector DMA) and is not combined with the per-tap
-    // luminance kernel or the ablation modes
-    const bool use_staged = tune.staged && p.staged_ok && !balance && tune.abl == 0 && tune.lean && (((uintptr_t)d_frames) & 15u) == 0;
-    a.sink = p.d_max;
-    a.nt_store = tune.nt;
+    // luminance kernel
+    const bool use_staged = tune.staged && p.staged_ok && !balance && tune.lean && (((uintptr_t)d_frames) & 15u) == 0;
     a.batch = batch;
     // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk
     int nb = tune.nb > 0 ? tune.nb : 8;
     if (batch < 8 * nb) nb = batch >= 8 ? batch / 8 : 1;
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
-    a.xcd_affine = tune.xcd_map == 2 ? 2 : (a.nchunks >= 8 ? tune.xcd_map : 0);
+    a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? 1 : 0;
     if (balance || sums) {
         const size_t need = (size_t)batch * p.ntiles * 3 * sizeof(uint32_t);
         if (need > p.psums_cap) {
@@ -1463,9 +1181,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0, tune.fuse != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, false, use_staged, tune.two_streams != 0, tune.fuse != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.abl, tune.wpb, tune.lds_pad, sums, tune.prefetch == 2, use_staged, tune.two_streams != 0, tune.fuse != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

@@ -82,14 +82,8 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         PlanTuning t;
         if (const char *s = getenv("BEVW_PLAN_NB")) t.nb = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LEAN")) t.lean = atoi(s);
-        if (const char *s = getenv("BEVW_ABL")) t.abl = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_WPB")) t.wpb = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_PREFETCH")) t.prefetch = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_NT")) t.nt = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_XCDMAP")) t.xcd_map = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_TWOSTREAMS")) t.two_streams = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_FUSE")) t.fuse = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         return t;
     }();
