@@ -532,17 +532,12 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 // fit a SIMD and the gathers of many tiles overlap.  Same block -> (chunk, tile) mapping as k_stitch_plan.
 // SUMS: emit per-tile channel sums (balance on pre-shifted frames) and leave the car to k_gain.
 // ---------------------------------------------------------------------------------------------------------------
+// one wave: tile `tile`, frames [b_begin, b_end); xpose_wave: 1 KB of LDS private to the wave (quad exchange)
 template <int LX, int NSLOT, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
+__device__ __forceinline__ void plan_gather_tile(const PlanArgs &a, int tile, int b_begin, int b_end, uint32_t *xpose_wave)
 {
     constexpr int LY = 64 / LX;
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
-    uint32_t chunk, group;
-    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
     const int lane = threadIdx.x & 63;
-    const int slot = (int)group * 4 + (threadIdx.x >> 6);
-    if (slot >= a.nlist) return;
-    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
     const bool interleaved = (hdr & kHdrInterleaved) != 0;
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
@@ -577,7 +572,6 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
     }
     const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
 
-    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
     const uint8_t *fb = a.frames + (size_t)b_begin * set_bytes;
     uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
 #pragma unroll 1
@@ -648,7 +642,7 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
                 ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
             }
         }
-        if (interleaved) quad_exchange(P, xpose + (threadIdx.x >> 6) * 256, lane);
+        if (interleaved) quad_exchange(P, xpose_wave, lane);
         if (car_any) add_car(P, car0, car1, car2);
         if (inimg) {
             uint32_t d0, d1, d2;
@@ -657,6 +651,19 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
             op[0] = d0; op[1] = d1; op[2] = d2;
         }
     }
+}
+
+template <int LX, int NSLOT, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    uint32_t chunk, group;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    const int slot = (int)group * 4 + (threadIdx.x >> 6);
+    if (slot >= a.nlist) return;
+    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
+    const int b_begin = (int)chunk * a.nb;
+    plan_gather_tile<LX, NSLOT, BLEND, SUMS>(a, tile, b_begin, min(a.batch, b_begin + a.nb), xpose + (threadIdx.x >> 6) * 256);
 }
 
 // tiles without any contributor (under the car): out = car (or 0) for every frame of the chunk
