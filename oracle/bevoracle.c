@@ -514,6 +514,9 @@ static double segment_distance(const int32_t line[4], double px, double py)
     return sqrt(min_num / min_den); /* sign dropped: the caller squares it */
 }
 
+/* |cv2.pointPolygonTest({P0, P1}, (px, py), True)| -- exported for tests that drive the primitive one point at a time */
+ORC_API double orc_segment_distance(const int32_t line[4], double px, double py) { return segment_distance(line, px, py); }
+
 /* maskA[y,x] = uint8(dA**2 / (dA**2 + dB**2 + 1e-6) * 255) on every pixel where (maskA & maskB) != 0.
  * CPython evaluates d**2 with libm pow(); pow(d, 2.0) is used here for the same reason. */
 ORC_API void orc_blend_mask(uint8_t *maskA, const uint8_t *maskB, int w, int h, const int32_t lineA[4],

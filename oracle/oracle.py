@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
             "orc_remap_u8": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
             "orc_fill_poly": (None, [vp, i32, i32, vp, i32, C.c_uint8]),
             "orc_blend_mask": (None, [vp, vp, i32, i32, vp, vp]),
+            "orc_segment_distance": (C.c_double, [vp, C.c_double, C.c_double]),
             "orc_hsv_tables": (None, [vp, vp]),
             "orc_bgr2hsv": (None, [vp, sz, vp]),
             "orc_hsv2bgr": (None, [vp, sz, vp]),

@@ -1,0 +1,32 @@
+"""Case list shared by make_goldens_with_cv2.py (computes each case with the real cv2 + the reference's own modules) and
+tests/test_cv2_goldens.py (computes the same case with the oracle).  A case is a name and a uint8 / int16 / uint16 array."""
+import hashlib
+
+import numpy as np
+
+CAMS = ("front", "back", "left", "right")
+MODES = [(False, False), (True, False), (False, True), (True, True)]
+RESIZE_FACTORS = (0.37, 0.5, 1.6, 2.0)
+MAIN_CAR = (200, 350)          # main.py:80-81
+PINHOLE_D = (-0.31, 0.12, 0.0015, -0.0007, -0.02)
+
+
+def digest(arr: np.ndarray) -> str:
+    a = np.ascontiguousarray(arr)
+    return hashlib.sha256(str(a.dtype).encode() + str(a.shape).encode() + a.tobytes()).hexdigest()
+
+
+def probe(arr: np.ndarray, n: int = 4096) -> np.ndarray:
+    """Deterministic strided sample for diagnostics when a digest differs."""
+    flat = np.ascontiguousarray(arr).reshape(-1)
+    step = max(1, flat.size // n)
+    return flat[::step][:n].copy()
+
+
+def pack(cases: dict) -> dict:
+    blob = {}
+    for name, arr in cases.items():
+        blob[name + "__sha"] = np.array(digest(arr))
+        blob[name + "__shape"] = np.array(arr.shape, np.int64)
+        blob[name + "__probe"] = probe(arr)
+    return blob

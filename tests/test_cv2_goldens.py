@@ -1,0 +1,85 @@
+"""Oracle vs a REAL OpenCV, through tests/golden/cv2_goldens.npz (written by tests/golden/make_goldens_with_cv2.py on a
+machine that has cv2 and the reference).  The file does not exist yet -- no cv2 in this image -- so these tests skip and
+DESIGN.md keeps saying "parity unpinned"; the day the file is committed they become the pin."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import _golden_cases as GC  # noqa: E402
+
+PATH = os.environ.get("BEVW_GOLDENS_FILE", os.path.join(ROOT, "tests", "golden", "cv2_goldens.npz"))
+pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="no cv2 goldens (tests/golden/make_goldens_with_cv2.py)")
+
+
+@pytest.fixture(scope="module")
+def goldens():
+    return np.load(PATH)
+
+
+def check(goldens, name, arr):
+    if name + "__sha" not in goldens.files:
+        pytest.skip("case %s not in the golden file" % name)
+    assert tuple(goldens[name + "__shape"]) == arr.shape, name
+    if str(goldens[name + "__sha"]) != GC.digest(arr):
+        d = np.abs(GC.probe(arr).astype(np.int64) - goldens[name + "__probe"].astype(np.int64))
+        pytest.fail("%s differs from OpenCV %s: probe max |diff| %d, %d of %d probe entries differ" %
+                    (name, goldens["cv2_version"], int(d.max()), int(np.count_nonzero(d)), d.size))
+
+
+@pytest.fixture(scope="module")
+def ref_default(oracle, repo_rig):
+    return {b: oracle.RefBevGenerator(repo_rig.rig, dict(oracle.DEFAULT_CFG), blend=b, balance=False) for b in (False, True)}
+
+
+@pytest.mark.parametrize("cam", range(4))
+def test_tables_masks_and_single_camera_remaps(goldens, ref_default, repo_rig, cam):
+    n = GC.CAMS[cam]
+    r = ref_default[False]
+    check(goldens, "und_map1_" + n, r.cameras[cam].undistort_maps[0])
+    check(goldens, "und_map2_" + n, r.cameras[cam].undistort_maps[1])
+    check(goldens, "bev_map1_" + n, r.cameras[cam].bev_maps[0])
+    check(goldens, "bev_map2_" + n, r.cameras[cam].bev_maps[1])
+    check(goldens, "mask_direct_" + n, r.masks[cam])
+    check(goldens, "mask_blend_" + n, ref_default[True].masks[cam])
+    check(goldens, "raw2bev_" + n, r.cameras[cam].raw2bev(repo_rig.frames()[cam]))
+    if cam == 0:
+        check(goldens, "undistort_front", r.cameras[0].undistort(repo_rig.frames()[0]))
+
+
+@pytest.mark.parametrize("blend,balance", GC.MODES)
+def test_bev_generator_modes(goldens, oracle, repo_rig, blend, balance):
+    cfg = dict(oracle.DEFAULT_CFG, CAR_WIDTH=GC.MAIN_CAR[0], CAR_HEIGHT=GC.MAIN_CAR[1])
+    ref = oracle.RefBevGenerator(repo_rig.rig, cfg, blend=blend, balance=balance)
+    car = oracle.padding(repo_rig.image("car"), cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"])
+    check(goldens, "car_padded", car)
+    tag = "bev_%d%d" % (blend, balance)
+    check(goldens, tag, ref(*repo_rig.frames()))
+    check(goldens, tag + "_car", ref(*repo_rig.frames(), car=car))
+
+
+def test_balance_helpers(goldens, oracle, repo_rig):
+    for n, out in zip(GC.CAMS, oracle.luminance_balance(repo_rig.frames())):
+        check(goldens, "lum_" + n, out)
+    check(goldens, "color_balance_back", oracle.color_balance(repo_rig.image("back")))
+
+
+def test_calibrator_paths(goldens, oracle, repo_rig):
+    K, D = repo_rig.rig["front"][0], repo_rig.rig["front"][1]
+    src = repo_rig.image("incalib")
+    h, w = src.shape[:2]
+    Kd = oracle.camera_mat_dst(K, w, h, 0.5, 1)
+    m1, m2 = oracle.fisheye_init_undistort_rectify_map(K, D, Kd, (w, h))
+    check(goldens, "incalib_undistort", oracle.remap(src, m1, m2))
+    p1, p2 = oracle.init_undistort_rectify_map(K, list(GC.PINHOLE_D), Kd, (w, h))
+    check(goldens, "pinhole_map1", p1)
+    check(goldens, "pinhole_map2", p2)
+    check(goldens, "excalib_warp", oracle.warp_perspective(repo_rig.image("excalib_src"), repo_rig.rig["back"][2], (1000, 1000)))
+    small = np.ascontiguousarray(repo_rig.image("back")[:301, :403])
+    check(goldens, "translate", oracle.translate(small, 403 // 2 - 100, 301 // 2 - 250))
+    for f in GC.RESIZE_FACTORS:
+        check(goldens, "resize_%g" % f, oracle.resize_linear(small, f, f))
