@@ -654,11 +654,10 @@ __device__ __forceinline__ void plan_gather_tile(const PlanArgs &a, int tile, in
 }
 
 template <int LX, int NSLOT, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
+__device__ __forceinline__ void plan_gather_block(const PlanArgs &a, uint32_t block_id, uint32_t *xpose)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
     uint32_t chunk, group;
-    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    if (!plan_block_map(a, block_id, chunk, group)) return;
     const int slot = (int)group * 4 + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
@@ -666,12 +665,19 @@ __global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
     plan_gather_tile<LX, NSLOT, BLEND, SUMS>(a, tile, b_begin, min(a.batch, b_begin + a.nb), xpose + (threadIdx.x >> 6) * 256);
 }
 
+template <int LX, int NSLOT, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_lean(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t xpose[4 * 256];
+    plan_gather_block<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, xpose);
+}
+
 // tiles without any contributor (under the car): out = car (or 0) for every frame of the chunk
 template <int LX>
-__global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a)
+__device__ __forceinline__ void plan_empty_body(const PlanArgs &a, uint32_t block_id)
 {
     constexpr int LY = 64 / LX;
-    const uint32_t chunk = blockIdx.x / (uint32_t)a.ngroups, group = blockIdx.x % (uint32_t)a.ngroups;
+    const uint32_t chunk = block_id / (uint32_t)a.ngroups, group = block_id % (uint32_t)a.ngroups;
     const int lane = threadIdx.x & 63;
     const int slot = (int)group * (int)(blockDim.x >> 6) + (threadIdx.x >> 6);
     if (slot >= a.nlist) return;
@@ -694,6 +700,9 @@ __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a)
         op[0] = c0; op[1] = c1; op[2] = c2;
     }
 }
+
+template <int LX>
+__global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a) { plan_empty_body<LX>(a, blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-staged schedule.  The gathers of k_plan_lean are bound by the per-instruction cost of the vector-memory pipe
@@ -927,6 +936,42 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
     plan_staged_body<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, stage_0, stage_1, stage_2);
 }
 
+// Every tile class of a step in ONE launch: the class kernels write disjoint tiles and never depend on each other, but
+// consecutive launches on a stream are separated by a barrier (the tail of one class and the ramp of the next cost
+// ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
+// (class c owns blocks start[c] .. start[c+1]; every start is a multiple of 8, so a block's XCD is unchanged).
+// Classes: 0 staged single, 1 staged double, 2 empty, 3 gather single, 4 gather double.
+struct PlanAllArgs {
+    PlanArgs a;
+    const uint32_t *list[5];
+    int nlist[5];
+    int ngroups[5];
+    uint32_t start[6];
+};
+
+// The two-contributor classes set the register budget (~140 VGPRs, 3 workgroups per CU); measured, the single-contributor
+// classes lose nothing at that occupancy (profiles/r01_sweeps.log: two launches split by register budget are slower).
+template <int LX, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
+    int cls = 0;
+#pragma unroll
+    for (int c = 1; c < 5; ++c) cls += blockIdx.x >= q.start[c] ? 1 : 0;
+    PlanArgs a = q.a;
+    a.tile_list = q.list[cls]; a.nlist = q.nlist[cls]; a.ngroups = q.ngroups[cls];
+    const uint32_t id = blockIdx.x - q.start[cls];
+    switch (cls) {
+        case 0: plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
+        case 1: plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
+        case 2: plan_empty_body<LX>(a, id); break;
+        case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
+        default: plan_gather_block<LX, 2, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
+    }
+}
+
 // psums[b][tile][3] -> chsums[b][3] ; grid = batch, block = 256
 __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, unsigned long long *__restrict__ chsums)
 {
@@ -1089,12 +1134,13 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
 
 // nb: frames per block (0 = default); lean: 0 = one generic kernel over every tile (debug); lds_pad: dynamic LDS added to the
 // single-contributor gather kernel to cap it at 5 waves per SIMD (more resident gather waves thrash the L1);
-// xcd_map: 1 = an XCD owns whole batch chunks; staged: 1 = LDS-staged kernels for the tiles that have a staging plan
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; };
+// xcd_map: 1 = an XCD owns whole batch chunks; staged: 1 = LDS-staged kernels for the tiles that have a staging plan;
+// one_launch: 1 = all tile classes of a step in one kernel (k_plan_all), 0 = one launch per class
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, bool staged)
+                                        bool sums, bool staged, bool one_launch)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1119,6 +1165,30 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     // the rest (k_plan_lean)
     void *l_single = staged ? p.list_rs_single : p.list_single, *l_double = staged ? p.list_rs_double : p.list_double;
     const int n_single = staged ? p.n_rs_single : p.n_single, n_double = staged ? p.n_rs_double : p.n_double;
+    if (staged && one_launch) {
+        PlanAllArgs q;
+        q.a = a;
+        void *lists[5] = {p.list_st_single, p.list_st_double, p.list_empty, l_single, l_double};
+        const int counts[5] = {p.n_st_single, p.n_st_double, p.n_empty, n_single, n_double};
+        uint32_t at = 0;
+        for (int c = 0; c < 5; ++c) {
+            q.list[c] = static_cast<const uint32_t *>(lists[c]); q.nlist[c] = counts[c]; q.ngroups[c] = (counts[c] + 3) / 4;
+            q.start[c] = at;
+            if (counts[c]) {
+                a.ngroups = q.ngroups[c];
+                const unsigned nblk = c == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
+                at += (nblk + 7u) & ~7u;
+            }
+        }
+        q.start[5] = at;
+        if (at) {
+            if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true>), dim3(at), block, 0, st, q);
+            else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false>), dim3(at), block, 0, st, q);
+            else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true>), dim3(at), block, 0, st, q);
+            else hipLaunchKernelGGL((k_plan_all<LX, false, false>), dim3(at), block, 0, st, q);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    } else {
 #define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM)                                                                       \
     do {                                                                                                            \
         const dim3 grid(grid_blocks());                                                                             \
@@ -1138,6 +1208,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     if (n_single) { set_list(l_single, n_single); BEVW_LAUNCH_CLASS(k_plan_lean, 1, lds_pad); }
     if (n_double) { set_list(l_double, n_double); BEVW_LAUNCH_CLASS(k_plan_lean, 2, 0); }
 #undef BEVW_LAUNCH_CLASS
+    }
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
         const dim3 grid(grid_blocks());
@@ -1188,9 +1259,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

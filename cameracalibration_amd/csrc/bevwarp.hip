@@ -85,6 +85,7 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         if (const char *s = getenv("BEVW_PLAN_XCDMAP")) t.xcd_map = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_ONELAUNCH")) t.one_launch = atoi(s);
         return t;
     }();
     hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune, sums);

@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round-end evidence, run on the GPU box from the repo root:  gpurun -- 'bash tools/collect_profiles.sh'
+# Everything lands under gpurun_out/final/; copy what should be judged into profiles/.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/final
+mkdir -p $O
+cd $R
+timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k; do
+  timeout 300 python bench.py --workload $w 2>/dev/null | tail -1 > $O/bench_$w.json
+  python -c "import json;d=json.load(open('$O/bench_$w.json'));print('$w',round(d['value']),d['unit'],'frac',round(d['roofline']['frac'],3),'cpu',d['cpu_baseline'] and round(d['cpu_baseline']['value'],1))"
+done
+BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
+  bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
+python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
+cd /tmp && export TMPDIR=/tmp
+for w in direct_stitch_b256 blend_balance_b256 undistort_b64; do
+  rm -rf /tmp/kt_$w
+  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
+  cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${w}_$c
+    timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1
+    cp $(find /tmp/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${w}_$c.csv 2>/dev/null
+  done
+done
+cd $R
+python tools/summarize_pmc.py $O
