@@ -12,7 +12,7 @@ UNITS = {"direct_stitch_b256": 256, "blend_balance_b256": 256, "undistort_b64": 
 # gfx950 (MI355X_MICROARCH.md, HBM section) -> doubled.  Calibration in this very run: k_vsum reads exactly
 # 256 x 4 x 1280 x 960 x 3 B = 3775 MB per launch and FETCH_SIZE reports half of that.
 WIDE_READERS = ("k_vsum", "k_gain", "k_reduce_psums")
-PER_STEP = ("k_plan_staged", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
+PER_STEP = ("k_plan_all", "k_plan_staged", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
 
 
 def kernel_sums(path):
