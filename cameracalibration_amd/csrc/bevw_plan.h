@@ -939,14 +939,15 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
 // Every tile class of a step in ONE launch: the class kernels write disjoint tiles and never depend on each other, but
 // consecutive launches on a stream are separated by a barrier (the tail of one class and the ramp of the next cost
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
-// (class c owns blocks start[c] .. start[c+1]; every start is a multiple of 8, so a block's XCD is unchanged).
-// Classes: 0 staged single, 1 staged double, 2 empty, 3 gather single, 4 gather double.
+// (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
+// block's XCD is what it was in the separate launch).
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[5];
     int nlist[5];
     int ngroups[5];
-    uint32_t start[6];
+    uint32_t start[6];   // block ranges in launch order
+    int kind[5];         // launch position -> class (0 staged single, 1 staged double, 2 empty, 3 gather single, 4 gather double)
 };
 
 // The two-contributor classes set the register budget (~140 VGPRs, 3 workgroups per CU); measured, the single-contributor
@@ -957,13 +958,13 @@ __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
     __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
     __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
     __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
-    int cls = 0;
+    int pos = 0;
 #pragma unroll
-    for (int c = 1; c < 5; ++c) cls += blockIdx.x >= q.start[c] ? 1 : 0;
+    for (int c = 1; c < 5; ++c) pos += blockIdx.x >= q.start[c] ? 1 : 0;
     PlanArgs a = q.a;
-    a.tile_list = q.list[cls]; a.nlist = q.nlist[cls]; a.ngroups = q.ngroups[cls];
-    const uint32_t id = blockIdx.x - q.start[cls];
-    switch (cls) {
+    a.tile_list = q.list[pos]; a.nlist = q.nlist[pos]; a.ngroups = q.ngroups[pos];
+    const uint32_t id = blockIdx.x - q.start[pos];
+    switch (q.kind[pos]) {
         case 0: plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
         case 1: plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
         case 2: plan_empty_body<LX>(a, id); break;
@@ -1170,12 +1171,17 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         q.a = a;
         void *lists[5] = {p.list_st_single, p.list_st_double, p.list_empty, l_single, l_double};
         const int counts[5] = {p.n_st_single, p.n_st_double, p.n_empty, n_single, n_double};
+        // launch order: the classes whose blocks run longest first (gather, then staged, then the empty tiles), so that the
+        // short blocks fill the tail of the grid: +1-2 % over staged-first (profiles/r01_sweeps.log)
+        static const int order[5] = {4, 3, 1, 0, 2};
         uint32_t at = 0;
-        for (int c = 0; c < 5; ++c) {
-            q.list[c] = static_cast<const uint32_t *>(lists[c]); q.nlist[c] = counts[c]; q.ngroups[c] = (counts[c] + 3) / 4;
-            q.start[c] = at;
+        for (int i = 0; i < 5; ++i) {
+            const int c = order[i];
+            q.kind[i] = c;
+            q.list[i] = static_cast<const uint32_t *>(lists[c]); q.nlist[i] = counts[c]; q.ngroups[i] = (counts[c] + 3) / 4;
+            q.start[i] = at;
             if (counts[c]) {
-                a.ngroups = q.ngroups[c];
+                a.ngroups = q.ngroups[i];
                 const unsigned nblk = c == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
                 at += (nblk + 7u) & ~7u;
             }
