@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libbevwarp.so")
 SOURCES = ["bevwarp.hip"]
 HEADERS = ["bevw_device.h", "bevw_kernels.h", "bevw_plan.h", os.path.join("..", "..", "include", "bevwarp.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wno-pass-failed"]
+         "-Wno-pass-failed", "-Wno-inline-asm"]
 
 
 def _stale() -> bool:
