@@ -15,22 +15,27 @@ import numpy as np
 from .. import _ffi
 from .._ffi import check, f64, lib, ptr
 
+# the reference's command line (Tools/undistort.py:7-23): flag, default, type, what it is
+_OPTIONS = (
+    ("width", 1280, int, "frame width in pixels"),
+    ("height", 1024, int, "frame height in pixels"),
+    ("load", True, bool, "read K / D from -path_k / -path_d (otherwise the built-in calibration)"),
+    ("path_read", "./data/", str, "directory of the distorted images"),
+    ("path_save", "./", str, "directory for the undistorted images"),
+    ("path_k", "./data/camera_0_K.npy", str, "camera matrix file (.npy)"),
+    ("path_d", "./data/camera_0_D.npy", str, "fisheye distortion coefficients file (.npy)"),
+    ("focalscale", 1, float, "focal length scale of the undistorted view"),
+    ("sizescale", 1, float, "size scale of the undistorted view"),
+    ("offset_h", 0, float, "horizontal shift of the optical axis in the undistorted view"),
+    ("offset_v", 0, float, "vertical shift of the optical axis in the undistorted view"),
+    ("srcformat", "jpg", str, "extension of the input files (jpg / png)"),
+    ("dstformat", "jpg", str, "extension of the output files (jpg / png)"),
+    ("quality", 100, int, "jpg quality 0-100, or png compression 9-0"),
+    ("name", None, str, "output file name prefix"),
+)
 parser = argparse.ArgumentParser(description="Fisheye Camera Undistortion")
-parser.add_argument('-width', default=1280, type=int, help='Camera Frame Width')
-parser.add_argument('-height', default=1024, type=int, help='Camera Frame Height')
-parser.add_argument('-load', default=True, type=bool, help='Load New Camera K/D Data (True/False)')
-parser.add_argument('-path_read', default='./data/', type=str, help='Original Image Read Path')
-parser.add_argument('-path_save', default='./', type=str, help='Undistortion Image Save Path')
-parser.add_argument('-path_k', default='./data/camera_0_K.npy', type=str, help='Camera K File Path')
-parser.add_argument('-path_d', default='./data/camera_0_D.npy', type=str, help='Camera D File Path')
-parser.add_argument('-focalscale', default=1, type=float, help='Camera Undistortion Focal Scale')
-parser.add_argument('-sizescale', default=1, type=float, help='Camera Undistortion Size Scale')
-parser.add_argument('-offset_h', default=0, type=float, help='Horizontal Offset of Optical Axis')
-parser.add_argument('-offset_v', default=0, type=float, help='Vertical Offset of Optical Axis')
-parser.add_argument('-srcformat', default='jpg', type=str, help='Original Image Format (jpg/png)')
-parser.add_argument('-dstformat', default='jpg', type=str, help='Final Image Format (jpg/png)')
-parser.add_argument('-quality', default=100, type=int, help='Save Image Quality (jpg:0-100, png:9-0 (low-high))')
-parser.add_argument('-name', default=None, type=str, help='Save Image Name')
+for _flag, _default, _type, _help in _OPTIONS:
+    parser.add_argument("-" + _flag, default=_default, type=_type, help=_help)
 
 # Tools/undistort.py:28-32: the built-in calibration used with -load False (identical to data/front's K and D)
 DEFAULT_K = np.array([[350.4931893001142, 0.0, 647.6297467576265],
