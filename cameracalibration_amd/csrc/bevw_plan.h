@@ -6,10 +6,12 @@
 // pixel up to two 8-byte entries {byte offset of the 2x2 footprint inside the 4-camera frame set, 5+5 bit
 // fractions, u8 mask/weight, camera}.  One wave64 owns a (4*LX) x (64/LX) pixel tile (4 horizontally adjacent
 // pixels per lane = one 12-byte store), loads its slice of the plan ONCE into registers, and then loops over the
-// frames of its batch chunk: per frame and pixel the only memory traffic is two unaligned 8-byte gathers (top and
-// bottom texel pair, base address in SGPRs + per-lane 32-bit offset) and the coalesced 12-byte store.
-// Address, weight and mask arithmetic is hoisted out of the batch loop; the fixed-point bilinear runs on
-// v_dot4_u32_u8 / v_dot2_u32_u16.
+// frames of its batch chunk.  Address, weight and mask arithmetic is hoisted out of the batch loop; the fixed-point
+// bilinear runs on v_dot4_u32_u8 / v_dot2_u32_u16.  Two ways to get the texels, chosen per tile when the plan is built:
+//   * LDS-staged (plan_staged_body): the tile's <= 32 distinct 64-byte source sectors arrive through two LDS-DMA
+//     instructions per frame, two frames ahead, and the 2x2 footprints are read back from LDS;
+//   * gather (plan_gather_tile): sparse tiles fetch every footprint row as an aligned 12-byte window from L1.
+// A step is ONE launch (k_plan_all): every tile class of the batch in one grid, longest-running classes first.
 //
 // Layout.  plan[tile][slot 0..7][lane 0..63] (8 B each, so every plan load is a fully coalesced 512 B wave access);
 // slots 0..3 = first contributor of the lane's 4 pixels, 4..7 = second contributor (only read when the tile header
