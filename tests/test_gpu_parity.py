@@ -338,6 +338,40 @@ def test_scale_image_mirror(ffi, oracle, repo_rig, square):
     assert got.shape == img.shape and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("seed", range(48))
+def test_random_rigs_modes_and_batches(ffi, SB, oracle, seed):
+    """Seeded fuzz over the geometry: frame / BEV / car sizes (odd ones included, so every schedule and every alignment
+    fallback is hit), focal and size scales, modes, batch sizes, with and without the car -- always bit-exact."""
+    rng = np.random.default_rng(1000 + seed)
+    fw = int(rng.choice([160, 200, 236, 320, 322, 400]))
+    fh = int(rng.choice([128, 150, 256, 258]))
+    bw = int(rng.choice([96, 124, 125, 200, 248, 250]))
+    bh = int(rng.choice([96, 130, 201, 250]))
+    cw, ch = int(rng.integers(0, bw // 3 + 1)), int(rng.integers(0, bh // 2 + 1))
+    cfg = dict(FRAME_WIDTH=fw, FRAME_HEIGHT=fh, BEV_WIDTH=bw, BEV_HEIGHT=bh, CAR_WIDTH=cw, CAR_HEIGHT=ch,
+               FOCAL_SCALE=float(rng.choice([0.8, 1.0, 1.25])), SIZE_SCALE=float(rng.choice([1.0, 1.5, 2.0])))
+    # the repo rig scaled to the frame (raw frame by fw/1280, fh/1024) and to the BEV (by bw/1000, bh/1000)
+    A = np.diag([fw / 1280.0, fh / 1024.0, 1.0])
+    U = np.diag([fw * cfg["SIZE_SCALE"] / 2560.0, fh * cfg["SIZE_SCALE"] / 2048.0, 1.0])   # undistorted grid scale
+    Bm = np.diag([bw / 1000.0, bh / 1000.0, 1.0])
+    rig = {n: (A @ K, D.copy(), Bm @ H @ np.linalg.inv(U)) for n, (K, D, H) in W.repo_rig().items()}
+    blend, balance = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    batch = int(rng.integers(1, 6))
+    frames = rng.integers(0, 256, (batch, 4, fh, fw, 3), dtype=np.uint8)
+    frames[:, 1] //= 2                       # unequal brightness: non-trivial luminance deltas
+    car = None
+    if rng.integers(0, 2) and cw and ch:
+        car = np.zeros((bh, bw, 3), np.uint8)
+        t, l = (bh - ch) // 2, (bw - cw) // 2
+        car[t:t + ch, l:l + cw] = rng.integers(0, 256, (ch, cw, 3), dtype=np.uint8)
+    bev, ref = make_pair(SB, oracle, rig, cfg, blend, balance, schedule=int(rng.choice([0, 0, 1])))
+    got = bev.batch(frames, car)
+    for b in range(batch):
+        want = ref(*frames[b], car=car)
+        assert np.array_equal(got[b], want), "seed %d cfg %s blend %d balance %d frame %d: %d bytes differ" % (
+            seed, cfg, blend, balance, b, np.count_nonzero(got[b] != want))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # full BASELINE sizes: size-independent properties + spot parity
 # ---------------------------------------------------------------------------------------------------------------
