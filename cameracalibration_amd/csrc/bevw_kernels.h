@@ -481,13 +481,16 @@ __global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__r
 // table entries per frame replace 3.5 M fp64 operations) and 12-byte vector accesses (4 pixels per lane).
 // Needs npx % 4 == 0 and 4-byte aligned images.  grid = (blocks, batch), block = 256; in place when in == out.
 __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
-                                                   const uint8_t *__restrict__ car, uint8_t *out)
+                                                   const uint8_t *__restrict__ car, uint8_t *out, uint32_t blocks_per_frame,
+                                                   uint32_t nframes)
 {
     __shared__ uint8_t lut[3][256];
+    uint32_t frame, blk;
+    if (!xcd_frame_map(blockIdx.x, blocks_per_frame, nframes, frame, blk)) return;   // grid: xcd_frame_grid()
     {
         const double n = (double)npx;
-        const double B = (double)chsums[blockIdx.y * 3 + 0] / n, G = (double)chsums[blockIdx.y * 3 + 1] / n,
-                     R = (double)chsums[blockIdx.y * 3 + 2] / n;
+        const double B = (double)chsums[frame * 3 + 0] / n, G = (double)chsums[frame * 3 + 1] / n,
+                     R = (double)chsums[frame * 3 + 2] / n;
         const double K = (R + G + B) / 3;
         const double gain[3] = {K / B, K / G, K / R};
         for (int i = threadIdx.x; i < 768; i += blockDim.x) {
@@ -496,8 +499,8 @@ __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx,
         }
     }
     __syncthreads();
-    const size_t base = (size_t)blockIdx.y * npx * 3, nq = npx / 4;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+    const size_t base = (size_t)frame * npx * 3, nq = npx / 4;
+    for (size_t q = (size_t)blk * blockDim.x + threadIdx.x; q < nq; q += (size_t)blocks_per_frame * blockDim.x) {
         const uint32_t *ip = reinterpret_cast<const uint32_t *>(in + base + q * 12);
         uint32_t w[3] = {ip[0], ip[1], ip[2]}, cw[3] = {0, 0, 0}, o[3] = {0, 0, 0};
         if (car != nullptr) {

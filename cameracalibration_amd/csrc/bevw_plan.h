@@ -277,14 +277,17 @@ __global__ void k_plan_touch(const uint2 *__restrict__ plan, int ntiles, int fw,
 // grid = (ceil(ngroups / 256), batch); block = 256.
 __global__ void __launch_bounds__(256) k_lum_groups(const uint8_t *__restrict__ frames, uint8_t *__restrict__ scratch, size_t set_bytes,
                                                      uint32_t frame_bytes, const uint32_t *__restrict__ groups, int ngroups,
-                                                     const int *__restrict__ deltas, const HsvTables *__restrict__ tab)
+                                                     const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
+                                                     uint32_t blocks_per_frame, uint32_t nframes)
 {
     __shared__ int sdiv[256], hdiv[256];
+    uint32_t frame, blk;
+    if (!xcd_frame_map(blockIdx.x, blocks_per_frame, nframes, frame, blk)) return;   // grid: xcd_frame_grid()
     for (int i = threadIdx.x; i < 256; i += 256) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
     __syncthreads();
-    const int gi = blockIdx.x * 256 + threadIdx.x;
+    const int gi = (int)blk * 256 + threadIdx.x;
     if (gi >= ngroups) return;
-    const int b = blockIdx.y;
+    const int b = (int)frame;
     const uint32_t goff = groups[gi];
     const size_t off = (size_t)b * set_bytes + goff;
     const AlignedU3 v = *reinterpret_cast<const AlignedU3 *>(frames + off);
@@ -1287,9 +1290,10 @@ static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint
     const size_t set_bytes = (size_t)p.fw * p.fh * 3 * p.ncams;
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-        hipLaunchKernelGGL(k_lum_groups, dim3((p.n_groups + 255) / 256, nb), dim3(256), 0, st, d_frames + (size_t)b0 * set_bytes,
+        const unsigned bpf = (unsigned)(p.n_groups + 255) / 256;
+        hipLaunchKernelGGL(k_lum_groups, dim3(xcd_frame_grid(bpf, (unsigned)nb)), dim3(256), 0, st, d_frames + (size_t)b0 * set_bytes,
                            d_scratch + (size_t)b0 * set_bytes, set_bytes, (uint32_t)p.fw * p.fh * 3,
-                           static_cast<const uint32_t *>(p.groups), p.n_groups, d_deltas + (size_t)b0 * 4, d_tab);
+                           static_cast<const uint32_t *>(p.groups), p.n_groups, d_deltas + (size_t)b0 * 4, d_tab, bpf, (uint32_t)nb);
     }
     return hipGetLastError();
 }

@@ -816,8 +816,9 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         for (int b0 = 0; b0 < batch; b0 += 65535) {
             const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
             if (npx % 4 == 0 && aligned4)
-                hipLaunchKernelGGL(k_gain_lut, dim3(32, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
-                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3);
+                hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
+                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3, 32u,
+                                   (uint32_t)nb);
             else
                 hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
                                    h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3);
@@ -1285,7 +1286,9 @@ int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_
             uint8_t *o = (uint8_t *)d_out + (size_t)b0 * npx * 3;
             unsigned long long *chs = h->chsums.as<unsigned long long>() + (size_t)b0 * 3;
             hipLaunchKernelGGL(k_channel_sums, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs);
-            if (npx % 4 == 0 && dwords) hipLaunchKernelGGL(k_gain_lut, dim3(32, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o);
+            if (npx % 4 == 0 && dwords)
+                hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o,
+                                   32u, (uint32_t)nb);
             else hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o);
         }
         BEVW_TRY(launch_check("k_channel_sums/k_gain"));
