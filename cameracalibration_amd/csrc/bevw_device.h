@@ -37,15 +37,17 @@ struct HsvTables {
 
 // One texel through BGR2HSV -> V = sat_u8(V + delta) -> HSV2BGR.  The round trip is lossy, so it is applied even
 // when delta == 0, exactly as the reference does.
-__device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int delta, const int *__restrict__ sdiv,
-                                                   const int *__restrict__ hdiv)
+// Packed form: texel in, texel out as B | G << 8 | R << 16 (byte 3 of the input is ignored, of the result 0).
+__device__ __forceinline__ uint32_t luminance_shift_bgr(uint32_t texel, int delta, const int *__restrict__ sdiv,
+                                                        const int *__restrict__ hdiv)
 {
+    const int b = (int)(texel & 255u), g = (int)((texel >> 8) & 255u), r = (int)((texel >> 16) & 255u);
     int v = max(b, max(g, r));
     int vmin = min(b, min(g, r));
     int diff = v - vmin;
-    int vr = (v == r) ? -1 : 0, vg = (v == g) ? -1 : 0;
     int s = (diff * sdiv[v] + (1 << 11)) >> 12;
-    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    // hue numerator: the channel that holds the maximum picks the formula (R first, then G, as OpenCV's masks do)
+    int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
     h = (h * hdiv[diff] + (1 << 11)) >> 12;
     h += h < 0 ? 180 : 0;
     h = sat_u8(h);
@@ -65,15 +67,26 @@ __device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int d
     const float t1 = fv * (1.f - fs);
     const float t2 = fv * (1.f - fs * fh);
     const float t3 = fv * (1.f - fs * (1.f - fh));
-    const uint32_t T = (uint32_t)sat_u8(rne_f(t0 * 255.f)) | ((uint32_t)sat_u8(rne_f(t1 * 255.f)) << 8) |
-                       ((uint32_t)sat_u8(rne_f(t2 * 255.f)) << 16) | ((uint32_t)sat_u8(rne_f(t3 * 255.f)) << 24);
+    // cvRound(t * 255) for t in [0, 1]: adding 1.5 * 2^23 rounds to nearest-even at unit precision and leaves the integer
+    // (0..255, no saturation possible) in the low mantissa byte -- same rounding as v_rndne + v_cvt, a third of the work
+    const float kMagic = 12582912.f;
+    const uint32_t u0 = __float_as_uint(t0 * 255.f + kMagic), u1 = __float_as_uint(t1 * 255.f + kMagic);
+    const uint32_t u2 = __float_as_uint(t2 * 255.f + kMagic), u3 = __float_as_uint(t3 * 255.f + kMagic);
+    // T = low bytes of (u0, u1, u2, u3)
+    const uint32_t T = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u3, u2, 0x0c0c0400u), __builtin_amdgcn_perm(u1, u0, 0x0c0c0400u), 0x05040100u);
     // sector table {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} -> candidate index of (b, g, r), as a byte selector
     const uint32_t sel = sector < 3 ? (sector == 0 ? 0x0c000301u : (sector == 1 ? 0x0c020001u : 0x0c010003u))
                                     : (sector == 3 ? 0x0c010200u : (sector == 4 ? 0x0c030100u : 0x0c000102u));
-    const uint32_t bgr = __builtin_amdgcn_perm(0u, T, sel);
-    b = (int)(bgr & 255u);
-    g = (int)((bgr >> 8) & 255u);
-    r = (int)((bgr >> 16) & 255u);
+    return __builtin_amdgcn_perm(0u, T, sel);
+}
+
+__device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int delta, const int *__restrict__ sdiv,
+                                                   const int *__restrict__ hdiv)
+{
+    const uint32_t o = luminance_shift_bgr((uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16), delta, sdiv, hdiv);
+    b = (int)(o & 255u);
+    g = (int)((o >> 8) & 255u);
+    r = (int)((o >> 16) & 255u);
 }
 
 // Linear block id of a 1-D grid -> (frame, block inside the frame) such that XCD id % 8 owns WHOLE frames: the rows a kernel

@@ -293,16 +293,12 @@ __global__ void __launch_bounds__(256) k_lum_groups(const uint8_t *__restrict__ 
     const AlignedU3 v = *reinterpret_cast<const AlignedU3 *>(frames + off);
     const uint32_t w[3] = {v.x, v.y, v.z};
     const int delta = deltas[b * 4 + (int)(goff / frame_bytes)];
-    uint32_t o[3] = {0, 0, 0};
+    // the 4 texels of the group as dwords (byte 3 is ignored), shifted, and packed back into the 12 bytes
+    uint32_t P[4] = {w[0], __builtin_amdgcn_alignbyte(w[1], w[0], 3), __builtin_amdgcn_alignbyte(w[2], w[1], 2), w[2] >> 8};
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        int c3[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const int bi = t * 3 + k; c3[k] = (int)((w[bi >> 2] >> ((bi & 3) * 8)) & 255u); }
-        luminance_shift_px(c3[0], c3[1], c3[2], delta, sdiv, hdiv);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { const int bi = t * 3 + k; o[bi >> 2] |= (uint32_t)c3[k] << ((bi & 3) * 8); }
-    }
+    for (int t = 0; t < 4; ++t) P[t] = luminance_shift_bgr(P[t], delta, sdiv, hdiv);
+    uint32_t o[3];
+    pack_pixels(P, o[0], o[1], o[2]);
     AlignedU3 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2];
     *reinterpret_cast<AlignedU3 *>(scratch + off) = ov;
 }
