@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbevwarp.so")
+LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
 ABI_VERSION = 1
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
