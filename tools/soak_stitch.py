@@ -1,0 +1,37 @@
+"""Parity soak (GPU box): random rigs / sizes / scales / modes / batches through BevGenerator.batch against the oracle.
+Usage: python tools/soak_stitch.py FIRST_SEED LAST_SEED   (prints every mismatch; round 1: seeds 0..600, none)"""
+import sys, numpy as np
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from cameracalibration_amd import workloads as W
+from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+from oracle import oracle as O
+O.build()
+bad = 0
+for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    rng = np.random.default_rng(50000 + seed)
+    fw = int(rng.choice([96, 160, 200, 236, 320, 322, 400, 512, 640])); fh = int(rng.choice([64, 128, 150, 256, 258, 384, 480]))
+    bw = int(rng.choice([64, 96, 124, 125, 200, 248, 250, 300, 400])); bh = int(rng.choice([64, 96, 130, 201, 250, 333, 400]))
+    cw, ch = int(rng.integers(0, bw // 3 + 1)), int(rng.integers(0, bh // 2 + 1))
+    cfg = dict(FRAME_WIDTH=fw, FRAME_HEIGHT=fh, BEV_WIDTH=bw, BEV_HEIGHT=bh, CAR_WIDTH=cw, CAR_HEIGHT=ch,
+               FOCAL_SCALE=float(rng.choice([0.5, 0.8, 1.0, 1.25, 2.0])), SIZE_SCALE=float(rng.choice([1.0, 1.5, 2.0, 2.5])))
+    A = np.diag([fw / 1280.0, fh / 1024.0, 1.0]); U = np.diag([fw * cfg["SIZE_SCALE"] / 2560.0, fh * cfg["SIZE_SCALE"] / 2048.0, 1.0]); Bm = np.diag([bw / 1000.0, bh / 1000.0, 1.0])
+    rig = {n: (A @ K, D.copy() * float(rng.choice([0.0, 1.0, 1.5])), Bm @ H @ np.linalg.inv(U)) for n, (K, D, H) in W.repo_rig().items()}
+    blend, balance = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)); batch = int(rng.choice([1, 2, 3, 8, 9, 17]))
+    kind = int(rng.integers(0, 3))
+    frames = rng.integers(0, 256, (batch, 4, fh, fw, 3), dtype=np.uint8) if kind == 0 else (np.full((batch, 4, fh, fw, 3), int(rng.integers(0, 256)), np.uint8) if kind == 1 else (rng.integers(0, 256, (batch, 4, fh, fw, 1), dtype=np.uint8).repeat(3, axis=4)))
+    frames[:, int(rng.integers(0, 4))] //= 2
+    car = None
+    if rng.integers(0, 2) and cw and ch:
+        car = np.zeros((bh, bw, 3), np.uint8); t, l = (bh - ch) // 2, (bw - cw) // 2
+        car[t:t + ch, l:l + cw] = rng.integers(0, 256, (ch, cw, 3), dtype=np.uint8)
+    ns = SB.BevGenerator.get_args()
+    for k, v in cfg.items(): setattr(ns, k, v)
+    bev = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=int(rng.choice([0, 0, 1])))
+    ref = O.RefBevGenerator(rig, cfg, blend=blend, balance=balance)
+    got = bev.batch(frames, car)
+    for b in range(batch):
+        want = ref(*frames[b], car=car)
+        if not np.array_equal(got[b], want):
+            bad += 1; print("MISMATCH seed", seed, cfg, blend, balance, b, np.count_nonzero(got[b] != want)); break
+    del bev
+print("soak", sys.argv[1], sys.argv[2], "mismatches", bad)
