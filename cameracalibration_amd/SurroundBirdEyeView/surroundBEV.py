@@ -318,7 +318,16 @@ class BevGenerator:
             if img.shape[:2] != (c.frame_height, c.frame_width):
                 raise Exception("camera frame is {}x{}, FRAME is {}x{}".format(img.shape[1], img.shape[0],
                                                                                c.frame_width, c.frame_height))
-        return self.batch(np.stack(images)[np.newaxis], car)[0]
+        car_p = None
+        if car is not None:
+            car = _ffi.as_u8_image(car, "car")
+            if car.shape[:2] != (c.bev_height, c.bev_width):
+                raise Exception("car must be padded to the BEV size (padding())")
+            car_p = ptr(car)
+        out = np.empty((c.bev_height, c.bev_width, 3), np.uint8)
+        check(lib().bevw_run_cameras(self._engine.h, ptr(images[0]), ptr(images[1]), ptr(images[2]), ptr(images[3]), car_p,
+                                     ptr(out)))
+        return out
 
     # ---- additive: batches ---------------------------------------------------------------------------------
     def batch(self, frames, car=None):

@@ -51,6 +51,7 @@ SIGNATURES = {
     "bevw_plan_info": (_i, [_vp, _vp]),
     "bevw_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "bevw_run_device": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "bevw_run_cameras": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bevw_camera_undistort": (_i, [_vp, _i, _vp, _i, _vp]),
     "bevw_camera_warp_homography": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     "bevw_camera_raw2bev": (_i, [_vp, _i, _vp, _i, _vp]),

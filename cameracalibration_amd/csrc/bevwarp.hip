@@ -1088,6 +1088,32 @@ int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *ca
     return BEVW_OK;
 }
 
+// BevGenerator.__call__ as the reference calls it: four separate camera arrays, one frame set (surroundBEV.py:312-325)
+int bevw_run_cameras(bevw_handle *h, const uint8_t *front, const uint8_t *back, const uint8_t *left, const uint8_t *right,
+                     const uint8_t *car, uint8_t *out)
+{
+    BEVW_TRY(need_built(h));
+    if (h->shard_n) return fail(BEVW_E_INVALID, "handle is a camera shard: use bevw_shard_run_device + bevw_combine_device");
+    if (!front || !back || !left || !right || !out) return fail(BEVW_E_INVALID, "bad argument");
+    const bevw_config &c = h->cfg;
+    const size_t frame = (size_t)c.frame_width * c.frame_height * 3, bev = (size_t)c.bev_width * c.bev_height * 3;
+    BEVW_TRY(h->in.reserve(frame * 4));
+    BEVW_TRY(h->out.reserve(bev));
+    const uint8_t *src[4] = {front, back, left, right};
+    for (int i = 0; i < 4; ++i)
+        HIP_TRY(hipMemcpyAsync(h->in.as<uint8_t>() + frame * i, src[i], frame, hipMemcpyHostToDevice, h->stream));
+    const uint8_t *d_car = nullptr;
+    if (car) {
+        BEVW_TRY(h->car.reserve(bev));
+        HIP_TRY(hipMemcpyAsync(h->car.p, car, bev, hipMemcpyHostToDevice, h->stream));
+        d_car = h->car.as<uint8_t>();
+    }
+    BEVW_TRY(run_device(h, h->in.as<uint8_t>(), 1, d_car, h->out.as<uint8_t>()));
+    HIP_TRY(hipMemcpyAsync(out, h->out.p, bev, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return BEVW_OK;
+}
+
 static int camera_remap(bevw_handle *h, const uint8_t *src, int sw, int sh, const int16_t *m1, const uint16_t *m2, int dw,
                         int dh, int batch, uint8_t *dst)
 {

@@ -95,6 +95,10 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8]);        /* [0] max contribut
 /* frames: [batch][4][FH][FW][3]; car: [BH][BW][3] or NULL (already padded, surroundBEV.py:28-41); out: [batch][BH][BW][3] */
 int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *car, uint8_t *out);
 int bevw_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_car, void *d_out);
+/* The reference's own call shape, bev(front, back, left, right, car) (surroundBEV.py:312, main.py:84): four separate
+ * [FH][FW][3] host arrays (no packing copy on the host), one frame set, out [BH][BW][3]. */
+int bevw_run_cameras(bevw_handle *h, const uint8_t *front, const uint8_t *back, const uint8_t *left, const uint8_t *right,
+                     const uint8_t *car, uint8_t *out);
 
 /* Camera.undistort / Camera.warp_homography / Camera.raw2bev (surroundBEV.py:110-117) on host images.
  * undistort: src [batch][FH][FW][3] -> dst [batch][int(FH*SS)][int(FW*SS)][3]
