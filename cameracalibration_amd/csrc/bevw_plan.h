@@ -853,9 +853,14 @@ __device__ __forceinline__ void plan_staged_body(const PlanArgs &a, uint32_t blo
         // instruction count per iteration is uniform)
         const int ahead = min(b + 2, b_end - 1) - b;
         stage_frame(fb + (size_t)ahead * set_bytes, patch_fill);
-        // at most the 2 * kStageInstr youngest vector-memory operations may still be in flight: frame b's patch (issued
-        // two iterations ago) has landed, whether or not the store of frame b-1 is among the youngest
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr) : "memory");
+        // frame b's patch (issued two iterations ago) must have landed.  Vector-memory operations retire in order, so it is
+        // enough to bound how many YOUNGER ones may still be in flight: the LDS-DMA of frames b+1 and b+2 (2 x kStageInstr)
+        // plus the pixel stores issued since (none for the chunk's first frame, one for its second, two afterwards; every
+        // tile has a lane inside the image, so that store is always issued, and the extra stores of SUMS only make the
+        // wait safer)
+        if (b == b_begin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr) : "memory");
+        else if (b == b_begin + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr + 2) : "memory");
         const uint2 *w = reinterpret_cast<const uint2 *>(patch_cur);
         uint32_t P[4];
         {
