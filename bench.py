@@ -274,7 +274,8 @@ def main():
         sync, tstart, tstop = bev.sync, bev.timer_start, bev.timer_stop
         info = bev.plan_info()
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
-                 "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3)}
+                 "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3),
+                 "tiles": {"staged": info["tiles_staged"], "gather": info["tiles_gather"], "border": info["tiles_border"]}}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     else:

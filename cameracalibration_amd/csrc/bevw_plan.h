@@ -64,6 +64,14 @@ struct Plan {
     void *list_st_single = nullptr, *list_st_double = nullptr, *list_rs_single = nullptr, *list_rs_double = nullptr;
     int n_st_single = 0, n_st_double = 0, n_rs_single = 0, n_rs_double = 0;
     bool staged_ok = false;
+    // pair-staged variant (bevw_pair.h): tiles whose footprints fit kPairRounds x 64 groups of 4 texels; pr_* lists hold
+    // them, rp_* the single / double tiles that stay on the L1-gather kernels when this schedule is selected
+    void *entries_pr = nullptr;  // uint2[ntiles][8][64]: x = LDS byte address of the pair entry of row 0 | row 1 << 16, y = meta
+    void *gsrc = nullptr;        // uint32[ntiles][kPairRounds][64]: per-lane source offset of each round's group
+    void *list_pr_single = nullptr, *list_pr_double = nullptr, *list_rp_single = nullptr, *list_rp_double = nullptr;
+    int n_pr_single = 0, n_pr_double = 0, n_rp_single = 0, n_rp_double = 0;
+    int pr_rounds[4] = {0, 0, 0, 0};   // tiles per round count (1..4), statistics
+    bool paired_ok = false;
 };
 
 struct __attribute__((packed, aligned(1))) PackedU2 { uint32_t x, y; };
@@ -410,6 +418,8 @@ struct PlanArgs {
     int batch, nb, nchunks, xcd_affine;
     const uint2 *plan_st;        // LDS-staged entries (k_plan_staged)
     const uint32_t *dma;         // LDS-DMA source offsets [ntiles][kStageInstr][64]
+    const uint2 *plan_pr;        // pair-staged entries (plan_pair_body)
+    const uint32_t *gsrc;        // group source offsets [ntiles][kPairRounds][64]
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
     int nlist;
 };
@@ -942,6 +952,10 @@ __global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
     plan_staged_body<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, stage_0, stage_1, stage_2);
 }
 
+}  // namespace bevw
+#include "bevw_pair.h"
+namespace bevw {
+
 // Every tile class of a step in ONE launch: the class kernels write disjoint tiles and never depend on each other, but
 // consecutive launches on a stream are separated by a barrier (the tail of one class and the ramp of the next cost
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
@@ -958,12 +972,13 @@ struct PlanAllArgs {
 
 // The two-contributor classes set the register budget (~140 VGPRs, 3 workgroups per CU); measured, the single-contributor
 // classes lose nothing at that occupancy (profiles/r01_sweeps.log: two launches split by register budget are slower).
-template <int LX, bool BLEND, bool SUMS>
+// ST: 1 = sector-staged classes (plan_staged_body, LDS-DMA ring), 2 = pair-staged classes (plan_pair_body, bevw_pair.h)
+template <int LX, bool BLEND, bool SUMS, int ST = 1>
 __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[ST == 2 ? 4 * kPairPatch : 4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_1[ST == 2 ? 16 : 4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_2[ST == 2 ? 16 : 4 * kStageBytes];
     int pos = 0;
 #pragma unroll
     for (int c = 1; c < 5; ++c) pos += blockIdx.x >= q.start[c] ? 1 : 0;
@@ -971,11 +986,21 @@ __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
     a.tile_list = q.list[pos]; a.nlist = q.nlist[pos]; a.ngroups = q.ngroups[pos];
     const uint32_t id = blockIdx.x - q.start[pos];
     switch (q.kind[pos]) {
-        case 0: plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
-        case 1: plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
+        case 0:
+            if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS>(a, id, stage_0);
+            else plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2);
+            break;
+        case 1:
+            if (ST == 2) plan_pair_body<LX, 2, BLEND, SUMS>(a, id, stage_0);
+            else plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2);
+            break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
-        default: plan_gather_block<LX, 2, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
+        default:
+            // pair-staged launches keep the two-contributor gather class (a handful of sparse seam tiles, 110+ VGPRs) out
+            // of the merged kernel: it would set the register budget of every other class
+            if (ST != 2) plan_gather_block<LX, 2, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0));
+            break;
     }
 }
 
@@ -1005,7 +1030,8 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries, p.hdr, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
+    void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr_single, p.list_pr_double, p.list_rp_single, p.list_rp_double,
+                    p.entries, p.hdr, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
                     p.list_st_double, p.list_rs_single, p.list_rs_double, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -1079,6 +1105,16 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = hipGetLastError()) != hipSuccess) return e;
         p.staged_ok = true;
     }
+    p.paired_ok = false;
+    if (fw % 4 == 0 && (size_t)fw * fh * 3 * ncams < (1ull << 31)) {   // rows are whole groups of 4 texels (12 bytes)
+        if ((e = hipMalloc(&p.entries_pr, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
+        if ((e = hipMalloc(&p.gsrc, (size_t)p.ntiles * kPairRounds * 64 * sizeof(uint32_t))) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_plan_pair_build, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries),
+                           static_cast<uint32_t *>(p.hdr), p.ntiles, (uint32_t)fw * 3, (uint32_t)((size_t)fw * fh * 3 * ncams),
+                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc));
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        p.paired_ok = true;
+    }
     std::vector<uint32_t> hdr((size_t)p.ntiles);
     if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
@@ -1127,6 +1163,18 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = plan_upload_list(rs, &p.list_rs_single)) != hipSuccess) return e;
         if ((e = plan_upload_list(rd, &p.list_rs_double)) != hipSuccess) return e;
     }
+    {
+        std::vector<uint32_t> ss, sd, rs, rd;
+        for (uint32_t t : ls) ((hdr[t] & kHdrPaired) ? ss : rs).push_back(t);
+        for (uint32_t t : ld) ((hdr[t] & kHdrPaired) ? sd : rd).push_back(t);
+        for (int t = 0; t < p.ntiles; ++t)
+            if (hdr[(size_t)t] & kHdrPaired) ++p.pr_rounds[(hdr[(size_t)t] >> 8) & 3u];
+        p.n_pr_single = (int)ss.size(); p.n_pr_double = (int)sd.size(); p.n_rp_single = (int)rs.size(); p.n_rp_double = (int)rd.size();
+        if ((e = plan_upload_list(ss, &p.list_pr_single)) != hipSuccess) return e;
+        if ((e = plan_upload_list(sd, &p.list_pr_double)) != hipSuccess) return e;
+        if ((e = plan_upload_list(rs, &p.list_rp_single)) != hipSuccess) return e;
+        if ((e = plan_upload_list(rd, &p.list_rp_double)) != hipSuccess) return e;
+    }
     p.n_single = (int)ls.size(); p.n_double = (int)ld.size(); p.n_slow = (int)lw.size(); p.n_empty = (int)le.size();
     if ((e = plan_upload_list(ls, &p.list_single)) != hipSuccess) return e;
     if ((e = plan_upload_list(ld, &p.list_double)) != hipSuccess) return e;
@@ -1143,11 +1191,12 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
 // single-contributor gather kernel to cap it at 5 waves per SIMD (more resident gather waves thrash the L1);
 // xcd_map: 1 = an XCD owns whole batch chunks; staged: 1 = LDS-staged kernels for the tiles that have a staging plan;
 // one_launch: 1 = all tile classes of a step in one kernel (k_plan_all), 0 = one launch per class
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; };
+// staged: 0 = gather classes only, 1 = sector-staged (LDS-DMA ring, round 1), 2 = pair-staged (bevw_pair.h, round 2)
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 2; int one_launch = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, bool staged, bool one_launch)
+                                        bool sums, int staged, bool one_launch)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1170,13 +1219,17 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     if (sums) a.car = nullptr;
     // class lists: with the LDS-staged schedule the single / double classes split into staged tiles (k_plan_staged) and
     // the rest (k_plan_lean)
-    void *l_single = staged ? p.list_rs_single : p.list_single, *l_double = staged ? p.list_rs_double : p.list_double;
-    const int n_single = staged ? p.n_rs_single : p.n_single, n_double = staged ? p.n_rs_double : p.n_double;
+    void *l_single = staged == 2 ? p.list_rp_single : staged ? p.list_rs_single : p.list_single;
+    void *l_double = staged == 2 ? p.list_rp_double : staged ? p.list_rs_double : p.list_double;
+    const int n_single = staged == 2 ? p.n_rp_single : staged ? p.n_rs_single : p.n_single;
+    const int n_double = staged == 2 ? p.n_rp_double : staged ? p.n_rs_double : p.n_double;
     if (staged && one_launch) {
         PlanAllArgs q;
         q.a = a;
-        void *lists[5] = {p.list_st_single, p.list_st_double, p.list_empty, l_single, l_double};
-        const int counts[5] = {p.n_st_single, p.n_st_double, p.n_empty, n_single, n_double};
+        void *lists[5] = {staged == 2 ? p.list_pr_single : p.list_st_single, staged == 2 ? p.list_pr_double : p.list_st_double,
+                          p.list_empty, l_single, l_double};
+        const int counts[5] = {staged == 2 ? p.n_pr_single : p.n_st_single, staged == 2 ? p.n_pr_double : p.n_st_double, p.n_empty,
+                               n_single, n_double};
         // launch order: the classes whose blocks run longest first (gather, then staged, then the empty tiles), so that the
         // short blocks fill the tail of the grid: +1-2 % over staged-first (profiles/r01_sweeps.log)
         static const int order[5] = {4, 3, 1, 0, 2};
@@ -1186,14 +1239,29 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
             q.kind[i] = c;
             q.list[i] = static_cast<const uint32_t *>(lists[c]); q.nlist[i] = counts[c]; q.ngroups[i] = (counts[c] + 3) / 4;
             q.start[i] = at;
-            if (counts[c]) {
+            if (counts[c] && !(staged == 2 && c == 4)) {
                 a.ngroups = q.ngroups[i];
                 const unsigned nblk = c == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
                 at += (nblk + 7u) & ~7u;
             }
         }
         q.start[5] = at;
-        if (at) {
+        if (at && staged == 2) {
+            if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true, 2>), dim3(at), block, 0, st, q);
+            else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false, 2>), dim3(at), block, 0, st, q);
+            else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true, 2>), dim3(at), block, 0, st, q);
+            else hipLaunchKernelGGL((k_plan_all<LX, false, false, 2>), dim3(at), block, 0, st, q);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (n_double) {   // the sparse two-contributor tiles (see k_plan_all)
+                set_list(l_double, n_double);
+                const dim3 grid(grid_blocks());
+                if (blend && sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, true>), grid, block, 0, st, a);
+                else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, false>), grid, block, 0, st, a);
+                else if (sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, true>), grid, block, 0, st, a);
+                else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, false>), grid, block, 0, st, a);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
+        } else if (at) {
             if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true>), dim3(at), block, 0, st, q);
             else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false>), dim3(at), block, 0, st, q);
             else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true>), dim3(at), block, 0, st, q);
@@ -1210,8 +1278,10 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else hipLaunchKernelGGL((KERNEL<LX, NS, false, false>), grid, block, SHMEM, st, a);                         \
         if ((e = hipGetLastError()) != hipSuccess) return e;                                                        \
     } while (0)
-    if (staged && p.n_st_single) { set_list(p.list_st_single, p.n_st_single); BEVW_LAUNCH_CLASS(k_plan_staged, 1, 0); }
-    if (staged && p.n_st_double) { set_list(p.list_st_double, p.n_st_double); BEVW_LAUNCH_CLASS(k_plan_staged, 2, 0); }
+    if (staged == 2 && p.n_pr_single) { set_list(p.list_pr_single, p.n_pr_single); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0); }
+    if (staged == 2 && p.n_pr_double) { set_list(p.list_pr_double, p.n_pr_double); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0); }
+    if (staged == 1 && p.n_st_single) { set_list(p.list_st_single, p.n_st_single); BEVW_LAUNCH_CLASS(k_plan_staged, 1, 0); }
+    if (staged == 1 && p.n_st_double) { set_list(p.list_st_double, p.n_st_double); BEVW_LAUNCH_CLASS(k_plan_staged, 2, 0); }
     if (p.n_empty) {
         set_list(p.list_empty, p.n_empty);
         hipLaunchKernelGGL((k_plan_empty<LX>), dim3((unsigned)(a.ngroups * a.nchunks)), block, 0, st, a);
@@ -1249,9 +1319,15 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.tile_list = nullptr; a.nlist = p.ntiles;
     a.plan_st = static_cast<const uint2 *>(p.entries_st);
     a.dma = static_cast<const uint32_t *>(p.dma);
+    a.plan_pr = static_cast<const uint2 *>(p.entries_pr);
+    a.gsrc = static_cast<const uint32_t *>(p.gsrc);
     // LDS-staged schedule: needs 16-byte aligned frame sets (whole-sector DMA) and is not combined with the per-tap
     // luminance kernel
-    const bool use_staged = tune.staged && p.staged_ok && !balance && tune.lean && (((uintptr_t)d_frames) & 15u) == 0;
+    int use_staged = 0;
+    if (!balance && tune.lean) {
+        if (tune.staged == 2 && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0) use_staged = 2;
+        else if (tune.staged && p.staged_ok && (((uintptr_t)d_frames) & 15u) == 0) use_staged = 1;
+    }
     a.batch = batch;
     // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk
     int nb = tune.nb > 0 ? tune.nb : 8;

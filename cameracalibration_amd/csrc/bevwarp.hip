@@ -73,11 +73,9 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     return BEVW_OK;
 }
 
-static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
-                       const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car, unsigned long long *d_chsums,
-                       uint8_t *d_out, bool sums = false)
+// tuning knobs for experiments (defaults are the shipped configuration)
+static const PlanTuning &plan_tuning()
 {
-    // tuning knobs for experiments (defaults are the shipped configuration)
     static const PlanTuning tune = [] {
         PlanTuning t;
         if (const char *s = getenv("BEVW_PLAN_NB")) t.nb = atoi(s);
@@ -88,6 +86,14 @@ static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int bat
         if (const char *s = getenv("BEVW_PLAN_ONELAUNCH")) t.one_launch = atoi(s);
         return t;
     }();
+    return tune;
+}
+
+static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
+                       const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car, unsigned long long *d_chsums,
+                       uint8_t *d_out, bool sums = false)
+{
+    const PlanTuning &tune = plan_tuning();
     hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune, sums);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "tile-plan stitch launch failed: %s", hipGetErrorString(e));
     return BEVW_OK;
@@ -1049,8 +1055,13 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[2] = h->schedule_in_use;
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
-    info[5] = h->plan.n_st_single + h->plan.n_st_double;   // tiles on the LDS-staged schedule
-    info[6] = h->plan.n_rs_single + h->plan.n_rs_double;   // single/double tiles left on the L1-gather kernels
+    if (plan_tuning().staged == 2 && h->plan.paired_ok) {
+        info[5] = h->plan.n_pr_single + h->plan.n_pr_double;   // tiles on the pair-staged schedule (bevw_pair.h)
+        info[6] = h->plan.n_rp_single + h->plan.n_rp_double;   // single/double tiles left on the L1-gather kernels
+    } else {
+        info[5] = h->plan.n_st_single + h->plan.n_st_double;   // tiles on the sector-staged schedule
+        info[6] = h->plan.n_rs_single + h->plan.n_rs_double;
+    }
     info[7] = h->plan.n_slow;
     return BEVW_OK;
 }
