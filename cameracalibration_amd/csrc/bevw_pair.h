@@ -2,9 +2,9 @@
 //
 // Why.  The sector-staged body (plan_staged_body) reads every 2x2 footprint back from LDS as raw interleaved BGR bytes
 // at an arbitrary byte offset: two 16-byte windows per pixel (ds_read2_b64, 8 LDS cycles each) and 14 select / realign
-// instructions in front of the dot products -- 124 integer VALU instructions (4.4 clk each on gfx950) and ~115 LDS cycles
-// per tile-frame, issued from 2.8 waves per SIMD (142 VGPRs).  Here the realignment is done ONCE PER SOURCE TEXEL while
-// the texels are staged instead of once per BEV pixel and tap:
+// instructions in front of the dot products -- 124 integer VALU instructions (4.7 clk each on gfx950,
+// profiles/r02/valu_rates.log) and ~115 LDS cycles per tile-frame, issued from 2.8 waves per SIMD (142 VGPRs).  Here the
+// realignment is done ONCE PER SOURCE TEXEL while the texels are staged instead of once per BEV pixel and tap:
 //
 //   * source texels are fetched in GROUPS: 16 bytes from a 4-byte aligned address 12 * g (g = group index inside the
 //     4-camera frame set; rows are whole numbers of groups because fw % 4 == 0), i.e. texels 4g .. 4g+4 of one source
@@ -16,41 +16,114 @@
 //   * a BEV pixel reads one 8-byte pair entry per footprint row (ds_read_b64, 2 LDS cycles, 8-byte aligned by
 //     construction) and needs 6 v_dot4 + 3 v_lshl_or + 3 v_dot2 + 2 v_perm: 14 VALU per pixel instead of 31.
 //
-// Frame b+1's groups are in flight in registers (one dwordx4 per round) while frame b is interpolated; the LDS patch is
-// single-buffered and wave-private (program order of one wave orders the reads of frame b before the writes of b+1).
-// Tiles whose footprints need more than kPairRounds * 64 groups stay on the L1-gather class.
+// Modes (per tile, chosen by the plan compiler; header bits 8..9):
+//   whole-tile staging, 1 / 2 / 4 rounds: every group of the tile is staged, then the lane's 4 pixels are interpolated
+//                                        (neighbouring pixels share groups; <= 256 groups per tile)
+//   sliced staging, 2 rounds per slice : sparse tiles (near the car every pixel samples its own texels: up to 2 groups per
+//                                        pixel and row pair, 512 per tile).  Pixel slot j of all lanes (64 pixels) is a
+//                                        slice with its own group list of <= 128 groups; the four slices of a frame are
+//                                        staged and interpolated one after the other through the same patch.  No tile is
+//                                        left for the per-pixel L1 gathers (8 gather instructions + 28 VALU per pixel).
+// Pipeline: the groups of the next TWO steps (step = frame, or slice of a frame) are in flight in registers (one dwordx4
+// per round and step) while the current step is interpolated; the LDS patch (<= 8 KB per wave) is single-buffered and
+// wave-private (program order of one wave orders the reads of step t before the writes of step t+1).  The loop body is
+// straight-line code (frame indices past the end of the chunk are clamped), so the compiler's vector-memory waits are
+// exact: the wait in front of a conversion covers the loads of that step only, never the younger loads or the store.
 // The arithmetic is the one of bilinear_rows_b2: (sum p * w + 512) >> 10 in the separable form, exact in integers.
 #pragma once
 
+// Ablation builds for profiling only (hipcc -DBEVW_ABL=n, never shipped): 1 no output store | 2 no source loads (synthetic
+// texels) | 3 every frame reads frame 0 (cache-resident source) | 4 every frame writes frame 0 (cache-resident output) |
+// 5 = 1 + 2 | 7 each wave stores 768 contiguous bytes (wrong place: cost of the 8 x 96-byte store shape) | 8 loads fetch whole
+// 128-byte lines, 8 lanes per line (wrong texels: cost of the per-lane 16-byte group requests)
+#ifndef BEVW_ABL
+#define BEVW_ABL 0
+#endif
+// frames whose groups are in flight ahead of the one being interpolated, whole-tile staging with 1 / 2 / 4 rounds
+#ifndef BEVW_PAIR_DEPTH1
+#define BEVW_PAIR_DEPTH1 2
+#endif
+#ifndef BEVW_PAIR_DEPTH2
+#define BEVW_PAIR_DEPTH2 2
+#endif
+#ifndef BEVW_PAIR_DEPTH4
+#define BEVW_PAIR_DEPTH4 2
+#endif
+
 namespace bevw {
 
-constexpr uint32_t kHdrPaired = 128u;        // tile has a pair-staging plan; rounds - 1 in header bits 8..9
-constexpr int kPairRounds = 4;               // max rounds (64 groups each) per tile-frame
+constexpr uint32_t kHdrPaired = 128u;        // tile has a pair-staging plan; mode in header bits 8..9
 constexpr int kPairRoundBytes = 2048;        // LDS per round: 64 groups x 4 pairs x 8 B
-constexpr int kPairPatch = kPairRounds * kPairRoundBytes;   // LDS per wave
+constexpr int kPairMaxRounds = 4;            // rounds per step of whole-tile staging
+constexpr int kPairSliceRounds = 2;          // rounds per step of sliced staging
+constexpr int kPairPatch = kPairMaxRounds * kPairRoundBytes;   // LDS per wave
+constexpr int kPairSrcSlots = 8;             // gsrc entries per tile and lane: [round] (whole tile) or [slice][2 rounds]
+// mode -> (slices, rounds): 0 = (1, 1), 1 = (1, 2), 2 = (1, 4), 3 = (4, 2)
+constexpr int kPairModes = 4;
+// Cooperative store: the 4 waves of a block whose tiles are x-neighbours of one tile row (a 128 x 8 pixel strip) exchange
+// their output bytes through LDS so that every wave stores two full 384-byte rows of the strip instead of eight 96-byte
+// row segments: 13-14 sector requests per store instruction instead of 19 (the L1 -> L2 request rate, not bytes, bounds
+// the step: profiles/r02/run6_ablations_store_shape_line_loads.log).  Two buffers, one barrier per frame.
+constexpr int kStripDwords = 800;                // per buffer: (64 / LX) rows x (4 * LX * 3 + 1) dwords (the + 1 spreads the rows over the banks)
+constexpr int kStripBytes = 2 * kStripDwords * 4;   // per block
+constexpr uint32_t kPairNoGroup = 0x80000000u;   // source offset of a lane without a group (frame sets are < 2 GB)
+constexpr uint32_t kBufferWord3 = 0x00020000u;   // raw buffer descriptor, dword 3 (gfx9 family: DATA_FORMAT 32)
 
 struct __attribute__((packed, aligned(4))) AlignedU4 { uint32_t x, y, z, w; };
 
-// plan compiler: one wave per tile.  Reads the base entries (byte offset of the footprint, meta), collects the distinct
-// groups in ascending address order (lane = slot % 64, round = slot / 64), and rewrites every entry to the LDS byte
-// addresses of its two pair entries.  Interleaved tiles are rewritten to store order exactly as k_plan_stage_build does.
+// distinct values of cand[lane * 16 + i] (i in the bit mask `use`) in ascending order -> list[], at most maxn;
+// returns the count, or maxn + 1 when there are more.  One wave; cand / list in LDS.
+__device__ inline int pair_distinct(const uint32_t *cand, uint32_t use, uint32_t *list, int maxn, int lane)
+{
+    uint32_t last = 0;
+    bool first = true;
+    int n = 0;
+    for (;;) {
+        uint32_t m = 0xffffffffu;
+        for (int i = 0; i < 16; ++i) {
+            if (!((use >> i) & 1u)) continue;
+            const uint32_t v = cand[lane * 16 + i];
+            if (v != 0xffffffffu && (first || v > last)) m = min(m, v);
+        }
+        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
+        if (m == 0xffffffffu) break;
+        if (n == maxn) return maxn + 1;
+        if (lane == 0) list[n] = m;
+        ++n;
+        last = m; first = false;
+    }
+    return n;
+}
+
+// plan compiler: one wave per tile.  Reads the base entries (byte offset of the footprint, meta), brings them to store
+// order (interleaved tiles are rewritten exactly as k_plan_stage_build does), picks the mode, assigns every distinct group
+// a slot (ascending address order: lane = slot % 64, round = slot / 64) and rewrites every entry to the LDS byte addresses
+// of its two pair entries.
 __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int ntiles,
                                                          uint32_t row_bytes, uint32_t set_bytes, uint2 *__restrict__ plan_pr,
-                                                         uint32_t *__restrict__ gsrc)
+                                                         uint32_t *__restrict__ gsrc, int perm)
 {
-    constexpr int kMaxGroups = kPairRounds * 64;
+    constexpr int kMax = kPairMaxRounds * 64;   // groups per step, whole-tile staging
+    constexpr int kMaxSlice = kPairSliceRounds * 64;
+    __shared__ uint2 ent[8][64];
     __shared__ uint32_t cand[64 * 16];
-    __shared__ uint32_t list[kMaxGroups + 1];
-    __shared__ int s_count;
+    __shared__ uint32_t list[kMax + 1];
     const int tile = blockIdx.x, lane = threadIdx.x;
     if (tile >= ntiles) return;
     const uint32_t h = hdr[tile];
     if (h & (kHdrSlow | kHdrEmpty)) return;
     const uint32_t gpr = row_bytes / 12u;   // groups per source row
+    const bool inter = (h & kHdrInterleaved) != 0;
+    for (int k = 0; k < 8; ++k) {
+        const int j = k & 3, sl = k & 4;
+        const int dst_lane = inter ? (lane & ~3) + j : lane, dst_slot = inter ? sl + (lane & 3) : k;
+        ent[dst_slot][dst_lane] = plan[((size_t)tile * 8 + k) * 64 + lane];
+    }
+    __syncthreads();
     uint2 e[8];
     bool overrun = false;
     for (int k = 0; k < 8; ++k) {
-        e[k] = plan[((size_t)tile * 8 + k) * 64 + lane];
+        e[k] = ent[k][lane];
         uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu;
         if (e[k].y & kMetaValid) {
             c0 = e[k].x / 12u;       // group of texel pair (sx, sx+1) in row sy: offset = (row * fw + sx) * 3 = 12 * (row * gpr) + 3 * sx
@@ -60,58 +133,81 @@ __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict_
         cand[lane * 16 + 2 * k] = c0;
         cand[lane * 16 + 2 * k + 1] = c1;
     }
-    if (lane == 0) s_count = 0;
     __syncthreads();
-    uint32_t last = 0;
-    bool first = true, fits = !__any(overrun);
-    for (int it = 0; it <= kMaxGroups && fits; ++it) {
-        uint32_t m = 0xffffffffu;
-        for (int i = 0; i < 16; ++i) {
-            const uint32_t v = cand[lane * 16 + i];
-            if (v != 0xffffffffu && (first || v > last)) m = min(m, v);
-        }
-        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
-        if (m == 0xffffffffu) break;
-        if (it == kMaxGroups) { fits = false; break; }
-        if (lane == 0) { list[it] = m; s_count = it + 1; }
-        last = m; first = false;
-    }
-    __syncthreads();
-    const int count = s_count;
-    if (!fits || count == 0) return;
-    auto slot_of = [&](uint32_t key) {
+    if (__any(overrun)) return;
+    auto slot_of = [&](uint32_t key, int count) {
         int lo = 0, hi = count;
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < key) lo = mid + 1; else hi = mid; }
         return (uint32_t)lo;
     };
-    auto lds_addr = [](uint32_t slot, uint32_t k) {
-        return (slot >> 6) * (uint32_t)kPairRoundBytes + (k >> 1) * 1024u + (slot & 63u) * 16u + (k & 1u) * 8u;
+    // slot (rank in ascending address order) -> lane of its round.  perm 0: lane = rank % 64 (consecutive lanes fetch
+    // consecutive groups of a row); 1: consecutive lane QUADS fetch groups 3 quads (144 bytes) apart; 2: consecutive lanes
+    // fetch groups 11 apart (132 bytes) -- so that neighbouring lanes of one load do not hit the same (pending) 128-byte line
+    auto lane_of = [perm](uint32_t pos) {
+        if (perm == 1) return (((pos >> 2) * 11u) & 15u) * 4u + (pos & 3u);
+        if (perm == 2) return (pos * 35u) & 63u;
+        return pos;
     };
-    const bool inter = (h & kHdrInterleaved) != 0;
-    for (int k = 0; k < 8; ++k) {
+    auto pos_of = [perm](uint32_t ln) {
+        if (perm == 1) return (((ln >> 2) * 3u) & 15u) * 4u + (ln & 3u);
+        if (perm == 2) return (ln * 11u) & 63u;
+        return ln;
+    };
+    auto lds_addr = [&](uint32_t slot, uint32_t k) {
+        return (slot >> 6) * (uint32_t)kPairRoundBytes + (k >> 1) * 1024u + lane_of(slot & 63u) * 16u + (k & 1u) * 8u;
+    };
+    auto rewrite = [&](int k, int count) {
         uint2 o = make_uint2(0u, e[k].y & ~kMetaValid);
         if (e[k].y & kMetaValid) {
             const uint32_t key = e[k].x / 12u, pk = (e[k].x - key * 12u) / 3u;
-            o = make_uint2(lds_addr(slot_of(key), pk) | (lds_addr(slot_of(key + gpr), pk) << 16), e[k].y);
+            o = make_uint2(lds_addr(slot_of(key, count), pk) | (lds_addr(slot_of(key + gpr, count), pk) << 16), e[k].y);
         }
-        const int j = k & 3, sl = k & 4;
-        const int dst_lane = inter ? (lane & ~3) + j : lane, dst_slot = inter ? sl + (lane & 3) : k;
-        plan_pr[((size_t)tile * 8 + dst_slot) * 64 + dst_lane] = o;
+        plan_pr[((size_t)tile * 8 + k) * 64 + lane] = o;
+    };
+    auto write_src = [&](int base, int count, int rounds) {
+        for (int r = 0; r < rounds; ++r) {
+            const int slot = r * 64 + (int)pos_of((uint32_t)lane);
+            // lanes without a group carry an out-of-range offset: the buffer load returns zeros without a memory access
+            gsrc[((size_t)tile * kPairSrcSlots + base + r) * 64 + lane] = slot < count ? list[slot] * 12u : kPairNoGroup;
+        }
+    };
+    int mode;
+    const int count = pair_distinct(cand, 0xffffu, list, kMax, lane);
+    __syncthreads();
+    if (count == 0) return;
+    // two-contributor tiles (seams, blend overlaps) have pair classes for <= 128 groups; the few sparser ones stay on the
+    // gather class
+    if ((h & kHdrSecond) && count > 128) return;
+    if (count <= kMax) {
+        mode = count <= 64 ? 0 : (count <= 128 ? 1 : 2);
+        write_src(0, count, kPairMaxRounds);
+        for (int k = 0; k < 8; ++k) rewrite(k, count);
+    } else {
+        // sliced: pixel slot j of every lane has its own group list (single-contributor tiles: <= 2 groups per pixel)
+        int worst = 0;
+        for (int j = 0; j < 4; ++j) {
+            __syncthreads();
+            const int cj = pair_distinct(cand, (3u << (2 * j)) | (3u << (2 * (4 + j))), list, kMaxSlice, lane);
+            if (cj > kMaxSlice) return;   // cannot happen for single-contributor tiles (2 groups per pixel)
+            worst = max(worst, cj);
+        }
+        for (int j = 0; j < 4; ++j) {
+            __syncthreads();
+            const int cj = pair_distinct(cand, (3u << (2 * j)) | (3u << (2 * (4 + j))), list, kMaxSlice, lane);
+            __syncthreads();
+            write_src(j * kPairSliceRounds, cj, kPairSliceRounds);
+            rewrite(j, cj);
+            rewrite(4 + j, cj);
+        }
+        (void)worst;
+        mode = 3;
     }
-    for (int r = 0; r < kPairRounds; ++r) {
-        const int slot = r * 64 + lane;
-        gsrc[((size_t)tile * kPairRounds + r) * 64 + lane] = (slot < count ? list[slot] : list[0]) * 12u;
-    }
-    if (lane == 0) hdr[tile] = h | kHdrPaired | ((uint32_t)((count + 63) / 64 - 1) << 8);
+    if (lane == 0) hdr[tile] = h | kHdrPaired | ((uint32_t)mode << 8);
 }
 
-// 16 source bytes (texels 4g .. 4g+4 of one row) -> the four pair entries, stored for lane `lane` of round patch `rp`
 typedef uint32_t pair_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ pair_u32x4 pair_load_group(const uint8_t *p)
-{
-    const AlignedU4 v = *reinterpret_cast<const AlignedU4 *>(p);   // one global_load_dwordx4 from a 4-byte aligned address
-    return pair_u32x4{v.x, v.y, v.z, v.w};
-}
+typedef uint32_t pair_u32x3 __attribute__((ext_vector_type(3)));
+// 16 source bytes (texels 4g .. 4g+4 of one row) -> the four pair entries, stored for lane `lane` of round patch `rp`
 __device__ __forceinline__ void pair_convert_store(const pair_u32x4 &d, uint8_t *rp, int lane)
 {
     uint4 A, B;
@@ -144,27 +240,40 @@ __device__ __forceinline__ void bilinear_pairs(uint2 q0, uint2 q1, uint32_t wxa,
 // 12 accumulators (result byte in bits 16..23) of a lane's 4 pixels -> the 12 output bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
 __device__ __forceinline__ void pack_accs(const uint32_t acc[4][3], uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {
-    // perm(hi, lo, sel): byte 2 of lo = index 2, byte 2 of hi = index 6
-    // the two halves of each output dword have zeros where the other half has data: combine with v_or_b32 (a 2-clk VOP2)
+    // perm(hi, lo, sel): byte 2 of lo = index 2, byte 2 of hi = index 6; the two halves of each output dword have zeros
+    // where the other half has data: combine with v_or_b32 (a 2.5-clk VOP2)
     d0 = __builtin_amdgcn_perm(acc[1][0], acc[0][2], 0x06020c0cu) | __builtin_amdgcn_perm(acc[0][1], acc[0][0], 0x0c0c0602u);
     d1 = __builtin_amdgcn_perm(acc[2][1], acc[2][0], 0x06020c0cu) | __builtin_amdgcn_perm(acc[1][2], acc[1][1], 0x0c0c0602u);
     d2 = __builtin_amdgcn_perm(acc[3][2], acc[3][1], 0x06020c0cu) | __builtin_amdgcn_perm(acc[3][0], acc[2][2], 0x0c0c0602u);
 }
 
-// one wave: tile from the class list, frames of the chunk.  lds: 4 * kPairPatch bytes (one patch per wave)
-template <int LX, int NSLOT, bool BLEND, bool SUMS>
+// one wave: tile from the class list, frames of the chunk.  lds: 4 * kPairPatch bytes (one patch per wave).
+// SLICES 1: whole-tile staging, 4: one slice per pixel slot (NSLOT == 1 only); ROUNDS: group rounds per step.
+template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
+__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds);
+
+template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
 __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
 {
-    constexpr int LY = 64 / LX;
     uint32_t chunk, group;
     if (!plan_block_map(a, block_id, chunk, group)) return;
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = (int)group * 4 + wave;
+    const bool coop = (int)group * 4 < a.ncoop;   // block-uniform: the block's 4 tiles are x-neighbours (all 4 waves are live)
     if (slot >= a.nlist) return;
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
-    const int nr = (int)((hdr >> 8) & 3u) + 1;
+    plan_pair_tile<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, tile, hdr, chunk, coop, lds);
+}
+
+template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
+__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds)
+{
+    static_assert(SLICES == 1 || (SLICES == 4 && NSLOT == 1), "sliced staging is built for single-contributor tiles");
+    static_assert(ROUNDS >= 1 && ROUNDS <= (SLICES == 1 ? kPairMaxRounds : kPairSliceRounds), "rounds per step");
+    constexpr int LY = 64 / LX;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     int lx_, ly_;
     lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
@@ -172,6 +281,18 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
     const bool inimg = x0 < a.bw && y < a.bh;
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
     const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    // store position: the lane's own pixel quad, or (cooperative blocks) quad (lane % 32) of strip row 2 * wave + lane / 32
+    uint32_t ooff_masked = inimg ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: not written
+    uint32_t *const strip = reinterpret_cast<uint32_t *>(lds + 4 * kPairPatch);
+    constexpr int kStripPitch = 4 * LX * 3 + 1;      // dwords per strip row
+    static_assert(LY * kStripPitch <= kStripDwords, "strip buffer");
+    const int srow = (64 * wave + lane) / (4 * LX), scol = (64 * wave + lane) % (4 * LX);   // pixel quad this lane stores
+    const uint32_t strip_wr = (uint32_t)ly_ * kStripPitch + (uint32_t)wave * (LX * 3) + (uint32_t)lx_ * 3;
+    const uint32_t strip_rd = (uint32_t)srow * kStripPitch + (uint32_t)scol * 3;
+    if (coop) {
+        const int sx0 = (tx - wave) * (LX * 4) + scol * 4, sy = ty * LY + srow;
+        ooff_masked = (sx0 < a.bw && sy < a.bh) ? ((uint32_t)sy * a.bw + sx0) * 3 : kPairNoGroup;
+    }
     uint8_t *const patch = lds + wave * kPairPatch;
     const uint2 *const pw = reinterpret_cast<const uint2 *>(patch);
 
@@ -191,9 +312,11 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
             wy[s][j] = ((32 - fy) << 6) | (fy << 22);           // y weights x 64
             wf[s][j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
         }
-    uint32_t gs[kPairRounds];
+    uint32_t gs[SLICES][ROUNDS];
 #pragma unroll
-    for (int r = 0; r < kPairRounds; ++r) gs[r] = r < nr ? a.gsrc[((size_t)tile * kPairRounds + r) * 64 + lane] : 0u;
+    for (int s = 0; s < SLICES; ++s)
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) gs[s][r] = a.gsrc[((size_t)tile * kPairSrcSlots + s * kPairSliceRounds + r) * 64 + lane];
     uint32_t car0 = 0, car1 = 0, car2 = 0;
     if (!SUMS && a.car != nullptr && inimg) {
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
@@ -203,99 +326,168 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
 
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
 
-    pair_u32x4 pf[kPairRounds];
-    // wave-uniform base + 32-bit lane offset: the loads and the store use the SGPR-base addressing form
-    auto issue = [&](int b) {
-        const uint8_t *src = a.frames + (size_t)b * set_bytes;
+    // D steps (frames, or slices of a frame) have their groups in flight in registers ahead of the one being interpolated
+    constexpr int D = SLICES == 4 ? 2 : (ROUNDS == 1 ? BEVW_PAIR_DEPTH1 : (ROUNDS == 2 ? BEVW_PAIR_DEPTH2 : BEVW_PAIR_DEPTH4));
+    pair_u32x4 pf[D][ROUNDS];
+    // Loads and stores go through raw buffer descriptors (wave-uniform base in SGPRs + 32-bit lane offset: no 64-bit address
+    // arithmetic, and a lane whose offset is out of range -- kPairNoGroup, or a pixel quad right of the image -- costs no
+    // memory access and no branch, so every vector-memory instruction is issued unconditionally and counted exactly).
+    auto issue = [&](int b, int s, int ring) {   // s, ring: compile-time after unrolling
+        const uint8_t *src = a.frames + (size_t)(BEVW_ABL == 3 ? 0 : min(b, b_end - 1)) * set_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
 #pragma unroll
-        for (int r = 0; r < kPairRounds; ++r)
-            if (r < nr) pf[r] = pair_load_group(src + gs[r]);
+        for (int r = 0; r < ROUNDS; ++r) {
+            if (BEVW_ABL == 2 || BEVW_ABL == 5)
+                pf[ring][r] = pair_u32x4{gs[s][r] + (uint32_t)b, gs[s][r] * 3u, gs[s][r] ^ 0x5a5a5a5au, gs[s][r] + 77u};
+            else if (BEVW_ABL == 8) {
+                const uint32_t g8 = (uint32_t)__shfl((int)gs[s][r], lane & ~7, 64);
+                pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g8 == kPairNoGroup ? g8 : (g8 & ~127u) + (uint32_t)(lane & 7) * 16u), 0, 0);
+            }
+            else pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[s][r], 0, 0);
+        }
     };
-    auto land = [&]() {
+    auto land = [&](int ring) {
 #pragma unroll
-        for (int r = 0; r < kPairRounds; ++r)
-            if (r < nr) pair_convert_store(pf[r], patch + r * kPairRoundBytes, lane);
+        for (int r = 0; r < ROUNDS; ++r) pair_convert_store(pf[ring][r], patch + r * kPairRoundBytes, lane);
     };
-    issue(b_begin);
-    land();
-#pragma unroll 1
-    for (int b = b_begin; b < b_end; ++b) {
-        // frame b+1's groups travel while frame b is interpolated (past the end of the chunk: the last frame again, so that
-        // the loop body is one straight line and the only vector-memory wait in it is the one in front of land())
-        issue(min(b + 1, b_end - 1));
-        uint32_t d0, d1, d2;
-        if (!BLEND && NSLOT == 1 && !SUMS) {
-            uint32_t acc[4][3];
+    // pixel j of contributor s from the patch -> accumulators
+    auto pixel = [&](int s, int j, uint32_t acc[3]) { bilinear_pairs(pw[i0[s][j]], pw[i1[s][j]], wxa[s][j], wxb[s][j], wy[s][j], acc); };
+    // generic path: per-tile channel sums (balance) and the car sprite on the 4 pixel dwords (B | G << 8 | R << 16)
+    auto finish = [&](int b, uint32_t P[4]) {
+        if (SUMS) {
+            uint32_t sb = 0, sg = 0, sr = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bilinear_pairs(pw[i0[0][j]], pw[i1[0][j]], wxa[0][j], wxb[0][j], wy[0][j], acc[j]);
-            if (car_any) {
+            for (int j = 0; j < 4; ++j) {
+                sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
+                sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
+                sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
+            }
+            uint32_t bg = sb | (sg << 16);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
+            if (lane == 0 && b < b_end) {
+                uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
+                ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
+            }
+        }
+        if (car_any) add_car(P, car0, car1, car2);
+    };
+    auto store = [&](int b, uint32_t d0, uint32_t d1, uint32_t d2) {
+        if (coop) {
+            uint32_t *sb = strip + ((b - b_begin) & 1) * kStripDwords;
+            sb[strip_wr] = d0; sb[strip_wr + 1] = d1; sb[strip_wr + 2] = d2;
+            __syncthreads();
+            d0 = sb[strip_rd]; d1 = sb[strip_rd + 1]; d2 = sb[strip_rd + 2];
+        }
+        // a frame index past the end of the chunk re-writes the last frame with the same bytes
+        if ((BEVW_ABL == 1 || BEVW_ABL == 5) && !(d0 == 0x12345679u && d1 == 0x9abcdef1u && d2 == 77u)) return;
+        uint8_t *img = a.out + (size_t)(BEVW_ABL == 4 ? 0 : min(b, b_end - 1)) * img_bytes;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
+        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)(BEVW_ABL == 7 ? (uint32_t)(tile % 4500) * 768u + (uint32_t)lane * 12u : ooff_masked), 0, 0);
+    };
+    // contribution of entry (s, j) accumulated onto px (saturating add of the second contributor)
+    auto contrib = [&](int s, int j, int px[3]) {
+        uint32_t acc[3];
+        pixel(s, j, acc);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t v = (acc[k] >> 16) & 255u;
+            const int c = BLEND ? (int)((float)v * wf[s][j]) : (int)v;
+            px[k] = s == 0 ? c : min(255, px[k] + c);
+        }
+    };
+    constexpr bool kFast = !BLEND && NSLOT == 1 && !SUMS;   // accumulators go straight to the output bytes
+    auto acc_to_px = [](const uint32_t acc[3]) {
+        return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
+    };
+
+    if (SLICES == 1) {
+        // step = frame; two frames per loop trip (ring slot = frame parity)
+        auto frame = [&](int b, int ring) {
+            issue(b + D, 0, ring);            // ring slot of frame b is free: its groups were converted one step ago
+            uint32_t d0, d1, d2;
+            if (kFast) {
+                uint32_t acc[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pixel(0, j, acc[j]);
+                if (car_any) {
+                    uint32_t P[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) P[j] = acc_to_px(acc[j]);
+                    add_car(P, car0, car1, car2);
+                    pack_pixels(P, d0, d1, d2);
+                } else {
+                    pack_accs(acc, d0, d1, d2);
+                }
+            } else {
                 uint32_t P[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    P[j] = __builtin_amdgcn_perm(acc[j][2], __builtin_amdgcn_perm(acc[j][1], acc[j][0], 0x0c0c0602u), 0x0c060100u);
-                add_car(P, car0, car1, car2);
+                for (int j = 0; j < 4; ++j) {
+                    int px[3];
+#pragma unroll
+                    for (int s = 0; s < NSLOT; ++s) contrib(s, j, px);
+                    P[j] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+                }
+                finish(b, P);
                 pack_pixels(P, d0, d1, d2);
-            } else {
-                pack_accs(acc, d0, d1, d2);
             }
-        } else {
-            uint32_t P[4];
-            int px[4][3];
+            land((ring + 1) % D);             // frame b+1 (issued D-1 steps ago); every LDS read of frame b is older
+            store(b, d0, d1, d2);
+        };
 #pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
+        for (int u = 0; u < D; ++u) issue(b_begin + u, 0, u);
+        land(0);
+#pragma unroll 1
+        for (int b = b_begin; b < b_end; b += D) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t acc[3];
-                    bilinear_pairs(pw[i0[s][j]], pw[i1[s][j]], wxa[s][j], wxb[s][j], wy[s][j], acc);
-                    if (!BLEND && NSLOT == 1) {
-                        P[j] = __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const uint32_t v = (acc[k] >> 16) & 255u;
-                            const int c = BLEND ? (int)((float)v * wf[s][j]) : (int)v;
-                            px[j][k] = s == 0 ? c : min(255, px[j][k] + c);
-                        }
-                    }
-                }
-            if (BLEND || NSLOT == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
-            }
-            if (SUMS) {
-                uint32_t sb = 0, sg = 0, sr = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
-                    sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
-                    sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
-                }
-                uint32_t bg = sb | (sg << 16);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
-                if (lane == 0) {
-                    uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
-                    ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
-                }
-            }
-            if (car_any) add_car(P, car0, car1, car2);
-            pack_pixels(P, d0, d1, d2);
+            for (int u = 0; u < D; ++u) frame(b + u, u);
         }
-        land();   // every LDS read of frame b precedes these writes in program order; waits for the loads only (the store
-                  // of frame b is issued after it, the store of frame b-1 is older than the loads)
-        if (inimg) {
-            uint32_t *op = reinterpret_cast<uint32_t *>(a.out + (size_t)b * img_bytes + ooff);
-            op[0] = d0; op[1] = d1; op[2] = d2;
+    } else {
+        // step = (frame, slice j): pixel slot j of all lanes; ring slot = slice parity
+        issue(b_begin, 0, 0);
+        issue(b_begin, 1, 1);
+        land(0);
+#pragma unroll 1
+        for (int b = b_begin; b < b_end; ++b) {
+            uint32_t acc[4][3];
+            uint32_t P[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                issue(j < 2 ? b : b + 1, (j + 2) & 3, j & 1);
+                if (kFast) {
+                    pixel(0, j, acc[j]);
+                } else {
+                    int px[3];
+                    contrib(0, j, px);
+                    P[j] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
+                }
+                land((j & 1) ^ 1);
+            }
+            uint32_t d0, d1, d2;
+            if (kFast && !car_any) {
+                pack_accs(acc, d0, d1, d2);
+            } else {
+                if (kFast) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) P[j] = acc_to_px(acc[j]);
+                    add_car(P, car0, car1, car2);
+                } else {
+                    finish(b, P);
+                }
+                pack_pixels(P, d0, d1, d2);
+            }
+            store(b, d0, d1, d2);
         }
     }
 }
 
-// the pair-staged class as a kernel of its own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit profiles are taken on)
-template <int LX, int NSLOT, bool BLEND, bool SUMS>
+// the pair-staged classes as kernels of their own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit profiles are
+// taken on)
+template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
 __global__ void __launch_bounds__(256) k_plan_pair(PlanArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kPairPatch];
-    plan_pair_body<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, patch);
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kPairPatch + kStripBytes];   // (the body uses ROUNDS * 2 KB of each wave's 8)
+    plan_pair_body<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, blockIdx.x, patch);
 }
 
 }  // namespace bevw

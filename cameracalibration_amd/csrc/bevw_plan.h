@@ -67,10 +67,16 @@ struct Plan {
     // pair-staged variant (bevw_pair.h): tiles whose footprints fit kPairRounds x 64 groups of 4 texels; pr_* lists hold
     // them, rp_* the single / double tiles that stay on the L1-gather kernels when this schedule is selected
     void *entries_pr = nullptr;  // uint2[ntiles][8][64]: x = LDS byte address of the pair entry of row 0 | row 1 << 16, y = meta
-    void *gsrc = nullptr;        // uint32[ntiles][kPairRounds][64]: per-lane source offset of each round's group
-    void *list_pr_single = nullptr, *list_pr_double = nullptr, *list_rp_single = nullptr, *list_rp_double = nullptr;
-    int n_pr_single = 0, n_pr_double = 0, n_rp_single = 0, n_rp_double = 0;
-    int pr_rounds[4] = {0, 0, 0, 0};   // tiles per round count (1..4), statistics
+    void *gsrc = nullptr;        // uint32[ntiles][8][64]: per-lane source offset of the group of [slice][round]
+    // pair classes: single-contributor tiles by mode (whole-tile 1 / 2 / 4 rounds, sliced), then two-contributor tiles
+    // (whole-tile 1 / 2 rounds)
+    void *list_pr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_pr[6] = {0, 0, 0, 0, 0, 0};
+    int n_pr_coop[6] = {0, 0, 0, 0, 0, 0};   // leading entries of each list that form blocks of 4 x-neighbouring tiles
+    void *list_spatial = nullptr;            // every tile k_plan_spatial runs (all but border and sparse two-contributor tiles)
+    int n_spatial = 0;
+    void *list_rp_single = nullptr, *list_rp_double = nullptr;
+    int n_rp_single = 0, n_rp_double = 0;
     bool paired_ok = false;
 };
 
@@ -422,6 +428,7 @@ struct PlanArgs {
     const uint32_t *gsrc;        // group source offsets [ntiles][kPairRounds][64]
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
     int nlist;
+    int ncoop;                   // pair classes: the first ncoop list entries are blocks of 4 x-neighbouring tiles (cooperative store)
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -715,6 +722,30 @@ __device__ __forceinline__ void plan_empty_body(const PlanArgs &a, uint32_t bloc
 template <int LX>
 __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a) { plan_empty_body<LX>(a, blockIdx.x); }
 
+// one wave, one empty tile
+template <int LX>
+__device__ __forceinline__ void plan_empty_tile(const PlanArgs &a, int tile, int b_begin, int b_end)
+{
+    constexpr int LY = 64 / LX;
+    const int lane = threadIdx.x & 63;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    int lx_, ly_;
+    lane_xy(lane, LX, false, lx_, ly_);
+    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
+    if (!(x0 < a.bw && y < a.bh)) return;
+    const size_t img_bytes = (size_t)a.bw * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if (a.car != nullptr) {
+        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
+        c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
+    }
+    for (int b = b_begin; b < b_end; ++b) {
+        uint32_t *op = reinterpret_cast<uint32_t *>(a.out + (size_t)b * img_bytes + ooff);
+        op[0] = c0; op[1] = c1; op[2] = c2;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LDS-staged schedule.  The gathers of k_plan_lean are bound by the per-instruction cost of the vector-memory pipe
 // (8 gather instructions per tile-frame, each carrying ~3 sector misses: DESIGN.md section 4).  Here the ~27 distinct
@@ -961,13 +992,18 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
+constexpr int kPlanAllMax = 8;   // classes of one merged launch
 struct PlanAllArgs {
     PlanArgs a;
-    const uint32_t *list[5];
-    int nlist[5];
-    int ngroups[5];
-    uint32_t start[6];   // block ranges in launch order
-    int kind[5];         // launch position -> class (0 staged single, 1 staged double, 2 empty, 3 gather single, 4 gather double)
+    const uint32_t *list[kPlanAllMax];
+    int nlist[kPlanAllMax];
+    int ngroups[kPlanAllMax];
+    int ncoop[kPlanAllMax];
+    uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
+    // launch position -> class: 0 sector-staged single, 1 sector-staged double, 2 empty, 3 gather single, 4 gather double,
+    // 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced), 9, 10 pair-staged double (1 / 2 rounds)
+    int kind[kPlanAllMax];
+    int n;                             // launch positions in use
 };
 
 // The two-contributor classes set the register budget (~140 VGPRs, 3 workgroups per CU); measured, the single-contributor
@@ -976,31 +1012,68 @@ struct PlanAllArgs {
 template <int LX, bool BLEND, bool SUMS, int ST = 1>
 __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[ST == 2 ? 4 * kPairPatch : 4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[ST == 2 ? 4 * kPairPatch + kStripBytes : 4 * kStageBytes];
     __shared__ __attribute__((aligned(16))) uint8_t stage_1[ST == 2 ? 16 : 4 * kStageBytes];
     __shared__ __attribute__((aligned(16))) uint8_t stage_2[ST == 2 ? 16 : 4 * kStageBytes];
     int pos = 0;
 #pragma unroll
-    for (int c = 1; c < 5; ++c) pos += blockIdx.x >= q.start[c] ? 1 : 0;
+    for (int c = 1; c < kPlanAllMax; ++c) pos += (c < q.n && blockIdx.x >= q.start[c]) ? 1 : 0;
     PlanArgs a = q.a;
-    a.tile_list = q.list[pos]; a.nlist = q.nlist[pos]; a.ngroups = q.ngroups[pos];
+    a.tile_list = q.list[pos]; a.nlist = q.nlist[pos]; a.ngroups = q.ngroups[pos]; a.ncoop = q.ncoop[pos];
     const uint32_t id = blockIdx.x - q.start[pos];
     switch (q.kind[pos]) {
-        case 0:
-            if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS>(a, id, stage_0);
-            else plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2);
-            break;
-        case 1:
-            if (ST == 2) plan_pair_body<LX, 2, BLEND, SUMS>(a, id, stage_0);
-            else plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2);
-            break;
+        case 0: if (ST == 1) plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
+        case 1: if (ST == 1) plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
+        case 5: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
+        case 6: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
+        case 7: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
+        case 8: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 4, 2>(a, id, stage_0); break;
+        case 9: if (ST == 2) plan_pair_body<LX, 2, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
+        case 10: if (ST == 2) plan_pair_body<LX, 2, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
-        default:
+        case 4:
             // pair-staged launches keep the two-contributor gather class (a handful of sparse seam tiles, 110+ VGPRs) out
             // of the merged kernel: it would set the register budget of every other class
             if (ST != 2) plan_gather_block<LX, 2, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0));
             break;
+        default: break;
+    }
+}
+
+// The same classes in ONE SPATIAL ORDER: the list holds every tile of the step (row-major inside a tile row), a block is 4
+// consecutive list entries (x-neighbours) and every WAVE runs the body of its own tile's class (waves never synchronise, so
+// the waves of a block may run different bodies).  Why: the classes of k_plan_all run one after the other, so two
+// x-neighbouring tiles of different classes write their shared output sector ~100 us apart, the L2 evicts it half-written
+// and HBM sees two partial (32-byte) writes: 3.1 M of 18.1 M write requests per launch, 14.3 M when nothing is partial
+// (profiles/r02/run8_pmc_store_shape.txt).  Sparse two-contributor tiles (kind 4) are left to their own launch.
+template <int LX, bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(256) k_plan_spatial(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kPairPatch + kStripBytes];
+    uint32_t chunk, group;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = (int)group * 4 + wave;
+    if (slot >= a.nlist) return;
+    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
+    const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    if (hdr & kHdrEmpty) {
+        plan_empty_tile<LX>(a, tile, b_begin, b_end);
+    } else if (hdr & kHdrPaired) {
+        const int mode = (int)((hdr >> 8) & 3u);
+        if (hdr & kHdrSecond) {
+            if (mode == 0) plan_pair_tile<LX, 2, BLEND, SUMS, 1, 1>(a, tile, hdr, chunk, false, stage_0);
+            else plan_pair_tile<LX, 2, BLEND, SUMS, 1, 2>(a, tile, hdr, chunk, false, stage_0);
+        } else {
+            if (mode == 0) plan_pair_tile<LX, 1, BLEND, SUMS, 1, 1>(a, tile, hdr, chunk, false, stage_0);
+            else if (mode == 1) plan_pair_tile<LX, 1, BLEND, SUMS, 1, 2>(a, tile, hdr, chunk, false, stage_0);
+            else if (mode == 2) plan_pair_tile<LX, 1, BLEND, SUMS, 1, 4>(a, tile, hdr, chunk, false, stage_0);
+            else plan_pair_tile<LX, 1, BLEND, SUMS, 4, 2>(a, tile, hdr, chunk, false, stage_0);
+        }
+    } else if (!(hdr & kHdrSecond)) {
+        plan_gather_tile<LX, 1, BLEND, SUMS>(a, tile, b_begin, b_end, reinterpret_cast<uint32_t *>(stage_0) + wave * 256);
     }
 }
 
@@ -1030,7 +1103,8 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr_single, p.list_pr_double, p.list_rp_single, p.list_rp_double,
+    void *ptrs[] = {p.list_spatial, p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5],
+                    p.list_rp_single, p.list_rp_double,
                     p.entries, p.hdr, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
                     p.list_st_double, p.list_rs_single, p.list_rs_double, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
@@ -1049,7 +1123,7 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
                                          int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
-                                         int ncams = 4)
+                                         int ncams = 4, int pair_perm = 0, int pair_coop = 0)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -1108,10 +1182,10 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     p.paired_ok = false;
     if (fw % 4 == 0 && (size_t)fw * fh * 3 * ncams < (1ull << 31)) {   // rows are whole groups of 4 texels (12 bytes)
         if ((e = hipMalloc(&p.entries_pr, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
-        if ((e = hipMalloc(&p.gsrc, (size_t)p.ntiles * kPairRounds * 64 * sizeof(uint32_t))) != hipSuccess) return e;
+        if ((e = hipMalloc(&p.gsrc, (size_t)p.ntiles * kPairSrcSlots * 64 * sizeof(uint32_t))) != hipSuccess) return e;
         hipLaunchKernelGGL(k_plan_pair_build, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries),
                            static_cast<uint32_t *>(p.hdr), p.ntiles, (uint32_t)fw * 3, (uint32_t)((size_t)fw * fh * 3 * ncams),
-                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc));
+                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc), pair_perm);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         p.paired_ok = true;
     }
@@ -1164,16 +1238,59 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = plan_upload_list(rd, &p.list_rs_double)) != hipSuccess) return e;
     }
     {
-        std::vector<uint32_t> ss, sd, rs, rd;
-        for (uint32_t t : ls) ((hdr[t] & kHdrPaired) ? ss : rs).push_back(t);
-        for (uint32_t t : ld) ((hdr[t] & kHdrPaired) ? sd : rd).push_back(t);
-        for (int t = 0; t < p.ntiles; ++t)
-            if (hdr[(size_t)t] & kHdrPaired) ++p.pr_rounds[(hdr[(size_t)t] >> 8) & 3u];
-        p.n_pr_single = (int)ss.size(); p.n_pr_double = (int)sd.size(); p.n_rp_single = (int)rs.size(); p.n_rp_double = (int)rd.size();
-        if ((e = plan_upload_list(ss, &p.list_pr_single)) != hipSuccess) return e;
-        if ((e = plan_upload_list(sd, &p.list_pr_double)) != hipSuccess) return e;
+        std::vector<uint32_t> pr[6], rs, rd;
+        for (uint32_t t : ls) { if (hdr[t] & kHdrPaired) pr[(hdr[t] >> 8) & 3u].push_back(t); else rs.push_back(t); }
+        for (uint32_t t : ld) { if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 1u)].push_back(t); else rd.push_back(t); }
+        for (int c = 0; c < 6; ++c) {
+            // blocks of 4 x-neighbouring tiles of one tile row first (cooperative store), the remaining tiles after them
+            std::vector<uint32_t> v = pr[c], quads, loose;
+            std::sort(v.begin(), v.end());
+            if (pair_coop) {
+                for (size_t i = 0; i < v.size();) {
+                    const uint32_t tx = (uint32_t)p.tiles_x;
+                    if (i + 3 < v.size() && v[i + 3] == v[i] + 3 && v[i] / tx == v[i + 3] / tx) { quads.insert(quads.end(), v.begin() + i, v.begin() + i + 4); i += 4; }
+                    else loose.push_back(v[i++]);
+                }
+                // the loose tiles keep the locality order of their class list
+                std::vector<uint32_t> keep;
+                for (uint32_t t : pr[c]) if (std::binary_search(loose.begin(), loose.end(), t)) keep.push_back(t);
+                pr[c] = quads;
+                pr[c].insert(pr[c].end(), keep.begin(), keep.end());
+            }
+            p.n_pr[c] = (int)pr[c].size();
+            p.n_pr_coop[c] = (int)quads.size();
+            if ((e = plan_upload_list(pr[c], &p.list_pr[c])) != hipSuccess) return e;
+        }
+        p.n_rp_single = (int)rs.size(); p.n_rp_double = (int)rd.size();
         if ((e = plan_upload_list(rs, &p.list_rp_single)) != hipSuccess) return e;
         if ((e = plan_upload_list(rd, &p.list_rp_double)) != hipSuccess) return e;
+        // spatial order: tile rows by descending cost (the sparse rows around the car first, so that the long-running waves
+        // do not end up in the tail of the grid), row-major inside a row
+        std::vector<uint32_t> all;
+        {
+            std::vector<std::pair<long, int>> rows;
+            auto cost = [&](uint32_t h) -> long {
+                if (h & kHdrEmpty) return 1;
+                if (!(h & kHdrPaired)) return 12;
+                static const long c[4] = {4, 6, 10, 24};
+                return c[(h >> 8) & 3u] * ((h & kHdrSecond) ? 2 : 1);
+            };
+            for (int ty = 0; ty < p.tiles_y; ++ty) {
+                long w = 0;
+                for (int tx = 0; tx < p.tiles_x; ++tx) w += cost(hdr[(size_t)ty * p.tiles_x + tx]);
+                rows.push_back({-w, ty});
+            }
+            std::stable_sort(rows.begin(), rows.end());
+            for (auto &r : rows)
+                for (int tx = 0; tx < p.tiles_x; ++tx) {
+                    const uint32_t t = (uint32_t)(r.second * p.tiles_x + tx), h = hdr[t];
+                    if (h & kHdrSlow) continue;
+                    if (!(h & (kHdrEmpty | kHdrPaired)) && (h & kHdrSecond)) continue;   // sparse two-contributor tile: own launch
+                    all.push_back(t);
+                }
+        }
+        p.n_spatial = (int)all.size();
+        if ((e = plan_upload_list(all, &p.list_spatial)) != hipSuccess) return e;
     }
     p.n_single = (int)ls.size(); p.n_double = (int)ld.size(); p.n_slow = (int)lw.size(); p.n_empty = (int)le.size();
     if ((e = plan_upload_list(ls, &p.list_single)) != hipSuccess) return e;
@@ -1190,13 +1307,14 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
 // nb: frames per block (0 = default); lean: 0 = one generic kernel over every tile (debug); lds_pad: dynamic LDS added to the
 // single-contributor gather kernel to cap it at 5 waves per SIMD (more resident gather waves thrash the L1);
 // xcd_map: 1 = an XCD owns whole batch chunks; staged: 1 = LDS-staged kernels for the tiles that have a staging plan;
-// one_launch: 1 = all tile classes of a step in one kernel (k_plan_all), 0 = one launch per class
+// one_launch: 2 = one kernel over all tiles in spatial order (k_plan_spatial, pair-staged schedule), 1 = one kernel, class
+// after class (k_plan_all), 0 = one launch per class
 // staged: 0 = gather classes only, 1 = sector-staged (LDS-DMA ring, round 1), 2 = pair-staged (bevw_pair.h, round 2)
 struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 2; int one_launch = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, int staged, bool one_launch)
+                                        bool sums, int staged, int one_launch)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1204,7 +1322,9 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         if (a.xcd_affine == 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
         return (unsigned)(a.ngroups * a.nchunks);
     };
-    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; };
+    auto set_list = [&](void *list, int n, int ncoop = 0) {
+        a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; a.ncoop = ncoop;
+    };
     if (balance || !lean) {
         // generic kernel over every tile (luminance round trip per tap, per-tile channel sums)
         set_list(nullptr, p.ntiles);
@@ -1223,44 +1343,59 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     void *l_double = staged == 2 ? p.list_rp_double : staged ? p.list_rs_double : p.list_double;
     const int n_single = staged == 2 ? p.n_rp_single : staged ? p.n_rs_single : p.n_single;
     const int n_double = staged == 2 ? p.n_rp_double : staged ? p.n_rs_double : p.n_double;
-    if (staged && one_launch) {
+    if (staged == 2 && one_launch == 2 && p.n_spatial) {
+        set_list(p.list_spatial, p.n_spatial);
+        const dim3 grid(grid_blocks());
+        if (blend && sums) hipLaunchKernelGGL((k_plan_spatial<LX, true, true>), grid, block, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_spatial<LX, true, false>), grid, block, 0, st, a);
+        else if (sums) hipLaunchKernelGGL((k_plan_spatial<LX, false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_plan_spatial<LX, false, false>), grid, block, 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (n_double) {   // the sparse two-contributor tiles
+            set_list(l_double, n_double);
+            const dim3 grid2(grid_blocks());
+            if (blend && sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, true>), grid2, block, 0, st, a);
+            else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, false>), grid2, block, 0, st, a);
+            else if (sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, true>), grid2, block, 0, st, a);
+            else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, false>), grid2, block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    } else if (staged && one_launch) {
         PlanAllArgs q;
         q.a = a;
-        void *lists[5] = {staged == 2 ? p.list_pr_single : p.list_st_single, staged == 2 ? p.list_pr_double : p.list_st_double,
-                          p.list_empty, l_single, l_double};
-        const int counts[5] = {staged == 2 ? p.n_pr_single : p.n_st_single, staged == 2 ? p.n_pr_double : p.n_st_double, p.n_empty,
-                               n_single, n_double};
-        // launch order: the classes whose blocks run longest first (gather, then staged, then the empty tiles), so that the
-        // short blocks fill the tail of the grid: +1-2 % over staged-first (profiles/r01_sweeps.log)
-        static const int order[5] = {4, 3, 1, 0, 2};
-        uint32_t at = 0;
-        for (int i = 0; i < 5; ++i) {
-            const int c = order[i];
-            q.kind[i] = c;
-            q.list[i] = static_cast<const uint32_t *>(lists[c]); q.nlist[i] = counts[c]; q.ngroups[i] = (counts[c] + 3) / 4;
-            q.start[i] = at;
-            if (counts[c] && !(staged == 2 && c == 4)) {
-                a.ngroups = q.ngroups[i];
-                const unsigned nblk = c == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
-                at += (nblk + 7u) & ~7u;
-            }
+        // launch order: the classes whose blocks run longest first (sparse tiles, then the staged classes, then the empty
+        // tiles), so that the short blocks fill the tail of the grid: +1-2 % over staged-first (profiles/r01_sweeps.log)
+        struct Cls { int kind; void *list; int n; int ncoop; };
+        std::vector<Cls> cls;
+        if (staged == 2) {
+            cls = {{8, p.list_pr[3], p.n_pr[3], p.n_pr_coop[3]}, {7, p.list_pr[2], p.n_pr[2], p.n_pr_coop[2]}, {3, l_single, n_single, 0},
+                   {10, p.list_pr[5], p.n_pr[5], p.n_pr_coop[5]}, {9, p.list_pr[4], p.n_pr[4], p.n_pr_coop[4]},
+                   {6, p.list_pr[1], p.n_pr[1], p.n_pr_coop[1]}, {5, p.list_pr[0], p.n_pr[0], p.n_pr_coop[0]}, {2, p.list_empty, p.n_empty, 0}};
+        } else {
+            cls = {{4, l_double, n_double, 0}, {3, l_single, n_single, 0}, {1, p.list_st_double, p.n_st_double, 0},
+                   {0, p.list_st_single, p.n_st_single, 0}, {2, p.list_empty, p.n_empty, 0}};
         }
-        q.start[5] = at;
+        uint32_t at = 0;
+        int np = 0;
+        for (const Cls &c : cls) {
+            if (!c.n) continue;
+            q.kind[np] = c.kind;
+            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = (c.n + 3) / 4; q.ncoop[np] = c.ncoop;
+            q.start[np] = at;
+            a.ngroups = q.ngroups[np];
+            const unsigned nblk = c.kind == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
+            at += (nblk + 7u) & ~7u;
+            ++np;
+        }
+        for (int i = np; i < kPlanAllMax; ++i) { q.kind[i] = -1; q.list[i] = nullptr; q.nlist[i] = 0; q.ngroups[i] = 1; q.ncoop[i] = 0; }
+        for (int i = np; i <= kPlanAllMax; ++i) q.start[i] = at;
+        q.n = np;
         if (at && staged == 2) {
             if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true, 2>), dim3(at), block, 0, st, q);
             else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false, 2>), dim3(at), block, 0, st, q);
             else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true, 2>), dim3(at), block, 0, st, q);
             else hipLaunchKernelGGL((k_plan_all<LX, false, false, 2>), dim3(at), block, 0, st, q);
             if ((e = hipGetLastError()) != hipSuccess) return e;
-            if (n_double) {   // the sparse two-contributor tiles (see k_plan_all)
-                set_list(l_double, n_double);
-                const dim3 grid(grid_blocks());
-                if (blend && sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, true>), grid, block, 0, st, a);
-                else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, false>), grid, block, 0, st, a);
-                else if (sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, true>), grid, block, 0, st, a);
-                else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, false>), grid, block, 0, st, a);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
-            }
         } else if (at) {
             if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true>), dim3(at), block, 0, st, q);
             else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false>), dim3(at), block, 0, st, q);
@@ -1268,18 +1403,32 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
             else hipLaunchKernelGGL((k_plan_all<LX, false, false>), dim3(at), block, 0, st, q);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
+        if (staged == 2 && n_double) {   // the sparse two-contributor tiles (see k_plan_all)
+            set_list(l_double, n_double);
+            const dim3 grid(grid_blocks());
+            if (blend && sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, true>), grid, block, 0, st, a);
+            else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, false>), grid, block, 0, st, a);
+            else if (sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, false>), grid, block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
     } else {
-#define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM)                                                                       \
+#define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM, ...)                                                                  \
     do {                                                                                                            \
         const dim3 grid(grid_blocks());                                                                             \
-        if (blend && sums) hipLaunchKernelGGL((KERNEL<LX, NS, true, true>), grid, block, SHMEM, st, a);             \
-        else if (blend) hipLaunchKernelGGL((KERNEL<LX, NS, true, false>), grid, block, SHMEM, st, a);               \
-        else if (sums) hipLaunchKernelGGL((KERNEL<LX, NS, false, true>), grid, block, SHMEM, st, a);                \
-        else hipLaunchKernelGGL((KERNEL<LX, NS, false, false>), grid, block, SHMEM, st, a);                         \
+        if (blend && sums) hipLaunchKernelGGL((KERNEL<LX, NS, true, true __VA_ARGS__>), grid, block, SHMEM, st, a);  \
+        else if (blend) hipLaunchKernelGGL((KERNEL<LX, NS, true, false __VA_ARGS__>), grid, block, SHMEM, st, a);    \
+        else if (sums) hipLaunchKernelGGL((KERNEL<LX, NS, false, true __VA_ARGS__>), grid, block, SHMEM, st, a);     \
+        else hipLaunchKernelGGL((KERNEL<LX, NS, false, false __VA_ARGS__>), grid, block, SHMEM, st, a);              \
         if ((e = hipGetLastError()) != hipSuccess) return e;                                                        \
     } while (0)
-    if (staged == 2 && p.n_pr_single) { set_list(p.list_pr_single, p.n_pr_single); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0); }
-    if (staged == 2 && p.n_pr_double) { set_list(p.list_pr_double, p.n_pr_double); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0); }
+#define BEVW_COMMA ,
+    if (staged == 2 && p.n_pr[0]) { set_list(p.list_pr[0], p.n_pr[0], p.n_pr_coop[0]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
+    if (staged == 2 && p.n_pr[1]) { set_list(p.list_pr[1], p.n_pr[1], p.n_pr_coop[1]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
+    if (staged == 2 && p.n_pr[2]) { set_list(p.list_pr[2], p.n_pr[2], p.n_pr_coop[2]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 4); }
+    if (staged == 2 && p.n_pr[3]) { set_list(p.list_pr[3], p.n_pr[3], p.n_pr_coop[3]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 4 BEVW_COMMA 2); }
+    if (staged == 2 && p.n_pr[4]) { set_list(p.list_pr[4], p.n_pr[4], p.n_pr_coop[4]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
+    if (staged == 2 && p.n_pr[5]) { set_list(p.list_pr[5], p.n_pr[5], p.n_pr_coop[5]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
     if (staged == 1 && p.n_st_single) { set_list(p.list_st_single, p.n_st_single); BEVW_LAUNCH_CLASS(k_plan_staged, 1, 0); }
     if (staged == 1 && p.n_st_double) { set_list(p.list_st_double, p.n_st_double); BEVW_LAUNCH_CLASS(k_plan_staged, 2, 0); }
     if (p.n_empty) {
@@ -1290,6 +1439,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     if (n_single) { set_list(l_single, n_single); BEVW_LAUNCH_CLASS(k_plan_lean, 1, lds_pad); }
     if (n_double) { set_list(l_double, n_double); BEVW_LAUNCH_CLASS(k_plan_lean, 2, 0); }
 #undef BEVW_LAUNCH_CLASS
+#undef BEVW_COMMA
     }
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
@@ -1316,7 +1466,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
     a.ncams = p.ncams;
-    a.tile_list = nullptr; a.nlist = p.ntiles;
+    a.tile_list = nullptr; a.nlist = p.ntiles; a.ncoop = 0;
     a.plan_st = static_cast<const uint2 *>(p.entries_st);
     a.dma = static_cast<const uint32_t *>(p.dma);
     a.plan_pr = static_cast<const uint2 *>(p.entries_pr);
@@ -1347,9 +1497,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {
