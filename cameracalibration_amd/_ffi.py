@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so
 ABI_VERSION = 1
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
+COMPAT_FILLPOLY, COMPAT_ADDWEIGHTED = 0, 1   # bevw_set_compat keys (include/bevwarp.h)
 
 
 class BevwError(Exception):
@@ -33,6 +34,8 @@ _vp, _i, _sz, _d = C.c_void_p, C.c_int, C.c_size_t, C.c_double
 _pvp = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "bevw_abi_version": (_i, []),
+    "bevw_set_compat": (_i, [_i, _i]),
+    "bevw_get_compat": (_i, [_i]),
     "bevw_device_count": (_i, []),
     "bevw_last_error": (C.c_char_p, []),
     "bevw_device_name": (_i, [_i, C.c_char_p, _sz]),

@@ -102,6 +102,7 @@ __global__ void k_bev_lut(Mat3 Minv, const int16_t *__restrict__ und1, const uin
 // = Bresenham boundary of every edge  UNION  even-odd scanline spans between XY_SHIFT=16 fixed-point edges.
 struct PolyEdge { int y0, y1; long long x, dx; };
 struct PolyJob {
+    int ceil_left;       // OpenCV < 4.5.2 span rule: left end rounded up (BEVW_COMPAT_FILLPOLY 0)
     int npts;
     int pts[8][2];       // integer vertices (after .astype(np.int32))
     int nedges;
@@ -192,7 +193,7 @@ __global__ void k_poly_fill(PolyJob job, uint8_t *__restrict__ img, int w, int h
         }
     }
     for (int i = 0; i + 1 < n; i += 2) {
-        int xa = (int)(xs[i] >> 16), xb = (int)(xs[i + 1] >> 16);
+        int xa = (int)((xs[i] + (job.ceil_left ? 65535 : 0)) >> 16), xb = (int)(xs[i + 1] >> 16);
         if (xa < w && xb >= 0) {
             if (xa < 0) xa = 0;
             if (xb >= w) xb = w - 1;
@@ -442,8 +443,13 @@ __global__ void k_channel_sums(const uint8_t *__restrict__ img, size_t npx, unsi
 // B,G,R means in fp64 from the integer sums; K = (R + G + B) / 3; gain_c = K / mean_c;
 // cv2.addWeighted(ch, gain, 0, 0, 0, ch) = sat_u8(cvRound(double(ch) * gain + 0*0 + 0)).
 // grid = (blocks, batch); in place when in == out.
+// f32: cv2.addWeighted evaluated in CV_32F instead of CV_64F (BEVW_COMPAT_ADDWEIGHTED 0)
+__device__ __forceinline__ int gain_px(int v, double gain, int f32)
+{
+    return f32 ? sat_u8(rne_f((float)v * (float)gain + 0.0f * 0.0f + 0.0f)) : sat_u8(rne_d((double)v * gain + 0.0 * 0.0 + 0.0));
+}
 __global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
-                       const uint8_t *__restrict__ car, uint8_t *out)
+                       const uint8_t *__restrict__ car, uint8_t *out, int f32 = 0)
 {
     const double n = (double)npx;
     const double B = (double)chsums[blockIdx.y * 3 + 0] / n, G = (double)chsums[blockIdx.y * 3 + 1] / n,
@@ -453,7 +459,7 @@ __global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *
     const size_t base = (size_t)blockIdx.y * npx * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < npx * 3; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % 3);
-        int v = sat_u8(rne_d((double)in[base + i] * gain[c] + 0.0 * 0.0 + 0.0));
+        int v = gain_px((int)in[base + i], gain[c], f32);
         if (car != nullptr) v = min(255, v + car[i]);
         out[base + i] = (uint8_t)v;
     }
@@ -482,7 +488,7 @@ __global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__r
 // Needs npx % 4 == 0 and 4-byte aligned images.  grid = (blocks, batch), block = 256; in place when in == out.
 __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
                                                    const uint8_t *__restrict__ car, uint8_t *out, uint32_t blocks_per_frame,
-                                                   uint32_t nframes)
+                                                   uint32_t nframes, int f32 = 0)
 {
     __shared__ uint8_t lut[3][256];
     uint32_t frame, blk;
@@ -495,7 +501,7 @@ __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx,
         const double gain[3] = {K / B, K / G, K / R};
         for (int i = threadIdx.x; i < 768; i += blockDim.x) {
             const int c = i >> 8, v = i & 255;
-            lut[c][v] = (uint8_t)sat_u8(rne_d((double)v * gain[c] + 0.0 * 0.0 + 0.0));
+            lut[c][v] = (uint8_t)gain_px(v, gain[c], f32);
         }
     }
     __syncthreads();

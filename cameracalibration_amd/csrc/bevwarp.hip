@@ -194,11 +194,16 @@ static bool host_clip_segment(int w, int h, long long &x1, long long &y1, long l
 
 // Edge table of cv2.fillPoly for one polygon (XY_SHIFT = 16): slopes come from the image-clipped end points,
 // the y extent from the original ones.  Only scalars are produced here; pixels are written by k_poly_*.
+// OpenCV-version-sensitive choices (include/bevwarp.h: bevw_set_compat); process-wide, read when tables are built / gains applied
+static int g_compat[2] = {1, 1};
+
 static PolyJob make_poly_job(const int (*pts)[2], int npts, int w, int h)
 {
     PolyJob job;
     memset(&job, 0, sizeof job);
     job.npts = npts;
+    const bool modern = g_compat[BEVW_COMPAT_FILLPOLY] != 0;   // OpenCV >= 4.5.2 edge collection
+    job.ceil_left = modern ? 0 : 1;
     for (int i = 0; i < npts; ++i) { job.pts[i][0] = pts[i][0]; job.pts[i][1] = pts[i][1]; }
     const long long HALF = 1 << 15;
     long long p0x = (long long)pts[npts - 1][0] << 16, p0y = pts[npts - 1][1];
@@ -206,7 +211,9 @@ static PolyJob make_poly_job(const int (*pts)[2], int npts, int w, int h)
         long long p1x = (long long)pts[i][0] << 16, p1y = pts[i][1];
         long long c0x = p0x, c0y = p0y, c1x = p1x, c1y = p1y;
         long long t0x = (p0x + HALF) >> 16, t0y = p0y, t1x = (p1x + HALF) >> 16, t1y = p1y;
-        if ((unsigned long long)t0x >= (unsigned long long)w || (unsigned long long)t1x >= (unsigned long long)w ||
+        if (!modern) {
+            // before 4.5.2 the edge runs between the raw vertices, without the half-pixel offset
+        } else if ((unsigned long long)t0x >= (unsigned long long)w || (unsigned long long)t1x >= (unsigned long long)w ||
             (unsigned long long)t0y >= (unsigned long long)h || (unsigned long long)t1y >= (unsigned long long)h) {
             host_clip_segment(w, h, t0x, t0y, t1x, t1y);
             if (t0y != t1y) {
@@ -417,6 +424,20 @@ static int remap_launch(hipStream_t st, const uint8_t *d_src, int sw, int sh, co
 extern "C" {
 
 int bevw_abi_version(void) { return BEVW_ABI_VERSION; }
+
+int bevw_set_compat(int key, int value)
+{
+    if (key < 0 || key >= 2) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
+    if (value != 0 && value != 1) return fail(BEVW_E_INVALID, "compatibility value must be 0 or 1");
+    g_compat[key] = value;
+    return BEVW_OK;
+}
+
+int bevw_get_compat(int key)
+{
+    if (key < 0 || key >= 2) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
+    return g_compat[key];
+}
 
 const char *bevw_last_error(void) { return g_err; }
 
@@ -827,10 +848,11 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
             if (npx % 4 == 0 && aligned4)
                 hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
                                    h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3, 32u,
-                                   (uint32_t)nb);
+                                   (uint32_t)nb, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
             else
                 hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
-                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3);
+                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3,
+                                   g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
         }
         BEVW_TRY(launch_check("k_gain"));
     }
@@ -1329,8 +1351,9 @@ int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_
             hipLaunchKernelGGL(k_channel_sums, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs);
             if (npx % 4 == 0 && dwords)
                 hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o,
-                                   32u, (uint32_t)nb);
-            else hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o);
+                                   32u, (uint32_t)nb, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+            else hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o,
+                                    g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
         }
         BEVW_TRY(launch_check("k_channel_sums/k_gain"));
     }
@@ -1408,7 +1431,7 @@ int bevw_color_balance(int device, const uint8_t *images, int batch, int width, 
                                cs.as<unsigned long long>() + (size_t)b0 * 3);
             hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, 0, in.as<uint8_t>() + (size_t)b0 * npx * 3, npx,
                                cs.as<unsigned long long>() + (size_t)b0 * 3, (const uint8_t *)nullptr,
-                               in.as<uint8_t>() + (size_t)b0 * npx * 3);
+                               in.as<uint8_t>() + (size_t)b0 * npx * 3, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
         }
         s = launch_check("k_channel_sums/k_gain");
     }

@@ -65,6 +65,19 @@ typedef struct bevw_remapper bevw_remapper; /* one fixed-point remap table on th
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
 int bevw_abi_version(void);
+
+/* OpenCV-version-sensitive arithmetic behind the reference's cv2 calls.  The reference pins no OpenCV version
+ * ("opencv(>=3.4.2)", README.md:14); two of the primitives it calls changed their results across releases, so the choice
+ * is a switch (process-wide; set before bevw_build / the run it should affect) instead of a constant:
+ *   BEVW_COMPAT_FILLPOLY    cv2.fillPoly (surroundBEV.py:159,234): 1 = OpenCV >= 4.5.2 edge collection (default),
+ *                           0 = OpenCV 2.4 .. 4.5.1 (edges between the raw vertices, left span end rounded up)
+ *   BEVW_COMPAT_ADDWEIGHTED cv2.addWeighted(ch, k, 0, 0, 0, ch) (surroundBEV.py:52-54): 1 = evaluated in CV_64F (default),
+ *                           0 = in CV_32F
+ * tests/golden/README.md: how a golden file from a real cv2 decides them. */
+#define BEVW_COMPAT_FILLPOLY 0
+#define BEVW_COMPAT_ADDWEIGHTED 1
+int bevw_set_compat(int key, int value);   /* 0 = OK */
+int bevw_get_compat(int key);              /* current value, < 0 on an unknown key */
 int bevw_device_count(void);               /* 0 when no GPU is visible (never negative) */
 const char *bevw_last_error(void);
 int bevw_device_name(int device, char *buf, size_t buflen);

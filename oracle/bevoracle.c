@@ -382,6 +382,15 @@ static void draw_line8(uint8_t *img, int w, int h, int64_t x1, int64_t y1, int64
     }
 }
 
+/* OpenCV-version-sensitive choices of this restatement, selectable so that a golden file from a real cv2 can flip them
+ * (tests/golden/README.md).  Keys as in include/bevwarp.h (BEVW_COMPAT_*):
+ *   0 fillPoly edge rule   : 1 = OpenCV >= 4.5.2 (edges from the clipped end points, x + 1/2 pixel, both span ends floored),
+ *                            0 = OpenCV 2.4 .. 4.5.1 (edges from the raw vertices, left span end rounded up, right end floored)
+ *   1 addWeighted work type: 1 = CV_64F (arithm_op picks the scalar's depth), 0 = CV_32F (float(ch) * float(k)) */
+static int g_variant[2] = {1, 1};
+ORC_API void orc_set_variant(int key, int value) { if (key >= 0 && key < 2) g_variant[key] = value; }
+ORC_API int orc_get_variant(int key) { return (key >= 0 && key < 2) ? g_variant[key] : -1; }
+
 typedef struct { int y0, y1; int64_t x, dx; } orc_edge;
 
 static int edge_less(const orc_edge *a, const orc_edge *b)
@@ -405,7 +414,9 @@ ORC_API void orc_fill_poly(uint8_t *img, int w, int h, const int32_t *pts, int n
         int64_t c0x = p0x, c0y = p0y, c1x = p1x, c1y = p1y;
         int64_t t0x = (p0x + XY_HALF) >> XY_SHIFT, t0y = p0y, t1x = (p1x + XY_HALF) >> XY_SHIFT, t1y = p1y;
         draw_line8(img, w, h, t0x, t0y, t1x, t1y, color);
-        if ((uint64_t)t0x >= (uint64_t)w || (uint64_t)t1x >= (uint64_t)w || (uint64_t)t0y >= (uint64_t)h ||
+        if (!g_variant[0]) {
+            /* CollectPolyEdges before 4.5.2: the edge runs between the raw vertices, no half-pixel offset */
+        } else if ((uint64_t)t0x >= (uint64_t)w || (uint64_t)t1x >= (uint64_t)w || (uint64_t)t0y >= (uint64_t)h ||
             (uint64_t)t1y >= (uint64_t)h) {
             clip_segment(w, h, &t0x, &t0y, &t1x, &t1y);
             if (t0y != t1y) {
@@ -460,8 +471,9 @@ ORC_API void orc_fill_poly(uint8_t *img, int w, int h, const int32_t *pts, int n
             orc_edge *a = &edges[merged[i]], *b = &edges[merged[i + 1]];
             if (y >= 0) {
                 int x1, x2;
-                if (a->x > b->x) { x1 = (int)(b->x >> XY_SHIFT); x2 = (int)(a->x >> XY_SHIFT); }
-                else             { x1 = (int)(a->x >> XY_SHIFT); x2 = (int)(b->x >> XY_SHIFT); }
+                const int64_t up = g_variant[0] ? 0 : ((int64_t)1 << XY_SHIFT) - 1;   /* before 4.5.2: left end rounded up */
+                if (a->x > b->x) { x1 = (int)((b->x + up) >> XY_SHIFT); x2 = (int)(a->x >> XY_SHIFT); }
+                else             { x1 = (int)((a->x + up) >> XY_SHIFT); x2 = (int)(b->x >> XY_SHIFT); }
                 if (x1 < w && x2 >= 0) {
                     if (x1 < 0) x1 = 0;
                     if (x2 >= w) x2 = w - 1;
@@ -669,7 +681,9 @@ ORC_API void orc_gain(uint8_t *img, size_t npx, const double gains[3])
 {
 #pragma omp parallel for schedule(static)
     for (size_t i = 0; i < npx; ++i)
-        for (int c = 0; c < 3; ++c) img[i * 3 + c] = sat_u8(rne_d((double)img[i * 3 + c] * gains[c] + 0.0 * 0.0 + 0.0));
+        for (int c = 0; c < 3; ++c)
+            img[i * 3 + c] = g_variant[1] ? sat_u8(rne_d((double)img[i * 3 + c] * gains[c] + 0.0 * 0.0 + 0.0))
+                                          : sat_u8(rne_f((float)img[i * 3 + c] * (float)gains[c] + 0.0f * 0.0f + 0.0f));
 }
 
 /* ------------------------------------------------------------------------------------------------ */

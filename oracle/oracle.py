@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
             "orc_add_sat": (None, [vp, vp, sz, vp]),
             "orc_channel_sums": (None, [vp, sz, vp]),
             "orc_gain": (None, [vp, sz, vp]),
+            "orc_set_variant": (None, [i32, i32]),
+            "orc_get_variant": (i32, [i32]),
             "orc_translate_u8c3": (None, [vp, i32, i32, i32, i32, vp]),
             "orc_resize_dsize": (None, [i32, i32, C.c_double, C.c_double, vp, vp]),
             "orc_resize_linear_u8c3": (None, [vp, i32, i32, C.c_double, C.c_double, vp, i32, i32]),
@@ -105,6 +107,20 @@ def _p(a: np.ndarray) -> int:
 
 def _c(a, dtype) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=dtype)
+
+
+# OpenCV-version-sensitive choices (bevoracle.c: g_variant; same keys as BEVW_COMPAT_* of include/bevwarp.h)
+VARIANT_FILLPOLY, VARIANT_ADDWEIGHTED = 0, 1
+VARIANT_NAMES = {VARIANT_FILLPOLY: {1: "fillPoly >= 4.5.2", 0: "fillPoly < 4.5.2"},
+                 VARIANT_ADDWEIGHTED: {1: "addWeighted in CV_64F", 0: "addWeighted in CV_32F"}}
+
+
+def set_variant(key: int, value: int) -> None:
+    lib().orc_set_variant(int(key), int(value))
+
+
+def get_variant(key: int) -> int:
+    return int(lib().orc_get_variant(int(key)))
 
 
 def set_threads(n: int) -> None:

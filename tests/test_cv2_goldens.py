@@ -31,6 +31,34 @@ def check(goldens, name, arr):
                     (name, goldens["cv2_version"], int(d.max()), int(np.count_nonzero(d)), d.size))
 
 
+@pytest.fixture(scope="module", autouse=True)
+def variants_decided_by_the_goldens(goldens, oracle, repo_rig):
+    """The golden file DECIDES the OpenCV-version-sensitive switches (oracle.set_variant / bevw_set_compat): the variant whose
+    direct masks / colour balance reproduce the cv2 outputs is selected for the rest of this module and printed, so that the
+    defaults in oracle/bevoracle.c and csrc/bevwarp.hip can be flipped to match the OpenCV that produced the file."""
+    chosen = {}
+    geo = (1000, 1000, 250, 400)
+    for v in (1, 0):
+        oracle.set_variant(oracle.VARIANT_FILLPOLY, v)
+        ok = all(str(goldens["mask_direct_%s__sha" % n]) == GC.digest(oracle.direct_mask(n, *geo)) for n in GC.CAMS
+                 if "mask_direct_%s__sha" % n in goldens.files)
+        if ok:
+            chosen["fillPoly"] = v
+            break
+    for v in (1, 0):
+        oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, v)
+        if "color_balance_back__sha" in goldens.files and \
+                str(goldens["color_balance_back__sha"]) == GC.digest(oracle.color_balance(repo_rig.image("back"))):
+            chosen["addWeighted"] = v
+            break
+    oracle.set_variant(oracle.VARIANT_FILLPOLY, chosen.get("fillPoly", 1))
+    oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, chosen.get("addWeighted", 1))
+    print("cv2 %s selects variants %s (1 = the shipped default)" % (goldens["cv2_version"], chosen))
+    yield chosen
+    oracle.set_variant(oracle.VARIANT_FILLPOLY, 1)
+    oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, 1)
+
+
 @pytest.fixture(scope="module")
 def ref_default(oracle, repo_rig):
     return {b: oracle.RefBevGenerator(repo_rig.rig, dict(oracle.DEFAULT_CFG), blend=b, balance=False) for b in (False, True)}

@@ -105,6 +105,34 @@ def test_direct_masks_odd_sizes(ffi, SB, oracle, geo):
         assert np.array_equal(bev.masks[i].mask, oracle.direct_mask(n, *geo)), n
 
 
+@pytest.mark.parametrize("fillpoly,addweighted", [(0, 1), (1, 0), (0, 0)])
+def test_compat_variants_bit_exact(ffi, SB, oracle, fillpoly, addweighted):
+    """The OpenCV-version switches (bevw_set_compat / oracle.set_variant, tests/golden/README.md) move engine and oracle together:
+    masks of the sample geometry and a blend + balance frame set stay bit-exact for every combination."""
+    L = ffi.lib()
+    try:
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_FILLPOLY, fillpoly))
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_ADDWEIGHTED, addweighted))
+        oracle.set_variant(oracle.VARIANT_FILLPOLY, fillpoly)
+        oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, addweighted)
+        assert L.bevw_get_compat(ffi.COMPAT_FILLPOLY) == fillpoly and L.bevw_get_compat(ffi.COMPAT_ADDWEIGHTED) == addweighted
+        for blend in (False, True):
+            bev, ref = make_pair(SB, oracle, W.repo_rig(), W.CONFIG_R, blend=blend, balance=False)
+            for i, n in enumerate(CAMS):
+                assert np.array_equal(bev.masks[i].mask, ref.masks[i]), f"{n} mask, blend={blend}"
+        rig = small_rig()
+        bev, ref = make_pair(SB, oracle, rig, SMALL_CFG, blend=True, balance=True)
+        frames = W.synthetic_frames(3, SMALL_CFG["FRAME_WIDTH"], SMALL_CFG["FRAME_HEIGHT"], kind="random")
+        got = bev.batch(frames)
+        for b in range(frames.shape[0]):
+            assert maxdiff(got[b], ref(*frames[b])) == 0
+    finally:
+        L.bevw_set_compat(ffi.COMPAT_FILLPOLY, 1)
+        L.bevw_set_compat(ffi.COMPAT_ADDWEIGHTED, 1)
+        oracle.set_variant(oracle.VARIANT_FILLPOLY, 1)
+        oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, 1)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BevGenerator.__call__ on the reference's own sample data (config 1)
 # ---------------------------------------------------------------------------------------------------------------
