@@ -128,14 +128,17 @@ def aggregate(world: int, batch: int, steps: int, wall: float, ev_ms: float, alg
 
 
 def measured_traffic(workload: str, batch: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json), or None."""
+    """(HBM bytes per launch, where the figure comes from) from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected with profiles/pmc_calibration.json), or
+    (None, None).  It is a STATIC figure of the round it was collected in, not a measurement of this run."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(workload)
         if rec and rec.get("units_per_launch") == batch:
-            return rec["fetch_bytes"] + rec["write_bytes"]
+            return rec["fetch_bytes"] + rec["write_bytes"], "profiles/hbm_traffic.json (static, rocprofv3 --pmc passes of round %s%s)" % (
+                rec.get("round", 1), ", counters calibrated on known byte counts" if rec.get("corrected") else "")
     except (OSError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def upload_replicated(buf, unique: np.ndarray, batch: int):
@@ -319,6 +322,7 @@ def main():
     wall = d.max(wall)
     ev_ms = d.max(ev_ms)
 
+    traffic, traffic_source = measured_traffic(a.workload, batch)
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
@@ -331,7 +335,7 @@ def main():
                                      else "frames across ranks, no data-path collective"), "device": _ffi.device_name(dev),
                         "unique_frame_sets": int(a.unique_sets)}, **extra),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(a.workload, batch),
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": launch_ms, "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
         "cpu_baseline": cpu,
     }

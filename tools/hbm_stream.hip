@@ -103,6 +103,41 @@ __global__ void __launch_bounds__(256) k_gathermix(const uint4 *__restrict__ src
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// The two access shapes of the pair-staged stitch kernels, each over DISTINCT bytes so that the byte count is known:
+//   k_group_loads : every lane loads 16 bytes from a 4-byte aligned address, lanes 12 bytes apart (texel groups of one source
+//                   row, cameracalibration_amd/csrc/bevw_pair.h); a wave covers one run of 64 * 12 + 4 = 772 bytes, runs are
+//                   spaced `pitch` bytes apart (a row pitch: 3840).  Unique bytes per wave-load = 772.
+//   k_tile_store  : every lane stores 12 bytes, a wave = one 32 x 8 pixel tile = 8 row segments of 96 bytes of a 1080-pixel-wide
+//                   image (row pitch 3240), 4 x-neighbouring tiles per block, `nb` images per wave.  Bytes per wave-store = 768.
+struct __attribute__((packed, aligned(4))) AU4 { uint32_t x, y, z, w; };
+__global__ void __launch_bounds__(256) k_group_loads(const uint8_t *__restrict__ src, size_t nruns, uint32_t pitch, uint32_t *__restrict__ sink)
+{
+    uint32_t acc = 0;
+    const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (size_t)gridDim.x * 4;
+    for (size_t r = wave; r < nruns; r += nwaves) {
+        const AU4 v = *reinterpret_cast<const AU4 *>(src + r * pitch + (threadIdx.x & 63) * 12);
+        acc += v.x ^ v.w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+__global__ void __launch_bounds__(256) k_tile_store(uint8_t *__restrict__ out, int tiles_x, int ntiles, int nb, size_t img_bytes, int bw, int bh)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t ng = (uint32_t)((ntiles + 3) / 4), xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const uint32_t chunk = xcd + 8u * (k / ng), group = k % ng;    // the stitch kernels' block map: an XCD owns whole chunks
+    const int tile = (int)group * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = (tx * 8 + lane % 8) * 4, y = ty * 8 + lane / 8;
+    if (x0 >= bw || y >= bh) return;
+    uint32_t v = tile * 64 + lane;
+    for (int b = 0; b < nb; ++b) {
+        uint32_t *op = reinterpret_cast<uint32_t *>(out + ((size_t)chunk * nb + b) * img_bytes + ((size_t)y * bw + x0) * 3);
+        op[0] = v; op[1] = v + 1; op[2] = v + 2;
+        v += 7;
+    }
+}
+
 static bool g_calib = false;
 template <typename F> static float timeit(F launch)
 {
@@ -155,6 +190,19 @@ int main(int argc, char **argv)
           report("gather " #R " x " #CH " B random : " #W " writes", ms, (double)nit * G * R * 4096, (double)nit * G * W * 4096); }
         GMIX(9, 0, 64); GMIX(9, 0, 128); GMIX(9, 0, 256);
         GMIX(9, 16, 64); GMIX(9, 16, 128); if (!g_calib) { GMIX(9, 16, 256); GMIX(9, 16, 1024); }
+    }
+    {
+        // group loads: 2 GB / 3840-byte pitch = 559 k runs of 772 unique bytes
+        const uint32_t pitch = 3840;
+        const size_t nruns = bytes / pitch - 1;
+        ms = timeit([&] { hipLaunchKernelGGL(k_group_loads, dim3(8192), dim3(256), 0, 0, (const uint8_t *)a, nruns, pitch, sink); });
+        report("group loads 16 B / lane, 12 B apart", ms, (double)nruns * 772, 0);
+        // tile stores: 256 images of 1080 x 1080 x 3 B (896 MB), 8 images per wave
+        const int bw = 1080, bh = 1080, tiles_x = 34, ntiles = 34 * 135, nb = 8, nchunks = 32;
+        const size_t img = (size_t)bw * bh * 3;
+        const unsigned grid = (unsigned)((ntiles + 3) / 4) * 8u * (unsigned)((nchunks + 7) / 8);
+        ms = timeit([&] { hipLaunchKernelGGL(k_tile_store, dim3(grid), dim3(256), 0, 0, (uint8_t *)b, tiles_x, ntiles, nb, img, bw, bh); });
+        report("tile stores 12 B / lane, 8 x 96 B", ms, 0, (double)img * nb * nchunks);
     }
     return 0;
 }
