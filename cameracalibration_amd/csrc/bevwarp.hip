@@ -814,6 +814,9 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
     return launch_check("k_vsum/k_lum_delta");
 }
 
+// (Round 2 measured, then removed: walking a balance batch in sub-batches of 16 / 32 / 64 / 128 frame sets so that every producer's
+// output is still in the 256 MB Infinity Cache when its consumer runs is SLOWER -- 3.02 / 2.63 / 2.42 / 2.36 ms against 2.29 ms for
+// the whole 256-set batch: the small grids cost more than the cache returns.  profiles/r02/sweeps.log)
 static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
 {
     const bevw_config &c = h->cfg;
