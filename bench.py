@@ -232,6 +232,7 @@ def main():
         for k, v in cfg.items():
             setattr(ns, k, v)
         t_build = time.perf_counter()
+        # the exchange is libbevwarp's native RCCL layer (csrc/bevw_comm.h); torch.distributed here is only the bench's barrier
         gen = CS.CameraShardedBev(w["blend"], w["balance"], rig=rig, rank=d.rank, world_size=d.world, device=dev)
         t_build = time.perf_counter() - t_build
         fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
@@ -254,7 +255,7 @@ def main():
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"], "schedule": "tile_plan",
                  "table_build_s": round(t_build, 3), "cameras_per_rank": len(gen.cams), "camera_groups": units_world,
                  "part_boxes": [list(b) for b in gen.boxes],
-                 "transport": "single rank" if d.world == 1 else ("rccl send/recv" if gen.transport.device_tensors else "host staged")}
+                 "transport": "single rank" if d.world == 1 else "rccl (native: ncclAllGather + grouped ncclSend/ncclRecv on the engine stream)"}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     elif w["kind"] == "bev":

@@ -15,10 +15,13 @@ With balance=True there is one more (tiny) exchange before the warp: the per-fra
 (luminance_balance needs the mean over all four, surroundBEV.py:60-66) are all-gathered inside the group; the white
 balance (color_balance, :321-322) and the car run on the stitch rank after the add.
 
-``torch.distributed`` is the transport (backend "nccl" = RCCL over xGMI: device buffers are torch tensors handed to the
-library by pointer; any other backend, e.g. "gloo": host-staged numpy).  The compute is libbevwarp only.
-Import torch BEFORE the first libbevwarp call in a process that uses both (bench.py and the test workers do): the
-wheel carries its own HIP runtime, and the first one loaded must serve both.
+Transport.  The data plane is RCCL over xGMI, called NATIVELY by libbevwarp (``bevw_comm_*``, ``bevw_shard_allgather_vsums``,
+``bevw_shard_gather_parts``: csrc/bevw_comm.h) on the engine's own HIP stream -- no PyTorch anywhere in this package, no host
+synchronisation between the rank-local stitch, the exchange and the combine.  Only the 128-byte RCCL unique id and the mask
+boxes (16 bytes per rank, once) travel out of band, over a plain TCP socket (``SocketGroup``; MASTER_ADDR / MASTER_PORT of the
+launcher).  A ``transport`` object with ``all_gather(array)`` / ``gather_parts(part, shapes, root)`` on host arrays can be
+injected instead: that is how the CPU tests stand in for RCCL (tests/_shard_common.py: gloo) -- test infrastructure, not a
+product path.
 """
 from __future__ import annotations
 
@@ -185,82 +188,139 @@ class HipShardEngine:
             pass
 
 
-class _Transport:
-    """The two exchanges of the camera-per-GPU mode inside one camera group, on numpy arrays.  Point-to-point
-    send/recv for the parts (boxes differ in size, and on xGMI every peer -> root transfer rides its own link)."""
+class SocketGroup:
+    """Out-of-band control channel of one camera group (a star over TCP, group rank 0 is the hub): carries the RCCL unique
+    id and the mask boxes once, at construction.  Plain sockets -- the data plane is RCCL."""
 
-    def __init__(self, rank, ranks):
-        self.rank, self.ranks = rank, list(ranks)
-        self.pg = None
-        if len(self.ranks) > 1:
-            import torch.distributed as dist
-            world = dist.get_world_size()
-            # every rank creates every group, in the same order (torch.distributed requirement)
-            ngroups = len({g for g, _ in camera_assignment(world)})
-            for g in range(ngroups):
-                rs = group_ranks(world, g)
-                pg = dist.new_group(rs)
-                if rs == self.ranks:
-                    self.pg = pg
-            self.device_tensors = dist.get_backend() == "nccl"
+    def __init__(self, rank: int, world: int, addr: str, port: int, timeout: float = 120.0):
+        import socket
+        import time
 
-    def _tensor(self, a: np.ndarray):
-        import torch
-        t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
-        return t.cuda() if self.device_tensors else t
+        self.rank, self.world = int(rank), int(world)
+        self.peers = []
+        if self.world == 1:
+            return
+        if self.rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(self.world)
+            srv.settimeout(timeout)
+            got = {}
+            while len(got) < self.world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                r = int.from_bytes(self._recv(c, 4), "little")
+                got[r] = c
+            srv.close()
+            self.peers = [got[r] for r in range(1, self.world)]
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=timeout)
+                    break
+                except OSError:
+                    if time.time() - t0 > timeout:
+                        raise
+                    time.sleep(0.05)
+            c.settimeout(timeout)
+            c.sendall(self.rank.to_bytes(4, "little"))
+            self.peers = [c]
 
-    def all_gather(self, a: np.ndarray):
-        """-> list of every group member's array (same shape / dtype everywhere), in group order."""
-        if len(self.ranks) == 1:
-            return [a]
-        import torch
-        import torch.distributed as dist
-        mine = self._tensor(a)
-        outs = [torch.empty_like(mine) for _ in self.ranks]
-        dist.all_gather(outs, mine, group=self.pg)
-        return [o.cpu().numpy().view(a.dtype).reshape(a.shape) for o in outs]
+    @staticmethod
+    def _recv(c, n):
+        buf = b""
+        while len(buf) < n:
+            chunk = c.recv(n - len(buf))
+            if not chunk:
+                raise Exception("control channel closed")
+            buf += chunk
+        return buf
 
-    def gather_parts(self, part: np.ndarray, shapes, root: int):
-        """-> on `root`: list of the parts in group order; elsewhere None."""
-        if len(self.ranks) == 1:
-            return [part]
-        import torch
-        import torch.distributed as dist
-        if self.rank != root:
-            dist.send(self._tensor(part), dst=root)
-            return None
-        bufs, reqs = [], []
-        for r, shp in zip(self.ranks, shapes):
-            if r == root:
-                bufs.append(None)
-                continue
-            t = torch.empty(int(np.prod(shp)), dtype=torch.uint8, device="cuda" if self.device_tensors else "cpu")
-            bufs.append(t)
-            reqs.append(dist.irecv(t, src=r))
-        for q in reqs:
-            q.wait()
-        return [part if t is None else t.cpu().numpy().reshape(shp) for t, shp in zip(bufs, shapes)]
+    def broadcast(self, payload, nbytes: int) -> bytes:
+        """bytes of group rank 0 -> every rank."""
+        if self.world == 1:
+            return bytes(payload)
+        if self.rank == 0:
+            for c in self.peers:
+                c.sendall(bytes(payload))
+            return bytes(payload)
+        return self._recv(self.peers[0], nbytes)
+
+    def all_gather(self, payload: bytes):
+        """-> [bytes of rank 0, rank 1, ...] on every rank (equal sizes)."""
+        if self.world == 1:
+            return [bytes(payload)]
+        n = len(payload)
+        if self.rank == 0:
+            parts = [bytes(payload)] + [self._recv(c, n) for c in self.peers]
+            blob = b"".join(parts)
+            for c in self.peers:
+                c.sendall(blob)
+            return parts
+        self.peers[0].sendall(bytes(payload))
+        blob = self._recv(self.peers[0], n * self.world)
+        return [blob[i * n:(i + 1) * n] for i in range(self.world)]
+
+    def close(self):
+        for c in self.peers:
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers = []
+
+
+def launcher_env():
+    """(rank, world_size, local_rank, master_addr, master_port) from the launcher's environment (the one-process-per-GPU launcher bench.py is started by,
+    mpirun wrappers, ...): RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT."""
+    import os
+
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0")),
+            os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")))
+
+
+class RcclGroup:
+    """The RCCL communicator of one camera group (bevw_comm, csrc/bevw_comm.h) plus its control channel."""
+
+    def __init__(self, group_rank, group_world, device, control: SocketGroup):
+        self.rank, self.world, self.control = int(group_rank), int(group_world), control
+        ident = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            check(lib().bevw_comm_unique_id(ident))
+        raw = control.broadcast(bytes(ident), 128)
+        ident = (C.c_uint8 * 128).from_buffer_copy(raw)
+        comm = C.c_void_p()
+        check(lib().bevw_comm_create(int(device), self.rank, self.world, ident, C.byref(comm)))
+        self.comm = comm
+
+    def close(self):
+        if getattr(self, "comm", None):
+            lib().bevw_comm_destroy(self.comm)
+            self.comm = None
+        self.control.close()
 
 
 class CameraShardedBev:
     """BevGenerator(blend, balance) spread one-camera-per-GPU.
 
     ``rig``: {'front': (K, D, H), ...} or None for the repo's data/ directory; sizes come from the module arguments of
-    surroundBEV (``BevGenerator.get_args()``), exactly as for BevGenerator.  ``torch.distributed`` must be initialised
-    by the caller when world_size > 1.  ``engine_factory(rig_list, cams, blend, balance, device)`` exists so the
-    exchange logic can be exercised without a GPU (tests); the default is the HIP engine and there is no CPU path.
+    surroundBEV (``BevGenerator.get_args()``), exactly as for BevGenerator.  ``rank`` / ``world_size`` default to the
+    launcher's RANK / WORLD_SIZE.  With more than one rank the exchange runs over RCCL (``RcclGroup``) unless a host-array
+    ``transport`` is injected (CPU tests); ``engine_factory(rig_list, cams, blend, balance, device)`` exists so the exchange
+    logic can be exercised without a GPU (tests) -- the default is the HIP engine and there is no CPU path.
     """
 
-    def __init__(self, blend=False, balance=False, *, rig=None, rank=None, world_size=None, device=0, engine_factory=None):
-        if world_size is None:
-            import torch.distributed as dist
-            on = dist.is_available() and dist.is_initialized()
-            world_size = dist.get_world_size() if on else 1
-            rank = dist.get_rank() if on else 0
-        self.rank, self.world_size = int(rank), int(world_size)
+    def __init__(self, blend=False, balance=False, *, rig=None, rank=None, world_size=None, device=0, engine_factory=None,
+                 transport=None, control_port_offset=1):
+        env_rank, env_world, _, addr, port = launcher_env()
+        self.rank = int(env_rank if rank is None else rank)
+        self.world_size = int(env_world if world_size is None else world_size)
         assign = camera_assignment(self.world_size)
         self.group, self.cams = assign[self.rank]
         self.ranks = group_ranks(self.world_size, self.group)
+        self.group_rank = self.ranks.index(self.rank)
         self.blend, self.balance = bool(blend), bool(balance)
         _sb.BevGenerator.init_args(None)   # args -> module sizes, as BevGenerator.__init__ does (surroundBEV.py:284)
         if rig is None:
@@ -270,10 +330,21 @@ class CameraShardedBev:
             rig_list = [rig[n] for n in CAMERA_NAMES]
         factory = engine_factory or HipShardEngine
         self.engine = factory(rig_list, self.cams, self.blend, self.balance, device)
-        self.transport = _Transport(self.rank, self.ranks)
-        boxes = self.transport.all_gather(np.asarray(self.engine.box, np.int32))
+        self.transport, self.rccl = transport, None
+        mine = np.asarray(self.engine.box, np.int32)
+        if len(self.ranks) == 1:
+            boxes = [mine]
+        elif transport is not None:
+            boxes = transport.all_gather(mine)
+        else:
+            if not isinstance(self.engine, HipShardEngine):
+                raise Exception("the RCCL exchange needs the HIP engine; inject a host transport for stand-in engines")
+            control = SocketGroup(self.group_rank, len(self.ranks), addr, port + control_port_offset + self.group)
+            self.rccl = RcclGroup(self.group_rank, len(self.ranks), device, control)
+            boxes = [np.frombuffer(b, np.int32) for b in control.all_gather(mine.tobytes())]
         self.boxes = [tuple(int(v) for v in b) for b in boxes]
         self.step = 0
+        self._pipe = None
 
     @property
     def camera_names(self):
@@ -294,31 +365,57 @@ class CameraShardedBev:
             raise Exception("stitch rank {} is not in camera group {}".format(root, self.ranks))
         frames = np.ascontiguousarray(frames)
         batch = frames.shape[0]
+        if self.rccl is not None:
+            return self._call_rccl(frames, car, root)
         all_vsums = None
         if self.balance:
             mine = self.engine.vsums(frames)                      # [B, ncams]
-            per_rank = self.transport.all_gather(mine)            # group order == ascending camera order
+            per_rank = [mine] if len(self.ranks) == 1 else self.transport.all_gather(mine)   # group order == camera order
             all_vsums = np.concatenate(per_rank, axis=1)
             assert all_vsums.shape == (batch, 4)
         part = self.engine.partial(frames, all_vsums)
         shapes = [(batch, b[3] - b[1], b[2] - b[0], 3) for b in self.boxes]
-        parts = self.transport.gather_parts(part, shapes, root)
+        parts = [part] if len(self.ranks) == 1 else self.transport.gather_parts(part, shapes, root)
         if self.rank != root:
             return None
         return self.engine.combine(parts, self.boxes, car)
 
+    def _call_rccl(self, frames, car, root):
+        """host arrays in, host array out, the exchange on the device over RCCL (the resident pipeline with an upload in
+        front and a download behind)."""
+        e, batch = self.engine, frames.shape[0]
+        if self._pipe is None or self._pipe.batch != batch:
+            if self._pipe is not None:
+                self._pipe.close()
+            self._pipe = ResidentShardPipeline(self, batch)
+        d_frames, _ = e._upload_frames(frames)
+        d_car = None
+        if car is not None:
+            c = _ffi.as_u8_image(car, "car image")
+            if c.shape != (e.bh, e.bw, 3):
+                raise Exception("car image must be padded to the BEV size")
+            d_car = e._buf("car", c.nbytes).upload(c).ptr
+        self._pipe.step(d_frames.ptr, d_car, root=root)
+        e.sync()
+        if self.rank != root:
+            return None
+        return self._pipe.out.download((batch, e.bh, e.bw, 3))
 
-class _CudaView:
-    """__cuda_array_interface__ over a bevw_malloc allocation, so that RCCL (torch.distributed "nccl") can move it."""
-
-    def __init__(self, ptr_, nbytes):
-        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr_), False), "version": 2}
+    def close(self):
+        if self._pipe is not None:
+            self._pipe.close()
+            self._pipe = None
+        if self.rccl is not None:
+            self.rccl.close()
+            self.rccl = None
+        self.engine.close()
 
 
 class ResidentShardPipeline:
-    """The same step with everything resident in HBM (what bench.py times): frames of the owned cameras stay in a
-    device buffer, parts travel device-to-device over RCCL send/recv when the backend is "nccl" (host-staged
-    otherwise), the stitch rank writes the BEV batch into its own device buffer."""
+    """The same step with everything resident in HBM (what bench.py times): frames of the owned cameras stay in a device
+    buffer, V sums and parts travel device-to-device over RCCL on the engine's stream (bevw_shard_allgather_vsums,
+    bevw_shard_gather_parts), the stitch rank writes the BEV batch into its own device buffer.  No host synchronisation inside
+    a step.  (With an injected host transport -- CPU-test stand-in -- the exchange is host-staged.)"""
 
     def __init__(self, gen: CameraShardedBev, batch: int):
         if not isinstance(gen.engine, HipShardEngine):
@@ -334,28 +431,20 @@ class ResidentShardPipeline:
         self.vs = D(8 * batch * n, dev)
         self.vs_all = D(8 * batch * 4, dev)
         self.multi = len(gen.ranks) > 1
-        self.on_device = self.multi and gen.transport.device_tensors
-
-    def _tensor(self, buf, nbytes=None):
-        import torch
-        return torch.as_tensor(_CudaView(buf.ptr, nbytes or buf.nbytes), device="cuda")
+        self.on_device = self.multi and gen.rccl is not None
+        nr = len(gen.ranks)
+        self._recv_ptrs = (C.c_void_p * nr)(*[C.c_void_p(b.ptr if b is not None else None) for b in self.recv])
+        self._recv_bytes = (C.c_size_t * nr)(*[batch * e.box_bytes(b) for b in gen.boxes])
 
     def _all_vsums(self, d_frames):
         e, g, B, n = self.e, self.gen, self.batch, len(self.e.cams)
         e.vsums_device(d_frames, B, self.vs.ptr)
         if not self.multi:
             return self.vs.ptr                                   # one rank owns all four: already [B][4]
-        e.sync()
-        import torch
-        import torch.distributed as dist
         if self.on_device:
-            mine = self._tensor(self.vs)
-            outs = [torch.empty_like(mine) for _ in g.ranks]
-            dist.all_gather(outs, mine, group=g.transport.pg)
-            allv = torch.cat([o.view(torch.int64).view(B, n) for o in outs], dim=1).contiguous()
-            self._tensor(self.vs_all).copy_(allv.view(torch.uint8).view(-1))
-            torch.cuda.current_stream().synchronize()
+            check(lib().bevw_shard_allgather_vsums(e.h, g.rccl.comm, self.vs.ptr, B, self.vs_all.ptr))
         else:
+            e.sync()
             per_rank = g.transport.all_gather(self.vs.download((B, n), np.uint64))
             self.vs_all.upload(np.ascontiguousarray(np.concatenate(per_rank, axis=1)))
         return self.vs_all.ptr
@@ -370,18 +459,11 @@ class ResidentShardPipeline:
         e.pack_device(self.full.ptr, B, self.packed.ptr)
         parts = [self.packed.ptr if b is None else b.ptr for b in self.recv]
         if self.multi:
-            import torch
-            import torch.distributed as dist
-            e.sync()
             if self.on_device:
-                if g.rank != root:
-                    dist.send(self._tensor(self.packed), dst=root)
-                else:
-                    reqs = [dist.irecv(self._tensor(b), src=r) for r, b in zip(g.ranks, self.recv) if b is not None]
-                    for q in reqs:
-                        q.wait()
-                torch.cuda.current_stream().synchronize()
+                check(lib().bevw_shard_gather_parts(e.h, g.rccl.comm, self.packed.ptr, self.packed.nbytes,
+                                                    g.ranks.index(root), self._recv_ptrs, self._recv_bytes))
             else:
+                e.sync()
                 shapes = [(B, b[3] - b[1], b[2] - b[0], 3) for b in g.boxes]
                 mine = self.packed.download(shapes[g.ranks.index(g.rank)])
                 got = g.transport.gather_parts(mine, shapes, root)

@@ -65,6 +65,13 @@ SIGNATURES = {
     "bevw_shard_run_device": (_i, [_vp, _vp, _i, _vp, _vp]),
     "bevw_shard_pack_device": (_i, [_vp, _vp, _i, _vp]),
     "bevw_combine_device": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "bevw_comm_available": (_i, []),
+    "bevw_comm_unique_id": (_i, [_vp]),
+    "bevw_comm_create": (_i, [_i, _i, _i, _vp, _pvp]),
+    "bevw_comm_destroy": (None, [_vp]),
+    "bevw_shard_allgather_vsums": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "bevw_shard_gather_parts": (_i, [_vp, _vp, _vp, _sz, _i, _vp, _vp]),
+    "bevw_comm_selftest": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "bevw_luminance_balance": (_i, [_i, _vp, _i, _i, _i, _vp]),
     "bevw_color_balance": (_i, [_i, _vp, _i, _i, _i, _vp]),
     "bevw_sync": (_i, [_vp]),

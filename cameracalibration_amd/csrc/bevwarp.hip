@@ -19,6 +19,7 @@
 
 #include "bevw_kernels.h"
 #include "bevw_plan.h"
+#include "bevw_comm.h"
 
 using namespace bevw;
 
@@ -736,6 +737,7 @@ struct bevw_handle {
     int shard_cams[4] = {0, 1, 2, 3};
     int shard_box[4] = {0, 0, 0, 0};   // x0, y0, x1, y1: bounding box of the owned masks
     DevBuf sdeltas;
+    DevBuf xchg;          // RCCL staging (rank-major V sums)
     bool owns(int cam) const
     {
         if (shard_n == 0) return true;
@@ -1284,6 +1286,114 @@ int bevw_shard_run_device(bevw_handle *h, const void *d_frames, int batch, const
     HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
     return plan_stitch(h->plan, h->stream, frames, batch, c.blend != 0, true, h->sdeltas.as<int>(), h->hsv.as<HsvTables>(), nullptr,
                        h->chsums.as<unsigned long long>(), (uint8_t *)d_out);
+}
+
+// ---- the exchange step over RCCL (bevw_comm.h) -------------------------------------------------------------------
+struct bevw_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+#define RCCL_TRY(expr)                                                                                        \
+    do {                                                                                                      \
+        ncclResult_t _r = (expr);                                                                             \
+        if (_r != ncclSuccess) return fail(BEVW_E_HIP, "%s failed: %s", #expr, rccl().GetErrorString(_r));     \
+    } while (0)
+
+int bevw_comm_available(void) { return rccl().ok ? 1 : 0; }
+
+int bevw_comm_unique_id(uint8_t id[128])
+{
+    if (!id) return fail(BEVW_E_INVALID, "null argument");
+    if (!rccl().ok) return fail(BEVW_E_NO_DEVICE, "RCCL is not available: %s", rccl().why);
+    ncclUniqueId u;
+    RCCL_TRY(rccl().GetUniqueId(&u));
+    static_assert(sizeof(u) == 128, "ncclUniqueId");
+    memcpy(id, &u, 128);
+    return BEVW_OK;
+}
+
+int bevw_comm_create(int device, int rank, int world, const uint8_t id[128], bevw_comm **out)
+{
+    if (!out || !id) return fail(BEVW_E_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(BEVW_E_INVALID, "rank %d of %d", rank, world);
+    BEVW_TRY(use_device(device));
+    if (!rccl().ok) return fail(BEVW_E_NO_DEVICE, "RCCL is not available: %s", rccl().why);
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    bevw_comm *c = new (std::nothrow) bevw_comm;
+    if (!c) return fail(BEVW_E_NOMEM, "out of host memory");
+    c->rank = rank; c->world = world; c->device = device;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(BEVW_E_HIP, "ncclCommInitRank failed: %s", rccl().GetErrorString(r)); }
+    *out = c;
+    return BEVW_OK;
+}
+
+void bevw_comm_destroy(bevw_comm *c)
+{
+    if (!c) return;
+    if (c->comm && rccl().ok) (void)rccl().CommDestroy(c->comm);
+    delete c;
+}
+
+// luminance_balance needs the V sums of all four cameras (surroundBEV.py:60-66): all-gather this rank's [batch][ncams]
+// sums inside the camera group and lay them out as [batch][4].  Ranks of a group own equally many cameras.
+int bevw_shard_allgather_vsums(bevw_handle *h, bevw_comm *c, const void *d_vsums, int batch, void *d_all_vsums)
+{
+    BEVW_TRY(need_shard(h));
+    if (!c || !d_vsums || !d_all_vsums || batch < 0) return fail(BEVW_E_INVALID, "bad argument");
+    if (h->shard_n * c->world != 4) return fail(BEVW_E_INVALID, "%d ranks x %d cameras do not make the 4-camera rig", c->world, h->shard_n);
+    if (batch == 0) return BEVW_OK;
+    const size_t mine = sizeof(unsigned long long) * (size_t)batch * h->shard_n;
+    BEVW_TRY(h->xchg.reserve(mine * (size_t)c->world));
+    RCCL_TRY(rccl().AllGather(d_vsums, h->xchg.p, mine, ncclUint8, c->comm, h->stream));
+    hipLaunchKernelGGL(k_vsums_interleave, dim3((batch * 4 + 255) / 256), dim3(256), 0, h->stream, h->xchg.as<unsigned long long>(),
+                       c->world, h->shard_n, batch, (unsigned long long *)d_all_vsums);
+    return launch_check("k_vsums_interleave");
+}
+
+// The parts travel to the stitch rank: every other rank sends its packed mask box, the stitch rank receives one box per peer
+// (d_recv[r], bytes[r] for r != root; its own entry is ignored).  One grouped call on the handle's stream, no host sync.
+int bevw_shard_gather_parts(bevw_handle *h, bevw_comm *c, const void *d_packed, size_t my_bytes, int root, void *const *d_recv,
+                            const size_t *bytes)
+{
+    BEVW_TRY(need_built(h));
+    if (!c || root < 0 || root >= c->world) return fail(BEVW_E_INVALID, "bad argument");
+    if (c->world == 1) return BEVW_OK;
+    if (c->rank != root) {
+        if (!d_packed) return fail(BEVW_E_INVALID, "null part");
+        RCCL_TRY(rccl().Send(d_packed, my_bytes, ncclUint8, root, c->comm, h->stream));
+        return BEVW_OK;
+    }
+    if (!d_recv || !bytes) return fail(BEVW_E_INVALID, "null receive list");
+    RCCL_TRY(rccl().GroupStart());
+    for (int r = 0; r < c->world; ++r) {
+        if (r == root) continue;
+        if (!d_recv[r]) { (void)rccl().GroupEnd(); return fail(BEVW_E_INVALID, "no receive buffer for rank %d", r); }
+        ncclResult_t e = rccl().Recv(d_recv[r], bytes[r], ncclUint8, r, c->comm, h->stream);
+        if (e != ncclSuccess) { (void)rccl().GroupEnd(); return fail(BEVW_E_HIP, "ncclRecv failed: %s", rccl().GetErrorString(e)); }
+    }
+    RCCL_TRY(rccl().GroupEnd());
+    return BEVW_OK;
+}
+
+// Self-test of the transport on ONE rank (a 1-GPU box): all-gather, and a grouped send + receive of `nbytes` to itself,
+// on the handle's stream.  d_dst receives a copy of d_src.
+int bevw_comm_selftest(bevw_handle *h, bevw_comm *c, const void *d_src, void *d_dst, size_t nbytes)
+{
+    BEVW_TRY(need_built(h));
+    if (!c || !d_src || !d_dst) return fail(BEVW_E_INVALID, "null argument");
+    if (c->world != 1) return fail(BEVW_E_INVALID, "the self-test runs on a 1-rank communicator");
+    BEVW_TRY(h->xchg.reserve(nbytes));
+    RCCL_TRY(rccl().AllGather(d_src, h->xchg.p, nbytes, ncclUint8, c->comm, h->stream));
+    RCCL_TRY(rccl().GroupStart());
+    ncclResult_t e1 = rccl().Send(h->xchg.p, nbytes, ncclUint8, 0, c->comm, h->stream);
+    ncclResult_t e2 = rccl().Recv(d_dst, nbytes, ncclUint8, 0, c->comm, h->stream);
+    RCCL_TRY(rccl().GroupEnd());
+    if (e1 != ncclSuccess || e2 != ncclSuccess) return fail(BEVW_E_HIP, "ncclSend/ncclRecv to self failed");
+    return BEVW_OK;
 }
 
 int bevw_shard_pack_device(bevw_handle *h, const void *d_full, int batch, void *d_packed)

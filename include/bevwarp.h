@@ -62,6 +62,7 @@ typedef struct bevw_config {
 
 typedef struct bevw_handle bevw_handle;   /* a BevGenerator: 4 cameras + masks        (surroundBEV.py:282-325) */
 typedef struct bevw_remapper bevw_remapper; /* one fixed-point remap table on the device (cv2.remap call sites)   */
+typedef struct bevw_comm bevw_comm;       /* an RCCL communicator of one camera group (camera-per-GPU mode)        */
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
 int bevw_abi_version(void);
@@ -151,6 +152,28 @@ int bevw_shard_pack_device(bevw_handle *h, const void *d_full, int batch, void *
  * Works on any built handle of the same BEV geometry (shard or not). */
 int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_t *boxes, int nparts, int batch,
                         const void *d_car, void *d_out);
+
+/* ---- the exchange step of the camera-per-GPU mode over RCCL / xGMI (no reference code: the reference is single
+ * process; BASELINE.json north_star "sharded one-camera-per-GPU ... with an RCCL gather over xGMI for the final stitch").
+ * librccl.so is dlopen'ed on first use, so the library loads and every single-GPU entry point works without it.
+ * A communicator spans ONE camera group (1, 2 or 4 ranks; rank order = ascending camera order).  Every call below is
+ * enqueued on the handle's own HIP stream: rank-local stitch, exchange and combine need no host synchronisation.
+ *   bevw_comm_unique_id  group rank 0 creates the 128-byte id; the caller carries it to the other ranks (any out-of-band
+ *                        channel: cameraShard.exchange_unique_id uses a TCP socket, bench.py its launcher's store)
+ *   bevw_comm_create     ncclCommInitRank on `device`
+ *   bevw_shard_allgather_vsums   balance only: ncclAllGather of the per-frame V sums, laid out as [batch][4]
+ *   bevw_shard_gather_parts      grouped ncclSend (non-root) / ncclRecv (root) of the packed mask boxes; d_recv / bytes are
+ *                                indexed by group rank, the root's own entry is ignored.  NEVER a summing collective:
+ *                                cv2.add saturates (surroundBEV.py:318-320), a wrapping u8 reduce is wrong on every seam pixel
+ *   bevw_comm_selftest   1-rank communicator: all-gather + send/receive to self (what a 1-GPU box can exercise) */
+int bevw_comm_available(void);                          /* 1 when librccl.so could be loaded */
+int bevw_comm_unique_id(uint8_t id[128]);
+int bevw_comm_create(int device, int rank, int world, const uint8_t id[128], bevw_comm **out);
+void bevw_comm_destroy(bevw_comm *c);
+int bevw_shard_allgather_vsums(bevw_handle *h, bevw_comm *c, const void *d_vsums, int batch, void *d_all_vsums);
+int bevw_shard_gather_parts(bevw_handle *h, bevw_comm *c, const void *d_packed, size_t my_bytes, int root, void *const *d_recv,
+                            const size_t *bytes);
+int bevw_comm_selftest(bevw_handle *h, bevw_comm *c, const void *d_src, void *d_dst, size_t nbytes);
 
 /* Module-level helpers of surroundBEV.py, exposed because the reference exports them:
  * luminance_balance(images) (:57-79): frames [batch][4][H][W][3] -> same shape;

@@ -38,3 +38,60 @@ def car(cfg=None):
     t, l = (c["BEV_HEIGHT"] - h) // 2, (c["BEV_WIDTH"] - w) // 2
     img[t:t + h, l:l + w] = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
     return img
+
+
+class GlooTransport:
+    """CPU stand-in for the RCCL exchange of cameraShard (TEST INFRASTRUCTURE: the product's data plane is RCCL, called natively
+    by libbevwarp): the two exchanges of one camera group on host arrays over torch.distributed (gloo).  Implements the transport
+    protocol CameraShardedBev accepts: all_gather(array) and gather_parts(part, shapes, root)."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+        from cameracalibration_amd.SurroundBirdEyeView import cameraShard as CS
+
+        self.rank = rank
+        group, _ = CS.camera_assignment(world)[rank]
+        self.ranks = CS.group_ranks(world, group)
+        self.pg = None
+        if len(self.ranks) > 1:
+            # every rank creates every group, in the same order (torch.distributed requirement)
+            for g in range(len({g for g, _ in CS.camera_assignment(world)})):
+                rs = CS.group_ranks(world, g)
+                pg = dist.new_group(rs)
+                if rs == self.ranks:
+                    self.pg = pg
+
+    @staticmethod
+    def _tensor(a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1))
+
+    def all_gather(self, a):
+        if len(self.ranks) == 1:
+            return [a]
+        import torch
+        import torch.distributed as dist
+        mine = self._tensor(a)
+        outs = [torch.empty_like(mine) for _ in self.ranks]
+        dist.all_gather(outs, mine, group=self.pg)
+        return [o.numpy().view(a.dtype).reshape(a.shape) for o in outs]
+
+    def gather_parts(self, part, shapes, root):
+        if len(self.ranks) == 1:
+            return [part]
+        import torch
+        import torch.distributed as dist
+        if self.rank != root:
+            dist.send(self._tensor(part), dst=root)
+            return None
+        bufs, reqs = [], []
+        for r, shp in zip(self.ranks, shapes):
+            if r == root:
+                bufs.append(None)
+                continue
+            t = torch.empty(int(np.prod(shp)), dtype=torch.uint8)
+            bufs.append(t)
+            reqs.append(dist.irecv(t, src=r))
+        for q in reqs:
+            q.wait()
+        return [part if t is None else t.numpy().reshape(shp) for t, shp in zip(bufs, shapes)]

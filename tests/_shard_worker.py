@@ -1,7 +1,9 @@
 """Worker for the camera-per-GPU tests: one process per rank (torch.distributed.run, gloo).
 
 argv: out_dir engine(oracle|hip) blend balance.  Every rank derives the same seeded frame sets, keeps only its own
-cameras, runs CameraShardedBev twice (two different stitch ranks) and the stitch rank writes the BEV images."""
+cameras, runs CameraShardedBev twice (two different stitch ranks) and the stitch rank writes the BEV images.
+The exchange goes through tests/_shard_common.GlooTransport -- the CPU stand-in for the RCCL data plane of the product
+(a 1-GPU box cannot host a multi-rank RCCL communicator)."""
 import os
 import sys
 
@@ -25,7 +27,8 @@ def main():
     factory = None
     if engine == "oracle":
         from _shard_oracle import OracleShardEngine as factory
-    gen = CS.CameraShardedBev(blend, balance, rig=SC.rig(), engine_factory=factory)
+    gen = CS.CameraShardedBev(blend, balance, rig=SC.rig(), rank=rank, world_size=world, engine_factory=factory,
+                              transport=SC.GlooTransport(rank, world))
     assert gen.world_size == world and gen.rank == rank
     frames, car = SC.frames(batch=2), SC.car()
     mine = np.ascontiguousarray(frames[:, list(gen.cams)])
