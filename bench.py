@@ -147,6 +147,37 @@ def upload_replicated(buf, unique: np.ndarray, batch: int):
         buf.upload(unique[b % unique.shape[0]], offset=b * per)
 
 
+class TimedOracle:
+    """The oracle source compiled -O3 -march=native ON THIS HOST for the timed cpu_baseline leg only (BASELINE.md section 4);
+    parity everywhere else uses the -O2 build.  Same set_threads / usable_cores surface as the oracle module."""
+
+    def __init__(self, O):
+        path = O.build_timed()
+        self.lib = O.load(path)
+        self.flags = "-O3 -march=native -fopenmp -ffp-contract=off" if "_timed" in path else "-O2 -fopenmp -ffp-contract=off"
+        self.usable_cores = O.usable_cores
+
+    def set_threads(self, n):
+        self.lib.orc_set_threads(int(n))
+
+
+def timed_loop(fn, seconds, cap):
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(n)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= cap:
+            return n, dt
+
+
+def timed_rate(T, threads, fn, seconds, cap) -> float:
+    T.set_threads(threads)
+    fn(0)
+    n, dt = timed_loop(fn, seconds, cap)
+    return n / dt
+
+
 def pick_threads(O, fn) -> int:
     """OpenMP thread count for the CPU baseline: the fastest of a few candidates up to the cores this process may use
     (a container can show far more cores than its quota allows; oversubscription thrashes)."""
@@ -155,9 +186,9 @@ def pick_threads(O, fn) -> int:
     best, best_t = 1, float("inf")
     for c in cands:
         O.set_threads(c)
-        fn()
+        fn(0)
         t0 = time.perf_counter()
-        fn(); fn()
+        fn(1); fn(2)
         dt = time.perf_counter() - t0
         if dt < best_t:
             best, best_t = c, dt
@@ -173,19 +204,19 @@ def cpu_baseline_bev(w, cfg, rig, unique, seconds):
 
     O.build()
     ref = O.RefBevGenerator(rig, cfg, blend=w["blend"], balance=w["balance"])
-    call = ref.make_fast_call()
     frames = [np.ascontiguousarray(unique[0][c]) for c in range(4)]
-    cores = pick_threads(O, lambda: call(frames))
-    n, t0 = 0, time.perf_counter()
-    while True:
-        call([np.ascontiguousarray(unique[n % unique.shape[0]][c]) for c in range(4)] if unique.shape[0] > 1 else frames)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 2000:
-            break
-    return {"value": n / dt, "unit": w["unit"], "cores": cores, "kind": "port",
+    want = ref.make_fast_call()(frames).copy()            # parity build (-O2), the checker
+    T = TimedOracle(O)                                     # the same source, -O3 -march=native, built on this host
+    call = ref.make_fast_call(T.lib)
+    assert np.array_equal(call(frames), want), "the -O3 -march=native oracle build changed the arithmetic"
+    one = timed_rate(T, 1, lambda i: call(frames), min(seconds / 3, 4.0), 400)
+    cores = pick_threads(T, lambda i: call(frames))
+    sets = [[np.ascontiguousarray(unique[k][c]) for c in range(4)] for k in range(unique.shape[0])]
+    n, dt = timed_loop(lambda i: call(sets[i % len(sets)]), seconds, 2000)
+    return {"value": n / dt, "unit": w["unit"], "cores": cores, "kind": "port", "value_1_thread": one,
+            "build": T.flags,
             "sample": f"{n} stitched frames in {dt:.1f} s (oracle/bevoracle.c orc_bev_call, OpenMP {cores} threads of "
-                      f"{os.cpu_count()} visible, reference op order: remap x4 -> mask -> 3 sat-adds)"}
+                      f"{os.cpu_count()} visible, reference op order: remap x4 -> mask -> 3 sat-adds); 1 thread: {one:.1f} {w['unit']}"}
 
 
 def cpu_baseline_undistort(w, K, D, ucfg, unique, seconds):
@@ -196,16 +227,20 @@ def cpu_baseline_undistort(w, K, D, ucfg, unique, seconds):
     Kd = O.camera_mat_dst(K, fw, fh, ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"])
     m1, m2 = O.fisheye_init_undistort_rectify_map(K, D, Kd, (int(fw * ucfg["SIZE_SCALE"]), int(fh * ucfg["SIZE_SCALE"])))
     img = np.ascontiguousarray(unique[0][0])
-    cores = pick_threads(O, lambda: O.remap(img, m1, m2))
-    n, t0 = 0, time.perf_counter()
-    while True:
-        O.remap(img, m1, m2)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 5000:
-            break
-    return {"value": n / dt, "unit": w["unit"], "cores": cores, "kind": "port",
-            "sample": f"{n} images in {dt:.1f} s (oracle orc_remap_u8, OpenMP {cores} threads)"}
+    want = O.remap(img, m1, m2)
+    T = TimedOracle(O)
+    out = np.empty_like(want)
+
+    def remap(_i=0):
+        T.lib.orc_remap_u8(img.ctypes.data, img.shape[1], img.shape[0], 3, m1.ctypes.data, m2.ctypes.data, m2.shape[1], m2.shape[0],
+                           out.ctypes.data)
+    remap()
+    assert np.array_equal(out, want), "the -O3 -march=native oracle build changed the arithmetic"
+    one = timed_rate(T, 1, remap, min(seconds / 3, 4.0), 2000)
+    cores = pick_threads(T, remap)
+    n, dt = timed_loop(remap, seconds, 5000)
+    return {"value": n / dt, "unit": w["unit"], "cores": cores, "kind": "port", "value_1_thread": one, "build": T.flags,
+            "sample": f"{n} images in {dt:.1f} s (oracle orc_remap_u8, OpenMP {cores} threads); 1 thread: {one:.1f} {w['unit']}"}
 
 
 def main():
@@ -251,6 +286,13 @@ def main():
             ms = C.c_float()
             _ffi.check(_ffi.lib().bevw_timer_stop(e.h, C.byref(ms)))
             return float(ms.value)
+        tmark = lambda i: _ffi.check(_ffi.lib().bevw_timer_mark(e.h, i))
+
+        def tbetween(a_, b_):
+            import ctypes as C
+            ms = C.c_float()
+            _ffi.check(_ffi.lib().bevw_timer_between(e.h, a_, b_, C.byref(ms)))
+            return float(ms.value)
         units_world = max(1, d.world // 4)
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"], "schedule": "tile_plan",
                  "table_build_s": round(t_build, 3), "cameras_per_rank": len(gen.cams), "camera_groups": units_world,
@@ -276,6 +318,7 @@ def main():
         upload_replicated(d_in, unique, batch)
         step = lambda: bev.run_device(d_in.ptr, batch, None, d_out.ptr)
         sync, tstart, tstop = bev.sync, bev.timer_start, bev.timer_stop
+        tmark, tbetween = bev.timer_mark, bev.timer_between
         info = bev.plan_info()
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
                  "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3),
@@ -304,6 +347,12 @@ def main():
             ms = C.c_float()
             _ffi.check(L.bevw_remapper_timer_stop(r, C.byref(ms)))
             return float(ms.value)
+        tmark = lambda i: _ffi.check(L.bevw_remapper_timer_mark(r, i))
+
+        def tbetween(a_, b_):
+            ms = C.c_float()
+            _ffi.check(L.bevw_remapper_timer_between(r, a_, b_, C.byref(ms)))
+            return float(ms.value)
         extra = {"frame": [fw, fh], "schedule": "per_pixel"}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_undistort(w, K, D, ucfg, unique, a.cpu_seconds)
@@ -314,8 +363,10 @@ def main():
     d.barrier()
     t0 = time.perf_counter()
     tstart()
-    for _ in range(a.steps):
+    for i in range(a.steps):
+        tmark(i)     # an event in front of every step, recorded on the engine's stream without synchronising
         step()
+    tmark(a.steps)
     ev_ms = tstop()  # records the stop event on the engine's stream and waits for it
     sync()
     d.barrier()
@@ -324,6 +375,9 @@ def main():
     ev_ms = d.max(ev_ms)
 
     traffic, traffic_source = measured_traffic(a.workload, batch)
+    # per-step durations from the marks: the median is robust against the one-off hiccups a 13 ms region is exposed to
+    laps = sorted(tbetween(i, i + 1) for i in range(a.steps))
+    lap_median = d.max(laps[len(laps) // 2] if len(laps) % 2 else 0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2]))
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
@@ -337,7 +391,9 @@ def main():
                         "unique_frame_sets": int(a.unique_sets)}, **extra),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel_ms": launch_ms, "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
+                     "kernel_ms": launch_ms, "kernel_ms_median": lap_median, "kernel_ms_min": laps[0], "kernel_ms_max": laps[-1],
+                     "frac_median": alg_bytes * batch / (lap_median * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
         "cpu_baseline": cpu,
     }
     if d.rank == 0:

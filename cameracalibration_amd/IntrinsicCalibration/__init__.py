@@ -1,2 +1,3 @@
-"""Drop-in for the hot-path part of the reference's IntrinsicCalibration package (InCalibrator.undistort)."""
-from .intrinsicCalib import InCalibrator  # noqa: F401
+"""Drop-in for the hot-path part of the reference's IntrinsicCalibration package (InCalibrator.undistort); the names
+main.py:5 imports exist, the calibration solver / capture driver raise (out of scope, see intrinsicCalib.py)."""
+from .intrinsicCalib import InCalibrator, CalibMode  # noqa: F401

@@ -175,3 +175,22 @@ class InCalibrator:
 
     def __call__(self, raw_frame):
         raise Exception("the calibration solver is out of scope of cameracalibration_amd (use set_calibration)")
+
+
+class CalibMode:
+    """intrinsicCalib.py:226-396 -- the reference's capture / calibration DRIVER (camera, video or image input feeding
+    chessboard frames to ``InCalibrator.__call__`` with cv2 GUI windows).  It is exported so that ``main.py:5``
+    (``from IntrinsicCalibration import InCalibrator, CalibMode``) imports unchanged; running it needs the calibration solver
+    and the cv2 GUI, both outside this engine's scope (iterative LM solver + corner
+    detector, offline, not data-parallel).  Calibrate with the reference, then hand K and D to ``set_calibration`` --
+    or load the ``camera_<id>_{K,D}.npy`` files its ``main()`` writes (intrinsicCalib.py:413-414)."""
+
+    def __init__(self, calibrator, input_type, mode):
+        self.calibrator = calibrator
+        self.input_type = input_type
+        self.mode = mode
+
+    def __call__(self):
+        raise Exception("CalibMode drives the chessboard calibration solver and the cv2 GUI, which are out of scope of "
+                        "cameracalibration_amd: calibrate with the reference and use InCalibrator.set_calibration(K, D)")
+

@@ -141,9 +141,20 @@ class Camera:
         self.name = name
         if K is None:
             base = _data_dir()
-            self.camera_mat = np.load(base + '/{}/camera_{}_K.npy'.format(name, name))
-            self.dist_coeff = np.load(base + '/{}/camera_{}_D.npy'.format(name, name))
-            self.homography = np.load(base + '/{}/camera_{}_H.npy'.format(name, name))
+            if os.path.exists(base + '/{}/camera_{}_K.npy'.format(name, name)):
+                self.camera_mat = np.load(base + '/{}/camera_{}_K.npy'.format(name, name))
+                self.dist_coeff = np.load(base + '/{}/camera_{}_D.npy'.format(name, name))
+                self.homography = np.load(base + '/{}/camera_{}_H.npy'.format(name, name))
+            else:
+                # The reference ships its sample calibration as data/<name>/camera_<name>_{K,D,H}.npy; this package does
+                # not redistribute the reference's files.  Without a data directory (or BEVW_DATA_DIR) the SAME twelve
+                # matrices come from workloads.repo_rig() -- checked value for value against the reference's files by
+                # tests/test_workloads.py -- so that BevGenerator() works out of the box as the reference's does.
+                try:
+                    from .. import workloads as _W
+                except ImportError:
+                    from cameracalibration_amd import workloads as _W
+                self.camera_mat, self.dist_coeff, self.homography = _W.repo_rig()[name]
         else:
             self.camera_mat = np.array(K, dtype=np.float64).reshape(3, 3)
             self.dist_coeff = np.array(D, dtype=np.float64).reshape(-1, 1)
@@ -359,6 +370,14 @@ class BevGenerator:
     def timer_stop(self) -> float:
         ms = C.c_float()
         check(lib().bevw_timer_stop(self._engine.h, C.byref(ms)))
+        return float(ms.value)
+
+    def timer_mark(self, slot: int) -> None:
+        check(lib().bevw_timer_mark(self._engine.h, int(slot)))
+
+    def timer_between(self, a: int, b: int) -> float:
+        ms = C.c_float()
+        check(lib().bevw_timer_between(self._engine.h, int(a), int(b), C.byref(ms)))
         return float(ms.value)
 
     def plan_info(self) -> dict:

@@ -31,7 +31,10 @@ class _Groups:
     def offset(self, stamp):
         """stamp minus the mean of the group under the cursor"""
         g = self.groups[self.at]
-        return stamp - sum(g) / len(g)
+        total = 0   # my_mean (Tools/timeAlign.py:12-16): naive left-to-right accumulation.  The builtin sum() of floats is
+        for x in g:  # compensated (Neumaier) from Python 3.12 on and can differ in the last ulp, which flips the
+            total += x   # abs(diff) < thresh comparison on the boundary
+        return stamp - total / len(g)
 
     def take(self, stamp):
         self.groups[self.at].append(stamp)

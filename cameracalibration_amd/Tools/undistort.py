@@ -108,25 +108,39 @@ def main(argv=None):
     und = Undistorter(camera_mat, dist_coeff, args.width, args.height, args.focalscale, args.sizescale, args.offset_h,
                       args.offset_v)
     names = [f for f in os.listdir(args.path_read) if f[-4:] == '.' + args.srcformat]
-    if not names:
-        return 0
-    batch = np.stack([np.ascontiguousarray(np.asarray(Image.open(os.path.join(args.path_read, f)).convert("RGB"))[:, :, ::-1])
-                      for f in names])
-    out = und(batch)
-    index = 1
-    for filename, img in zip(names, out):
-        print(filename)
-        if args.name is not None:
-            filename = args.name + '_{:04d}.'.format(index) + args.srcformat
-            index += 1
-        pil = Image.fromarray(np.ascontiguousarray(img[:, :, ::-1]))
-        if args.dstformat == 'jpg':
-            pil.save(os.path.join(args.path_save, filename[:-4] + '.jpg'), quality=args.quality, subsampling=0 if args.quality >= 100 else -1)
-        elif args.dstformat == 'png':
-            pil.save(os.path.join(args.path_save, filename[:-4] + '.png'), compress_level=min(9, max(0, args.quality)))
-        else:
-            pil.save(filename[:-4] + '.' + args.dstformat)
-    return len(names)
+    # The reference streams image by image (Tools/undistort.py:60-77).  Here the directory is walked in bounded chunks:
+    # host and device memory stay at CHUNK images whatever the directory holds, and a file of another size is reported
+    # and skipped instead of aborting the run.
+    CHUNK = 64
+    index, done = 1, 0
+    for c0 in range(0, len(names), CHUNK):
+        keep, imgs = [], []
+        for f in names[c0:c0 + CHUNK]:
+            img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(args.path_read, f)).convert("RGB"))[:, :, ::-1])
+            if img.shape != (args.height, args.width, 3):
+                print("{}: {}x{} is not {}x{}, skipped".format(f, img.shape[1], img.shape[0], args.width, args.height))
+                continue
+            keep.append(f)
+            imgs.append(img)
+        if not imgs:
+            continue
+        out = und(np.stack(imgs))
+        for filename, img in zip(keep, out):
+            print(filename)
+            if args.name is not None:
+                filename = args.name + '_{:04d}.'.format(index) + args.srcformat
+                index += 1
+            pil = Image.fromarray(np.ascontiguousarray(img[:, :, ::-1]))
+            if args.dstformat == 'jpg':
+                # cv2.imwrite(..., [IMWRITE_JPEG_QUALITY, q]) keeps libjpeg's default 4:2:0 subsampling at every quality
+                pil.save(os.path.join(args.path_save, filename[:-4] + '.jpg'), quality=args.quality, subsampling=2)
+            elif args.dstformat == 'png':
+                pil.save(os.path.join(args.path_save, filename[:-4] + '.png'), compress_level=min(9, max(0, args.quality)))
+            else:
+                pil.save(filename[:-4] + '.' + args.dstformat)
+            done += 1
+    return done
+
 
 
 if __name__ == '__main__':

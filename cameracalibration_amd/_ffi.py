@@ -77,6 +77,8 @@ SIGNATURES = {
     "bevw_sync": (_i, [_vp]),
     "bevw_timer_start": (_i, [_vp]),
     "bevw_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "bevw_timer_mark": (_i, [_vp, _i]),
+    "bevw_timer_between": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "bevw_fisheye_remapper_create": (_i, [_i, _i, _i, _vp, _vp, _d, _d, _d, _d, _pvp]),
     "bevw_pinhole_remapper_create": (_i, [_i, _i, _i, _vp, _vp, _i, _d, _d, _d, _d, _pvp]),
     "bevw_remapper_from_maps": (_i, [_i, _i, _i, _vp, _vp, _i, _i, _pvp]),
@@ -87,6 +89,8 @@ SIGNATURES = {
     "bevw_remapper_sync": (_i, [_vp]),
     "bevw_remapper_timer_start": (_i, [_vp]),
     "bevw_remapper_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
+    "bevw_remapper_timer_mark": (_i, [_vp, _i]),
+    "bevw_remapper_timer_between": (_i, [_vp, _i, _i, C.POINTER(C.c_float)]),
     "bevw_remapper_destroy": (None, [_vp]),
     "bevw_warp_perspective_u8c3": (_i, [_i, _vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "bevw_translate_u8c3": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp]),

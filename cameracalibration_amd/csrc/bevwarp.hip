@@ -277,9 +277,37 @@ struct MaskGeometry {
 // ---------------------------------------------------------------------------------------------------------------
 // device buffer helper
 // ---------------------------------------------------------------------------------------------------------------
+// Lap timer: HIP events recorded on an engine's own stream WITHOUT synchronising, read back after the caller's final sync
+// (bench.py: one mark in front of every step -> per-step durations, median instead of one mean over a 13 ms region).
+struct LapTimer {
+    std::vector<hipEvent_t> ev;
+    int mark(int slot, hipStream_t st)
+    {
+        if (slot < 0 || slot >= 65536) return fail(BEVW_E_INVALID, "timer slot %d out of range", slot);
+        if ((size_t)slot >= ev.size()) ev.resize((size_t)slot + 1, nullptr);
+        if (!ev[slot]) HIP_TRY(hipEventCreate(&ev[slot]));
+        HIP_TRY(hipEventRecord(ev[slot], st));
+        return BEVW_OK;
+    }
+    int between(int a, int b, float *ms)
+    {
+        if (!ms || a < 0 || b < 0 || (size_t)a >= ev.size() || (size_t)b >= ev.size() || !ev[a] || !ev[b])
+            return fail(BEVW_E_INVALID, "timer slots %d / %d were not marked", a, b);
+        HIP_TRY(hipEventSynchronize(ev[b]));
+        HIP_TRY(hipEventElapsedTime(ms, ev[a], ev[b]));
+        return BEVW_OK;
+    }
+    void release() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); ev.clear(); }
+};
+
+// owns one device allocation: released on every exit path (early HIP_TRY / BEVW_TRY returns included)
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
     int reserve(size_t n)
     {
         if (n <= cap) return BEVW_OK;
@@ -367,6 +395,7 @@ struct bevw_remapper {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LapTimer laps;
     int sw = 0, sh = 0, dw = 0, dh = 0;
     DevBuf map1, map2, in, out, ones;
     Plan plan;            // single-image contributor plan (same kernels as the BEV stitch, ncams = 1)
@@ -395,6 +424,7 @@ static int remapper_alloc(int device, int sw, int sh, int dw, int dh, bevw_remap
     if (!out) return fail(BEVW_E_INVALID, "null output pointer");
     *out = nullptr;
     if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return fail(BEVW_E_INVALID, "non-positive image size");
+    if (dh > 65535 || sh > 65535) return fail(BEVW_E_INVALID, "image height > 65535 (rows ride in grid.y)");
     BEVW_TRY(use_device(device));
     bevw_remapper *r = new (std::nothrow) bevw_remapper();
     if (!r) return fail(BEVW_E_NOMEM, "out of host memory");
@@ -604,6 +634,18 @@ int bevw_remapper_timer_start(bevw_remapper *r)
     HIP_TRY(hipEventRecord(r->ev0, r->stream));
     return BEVW_OK;
 }
+int bevw_remapper_timer_mark(bevw_remapper *r, int slot)
+{
+    if (!r) return fail(BEVW_E_INVALID, "null remapper");
+    BEVW_TRY(use_device(r->device));
+    return r->laps.mark(slot, r->stream);
+}
+int bevw_remapper_timer_between(bevw_remapper *r, int slot_a, int slot_b, float *elapsed_ms)
+{
+    if (!r) return fail(BEVW_E_INVALID, "null remapper");
+    BEVW_TRY(use_device(r->device));
+    return r->laps.between(slot_a, slot_b, elapsed_ms);
+}
 int bevw_remapper_timer_stop(bevw_remapper *r, float *elapsed_ms)
 {
     if (!r || !elapsed_ms) return fail(BEVW_E_INVALID, "null argument");
@@ -621,6 +663,7 @@ void bevw_remapper_destroy(bevw_remapper *r)
         if (r->stream) (void)hipStreamSynchronize(r->stream);
         r->map1.release(); r->map2.release(); r->in.release(); r->out.release(); r->ones.release();
         plan_release(r->plan);
+        r->laps.release();
         if (r->ev0) (void)hipEventDestroy(r->ev0);
         if (r->ev1) (void)hipEventDestroy(r->ev1);
         if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -723,6 +766,7 @@ struct bevw_handle {
     bevw_config cfg;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LapTimer laps;
     bool cam_set[4] = {false, false, false, false};
     double K[4][9], D[4][4], H[4][9];
     bool built = false;
@@ -802,7 +846,7 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
     const size_t frame_bytes = (size_t)fw * fh * 3;
     HIP_TRY(hipMemsetAsync(d_vsums, 0, sizeof(unsigned long long) * 4 * (size_t)nsets, st));
     const int nframes = nsets * 4;
-    const int vec_ok = (frame_bytes % 16 == 0) ? 1 : 0;
+    const int vec_ok = (frame_bytes % 16 == 0 && ((uintptr_t)d_frames & 15u) == 0) ? 1 : 0;   // k_vsum's uint4 loads
     int bpf = 2048 / (nframes > 0 ? nframes : 1);
     if (bpf < 8) bpf = 8;
     if (bpf > 256) bpf = 256;
@@ -873,6 +917,8 @@ int bevw_create(const bevw_config *cfg, bevw_handle **out)
     if (cfg->frame_width <= 0 || cfg->frame_height <= 0 || cfg->bev_width <= 0 || cfg->bev_height <= 0)
         return fail(BEVW_E_INVALID, "non-positive frame/BEV size");
     if (cfg->car_width < 0 || cfg->car_height < 0) return fail(BEVW_E_INVALID, "negative car size");
+    if (cfg->bev_height > 65535 || cfg->frame_height * cfg->size_scale > 65535.0)
+        return fail(BEVW_E_INVALID, "BEV / undistort grid height > 65535 (rows ride in grid.y)");
     if (!(cfg->size_scale > 0) || !(cfg->focal_scale > 0)) return fail(BEVW_E_INVALID, "scales must be positive");
     if ((int)(cfg->frame_width * cfg->size_scale) <= 0 || (int)(cfg->frame_height * cfg->size_scale) <= 0)
         return fail(BEVW_E_INVALID, "empty undistort grid");
@@ -1034,6 +1080,7 @@ void bevw_destroy(bevw_handle *h)
         h->hsv.release(); h->vsums.release(); h->deltas.release(); h->chsums.release(); h->sdeltas.release();
         h->in.release(); h->out.release(); h->car.release(); h->tmp.release();
         plan_release(h->plan);
+        h->laps.release();
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
         if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1566,6 +1613,18 @@ int bevw_timer_start(bevw_handle *h)
     BEVW_TRY(use_device(h->cfg.device));
     HIP_TRY(hipEventRecord(h->ev0, h->stream));
     return BEVW_OK;
+}
+int bevw_timer_mark(bevw_handle *h, int slot)
+{
+    if (!h) return fail(BEVW_E_INVALID, "null handle");
+    BEVW_TRY(use_device(h->cfg.device));
+    return h->laps.mark(slot, h->stream);
+}
+int bevw_timer_between(bevw_handle *h, int slot_a, int slot_b, float *elapsed_ms)
+{
+    if (!h) return fail(BEVW_E_INVALID, "null handle");
+    BEVW_TRY(use_device(h->cfg.device));
+    return h->laps.between(slot_a, slot_b, elapsed_ms);
 }
 int bevw_timer_stop(bevw_handle *h, float *elapsed_ms)
 {

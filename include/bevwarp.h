@@ -185,6 +185,10 @@ int bevw_color_balance(int device, const uint8_t *images, int batch, int width, 
 int bevw_sync(bevw_handle *h);
 int bevw_timer_start(bevw_handle *h);
 int bevw_timer_stop(bevw_handle *h, float *elapsed_ms); /* records + synchronises the stop event */
+/* Lap marks: an event recorded on the engine's stream WITHOUT synchronising (slot 0..65535); elapsed time between two marks
+ * after the caller's sync.  bench.py marks every step: per-step durations and their median instead of one mean. */
+int bevw_timer_mark(bevw_handle *h, int slot);
+int bevw_timer_between(bevw_handle *h, int slot_a, int slot_b, float *elapsed_ms);
 
 /* ---- cv2.remap with fixed-point maps: InCalibrator.undistort (intrinsicCalib.py:193-195), ----------------- */
 /* ---- Tools/undistort.py:50-52,66, Camera.undistort (surroundBEV.py:110-111) ------------------------------- */
@@ -210,6 +214,8 @@ int bevw_remap_device(bevw_remapper *r, const void *d_src, int batch, void *d_ds
 int bevw_remapper_sync(bevw_remapper *r);
 int bevw_remapper_timer_start(bevw_remapper *r);
 int bevw_remapper_timer_stop(bevw_remapper *r, float *elapsed_ms);
+int bevw_remapper_timer_mark(bevw_remapper *r, int slot);
+int bevw_remapper_timer_between(bevw_remapper *r, int slot_a, int slot_b, float *elapsed_ms);
 void bevw_remapper_destroy(bevw_remapper *r);
 
 /* ---- cv2.warpPerspective(src_8UC3, H, (dst_w, dst_h)): ExCalibrator.warp (extrinsicCalib.py:166-169) ------ */

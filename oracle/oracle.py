@@ -53,51 +53,76 @@ def usable_cores(cap: int = 64) -> int:
     return max(1, min(n, cap))
 
 
+def build_timed() -> str:
+    """The SAME source compiled -O3 -march=native for the host it runs on, used ONLY by the timed
+    cpu_baseline leg of bench.py: an -march=native object does not travel between machines, so it is built where it is
+    timed (gcc, ~2 s) into oracle/_timed/.  -ffp-contract=off stays: the arithmetic must not change.  Falls back to the
+    parity build when the compiler is missing."""
+    out_dir = os.path.join(_HERE, "_timed")
+    out = os.path.join(out_dir, "libbevoracle_timed.so")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-fast-math",
+                        "-fvisibility=hidden", "-shared", "-o", out, os.path.join(_HERE, "bevoracle.c"), "-lm"],
+                       check=True, capture_output=True, timeout=120)
+        return out
+    except (OSError, subprocess.SubprocessError):
+        return build()
+
+
+def load(path: str) -> C.CDLL:
+    """A configured CDLL of an oracle build (signatures set)."""
+    return _configure(C.CDLL(path))
+
+
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        L = C.CDLL(_LIB_PATH)
-        vp, i32, u64, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
-        sig = {
-            "orc_set_threads": (None, [i32]),
-            "orc_max_threads": (i32, []),
-            "orc_newcam_inverse": (None, [vp, vp]),
-            "orc_fisheye_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
-            "orc_invert3x3": (i32, [vp, vp]),
-            "orc_pinhole_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
-            "orc_perspective_coords": (None, [vp, i32, i32, vp, vp]),
-            "orc_remap_s16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
-            "orc_remap_u16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
-            "orc_remap_u8": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
-            "orc_fill_poly": (None, [vp, i32, i32, vp, i32, C.c_uint8]),
-            "orc_blend_mask": (None, [vp, vp, i32, i32, vp, vp]),
-            "orc_segment_distance": (C.c_double, [vp, C.c_double, C.c_double]),
-            "orc_hsv_tables": (None, [vp, vp]),
-            "orc_bgr2hsv": (None, [vp, sz, vp]),
-            "orc_hsv2bgr": (None, [vp, sz, vp]),
-            "orc_sum_v": (u64, [vp, sz]),
-            "orc_round_delta": (i32, [C.c_double]),
-            "orc_luminance_shift": (None, [vp, sz, i32, vp]),
-            "orc_mask_select": (None, [vp, vp, sz, vp]),
-            "orc_weight_mul": (None, [vp, vp, sz, vp]),
-            "orc_add_sat": (None, [vp, vp, sz, vp]),
-            "orc_channel_sums": (None, [vp, sz, vp]),
-            "orc_gain": (None, [vp, sz, vp]),
-            "orc_set_variant": (None, [i32, i32]),
-            "orc_get_variant": (i32, [i32]),
-            "orc_translate_u8c3": (None, [vp, i32, i32, i32, i32, vp]),
-            "orc_resize_dsize": (None, [i32, i32, C.c_double, C.c_double, vp, vp]),
-            "orc_resize_linear_u8c3": (None, [vp, i32, i32, C.c_double, C.c_double, vp, i32, i32]),
-            "orc_bev_call": (None, [vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
-        }
-        for name, (res, args) in sig.items():
-            fn = getattr(L, name)
-            fn.restype, fn.argtypes = res, args
-        L.orc_set_threads(usable_cores(16))
-        _lib = L
+        _lib = _configure(C.CDLL(_LIB_PATH))
     return _lib
+
+
+def _configure(L: C.CDLL) -> C.CDLL:
+    vp, i32, u64, sz = C.c_void_p, C.c_int, C.c_uint64, C.c_size_t
+    sig = {
+        "orc_set_threads": (None, [i32]),
+        "orc_max_threads": (i32, []),
+        "orc_newcam_inverse": (None, [vp, vp]),
+        "orc_fisheye_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
+        "orc_invert3x3": (i32, [vp, vp]),
+        "orc_pinhole_undistort_map": (None, [vp, vp, vp, i32, i32, vp, vp]),
+        "orc_perspective_coords": (None, [vp, i32, i32, vp, vp]),
+        "orc_remap_s16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
+        "orc_remap_u16_f32": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
+        "orc_remap_u8": (None, [vp, i32, i32, i32, vp, vp, i32, i32, vp]),
+        "orc_fill_poly": (None, [vp, i32, i32, vp, i32, C.c_uint8]),
+        "orc_blend_mask": (None, [vp, vp, i32, i32, vp, vp]),
+        "orc_segment_distance": (C.c_double, [vp, C.c_double, C.c_double]),
+        "orc_hsv_tables": (None, [vp, vp]),
+        "orc_bgr2hsv": (None, [vp, sz, vp]),
+        "orc_hsv2bgr": (None, [vp, sz, vp]),
+        "orc_sum_v": (u64, [vp, sz]),
+        "orc_round_delta": (i32, [C.c_double]),
+        "orc_luminance_shift": (None, [vp, sz, i32, vp]),
+        "orc_mask_select": (None, [vp, vp, sz, vp]),
+        "orc_weight_mul": (None, [vp, vp, sz, vp]),
+        "orc_add_sat": (None, [vp, vp, sz, vp]),
+        "orc_channel_sums": (None, [vp, sz, vp]),
+        "orc_gain": (None, [vp, sz, vp]),
+        "orc_set_variant": (None, [i32, i32]),
+        "orc_get_variant": (i32, [i32]),
+        "orc_translate_u8c3": (None, [vp, i32, i32, i32, i32, vp]),
+        "orc_resize_dsize": (None, [i32, i32, C.c_double, C.c_double, vp, vp]),
+        "orc_resize_linear_u8c3": (None, [vp, i32, i32, C.c_double, C.c_double, vp, i32, i32]),
+        "orc_bev_call": (None, [vp, i32, i32, vp, vp, i32, i32, vp, vp, i32, i32, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    L.orc_set_threads(usable_cores(16))
+    return L
 
 
 def _p(a: np.ndarray) -> int:
@@ -425,7 +450,8 @@ class RefBevGenerator:
         return surround
 
     # ---- single fused C call in the same op order: used for the timed CPU baseline ----
-    def make_fast_call(self):
+    def make_fast_call(self, L=None):
+        """L: an oracle build (default: the parity build; bench.py passes the -O3 -march=native one for the timed leg)."""
         c = self.cfg
         fw, fh, bw, bh = c["FRAME_WIDTH"], c["FRAME_HEIGHT"], c["BEV_WIDTH"], c["BEV_HEIGHT"]
         P4 = C.c_void_p * 4
@@ -435,7 +461,7 @@ class RefBevGenerator:
         wt = P4(*[(_p(w) if w is not None else None) for w in self.weights])
         scratch = np.empty(5 * bw * bh * 3 + 4 * fw * fh * 3, np.uint8)
         out = np.empty((bh, bw, 3), np.uint8)
-        L = lib()
+        L = L or lib()
 
         def call(frames4, car=None):
             fr = P4(*[_p(f) for f in frames4])

@@ -432,6 +432,33 @@ def test_full_size_batch_properties(ffi, SB, oracle, blend, balance):
     assert np.array_equal(rag[:2], out[:2]) and np.array_equal(rag[4], out[0])
 
 
+@pytest.mark.parametrize("blend", [False, True])
+def test_bench_configuration_batch_256_all_random(ffi, SB, oracle, blend):
+    """The bench's own configuration (config S, batch 256 frame sets resident in HBM, what BENCH_rNN.json times) on the
+    WORST-CASE input for parity: every byte of every frame uniform random, 3 distinct frame sets cycled through the batch.
+    Every one of the 256 BEVs must equal the oracle's BEV of its frame set -- bit-exact."""
+    cfg, rig = W.CONFIG_S, W.rig_s()
+    batch, uniq = 256, 3
+    frames = W.synthetic_frames(uniq, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=W.SEED + 17, kind="random")
+    bev, ref = make_pair(SB, oracle, rig, cfg, blend, False)
+    assert bev.plan_info()["schedule"] == 2
+    d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
+    d_out = ffi.DeviceBuffer(batch * 1080 * 1080 * 3)
+    d_out.fill(0x5A)
+    for b in range(batch):
+        d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
+    bev.run_device(d_in.ptr, batch, None, d_out.ptr)
+    bev.sync()
+    want = [ref(*frames[u]) for u in range(uniq)]
+    per = 1080 * 1080 * 3
+    for b0 in range(0, batch, 32):   # download in slices: the whole batch is 0.9 GB
+        out = d_out.download((32, 1080, 1080, 3), offset=b0 * per)
+        for k in range(32):
+            assert np.array_equal(out[k], want[(b0 + k) % uniq]), "frame %d of the batch differs from the oracle" % (b0 + k)
+    d_in.free()
+    d_out.free()
+
+
 def test_4k_rig_spot(ffi, SB, oracle):
     cfg, rig = W.CONFIG_4K, W.rig_4k()
     frames = W.synthetic_frames(1, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=9, kind="random")
