@@ -35,7 +35,8 @@
 // Ablation builds for profiling only (hipcc -DBEVW_ABL=n, never shipped): 1 no output store | 2 no source loads (synthetic
 // texels) | 3 every frame reads frame 0 (cache-resident source) | 4 every frame writes frame 0 (cache-resident output) |
 // 5 = 1 + 2 | 7 each wave stores 768 contiguous bytes (wrong place: cost of the 8 x 96-byte store shape) | 8 loads fetch whole
-// 128-byte lines, 8 lanes per line (wrong texels: cost of the per-lane 16-byte group requests)
+// 128-byte lines, 8 lanes per line (wrong texels: cost of the per-lane 16-byte group requests) | 9 = 7 + the 4 waves of a block
+// fetch ONE tile's groups (shared staging) | 10 = 9 with whole-line loads
 #ifndef BEVW_ABL
 #define BEVW_ABL 0
 #endif
@@ -250,7 +251,8 @@ __device__ __forceinline__ void pack_accs(const uint32_t acc[4][3], uint32_t &d0
 // one wave: tile from the class list, frames of the chunk.  lds: 4 * kPairPatch bytes (one patch per wave).
 // SLICES 1: whole-tile staging, 4: one slice per pixel slot (NSLOT == 1 only); ROUNDS: group rounds per step.
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
-__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds);
+__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds,
+                                               int tile_slot = 0);
 
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
 __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
@@ -263,11 +265,12 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
     if (slot >= a.nlist) return;
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
-    plan_pair_tile<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, tile, hdr, chunk, coop, lds);
+    plan_pair_tile<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, tile, hdr, chunk, coop, lds, slot);
 }
 
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
-__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds)
+__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds,
+                                               int tile_slot)
 {
     static_assert(SLICES == 1 || (SLICES == 4 && NSLOT == 1), "sliced staging is built for single-contributor tiles");
     static_assert(ROUNDS >= 1 && ROUNDS <= (SLICES == 1 ? kPairMaxRounds : kPairSliceRounds), "rounds per step");
@@ -316,7 +319,12 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
 #pragma unroll
     for (int s = 0; s < SLICES; ++s)
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) gs[s][r] = a.gsrc[((size_t)tile * kPairSrcSlots + s * kPairSliceRounds + r) * 64 + lane];
+        for (int r = 0; r < ROUNDS; ++r) {
+            // ablation 9 / 10: all four waves of a block fetch the group set of the block's FIRST tile (what block-cooperative
+            // staging would request from the L2: one copy per strip instead of one per tile)
+            const int src_tile = (BEVW_ABL == 9 || BEVW_ABL == 10) ? (int)__builtin_amdgcn_readfirstlane(a.tile_list[((int)(&a.tile_list[0] != nullptr) ? (tile_slot & ~3) : 0)]) : tile;
+            gs[s][r] = a.gsrc[((size_t)src_tile * kPairSrcSlots + s * kPairSliceRounds + r) * 64 + lane];
+        }
     uint32_t car0 = 0, car1 = 0, car2 = 0;
     if (!SUMS && a.car != nullptr && inimg) {
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
@@ -339,7 +347,7 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
         for (int r = 0; r < ROUNDS; ++r) {
             if (BEVW_ABL == 2 || BEVW_ABL == 5)
                 pf[ring][r] = pair_u32x4{gs[s][r] + (uint32_t)b, gs[s][r] * 3u, gs[s][r] ^ 0x5a5a5a5au, gs[s][r] + 77u};
-            else if (BEVW_ABL == 8) {
+            else if (BEVW_ABL == 8 || BEVW_ABL == 10) {
                 const uint32_t g8 = (uint32_t)__shfl((int)gs[s][r], lane & ~7, 64);
                 pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g8 == kPairNoGroup ? g8 : (g8 & ~127u) + (uint32_t)(lane & 7) * 16u), 0, 0);
             }
@@ -383,7 +391,7 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
         if ((BEVW_ABL == 1 || BEVW_ABL == 5) && !(d0 == 0x12345679u && d1 == 0x9abcdef1u && d2 == 77u)) return;
         uint8_t *img = a.out + (size_t)(BEVW_ABL == 4 ? 0 : min(b, b_end - 1)) * img_bytes;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)(BEVW_ABL == 7 ? (uint32_t)(tile % 4500) * 768u + (uint32_t)lane * 12u : ooff_masked), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)((BEVW_ABL == 7 || BEVW_ABL == 9 || BEVW_ABL == 10) ? (uint32_t)(tile % 4500) * 768u + (uint32_t)lane * 12u : ooff_masked), 0, 0);
     };
     // contribution of entry (s, j) accumulated onto px (saturating add of the second contributor)
     auto contrib = [&](int s, int j, int px[3]) {
@@ -483,10 +491,67 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
 
 // the pair-staged classes as kernels of their own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit profiles are
 // taken on)
+// EXPERIMENT (hipcc -DBEVW_SPF=1, per-class launches): a fifth wave per block pulls the 64-byte source sectors of its block's four
+// tiles into the L2 through the SCALAR cache path (s_load_dwordx16, data discarded), ahead of the four interpolating waves.
+// Idea: a vector load that misses to HBM occupies the CU's vector-L1 miss path ~12 clk, one that hits the L2 ~2.5 clk
+// (profiles/r02/sweeps.log); the scalar path is otherwise idle.
+#ifndef BEVW_SPF
+#define BEVW_SPF 0
+#endif
+typedef uint32_t pair_u32x16 __attribute__((ext_vector_type(16)));
+template <int ROUNDS>
+__device__ __forceinline__ void pair_prefetch_wave(const PlanArgs &a, uint32_t block_id)
+{
+    uint32_t chunk, group;
+    if (!plan_block_map(a, block_id, chunk, group)) return;
+    const int lane = threadIdx.x & 63;
+    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams;
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    uint32_t so[4][ROUNDS];
+    unsigned long long m[4][ROUNDS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int slot = (int)group * 4 + k;
+        const int tile = slot < a.nlist ? (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]) : -1;
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const uint32_t g = tile >= 0 ? a.gsrc[((size_t)tile * kPairSrcSlots + r) * 64 + lane] : kPairNoGroup;
+            const uint32_t sec = g & ~63u;
+            const uint32_t prev = (uint32_t)__shfl_up((int)sec, 1, 64);
+            so[k][r] = sec;
+            m[k][r] = __builtin_amdgcn_ballot_w64(g != kPairNoGroup && (lane == 0 || sec != prev));
+        }
+    }
+    pair_u32x16 sink = {};
+    for (int b = b_begin; b < b_end; ++b) {
+        const uint8_t *base = a.frames + (size_t)b * set_bytes;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int r = 0; r < ROUNDS; ++r) {
+                unsigned long long mask = m[k][r];
+                while (mask) {
+                    const int l = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const uint8_t *p = base + (uint32_t)__builtin_amdgcn_readlane((int)so[k][r], l);
+                    // "+s": the 16 destination SGPRs stay reserved for `sink` over the whole loop -- with "=s" the compiler treats
+                    // them as free after the statement and parks loop temporaries there, which the returning load then overwrites
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "+s"(sink) : "s"(p));
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink));
+    }
+    if (sink[0] == 0x12345678u && lane == 0) a.psums[0] = sink[1];   // keeps the loads alive
+}
+
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
-__global__ void __launch_bounds__(256) k_plan_pair(PlanArgs a)
+__global__ void __launch_bounds__(BEVW_SPF ? 320 : 256) k_plan_pair(PlanArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kPairPatch + kStripBytes];   // (the body uses ROUNDS * 2 KB of each wave's 8)
+    if (BEVW_SPF && threadIdx.x >= 256) {   // the fifth wave: prefetch (whole-tile classes) or nothing
+        if (SLICES == 1) pair_prefetch_wave<ROUNDS>(a, blockIdx.x);
+        return;
+    }
     plan_pair_body<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, blockIdx.x, patch);
 }
 

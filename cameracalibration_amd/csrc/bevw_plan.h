@@ -1416,6 +1416,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
 #define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM, ...)                                                                  \
     do {                                                                                                            \
         const dim3 grid(grid_blocks());                                                                             \
+        const dim3 block((#KERNEL)[7] == 'p' && BEVW_SPF ? 320 : 256);   /* k_plan_pair + its prefetch wave */        \
         if (blend && sums) hipLaunchKernelGGL((KERNEL<LX, NS, true, true __VA_ARGS__>), grid, block, SHMEM, st, a);  \
         else if (blend) hipLaunchKernelGGL((KERNEL<LX, NS, true, false __VA_ARGS__>), grid, block, SHMEM, st, a);    \
         else if (sums) hipLaunchKernelGGL((KERNEL<LX, NS, false, true __VA_ARGS__>), grid, block, SHMEM, st, a);     \
