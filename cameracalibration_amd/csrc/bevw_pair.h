@@ -1,10 +1,10 @@
 // bevw_pair.h -- the PAIR-STAGED schedule of the tile plan (included by bevw_plan.h; round 2).
 //
-// Why.  The sector-staged body (plan_staged_body) reads every 2x2 footprint back from LDS as raw interleaved BGR bytes
-// at an arbitrary byte offset: two 16-byte windows per pixel (ds_read2_b64, 8 LDS cycles each) and 14 select / realign
-// instructions in front of the dot products -- 124 integer VALU instructions (4.7 clk each on gfx950,
-// profiles/r02/valu_rates.log) and ~115 LDS cycles per tile-frame, issued from 2.8 waves per SIMD (142 VGPRs).  Here the
-// realignment is done ONCE PER SOURCE TEXEL while the texels are staged instead of once per BEV pixel and tap:
+// Why.  Round 1's sector-staged body (removed; profiles/r01/, profiles/r02/sweeps.log) read every 2x2 footprint back from
+// LDS as raw interleaved BGR bytes at an arbitrary byte offset: two 16-byte windows per pixel (ds_read2_b64, 8 LDS cycles
+// each) and 14 select / realign instructions in front of the dot products -- 124 integer VALU instructions (4.7 clk each
+// on gfx950, profiles/r02/valu_rates.log) and ~115 LDS cycles per tile-frame, issued from 2.8 waves per SIMD (142 VGPRs).
+// Here the realignment is done ONCE PER SOURCE TEXEL while the texels are staged instead of once per BEV pixel and tap:
 //
 //   * source texels are fetched in GROUPS: 16 bytes from a 4-byte aligned address 12 * g (g = group index inside the
 //     4-camera frame set; rows are whole numbers of groups because fw % 4 == 0), i.e. texels 4g .. 4g+4 of one source
@@ -32,25 +32,6 @@
 // The arithmetic is the one of bilinear_rows_b2: (sum p * w + 512) >> 10 in the separable form, exact in integers.
 #pragma once
 
-// Ablation builds for profiling only (hipcc -DBEVW_ABL=n, never shipped): 1 no output store | 2 no source loads (synthetic
-// texels) | 3 every frame reads frame 0 (cache-resident source) | 4 every frame writes frame 0 (cache-resident output) |
-// 5 = 1 + 2 | 7 each wave stores 768 contiguous bytes (wrong place: cost of the 8 x 96-byte store shape) | 8 loads fetch whole
-// 128-byte lines, 8 lanes per line (wrong texels: cost of the per-lane 16-byte group requests) | 9 = 7 + the 4 waves of a block
-// fetch ONE tile's groups (shared staging) | 10 = 9 with whole-line loads
-#ifndef BEVW_ABL
-#define BEVW_ABL 0
-#endif
-// frames whose groups are in flight ahead of the one being interpolated, whole-tile staging with 1 / 2 / 4 rounds
-#ifndef BEVW_PAIR_DEPTH1
-#define BEVW_PAIR_DEPTH1 2
-#endif
-#ifndef BEVW_PAIR_DEPTH2
-#define BEVW_PAIR_DEPTH2 2
-#endif
-#ifndef BEVW_PAIR_DEPTH4
-#define BEVW_PAIR_DEPTH4 2
-#endif
-
 namespace bevw {
 
 constexpr uint32_t kHdrPaired = 128u;        // tile has a pair-staging plan; mode in header bits 8..9
@@ -61,12 +42,6 @@ constexpr int kPairPatch = kPairMaxRounds * kPairRoundBytes;   // LDS per wave
 constexpr int kPairSrcSlots = 8;             // gsrc entries per tile and lane: [round] (whole tile) or [slice][2 rounds]
 // mode -> (slices, rounds): 0 = (1, 1), 1 = (1, 2), 2 = (1, 4), 3 = (4, 2)
 constexpr int kPairModes = 4;
-// Cooperative store: the 4 waves of a block whose tiles are x-neighbours of one tile row (a 128 x 8 pixel strip) exchange
-// their output bytes through LDS so that every wave stores two full 384-byte rows of the strip instead of eight 96-byte
-// row segments: 13-14 sector requests per store instruction instead of 19 (the L1 -> L2 request rate, not bytes, bounds
-// the step: profiles/r02/run6_ablations_store_shape_line_loads.log).  Two buffers, one barrier per frame.
-constexpr int kStripDwords = 800;                // per buffer: (64 / LX) rows x (4 * LX * 3 + 1) dwords (the + 1 spreads the rows over the banks)
-constexpr int kStripBytes = 2 * kStripDwords * 4;   // per block
 constexpr uint32_t kPairNoGroup = 0x80000000u;   // source offset of a lane without a group (frame sets are < 2 GB)
 constexpr uint32_t kBufferWord3 = 0x00020000u;   // raw buffer descriptor, dword 3 (gfx9 family: DATA_FORMAT 32)
 
@@ -97,12 +72,12 @@ __device__ inline int pair_distinct(const uint32_t *cand, uint32_t use, uint32_t
 }
 
 // plan compiler: one wave per tile.  Reads the base entries (byte offset of the footprint, meta), brings them to store
-// order (interleaved tiles are rewritten exactly as k_plan_stage_build does), picks the mode, assigns every distinct group
+// order (tiles compiled lane-interleaved are rewritten to pixel slot j of lane l = pixel 4 l + j), picks the mode, assigns every distinct group
 // a slot (ascending address order: lane = slot % 64, round = slot / 64) and rewrites every entry to the LDS byte addresses
 // of its two pair entries.
 __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int ntiles,
                                                          uint32_t row_bytes, uint32_t set_bytes, uint2 *__restrict__ plan_pr,
-                                                         uint32_t *__restrict__ gsrc, int perm)
+                                                         uint32_t *__restrict__ gsrc)
 {
     constexpr int kMax = kPairMaxRounds * 64;   // groups per step, whole-tile staging
     constexpr int kMaxSlice = kPairSliceRounds * 64;
@@ -141,21 +116,8 @@ __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict_
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (list[mid] < key) lo = mid + 1; else hi = mid; }
         return (uint32_t)lo;
     };
-    // slot (rank in ascending address order) -> lane of its round.  perm 0: lane = rank % 64 (consecutive lanes fetch
-    // consecutive groups of a row); 1: consecutive lane QUADS fetch groups 3 quads (144 bytes) apart; 2: consecutive lanes
-    // fetch groups 11 apart (132 bytes) -- so that neighbouring lanes of one load do not hit the same (pending) 128-byte line
-    auto lane_of = [perm](uint32_t pos) {
-        if (perm == 1) return (((pos >> 2) * 11u) & 15u) * 4u + (pos & 3u);
-        if (perm == 2) return (pos * 35u) & 63u;
-        return pos;
-    };
-    auto pos_of = [perm](uint32_t ln) {
-        if (perm == 1) return (((ln >> 2) * 3u) & 15u) * 4u + (ln & 3u);
-        if (perm == 2) return (ln * 11u) & 63u;
-        return ln;
-    };
-    auto lds_addr = [&](uint32_t slot, uint32_t k) {
-        return (slot >> 6) * (uint32_t)kPairRoundBytes + (k >> 1) * 1024u + lane_of(slot & 63u) * 16u + (k & 1u) * 8u;
+    auto lds_addr = [](uint32_t slot, uint32_t k) {
+        return (slot >> 6) * (uint32_t)kPairRoundBytes + (k >> 1) * 1024u + (slot & 63u) * 16u + (k & 1u) * 8u;
     };
     auto rewrite = [&](int k, int count) {
         uint2 o = make_uint2(0u, e[k].y & ~kMetaValid);
@@ -167,7 +129,7 @@ __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict_
     };
     auto write_src = [&](int base, int count, int rounds) {
         for (int r = 0; r < rounds; ++r) {
-            const int slot = r * 64 + (int)pos_of((uint32_t)lane);
+            const int slot = r * 64 + lane;
             // lanes without a group carry an out-of-range offset: the buffer load returns zeros without a memory access
             gsrc[((size_t)tile * kPairSrcSlots + base + r) * 64 + lane] = slot < count ? list[slot] * 12u : kPairNoGroup;
         }
@@ -248,30 +210,17 @@ __device__ __forceinline__ void pack_accs(const uint32_t acc[4][3], uint32_t &d0
     d2 = __builtin_amdgcn_perm(acc[3][2], acc[3][1], 0x06020c0cu) | __builtin_amdgcn_perm(acc[3][0], acc[2][2], 0x0c0c0602u);
 }
 
-// one wave: tile from the class list, frames of the chunk.  lds: 4 * kPairPatch bytes (one patch per wave).
+// one wave: tile from the class list, frames of the chunk.  lds: the block's patches, 4 x (rounds per step x 2 KB).
 // SLICES 1: whole-tile staging, 4: one slice per pixel slot (NSLOT == 1 only); ROUNDS: group rounds per step.
-template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
-__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds,
-                                               int tile_slot = 0);
-
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
 __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
 {
     uint32_t chunk, group;
     if (!plan_block_map(a, block_id, chunk, group)) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = (int)group * 4 + wave;
-    const bool coop = (int)group * 4 < a.ncoop;   // block-uniform: the block's 4 tiles are x-neighbours (all 4 waves are live)
+    const int slot = (int)group * 4 + (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (slot >= a.nlist) return;
     const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
     const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
-    plan_pair_tile<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, tile, hdr, chunk, coop, lds, slot);
-}
-
-template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
-__device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint32_t hdr, uint32_t chunk, bool coop, uint8_t *lds,
-                                               int tile_slot)
-{
     static_assert(SLICES == 1 || (SLICES == 4 && NSLOT == 1), "sliced staging is built for single-contributor tiles");
     static_assert(ROUNDS >= 1 && ROUNDS <= (SLICES == 1 ? kPairMaxRounds : kPairSliceRounds), "rounds per step");
     constexpr int LY = 64 / LX;
@@ -284,19 +233,9 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
     const bool inimg = x0 < a.bw && y < a.bh;
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
     const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
-    // store position: the lane's own pixel quad, or (cooperative blocks) quad (lane % 32) of strip row 2 * wave + lane / 32
-    uint32_t ooff_masked = inimg ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: not written
-    uint32_t *const strip = reinterpret_cast<uint32_t *>(lds + 4 * kPairPatch);
-    constexpr int kStripPitch = 4 * LX * 3 + 1;      // dwords per strip row
-    static_assert(LY * kStripPitch <= kStripDwords, "strip buffer");
-    const int srow = (64 * wave + lane) / (4 * LX), scol = (64 * wave + lane) % (4 * LX);   // pixel quad this lane stores
-    const uint32_t strip_wr = (uint32_t)ly_ * kStripPitch + (uint32_t)wave * (LX * 3) + (uint32_t)lx_ * 3;
-    const uint32_t strip_rd = (uint32_t)srow * kStripPitch + (uint32_t)scol * 3;
-    if (coop) {
-        const int sx0 = (tx - wave) * (LX * 4) + scol * 4, sy = ty * LY + srow;
-        ooff_masked = (sx0 < a.bw && sy < a.bh) ? ((uint32_t)sy * a.bw + sx0) * 3 : kPairNoGroup;
-    }
-    uint8_t *const patch = lds + wave * kPairPatch;
+    const uint32_t ooff_masked = inimg ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: not written
+    constexpr int kWavePatch = (SLICES == 1 ? ROUNDS : kPairSliceRounds) * kPairRoundBytes;   // LDS this class needs per wave
+    uint8_t *const patch = lds + wave * kWavePatch;
     const uint2 *const pw = reinterpret_cast<const uint2 *>(patch);
 
     // per entry (store order): qword index of the two pair entries inside the wave's patch, x / y weights
@@ -319,12 +258,7 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
 #pragma unroll
     for (int s = 0; s < SLICES; ++s)
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            // ablation 9 / 10: all four waves of a block fetch the group set of the block's FIRST tile (what block-cooperative
-            // staging would request from the L2: one copy per strip instead of one per tile)
-            const int src_tile = (BEVW_ABL == 9 || BEVW_ABL == 10) ? (int)__builtin_amdgcn_readfirstlane(a.tile_list[((int)(&a.tile_list[0] != nullptr) ? (tile_slot & ~3) : 0)]) : tile;
-            gs[s][r] = a.gsrc[((size_t)src_tile * kPairSrcSlots + s * kPairSliceRounds + r) * 64 + lane];
-        }
+        for (int r = 0; r < ROUNDS; ++r) gs[s][r] = a.gsrc[((size_t)tile * kPairSrcSlots + s * kPairSliceRounds + r) * 64 + lane];
     uint32_t car0 = 0, car1 = 0, car2 = 0;
     if (!SUMS && a.car != nullptr && inimg) {
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
@@ -335,24 +269,17 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
 
     // D steps (frames, or slices of a frame) have their groups in flight in registers ahead of the one being interpolated
-    constexpr int D = SLICES == 4 ? 2 : (ROUNDS == 1 ? BEVW_PAIR_DEPTH1 : (ROUNDS == 2 ? BEVW_PAIR_DEPTH2 : BEVW_PAIR_DEPTH4));
+    // (4 and 8 measured no faster: profiles/r02/sweeps.log)
+    constexpr int D = 2;
     pair_u32x4 pf[D][ROUNDS];
     // Loads and stores go through raw buffer descriptors (wave-uniform base in SGPRs + 32-bit lane offset: no 64-bit address
     // arithmetic, and a lane whose offset is out of range -- kPairNoGroup, or a pixel quad right of the image -- costs no
     // memory access and no branch, so every vector-memory instruction is issued unconditionally and counted exactly).
     auto issue = [&](int b, int s, int ring) {   // s, ring: compile-time after unrolling
-        const uint8_t *src = a.frames + (size_t)(BEVW_ABL == 3 ? 0 : min(b, b_end - 1)) * set_bytes;
+        const uint8_t *src = a.frames + (size_t)min(b, b_end - 1) * set_bytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            if (BEVW_ABL == 2 || BEVW_ABL == 5)
-                pf[ring][r] = pair_u32x4{gs[s][r] + (uint32_t)b, gs[s][r] * 3u, gs[s][r] ^ 0x5a5a5a5au, gs[s][r] + 77u};
-            else if (BEVW_ABL == 8 || BEVW_ABL == 10) {
-                const uint32_t g8 = (uint32_t)__shfl((int)gs[s][r], lane & ~7, 64);
-                pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(g8 == kPairNoGroup ? g8 : (g8 & ~127u) + (uint32_t)(lane & 7) * 16u), 0, 0);
-            }
-            else pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[s][r], 0, 0);
-        }
+        for (int r = 0; r < ROUNDS; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[s][r], 0, 0);
     };
     auto land = [&](int ring) {
 #pragma unroll
@@ -381,17 +308,10 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
         if (car_any) add_car(P, car0, car1, car2);
     };
     auto store = [&](int b, uint32_t d0, uint32_t d1, uint32_t d2) {
-        if (coop) {
-            uint32_t *sb = strip + ((b - b_begin) & 1) * kStripDwords;
-            sb[strip_wr] = d0; sb[strip_wr + 1] = d1; sb[strip_wr + 2] = d2;
-            __syncthreads();
-            d0 = sb[strip_rd]; d1 = sb[strip_rd + 1]; d2 = sb[strip_rd + 2];
-        }
         // a frame index past the end of the chunk re-writes the last frame with the same bytes
-        if ((BEVW_ABL == 1 || BEVW_ABL == 5) && !(d0 == 0x12345679u && d1 == 0x9abcdef1u && d2 == 77u)) return;
-        uint8_t *img = a.out + (size_t)(BEVW_ABL == 4 ? 0 : min(b, b_end - 1)) * img_bytes;
+        uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)((BEVW_ABL == 7 || BEVW_ABL == 9 || BEVW_ABL == 10) ? (uint32_t)(tile % 4500) * 768u + (uint32_t)lane * 12u : ooff_masked), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked, 0, 0);
     };
     // contribution of entry (s, j) accumulated onto px (saturating add of the second contributor)
     auto contrib = [&](int s, int j, int px[3]) {
@@ -491,67 +411,10 @@ __device__ __forceinline__ void plan_pair_tile(const PlanArgs &a, int tile, uint
 
 // the pair-staged classes as kernels of their own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit profiles are
 // taken on)
-// EXPERIMENT (hipcc -DBEVW_SPF=1, per-class launches): a fifth wave per block pulls the 64-byte source sectors of its block's four
-// tiles into the L2 through the SCALAR cache path (s_load_dwordx16, data discarded), ahead of the four interpolating waves.
-// Idea: a vector load that misses to HBM occupies the CU's vector-L1 miss path ~12 clk, one that hits the L2 ~2.5 clk
-// (profiles/r02/sweeps.log); the scalar path is otherwise idle.
-#ifndef BEVW_SPF
-#define BEVW_SPF 0
-#endif
-typedef uint32_t pair_u32x16 __attribute__((ext_vector_type(16)));
-template <int ROUNDS>
-__device__ __forceinline__ void pair_prefetch_wave(const PlanArgs &a, uint32_t block_id)
-{
-    uint32_t chunk, group;
-    if (!plan_block_map(a, block_id, chunk, group)) return;
-    const int lane = threadIdx.x & 63;
-    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams;
-    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
-    uint32_t so[4][ROUNDS];
-    unsigned long long m[4][ROUNDS];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int slot = (int)group * 4 + k;
-        const int tile = slot < a.nlist ? (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]) : -1;
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const uint32_t g = tile >= 0 ? a.gsrc[((size_t)tile * kPairSrcSlots + r) * 64 + lane] : kPairNoGroup;
-            const uint32_t sec = g & ~63u;
-            const uint32_t prev = (uint32_t)__shfl_up((int)sec, 1, 64);
-            so[k][r] = sec;
-            m[k][r] = __builtin_amdgcn_ballot_w64(g != kPairNoGroup && (lane == 0 || sec != prev));
-        }
-    }
-    pair_u32x16 sink = {};
-    for (int b = b_begin; b < b_end; ++b) {
-        const uint8_t *base = a.frames + (size_t)b * set_bytes;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int r = 0; r < ROUNDS; ++r) {
-                unsigned long long mask = m[k][r];
-                while (mask) {
-                    const int l = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const uint8_t *p = base + (uint32_t)__builtin_amdgcn_readlane((int)so[k][r], l);
-                    // "+s": the 16 destination SGPRs stay reserved for `sink` over the whole loop -- with "=s" the compiler treats
-                    // them as free after the statement and parks loop temporaries there, which the returning load then overwrites
-                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "+s"(sink) : "s"(p));
-                }
-            }
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink));
-    }
-    if (sink[0] == 0x12345678u && lane == 0) a.psums[0] = sink[1];   // keeps the loads alive
-}
-
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
-__global__ void __launch_bounds__(BEVW_SPF ? 320 : 256) k_plan_pair(PlanArgs a)
+__global__ void __launch_bounds__(256) k_plan_pair(PlanArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * kPairPatch + kStripBytes];   // (the body uses ROUNDS * 2 KB of each wave's 8)
-    if (BEVW_SPF && threadIdx.x >= 256) {   // the fifth wave: prefetch (whole-tile classes) or nothing
-        if (SLICES == 1) pair_prefetch_wave<ROUNDS>(a, blockIdx.x);
-        return;
-    }
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * (SLICES == 1 ? ROUNDS : kPairSliceRounds) * kPairRoundBytes];
     plan_pair_body<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, blockIdx.x, patch);
 }
 

@@ -8,9 +8,12 @@
 // pixels per lane = one 12-byte store), loads its slice of the plan ONCE into registers, and then loops over the
 // frames of its batch chunk.  Address, weight and mask arithmetic is hoisted out of the batch loop; the fixed-point
 // bilinear runs on v_dot4_u32_u8 / v_dot2_u32_u16.  Two ways to get the texels, chosen per tile when the plan is built:
-//   * LDS-staged (plan_staged_body): the tile's <= 32 distinct 64-byte source sectors arrive through two LDS-DMA
-//     instructions per frame, two frames ahead, and the 2x2 footprints are read back from LDS;
-//   * gather (plan_gather_tile): sparse tiles fetch every footprint row as an aligned 12-byte window from L1.
+//   * pair-staged (bevw_pair.h, round 2): the tile's source texels are fetched in row-run groups, turned ONCE into
+//     dot-product-ready texel pairs in a wave-private LDS patch, and every pixel reads two 8-byte pair entries;
+//   * gather (plan_gather_tile): the schedule of round 1 for what cannot be pair-staged (frame widths that are not a
+//     multiple of 4 pixels, the handful of sparse two-contributor tiles): every footprint row as an aligned 12-byte window.
+// (Round 1's sector-staged schedule -- 64-byte sectors through an LDS-DMA ring, footprints realigned per pixel -- was
+// measured against the pair-staged one, profiles/r02/sweeps.log, and removed.)
 // A step is ONE launch (k_plan_all): every tile class of the batch in one grid, longest-running classes first.
 //
 // Layout.  plan[tile][slot 0..7][lane 0..63] (8 B each, so every plan load is a fully coalesced 512 B wave access);
@@ -33,10 +36,6 @@ constexpr uint32_t kHdrSlow = 2u;          // some entry of the tile needs the p
 constexpr uint32_t kHdrEmpty = 4u;         // no contributor at all (car rectangle): tile is zero + car
 constexpr uint32_t kHdrTransposed = 16u;   // lanes of a quad run along BEV y (see lane_xy)
 constexpr uint32_t kHdrInterleaved = 32u;  // x-major tile whose lanes COMPUTE interleaved pixels (see pixel ownership)
-constexpr uint32_t kHdrStaged = 64u;       // tile has an LDS staging plan (<= kStageSectors source sectors)
-constexpr int kStageInstr = 2;             // LDS-DMA instructions per tile-frame (1 KB = 16 sectors each)
-constexpr int kStageSectors = 16 * kStageInstr;
-constexpr int kStageBytes = 1024 * kStageInstr + 64;   // per wave and buffer (64 B slack for the 12-byte read windows)
 constexpr int kPlanLXDefault = 8;          // lanes along x -> 32 x 8 pixel tiles (best of 4 / 8 / 16 on config 3)
 
 struct Plan {
@@ -57,13 +56,6 @@ struct Plan {
     // tile classes (lists of tile indices, row-major order kept): each class has its own lean kernel
     void *list_single = nullptr, *list_double = nullptr, *list_slow = nullptr, *list_empty = nullptr;
     int n_single = 0, n_double = 0, n_slow = 0, n_empty = 0;
-    // LDS-staged variant: tiles whose footprints fit kStageSectors sectors get a second entry table (LDS addresses) and a
-    // DMA list; st_* lists hold them, rs_* the single/double tiles that stay on the L1-gather kernels
-    void *entries_st = nullptr;  // uint2[ntiles][8][64]: x = LDS byte address of footprint row 0 | row 1 << 16, y = meta
-    void *dma = nullptr;         // uint32[ntiles][kStageInstr][64]: per-lane source offset of each LDS-DMA instruction
-    void *list_st_single = nullptr, *list_st_double = nullptr, *list_rs_single = nullptr, *list_rs_double = nullptr;
-    int n_st_single = 0, n_st_double = 0, n_rs_single = 0, n_rs_double = 0;
-    bool staged_ok = false;
     // pair-staged variant (bevw_pair.h): tiles whose footprints fit kPairRounds x 64 groups of 4 texels; pr_* lists hold
     // them, rp_* the single / double tiles that stay on the L1-gather kernels when this schedule is selected
     void *entries_pr = nullptr;  // uint2[ntiles][8][64]: x = LDS byte address of the pair entry of row 0 | row 1 << 16, y = meta
@@ -72,9 +64,7 @@ struct Plan {
     // (whole-tile 1 / 2 rounds)
     void *list_pr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_pr[6] = {0, 0, 0, 0, 0, 0};
-    int n_pr_coop[6] = {0, 0, 0, 0, 0, 0};   // leading entries of each list that form blocks of 4 x-neighbouring tiles
-    void *list_spatial = nullptr;            // every tile k_plan_spatial runs (all but border and sparse two-contributor tiles)
-    int n_spatial = 0;
+
     void *list_rp_single = nullptr, *list_rp_double = nullptr;
     int n_rp_single = 0, n_rp_double = 0;
     bool paired_ok = false;
@@ -422,13 +412,10 @@ struct PlanArgs {
     int tiles_x, ntiles, ngroups;
     int ncams;                   // images per frame set: 4 for BevGenerator, 1 for a plain cv2.remap
     int batch, nb, nchunks, xcd_affine;
-    const uint2 *plan_st;        // LDS-staged entries (k_plan_staged)
-    const uint32_t *dma;         // LDS-DMA source offsets [ntiles][kStageInstr][64]
     const uint2 *plan_pr;        // pair-staged entries (plan_pair_body)
     const uint32_t *gsrc;        // group source offsets [ntiles][kPairRounds][64]
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
     int nlist;
-    int ncoop;                   // pair classes: the first ncoop list entries are blocks of 4 x-neighbouring tiles (cooperative store)
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -544,8 +531,8 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
 
 // ---------------------------------------------------------------------------------------------------------------
 // gather class kernels (no luminance round trip): every contributor of the tile is an interior footprint.
-//   NSLOT = 1: <= 1 contributor per pixel (inside a trapezoid)                -> list_single / list_rs_single
-//   NSLOT = 2: some pixel has two (direct-stitch seams, blend overlaps)       -> list_double / list_rs_double
+//   NSLOT = 1: <= 1 contributor per pixel (inside a trapezoid)                -> list_single / list_rp_single
+//   NSLOT = 2: some pixel has two (direct-stitch seams, blend overlaps)       -> list_double / list_rp_double
 // Register diet: per pixel and slot only {offset, misalignment, wx, wy (, wf)} live across the batch loop, so many waves
 // fit a SIMD and the gathers of many tiles overlap.  Same block -> (chunk, tile) mapping as k_stitch_plan.
 // SUMS: emit per-tile channel sums (balance on pre-shifted frames) and leave the car to k_gain.
@@ -722,267 +709,6 @@ __device__ __forceinline__ void plan_empty_body(const PlanArgs &a, uint32_t bloc
 template <int LX>
 __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a) { plan_empty_body<LX>(a, blockIdx.x); }
 
-// one wave, one empty tile
-template <int LX>
-__device__ __forceinline__ void plan_empty_tile(const PlanArgs &a, int tile, int b_begin, int b_end)
-{
-    constexpr int LY = 64 / LX;
-    const int lane = threadIdx.x & 63;
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    int lx_, ly_;
-    lane_xy(lane, LX, false, lx_, ly_);
-    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
-    if (!(x0 < a.bw && y < a.bh)) return;
-    const size_t img_bytes = (size_t)a.bw * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
-    if (a.car != nullptr) {
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
-        c0 = cp[0]; c1 = cp[1]; c2 = cp[2];
-    }
-    for (int b = b_begin; b < b_end; ++b) {
-        uint32_t *op = reinterpret_cast<uint32_t *>(a.out + (size_t)b * img_bytes + ooff);
-        op[0] = c0; op[1] = c1; op[2] = c2;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-staged schedule.  The gathers of k_plan_lean are bound by the per-instruction cost of the vector-memory pipe
-// (8 gather instructions per tile-frame, each carrying ~3 sector misses: DESIGN.md section 4).  Here the ~27 distinct
-// 64-byte source sectors of a tile-frame are fetched by TWO LDS-DMA instructions (global_load_lds_dwordx4: every lane
-// brings 16 bytes, 4 lanes = one sector, the data lands in LDS in lane order) into a wave-private, double-buffered
-// 2 KB patch, one frame ahead of its use; the 2x2 footprints are then read back from LDS (4-byte aligned 12-byte
-// windows, same v_alignbyte realignment as the global path).  The plan compiler assigns every distinct sector of the
-// tile a slot (ascending address order, so a footprint that straddles two sectors of a row finds them adjacent) and
-// rewrites the entries to LDS byte addresses.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) k_plan_stage_build(const uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int ntiles,
-                                                          uint32_t row_bytes, uint32_t set_bytes, uint2 *__restrict__ plan_st,
-                                                          uint32_t *__restrict__ dma)
-{
-    __shared__ uint32_t cand[64 * 32];
-    __shared__ uint32_t list[kStageSectors + 1];
-    __shared__ int s_count;
-    const int tile = blockIdx.x, lane = threadIdx.x;
-    if (tile >= ntiles) return;
-    const uint32_t h = hdr[tile];
-    if (h & (kHdrSlow | kHdrEmpty)) return;
-    uint2 e[8];
-    bool overrun = false;
-    for (int k = 0; k < 8; ++k) {
-        e[k] = plan[((size_t)tile * 8 + k) * 64 + lane];
-        uint32_t c[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        if (e[k].y & kMetaValid) {
-            const uint32_t o0 = e[k].x, o1 = o0 + row_bytes;
-            c[0] = o0 >> 6; c[1] = (o0 + 5) >> 6; c[2] = o1 >> 6; c[3] = (o1 + 5) >> 6;
-            if (((o1 + 5) >> 6) * 64 + 64 > set_bytes) overrun = true;   // DMA moves whole sectors
-        }
-        for (int i = 0; i < 4; ++i) cand[lane * 32 + k * 4 + i] = c[i];
-    }
-    if (lane == 0) s_count = 0;
-    __syncthreads();
-    // distinct sectors in ascending order: repeated extraction of the smallest candidate above the last one taken
-    uint32_t last = 0;
-    bool first = true, fits = !__any(overrun);
-    for (int it = 0; it <= kStageSectors && fits; ++it) {
-        uint32_t m = 0xffffffffu;
-        for (int i = 0; i < 32; ++i) {
-            const uint32_t v = cand[lane * 32 + i];
-            if (v != 0xffffffffu && (first || v > last)) m = min(m, v);
-        }
-        for (int off = 32; off > 0; off >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, off, 64));
-        if (m == 0xffffffffu) break;
-        if (it == kStageSectors) { fits = false; break; }
-        if (lane == 0) { list[it] = m; s_count = it + 1; }
-        last = m; first = false;
-    }
-    __syncthreads();
-    const int count = s_count;
-    if (!fits || count == 0) return;
-    // The staged kernel needs no quad coalescing, so interleaved tiles are rewritten to store order here: compute pixel
-    // (slot j of lane l) -> the lane that STORES it (lane (l & ~3) + j, slot l & 3) -- and the LDS exchange disappears.
-    const bool inter = (h & kHdrInterleaved) != 0;
-    for (int k = 0; k < 8; ++k) {
-        uint2 o = make_uint2(0u, e[k].y & ~kMetaValid);
-        if (e[k].y & kMetaValid) {
-            const uint32_t o0 = e[k].x, o1 = o0 + row_bytes;
-            uint32_t s0 = 0, s1 = 0;
-            for (int i = 0; i < count; ++i) { if (list[i] == (o0 >> 6)) s0 = i; if (list[i] == (o1 >> 6)) s1 = i; }
-            o = make_uint2((s0 * 64 + (o0 & 63u)) | ((s1 * 64 + (o1 & 63u)) << 16), e[k].y);
-        }
-        const int j = k & 3, sl = k & 4;
-        const int dst_lane = inter ? (lane & ~3) + j : lane, dst_slot = inter ? sl + (lane & 3) : k;
-        plan_st[((size_t)tile * 8 + dst_slot) * 64 + dst_lane] = o;
-    }
-    for (int k = 0; k < kStageInstr; ++k) {
-        const int slot = k * 16 + lane / 4;
-        dma[((size_t)tile * kStageInstr + k) * 64 + lane] = slot < count ? list[slot] * 64u + (uint32_t)(lane % 4) * 16u : 0u;
-    }
-    if (lane == 0) hdr[tile] = h | kHdrStaged;
-}
-
-// three LDS patches per wave (stage_0/1/2, 4 waves x kStageBytes each): frame b is read while b+1 and b+2 are in flight (one
-// HBM round trip is longer than one frame of work of all the waves of a SIMD, so a plain double buffer still stalls)
-template <int LX, int NSLOT, bool BLEND, bool SUMS>
-__device__ __forceinline__ void plan_staged_body(const PlanArgs &a, uint32_t block_id, uint8_t *stage_0, uint8_t *stage_1,
-                                                 uint8_t *stage_2)
-{
-    constexpr int LY = 64 / LX;
-    uint32_t chunk, group;
-    if (!plan_block_map(a, block_id, chunk, group)) return;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = (int)group * 4 + wave;
-    if (slot >= a.nlist) return;
-    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
-    const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
-    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    int lx_, ly_;
-    lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
-    const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
-    const bool inimg = x0 < a.bw && y < a.bh;
-    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
-
-    // per entry (already in store order: k_plan_stage_build): qword index of the 16-byte window (two 8-byte aligned LDS
-    // words, one ds_read2_b64) of each footprint row inside the wave's patch, byte offset 0..7 of the footprint inside
-    // it, x / y weights (as in k_plan_lean)
-    uint32_t i0[NSLOT][4], i1[NSLOT][4], mis[NSLOT][4], wx[NSLOT][4], wy[NSLOT][4];
-    float wf[NSLOT][4];
-#pragma unroll
-    for (int s = 0; s < NSLOT; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint2 e = a.plan_st[((size_t)tile * 8 + s * 4 + j) * 64 + lane];
-            const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
-            const bool valid = e.y & kMetaValid;
-            const uint32_t a0 = e.x & 0xffffu, a1 = e.x >> 16;
-            i0[s][j] = a0 >> 3; i1[s][j] = a1 >> 3; mis[s][j] = a0 & 7u;   // rows are a multiple of 64 bytes apart: same offset
-            wx[s][j] = valid ? ((32 - fx) | (fx << 24)) : 0u;
-            wy[s][j] = ((32 - fy) << 6) | (fy << 22);
-            wf[s][j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
-        }
-    uint32_t dsrc[kStageInstr];
-#pragma unroll
-    for (int k = 0; k < kStageInstr; ++k) dsrc[k] = a.dma[((size_t)tile * kStageInstr + k) * 64 + lane];
-    uint32_t car0 = 0, car1 = 0, car2 = 0;
-    if (!SUMS && a.car != nullptr && inimg) {
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
-        car0 = cp[0]; car1 = cp[1]; car2 = cp[2];
-    }
-    const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
-
-    typedef __attribute__((address_space(3))) uint8_t lds_u8;
-    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
-    const uint8_t *fb = a.frames + (size_t)b_begin * set_bytes;
-    uint8_t *ob = a.out + (size_t)b_begin * img_bytes + ooff;
-
-    // The LDS-DMA is issued through inline asm: the compiler orders every later LDS read behind ALL pending LDS-DMA it
-    // knows about (vmcnt(0)), which would serialise the ring.  Hidden from it, only the explicit vmcnt below governs
-    // the patches.  (Unknown vector loads can only make compiler-placed vmcnt waits longer, never shorter: loads retire
-    // in issue order.)
-    auto stage_frame = [&](const uint8_t *src, uint8_t *dst_generic) {
-        const uint32_t dst = (uint32_t)(uintptr_t)(lds_u8 *)dst_generic;
-#pragma unroll
-        for (int k = 0; k < kStageInstr; ++k) {
-            const uint8_t *g = src + dsrc[k];
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst + k * 1024), "v"(g) : "memory", "m0");
-        }
-    };
-    auto one_frame = [&](const uint8_t *patch_cur, uint8_t *patch_fill, int b) {
-        // refill the patch that frame b-1 used with frame b+2 (past the end of the chunk: the last frame again, so the
-        // instruction count per iteration is uniform)
-        const int ahead = min(b + 2, b_end - 1) - b;
-        stage_frame(fb + (size_t)ahead * set_bytes, patch_fill);
-        // frame b's patch (issued two iterations ago) must have landed.  Vector-memory operations retire in order, so it is
-        // enough to bound how many YOUNGER ones may still be in flight: the LDS-DMA of frames b+1 and b+2 (2 x kStageInstr)
-        // plus the pixel stores issued since (none for the chunk's first frame, one for its second, two afterwards; every
-        // tile has a lane inside the image, so that store is always issued, and the extra stores of SUMS only make the
-        // wait safer)
-        if (b == b_begin) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr) : "memory");
-        else if (b == b_begin + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr + 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kStageInstr + 2) : "memory");
-        const uint2 *w = reinterpret_cast<const uint2 *>(patch_cur);
-        uint32_t P[4];
-        {
-            int px[4][3];
-#pragma unroll
-            for (int s = 0; s < NSLOT; ++s)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t k0 = i0[s][j], k1 = i1[s][j], m = mis[s][j];
-                    // 16-byte window = LDS qwords k, k+1 (one ds_read2_b64); the footprint starts at byte m (0..7) of it:
-                    // pick the three dwords that hold bytes m..m+5, then realign by m & 3 as on the global path
-                    const uint2 q00 = w[k0], q01 = w[k0 + 1], q10 = w[k1], q11 = w[k1 + 1];
-                    const bool up = m >= 4;
-                    const uint32_t a0 = up ? q00.y : q00.x, b0 = up ? q01.x : q00.y, c0 = up ? q01.y : q01.x;
-                    const uint32_t a1 = up ? q10.y : q10.x, b1 = up ? q11.x : q10.y, c1 = up ? q11.y : q11.x;
-                    const uint2 r0 = make_uint2(__builtin_amdgcn_alignbyte(b0, a0, m), __builtin_amdgcn_alignbyte(c0, b0, m));
-                    const uint2 r1 = make_uint2(__builtin_amdgcn_alignbyte(b1, a1, m), __builtin_amdgcn_alignbyte(c1, b1, m));
-                    uint32_t acc[3];
-                    bilinear_rows_b2(r0, r1, wx[s][j], wy[s][j], acc);
-                    if (!BLEND && NSLOT == 1) {
-                        P[j] = __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            const uint32_t v = (acc[k] >> 16) & 255u;
-                            const int c = BLEND ? (int)((float)v * wf[s][j]) : (int)v;
-                            px[j][k] = s == 0 ? c : min(255, px[j][k] + c);
-                        }
-                    }
-                }
-            if (BLEND || NSLOT == 2) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) P[j] = (uint32_t)px[j][0] | ((uint32_t)px[j][1] << 8) | ((uint32_t)px[j][2] << 16);
-            }
-        }
-        if (SUMS) {
-            uint32_t sb = 0, sg = 0, sr = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
-                sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
-                sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
-            }
-            uint32_t bg = sb | (sg << 16);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
-            if (lane == 0) {
-                uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
-                ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr;
-            }
-        }
-        if (car_any) add_car(P, car0, car1, car2);
-        if (inimg) {
-            uint32_t d0, d1, d2;
-            pack_pixels(P, d0, d1, d2);
-            uint32_t *op = reinterpret_cast<uint32_t *>(ob);
-            op[0] = d0; op[1] = d1; op[2] = d2;
-        }
-        fb += set_bytes;
-        ob += img_bytes;
-    };
-    uint8_t *const p0 = stage_0 + wave * kStageBytes, *const p1 = stage_1 + wave * kStageBytes, *const p2 = stage_2 + wave * kStageBytes;
-    stage_frame(fb, p0);
-    stage_frame(b_begin + 1 < b_end ? fb + set_bytes : fb, p1);
-#pragma unroll 1
-    for (int b = b_begin; b < b_end; b += 3) {
-        one_frame(p0, p2, b);
-        if (b + 1 < b_end) one_frame(p1, p0, b + 1);
-        if (b + 2 < b_end) one_frame(p2, p1, b + 2);
-    }
-}
-
-template <int LX, int NSLOT, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_staged(PlanArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_1[4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_2[4 * kStageBytes];
-    plan_staged_body<LX, NSLOT, BLEND, SUMS>(a, blockIdx.x, stage_0, stage_1, stage_2);
-}
-
 }  // namespace bevw
 #include "bevw_pair.h"
 namespace bevw {
@@ -998,82 +724,37 @@ struct PlanAllArgs {
     const uint32_t *list[kPlanAllMax];
     int nlist[kPlanAllMax];
     int ngroups[kPlanAllMax];
-    int ncoop[kPlanAllMax];
     uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
-    // launch position -> class: 0 sector-staged single, 1 sector-staged double, 2 empty, 3 gather single, 4 gather double,
-    // 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced), 9, 10 pair-staged double (1 / 2 rounds)
+    // launch position -> class: 2 empty, 3 gather single, 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced),
+    // 9, 10 pair-staged double (1 / 2 rounds)
     int kind[kPlanAllMax];
     int n;                             // launch positions in use
 };
 
 // The two-contributor classes set the register budget (~140 VGPRs, 3 workgroups per CU); measured, the single-contributor
 // classes lose nothing at that occupancy (profiles/r01_sweeps.log: two launches split by register budget are slower).
-// ST: 1 = sector-staged classes (plan_staged_body, LDS-DMA ring), 2 = pair-staged classes (plan_pair_body, bevw_pair.h)
-template <int LX, bool BLEND, bool SUMS, int ST = 1>
+template <int LX, bool BLEND, bool SUMS>
 __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[ST == 2 ? 4 * kPairPatch + kStripBytes : 4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_1[ST == 2 ? 16 : 4 * kStageBytes];
-    __shared__ __attribute__((aligned(16))) uint8_t stage_2[ST == 2 ? 16 : 4 * kStageBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kPairPatch];
     int pos = 0;
 #pragma unroll
     for (int c = 1; c < kPlanAllMax; ++c) pos += (c < q.n && blockIdx.x >= q.start[c]) ? 1 : 0;
     PlanArgs a = q.a;
-    a.tile_list = q.list[pos]; a.nlist = q.nlist[pos]; a.ngroups = q.ngroups[pos]; a.ncoop = q.ncoop[pos];
+    a.tile_list = q.list[pos]; a.nlist = q.nlist[pos]; a.ngroups = q.ngroups[pos];
     const uint32_t id = blockIdx.x - q.start[pos];
     switch (q.kind[pos]) {
-        case 0: if (ST == 1) plan_staged_body<LX, 1, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
-        case 1: if (ST == 1) plan_staged_body<LX, 2, BLEND, SUMS>(a, id, stage_0, stage_1, stage_2); break;
-        case 5: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
-        case 6: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
-        case 7: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
-        case 8: if (ST == 2) plan_pair_body<LX, 1, BLEND, SUMS, 4, 2>(a, id, stage_0); break;
-        case 9: if (ST == 2) plan_pair_body<LX, 2, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
-        case 10: if (ST == 2) plan_pair_body<LX, 2, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
+        case 5: plan_pair_body<LX, 1, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
+        case 6: plan_pair_body<LX, 1, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
+        case 7: plan_pair_body<LX, 1, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
+        case 8: plan_pair_body<LX, 1, BLEND, SUMS, 4, 2>(a, id, stage_0); break;
+        case 9: plan_pair_body<LX, 2, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
+        case 10: plan_pair_body<LX, 2, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
-        case 4:
-            // pair-staged launches keep the two-contributor gather class (a handful of sparse seam tiles, 110+ VGPRs) out
-            // of the merged kernel: it would set the register budget of every other class
-            if (ST != 2) plan_gather_block<LX, 2, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0));
-            break;
+        // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
+        // would set the register budget of every other class; plan_launch_lx gives it its own launch)
         default: break;
-    }
-}
-
-// The same classes in ONE SPATIAL ORDER: the list holds every tile of the step (row-major inside a tile row), a block is 4
-// consecutive list entries (x-neighbours) and every WAVE runs the body of its own tile's class (waves never synchronise, so
-// the waves of a block may run different bodies).  Why: the classes of k_plan_all run one after the other, so two
-// x-neighbouring tiles of different classes write their shared output sector ~100 us apart, the L2 evicts it half-written
-// and HBM sees two partial (32-byte) writes: 3.1 M of 18.1 M write requests per launch, 14.3 M when nothing is partial
-// (profiles/r02/run8_pmc_store_shape.txt).  Sparse two-contributor tiles (kind 4) are left to their own launch.
-template <int LX, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_spatial(PlanArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kPairPatch + kStripBytes];
-    uint32_t chunk, group;
-    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int slot = (int)group * 4 + wave;
-    if (slot >= a.nlist) return;
-    const int tile = (int)__builtin_amdgcn_readfirstlane(a.tile_list[slot]);
-    const uint32_t hdr = __builtin_amdgcn_readfirstlane(a.hdr[tile]);
-    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
-    if (hdr & kHdrEmpty) {
-        plan_empty_tile<LX>(a, tile, b_begin, b_end);
-    } else if (hdr & kHdrPaired) {
-        const int mode = (int)((hdr >> 8) & 3u);
-        if (hdr & kHdrSecond) {
-            if (mode == 0) plan_pair_tile<LX, 2, BLEND, SUMS, 1, 1>(a, tile, hdr, chunk, false, stage_0);
-            else plan_pair_tile<LX, 2, BLEND, SUMS, 1, 2>(a, tile, hdr, chunk, false, stage_0);
-        } else {
-            if (mode == 0) plan_pair_tile<LX, 1, BLEND, SUMS, 1, 1>(a, tile, hdr, chunk, false, stage_0);
-            else if (mode == 1) plan_pair_tile<LX, 1, BLEND, SUMS, 1, 2>(a, tile, hdr, chunk, false, stage_0);
-            else if (mode == 2) plan_pair_tile<LX, 1, BLEND, SUMS, 1, 4>(a, tile, hdr, chunk, false, stage_0);
-            else plan_pair_tile<LX, 1, BLEND, SUMS, 4, 2>(a, tile, hdr, chunk, false, stage_0);
-        }
-    } else if (!(hdr & kHdrSecond)) {
-        plan_gather_tile<LX, 1, BLEND, SUMS>(a, tile, b_begin, b_end, reinterpret_cast<uint32_t *>(stage_0) + wave * 256);
     }
 }
 
@@ -1103,10 +784,9 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.list_spatial, p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5],
+    void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5],
                     p.list_rp_single, p.list_rp_double,
-                    p.entries, p.hdr, p.groups, p.psums, p.d_max, p.entries_st, p.dma, p.list_st_single,
-                    p.list_st_double, p.list_rs_single, p.list_rs_double, p.list_single, p.list_double, p.list_slow, p.list_empty};
+                    p.entries, p.hdr, p.groups, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = Plan();
@@ -1123,7 +803,7 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
                                          int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
-                                         int ncams = 4, int pair_perm = 0, int pair_coop = 0)
+                                         int ncams = 4)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -1169,23 +849,13 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = plan_upload_list(list, &p.groups)) != hipSuccess) return e;
         p.band_ok = true;
     }
-    p.staged_ok = false;
-    if (fw % 8 == 0 && ((size_t)fw * fh * 3 * ncams) % 16 == 0) {   // row pitch % 8 == 0: both footprint rows share the offset
-        if ((e = hipMalloc(&p.entries_st, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
-        if ((e = hipMalloc(&p.dma, (size_t)p.ntiles * kStageInstr * 64 * sizeof(uint32_t))) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_plan_stage_build, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries),
-                           static_cast<uint32_t *>(p.hdr), p.ntiles, (uint32_t)fw * 3, (uint32_t)((size_t)fw * fh * 3 * ncams),
-                           static_cast<uint2 *>(p.entries_st), static_cast<uint32_t *>(p.dma));
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        p.staged_ok = true;
-    }
     p.paired_ok = false;
     if (fw % 4 == 0 && (size_t)fw * fh * 3 * ncams < (1ull << 31)) {   // rows are whole groups of 4 texels (12 bytes)
         if ((e = hipMalloc(&p.entries_pr, (size_t)p.ntiles * 8 * 64 * sizeof(uint2))) != hipSuccess) return e;
         if ((e = hipMalloc(&p.gsrc, (size_t)p.ntiles * kPairSrcSlots * 64 * sizeof(uint32_t))) != hipSuccess) return e;
         hipLaunchKernelGGL(k_plan_pair_build, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries),
                            static_cast<uint32_t *>(p.hdr), p.ntiles, (uint32_t)fw * 3, (uint32_t)((size_t)fw * fh * 3 * ncams),
-                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc), pair_perm);
+                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc));
         if ((e = hipGetLastError()) != hipSuccess) return e;
         p.paired_ok = true;
     }
@@ -1228,69 +898,16 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     };
     order(ls); order(ld); order(lw);
     {
-        std::vector<uint32_t> ss, sd, rs, rd;
-        for (uint32_t t : ls) ((hdr[t] & kHdrStaged) ? ss : rs).push_back(t);
-        for (uint32_t t : ld) ((hdr[t] & kHdrStaged) ? sd : rd).push_back(t);
-        p.n_st_single = (int)ss.size(); p.n_st_double = (int)sd.size(); p.n_rs_single = (int)rs.size(); p.n_rs_double = (int)rd.size();
-        if ((e = plan_upload_list(ss, &p.list_st_single)) != hipSuccess) return e;
-        if ((e = plan_upload_list(sd, &p.list_st_double)) != hipSuccess) return e;
-        if ((e = plan_upload_list(rs, &p.list_rs_single)) != hipSuccess) return e;
-        if ((e = plan_upload_list(rd, &p.list_rs_double)) != hipSuccess) return e;
-    }
-    {
         std::vector<uint32_t> pr[6], rs, rd;
         for (uint32_t t : ls) { if (hdr[t] & kHdrPaired) pr[(hdr[t] >> 8) & 3u].push_back(t); else rs.push_back(t); }
         for (uint32_t t : ld) { if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 1u)].push_back(t); else rd.push_back(t); }
         for (int c = 0; c < 6; ++c) {
-            // blocks of 4 x-neighbouring tiles of one tile row first (cooperative store), the remaining tiles after them
-            std::vector<uint32_t> v = pr[c], quads, loose;
-            std::sort(v.begin(), v.end());
-            if (pair_coop) {
-                for (size_t i = 0; i < v.size();) {
-                    const uint32_t tx = (uint32_t)p.tiles_x;
-                    if (i + 3 < v.size() && v[i + 3] == v[i] + 3 && v[i] / tx == v[i + 3] / tx) { quads.insert(quads.end(), v.begin() + i, v.begin() + i + 4); i += 4; }
-                    else loose.push_back(v[i++]);
-                }
-                // the loose tiles keep the locality order of their class list
-                std::vector<uint32_t> keep;
-                for (uint32_t t : pr[c]) if (std::binary_search(loose.begin(), loose.end(), t)) keep.push_back(t);
-                pr[c] = quads;
-                pr[c].insert(pr[c].end(), keep.begin(), keep.end());
-            }
             p.n_pr[c] = (int)pr[c].size();
-            p.n_pr_coop[c] = (int)quads.size();
             if ((e = plan_upload_list(pr[c], &p.list_pr[c])) != hipSuccess) return e;
         }
         p.n_rp_single = (int)rs.size(); p.n_rp_double = (int)rd.size();
         if ((e = plan_upload_list(rs, &p.list_rp_single)) != hipSuccess) return e;
         if ((e = plan_upload_list(rd, &p.list_rp_double)) != hipSuccess) return e;
-        // spatial order: tile rows by descending cost (the sparse rows around the car first, so that the long-running waves
-        // do not end up in the tail of the grid), row-major inside a row
-        std::vector<uint32_t> all;
-        {
-            std::vector<std::pair<long, int>> rows;
-            auto cost = [&](uint32_t h) -> long {
-                if (h & kHdrEmpty) return 1;
-                if (!(h & kHdrPaired)) return 12;
-                static const long c[4] = {4, 6, 10, 24};
-                return c[(h >> 8) & 3u] * ((h & kHdrSecond) ? 2 : 1);
-            };
-            for (int ty = 0; ty < p.tiles_y; ++ty) {
-                long w = 0;
-                for (int tx = 0; tx < p.tiles_x; ++tx) w += cost(hdr[(size_t)ty * p.tiles_x + tx]);
-                rows.push_back({-w, ty});
-            }
-            std::stable_sort(rows.begin(), rows.end());
-            for (auto &r : rows)
-                for (int tx = 0; tx < p.tiles_x; ++tx) {
-                    const uint32_t t = (uint32_t)(r.second * p.tiles_x + tx), h = hdr[t];
-                    if (h & kHdrSlow) continue;
-                    if (!(h & (kHdrEmpty | kHdrPaired)) && (h & kHdrSecond)) continue;   // sparse two-contributor tile: own launch
-                    all.push_back(t);
-                }
-        }
-        p.n_spatial = (int)all.size();
-        if ((e = plan_upload_list(all, &p.list_spatial)) != hipSuccess) return e;
     }
     p.n_single = (int)ls.size(); p.n_double = (int)ld.size(); p.n_slow = (int)lw.size(); p.n_empty = (int)le.size();
     if ((e = plan_upload_list(ls, &p.list_single)) != hipSuccess) return e;
@@ -1306,15 +923,14 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
 
 // nb: frames per block (0 = default); lean: 0 = one generic kernel over every tile (debug); lds_pad: dynamic LDS added to the
 // single-contributor gather kernel to cap it at 5 waves per SIMD (more resident gather waves thrash the L1);
-// xcd_map: 1 = an XCD owns whole batch chunks; staged: 1 = LDS-staged kernels for the tiles that have a staging plan;
-// one_launch: 2 = one kernel over all tiles in spatial order (k_plan_spatial, pair-staged schedule), 1 = one kernel, class
-// after class (k_plan_all), 0 = one launch per class
-// staged: 0 = gather classes only, 1 = sector-staged (LDS-DMA ring, round 1), 2 = pair-staged (bevw_pair.h, round 2)
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 2; int one_launch = 1; };
+// xcd_map: 1 = an XCD owns whole batch chunks; staged: 0 = gather classes only (k_plan_lean), 1 = pair-staged classes
+// (bevw_pair.h) for every tile that has a pair plan; one_launch: 1 = all tile classes of a step in one kernel
+// (k_plan_all), 0 = one launch per class
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, int staged, int one_launch)
+                                        bool sums, bool staged, bool one_launch)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1322,9 +938,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         if (a.xcd_affine == 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
         return (unsigned)(a.ngroups * a.nchunks);
     };
-    auto set_list = [&](void *list, int n, int ncoop = 0) {
-        a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; a.ncoop = ncoop;
-    };
+    auto set_list = [&](void *list, int n) { a.tile_list = static_cast<const uint32_t *>(list); a.nlist = n; a.ngroups = (n + 3) / 4; };
     if (balance || !lean) {
         // generic kernel over every tile (luminance round trip per tap, per-tile channel sums)
         set_list(nullptr, p.ntiles);
@@ -1337,86 +951,15 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     }
     // sums = balance on pre-shifted frames: per-tile channel sums, the car is added by k_gain afterwards
     if (sums) a.car = nullptr;
-    // class lists: with the LDS-staged schedule the single / double classes split into staged tiles (k_plan_staged) and
-    // the rest (k_plan_lean)
-    void *l_single = staged == 2 ? p.list_rp_single : staged ? p.list_rs_single : p.list_single;
-    void *l_double = staged == 2 ? p.list_rp_double : staged ? p.list_rs_double : p.list_double;
-    const int n_single = staged == 2 ? p.n_rp_single : staged ? p.n_rs_single : p.n_single;
-    const int n_double = staged == 2 ? p.n_rp_double : staged ? p.n_rs_double : p.n_double;
-    if (staged == 2 && one_launch == 2 && p.n_spatial) {
-        set_list(p.list_spatial, p.n_spatial);
-        const dim3 grid(grid_blocks());
-        if (blend && sums) hipLaunchKernelGGL((k_plan_spatial<LX, true, true>), grid, block, 0, st, a);
-        else if (blend) hipLaunchKernelGGL((k_plan_spatial<LX, true, false>), grid, block, 0, st, a);
-        else if (sums) hipLaunchKernelGGL((k_plan_spatial<LX, false, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_plan_spatial<LX, false, false>), grid, block, 0, st, a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        if (n_double) {   // the sparse two-contributor tiles
-            set_list(l_double, n_double);
-            const dim3 grid2(grid_blocks());
-            if (blend && sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, true>), grid2, block, 0, st, a);
-            else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, false>), grid2, block, 0, st, a);
-            else if (sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, true>), grid2, block, 0, st, a);
-            else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, false>), grid2, block, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-    } else if (staged && one_launch) {
-        PlanAllArgs q;
-        q.a = a;
-        // launch order: the classes whose blocks run longest first (sparse tiles, then the staged classes, then the empty
-        // tiles), so that the short blocks fill the tail of the grid: +1-2 % over staged-first (profiles/r01_sweeps.log)
-        struct Cls { int kind; void *list; int n; int ncoop; };
-        std::vector<Cls> cls;
-        if (staged == 2) {
-            cls = {{8, p.list_pr[3], p.n_pr[3], p.n_pr_coop[3]}, {7, p.list_pr[2], p.n_pr[2], p.n_pr_coop[2]}, {3, l_single, n_single, 0},
-                   {10, p.list_pr[5], p.n_pr[5], p.n_pr_coop[5]}, {9, p.list_pr[4], p.n_pr[4], p.n_pr_coop[4]},
-                   {6, p.list_pr[1], p.n_pr[1], p.n_pr_coop[1]}, {5, p.list_pr[0], p.n_pr[0], p.n_pr_coop[0]}, {2, p.list_empty, p.n_empty, 0}};
-        } else {
-            cls = {{4, l_double, n_double, 0}, {3, l_single, n_single, 0}, {1, p.list_st_double, p.n_st_double, 0},
-                   {0, p.list_st_single, p.n_st_single, 0}, {2, p.list_empty, p.n_empty, 0}};
-        }
-        uint32_t at = 0;
-        int np = 0;
-        for (const Cls &c : cls) {
-            if (!c.n) continue;
-            q.kind[np] = c.kind;
-            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = (c.n + 3) / 4; q.ncoop[np] = c.ncoop;
-            q.start[np] = at;
-            a.ngroups = q.ngroups[np];
-            const unsigned nblk = c.kind == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
-            at += (nblk + 7u) & ~7u;
-            ++np;
-        }
-        for (int i = np; i < kPlanAllMax; ++i) { q.kind[i] = -1; q.list[i] = nullptr; q.nlist[i] = 0; q.ngroups[i] = 1; q.ncoop[i] = 0; }
-        for (int i = np; i <= kPlanAllMax; ++i) q.start[i] = at;
-        q.n = np;
-        if (at && staged == 2) {
-            if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true, 2>), dim3(at), block, 0, st, q);
-            else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false, 2>), dim3(at), block, 0, st, q);
-            else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true, 2>), dim3(at), block, 0, st, q);
-            else hipLaunchKernelGGL((k_plan_all<LX, false, false, 2>), dim3(at), block, 0, st, q);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        } else if (at) {
-            if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true>), dim3(at), block, 0, st, q);
-            else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false>), dim3(at), block, 0, st, q);
-            else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true>), dim3(at), block, 0, st, q);
-            else hipLaunchKernelGGL((k_plan_all<LX, false, false>), dim3(at), block, 0, st, q);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-        if (staged == 2 && n_double) {   // the sparse two-contributor tiles (see k_plan_all)
-            set_list(l_double, n_double);
-            const dim3 grid(grid_blocks());
-            if (blend && sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, true>), grid, block, 0, st, a);
-            else if (blend) hipLaunchKernelGGL((k_plan_lean<LX, 2, true, false>), grid, block, 0, st, a);
-            else if (sums) hipLaunchKernelGGL((k_plan_lean<LX, 2, false, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((k_plan_lean<LX, 2, false, false>), grid, block, 0, st, a);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
-    } else {
+    // class lists: with the pair-staged schedule the single / double classes split into the pair classes (list_pr[]) and
+    // the sparse rest, which stays on the gather kernel (k_plan_lean)
+    void *l_single = staged ? p.list_rp_single : p.list_single;
+    void *l_double = staged ? p.list_rp_double : p.list_double;
+    const int n_single = staged ? p.n_rp_single : p.n_single;
+    const int n_double = staged ? p.n_rp_double : p.n_double;
 #define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM, ...)                                                                  \
     do {                                                                                                            \
         const dim3 grid(grid_blocks());                                                                             \
-        const dim3 block((#KERNEL)[7] == 'p' && BEVW_SPF ? 320 : 256);   /* k_plan_pair + its prefetch wave */        \
         if (blend && sums) hipLaunchKernelGGL((KERNEL<LX, NS, true, true __VA_ARGS__>), grid, block, SHMEM, st, a);  \
         else if (blend) hipLaunchKernelGGL((KERNEL<LX, NS, true, false __VA_ARGS__>), grid, block, SHMEM, st, a);    \
         else if (sums) hipLaunchKernelGGL((KERNEL<LX, NS, false, true __VA_ARGS__>), grid, block, SHMEM, st, a);     \
@@ -1424,24 +967,56 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         if ((e = hipGetLastError()) != hipSuccess) return e;                                                        \
     } while (0)
 #define BEVW_COMMA ,
-    if (staged == 2 && p.n_pr[0]) { set_list(p.list_pr[0], p.n_pr[0], p.n_pr_coop[0]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
-    if (staged == 2 && p.n_pr[1]) { set_list(p.list_pr[1], p.n_pr[1], p.n_pr_coop[1]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
-    if (staged == 2 && p.n_pr[2]) { set_list(p.list_pr[2], p.n_pr[2], p.n_pr_coop[2]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 4); }
-    if (staged == 2 && p.n_pr[3]) { set_list(p.list_pr[3], p.n_pr[3], p.n_pr_coop[3]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 4 BEVW_COMMA 2); }
-    if (staged == 2 && p.n_pr[4]) { set_list(p.list_pr[4], p.n_pr[4], p.n_pr_coop[4]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
-    if (staged == 2 && p.n_pr[5]) { set_list(p.list_pr[5], p.n_pr[5], p.n_pr_coop[5]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
-    if (staged == 1 && p.n_st_single) { set_list(p.list_st_single, p.n_st_single); BEVW_LAUNCH_CLASS(k_plan_staged, 1, 0); }
-    if (staged == 1 && p.n_st_double) { set_list(p.list_st_double, p.n_st_double); BEVW_LAUNCH_CLASS(k_plan_staged, 2, 0); }
-    if (p.n_empty) {
-        set_list(p.list_empty, p.n_empty);
-        hipLaunchKernelGGL((k_plan_empty<LX>), dim3((unsigned)(a.ngroups * a.nchunks)), block, 0, st, a);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (staged && one_launch) {
+        PlanAllArgs q;
+        q.a = a;
+        // launch order: the classes whose blocks run longest first (the sliced and 4-round pair tiles, the sparse gather
+        // tiles, then the shorter pair classes, then the empty tiles), so that the short blocks fill the tail of the grid
+        // (profiles/r01_sweeps.log, profiles/r02/sweeps.log)
+        struct Cls { int kind; void *list; int n; };
+        const Cls cls[] = {{8, p.list_pr[3], p.n_pr[3]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
+                           {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]}, {2, p.list_empty, p.n_empty}};
+        uint32_t at = 0;
+        int np = 0;
+        for (const Cls &c : cls) {
+            if (!c.n) continue;
+            q.kind[np] = c.kind;
+            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = (c.n + 3) / 4;
+            q.start[np] = at;
+            a.ngroups = q.ngroups[np];
+            const unsigned nblk = c.kind == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
+            at += (nblk + 7u) & ~7u;
+            ++np;
+        }
+        for (int i = np; i < kPlanAllMax; ++i) { q.kind[i] = -1; q.list[i] = nullptr; q.nlist[i] = 0; q.ngroups[i] = 1; }
+        for (int i = np; i <= kPlanAllMax; ++i) q.start[i] = at;
+        q.n = np;
+        if (at) {
+            if (blend && sums) hipLaunchKernelGGL((k_plan_all<LX, true, true>), dim3(at), block, 0, st, q);
+            else if (blend) hipLaunchKernelGGL((k_plan_all<LX, true, false>), dim3(at), block, 0, st, q);
+            else if (sums) hipLaunchKernelGGL((k_plan_all<LX, false, true>), dim3(at), block, 0, st, q);
+            else hipLaunchKernelGGL((k_plan_all<LX, false, false>), dim3(at), block, 0, st, q);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        // the sparse two-contributor tiles: their 142-VGPR body would cap the merged kernel's occupancy (see k_plan_all)
+        if (n_double) { set_list(l_double, n_double); BEVW_LAUNCH_CLASS(k_plan_lean, 2, 0); }
+    } else {
+        if (staged && p.n_pr[0]) { set_list(p.list_pr[0], p.n_pr[0]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
+        if (staged && p.n_pr[1]) { set_list(p.list_pr[1], p.n_pr[1]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
+        if (staged && p.n_pr[2]) { set_list(p.list_pr[2], p.n_pr[2]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 1 BEVW_COMMA 4); }
+        if (staged && p.n_pr[3]) { set_list(p.list_pr[3], p.n_pr[3]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 4 BEVW_COMMA 2); }
+        if (staged && p.n_pr[4]) { set_list(p.list_pr[4], p.n_pr[4]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
+        if (staged && p.n_pr[5]) { set_list(p.list_pr[5], p.n_pr[5]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
+        if (p.n_empty) {
+            set_list(p.list_empty, p.n_empty);
+            hipLaunchKernelGGL((k_plan_empty<LX>), dim3((unsigned)(a.ngroups * a.nchunks)), block, 0, st, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (n_single) { set_list(l_single, n_single); BEVW_LAUNCH_CLASS(k_plan_lean, 1, lds_pad); }
+        if (n_double) { set_list(l_double, n_double); BEVW_LAUNCH_CLASS(k_plan_lean, 2, 0); }
     }
-    if (n_single) { set_list(l_single, n_single); BEVW_LAUNCH_CLASS(k_plan_lean, 1, lds_pad); }
-    if (n_double) { set_list(l_double, n_double); BEVW_LAUNCH_CLASS(k_plan_lean, 2, 0); }
 #undef BEVW_LAUNCH_CLASS
 #undef BEVW_COMMA
-    }
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
         const dim3 grid(grid_blocks());
@@ -1467,18 +1042,12 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
     a.ncams = p.ncams;
-    a.tile_list = nullptr; a.nlist = p.ntiles; a.ncoop = 0;
-    a.plan_st = static_cast<const uint2 *>(p.entries_st);
-    a.dma = static_cast<const uint32_t *>(p.dma);
+    a.tile_list = nullptr; a.nlist = p.ntiles;
     a.plan_pr = static_cast<const uint2 *>(p.entries_pr);
     a.gsrc = static_cast<const uint32_t *>(p.gsrc);
-    // LDS-staged schedule: needs 16-byte aligned frame sets (whole-sector DMA) and is not combined with the per-tap
-    // luminance kernel
-    int use_staged = 0;
-    if (!balance && tune.lean) {
-        if (tune.staged == 2 && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0) use_staged = 2;
-        else if (tune.staged && p.staged_ok && (((uintptr_t)d_frames) & 15u) == 0) use_staged = 1;
-    }
+    // pair-staged schedule: needs 4-byte aligned frame sets (dword-addressed group loads) and is not combined with the
+    // per-tap luminance kernel
+    const bool use_staged = !balance && tune.lean && tune.staged && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0;
     a.batch = batch;
     // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk
     int nb = tune.nb > 0 ? tune.nb : 8;
@@ -1498,9 +1067,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

@@ -69,10 +69,7 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     static const int inter_env = [] { const char *s = getenv("BEVW_PLAN_INTERLEAVE"); return s ? atoi(s) : 1; }();
     static const int colmajor_env = [] { const char *s = getenv("BEVW_PLAN_COLMAJOR"); return s ? atoi(s) : 1; }();
     static const int super_env = [] { const char *s = getenv("BEVW_PLAN_SUPER"); return s ? atoi(s) : 1; }();
-    static const int perm_env = [] { const char *s = getenv("BEVW_PAIR_PERM"); return s ? atoi(s) : 0; }();
-    static const int coop_env = [] { const char *s = getenv("BEVW_PAIR_COOP"); return s ? atoi(s) : 0; }();
-    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams, perm_env,
-                                   coop_env);
+    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -1132,13 +1129,11 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[2] = h->schedule_in_use;
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
-    if (plan_tuning().staged == 2 && h->plan.paired_ok) {
-        info[5] = 0;                                            // tiles on the pair-staged schedule (bevw_pair.h)
-        for (int c = 0; c < 6; ++c) info[5] += h->plan.n_pr[c];
-        info[6] = h->plan.n_rp_single + h->plan.n_rp_double;   // single/double tiles left on the L1-gather kernels
+    if (plan_tuning().staged && h->plan.paired_ok) {
+        for (int c = 0; c < 6; ++c) info[5] += h->plan.n_pr[c];   // tiles on the pair-staged schedule (bevw_pair.h)
+        info[6] = h->plan.n_rp_single + h->plan.n_rp_double;      // single / double tiles left on the L1-gather kernels
     } else {
-        info[5] = h->plan.n_st_single + h->plan.n_st_double;   // tiles on the sector-staged schedule
-        info[6] = h->plan.n_rs_single + h->plan.n_rs_double;
+        info[6] = h->plan.n_single + h->plan.n_double;
     }
     info[7] = h->plan.n_slow;
     return BEVW_OK;
