@@ -231,8 +231,8 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
     lane_xy(lane, LX, (hdr & kHdrTransposed) != 0, lx_, ly_);
     const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const bool inimg = x0 < a.bw && y < a.bh;
-    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.pitch + x0) * 3;
     const uint32_t ooff_masked = inimg ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: not written
     constexpr int kWavePatch = (SLICES == 1 ? ROUNDS : kPairSliceRounds) * kPairRoundBytes;   // LDS this class needs per wave
     uint8_t *const patch = lds + wave * kWavePatch;

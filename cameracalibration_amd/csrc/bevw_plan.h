@@ -43,6 +43,12 @@ struct Plan {
     void *hdr = nullptr;         // uint32[ntiles]
     void *psums = nullptr;       // uint32[batch][ntiles][3]  (balance: per-tile channel sums)
     size_t psums_cap = 0;
+    // destination widths that are not a multiple of 4 pixels: the kernels' 12-byte stores need dword-aligned pixel quads,
+    // so they write rows of `pitch` = bw rounded up to 4 pixels into pad_out and k_plan_unpad compacts them (one more
+    // pass over the output instead of the per-pixel schedule)
+    int pitch = 0;
+    void *pad_out = nullptr, *pad_car = nullptr;
+    size_t pad_cap = 0;
     int *d_max = nullptr;
     int fw = 0, fh = 0, bw = 0, bh = 0;
     int tiles_x = 0, tiles_y = 0, ntiles = 0;
@@ -409,6 +415,7 @@ struct PlanArgs {
     uint32_t *psums;
     uint8_t *out;
     int fw, fh, bw, bh;
+    int pitch;                   // pixels per row of `out` / `car`: bw, or bw rounded up to 4 (padded scratch, see plan_stitch_impl)
     int tiles_x, ntiles, ngroups;
     int ncams;                   // images per frame set: 4 for BevGenerator, 1 for a plain cv2.remap
     int batch, nb, nchunks, xcd_affine;
@@ -464,8 +471,8 @@ __global__ void __launch_bounds__(1024) k_stitch_plan(PlanArgs a)
     const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const bool inimg = x0 < a.bw && y < a.bh;
     const uint32_t frame_bytes = (uint32_t)a.fw * a.fh * 3, row_bytes = (uint32_t)a.fw * 3;
-    const size_t set_bytes = (size_t)frame_bytes * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    const size_t set_bytes = (size_t)frame_bytes * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.pitch + x0) * 3;
 
     EntryRegs e0[4], e1[4];
 #pragma unroll
@@ -551,8 +558,8 @@ __device__ __forceinline__ void plan_gather_tile(const PlanArgs &a, int tile, in
     const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     const bool inimg = x0 < a.bw && y < a.bh;
     const uint32_t row_bytes = (uint32_t)a.fw * 3;
-    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.bw * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.pitch + x0) * 3;
 
     uint32_t off[NSLOT][4], mis[NSLOT][4], wx[NSLOT][4], wy[NSLOT][4];
     float wf[NSLOT][4];
@@ -692,8 +699,8 @@ __device__ __forceinline__ void plan_empty_body(const PlanArgs &a, uint32_t bloc
     lane_xy(lane, LX, false, lx_, ly_);
     const int x0 = (tx * LX + lx_) * 4, y = ty * LY + ly_;
     if (!(x0 < a.bw && y < a.bh)) return;
-    const size_t img_bytes = (size_t)a.bw * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.bw + x0) * 3;
+    const size_t img_bytes = (size_t)a.pitch * a.bh * 3;
+    const uint32_t ooff = ((uint32_t)y * a.pitch + x0) * 3;
     uint32_t c0 = 0, c1 = 0, c2 = 0;
     if (a.car != nullptr) {
         const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
@@ -786,7 +793,7 @@ static inline void plan_release(Plan &p)
 {
     void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5],
                     p.list_rp_single, p.list_rp_double,
-                    p.entries, p.hdr, p.groups, p.psums, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
+                    p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = Plan();
@@ -914,11 +921,29 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     if ((e = plan_upload_list(ld, &p.list_double)) != hipSuccess) return e;
     if ((e = plan_upload_list(lw, &p.list_slow)) != hipSuccess) return e;
     if ((e = plan_upload_list(le, &p.list_empty)) != hipSuccess) return e;
-    // 12-byte stores need 4-byte aligned pixel quads: bw % 4 == 0 makes every row and every image start aligned
+    // 12-byte stores need 4-byte aligned pixel quads: rows of `pitch` pixels (bw % 4 != 0: padded scratch + k_plan_unpad)
     // and the aligned 12-byte footprint reads need every frame of a set to start on a 4-byte boundary
-    p.usable = p.max_contrib <= 2 && (bw % 4 == 0) && (((size_t)fw * fh * 3) % 4 == 0) &&
-               (size_t)fw * fh * 3 * ncams < (1ull << 31);
+    p.pitch = (bw + 3) & ~3;
+    p.usable = p.max_contrib <= 2 && (((size_t)fw * fh * 3) % 4 == 0) && (size_t)fw * fh * 3 * ncams < (1ull << 31);
     return hipSuccess;
+}
+
+// rows of `pitch` pixels <-> rows of `bw` pixels (destination widths that are not a multiple of 4, see Plan::pitch)
+__global__ void k_plan_pad(const uint8_t *__restrict__ src, int bw, int pitch, int rows, uint8_t *__restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row_bytes = (size_t)pitch * 3;
+    if (i >= row_bytes * rows) return;
+    const size_t y = i / row_bytes, k = i % row_bytes;
+    dst[i] = k < (size_t)bw * 3 ? src[y * bw * 3 + k] : (uint8_t)0;
+}
+__global__ void k_plan_unpad(const uint8_t *__restrict__ src, int bw, int pitch, size_t rows, uint8_t *__restrict__ dst)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row_bytes = (size_t)bw * 3;
+    if (i >= row_bytes * rows) return;
+    const size_t y = i / row_bytes, k = i % row_bytes;
+    dst[i] = src[y * pitch * 3 + k];
 }
 
 // nb: frames per block (0 = default); lean: 0 = one generic kernel over every tile (debug); lds_pad: dynamic LDS added to the
@@ -1040,6 +1065,24 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.frames = d_frames; a.plan = static_cast<const uint2 *>(p.entries); a.hdr = static_cast<const uint32_t *>(p.hdr);
     a.deltas = d_deltas; a.tab = d_tab; a.car = d_car; a.out = d_out;
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
+    a.pitch = p.pitch;
+    const bool padded = p.pitch != p.bw;
+    if (padded) {
+        const size_t img = (size_t)p.pitch * p.bh * 3, need = img * (size_t)batch;
+        if (need > p.pad_cap) {
+            if (p.pad_out) (void)hipFree(p.pad_out);
+            p.pad_out = nullptr; p.pad_cap = 0;
+            if ((e = hipMalloc(&p.pad_out, need)) != hipSuccess) return e;
+            p.pad_cap = need;
+        }
+        if (d_car && !p.pad_car && (e = hipMalloc(&p.pad_car, img)) != hipSuccess) return e;
+        if (d_car) {
+            hipLaunchKernelGGL(k_plan_pad, dim3((unsigned)((img + 255) / 256)), dim3(256), 0, st, d_car, p.bw, p.pitch, p.bh,
+                               static_cast<uint8_t *>(p.pad_car));
+            a.car = static_cast<const uint8_t *>(p.pad_car);
+        }
+        a.out = static_cast<uint8_t *>(p.pad_out);
+    }
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
     a.ncams = p.ncams;
     a.tile_list = nullptr; a.nlist = p.ntiles;
@@ -1074,6 +1117,15 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     if (e != hipSuccess) return e;
     if (balance || sums) {
         hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, p.ntiles, d_chsums);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (padded) {
+        const size_t rows = (size_t)batch * p.bh;
+        for (size_t r0 = 0; r0 < rows; r0 += (size_t)1 << 20) {   // <= 2^20 rows per launch keeps the grid below 2^31 blocks
+            const size_t nr = rows - r0 < ((size_t)1 << 20) ? rows - r0 : ((size_t)1 << 20);
+            hipLaunchKernelGGL(k_plan_unpad, dim3((unsigned)((nr * p.bw * 3 + 255) / 256)), dim3(256), 0, st,
+                               static_cast<const uint8_t *>(p.pad_out) + r0 * p.pitch * 3, p.bw, p.pitch, nr, d_out + r0 * p.bw * 3);
+        }
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;

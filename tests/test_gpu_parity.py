@@ -184,8 +184,34 @@ def test_small_rig_batches(ffi, SB, oracle, blend, balance, kind):
     assert np.array_equal(outs[1], outs[2])
 
 
-def test_odd_bev_width_falls_back_to_per_pixel(ffi, SB, oracle):
-    cfg = dict(SMALL_CFG, BEV_WIDTH=250, BEV_HEIGHT=251)
+@pytest.mark.parametrize("bw,blend,balance,with_car", [(250, True, False, False), (249, False, False, True), (251, True, True, True),
+                                                        (250, False, True, False)])
+def test_bev_width_not_a_multiple_of_4_stays_on_the_tile_plan(ffi, SB, oracle, bw, blend, balance, with_car):
+    """no per-pixel cliff for bw % 4 != 0 -- the plan kernels write rows of a padded pitch and one
+    compaction pass brings them to the caller's layout (Plan::pitch, k_plan_unpad)."""
+    cfg = dict(SMALL_CFG, BEV_WIDTH=bw, BEV_HEIGHT=251)
+    rig = small_rig()
+    bev, ref = make_pair(SB, oracle, rig, cfg, blend, balance, 0)
+    info = bev.plan_info()
+    assert info["schedule"] == 2 and info["plan_usable"]
+    frames = W.synthetic_frames(3, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=11, kind="random")
+    car = None
+    if with_car:
+        car = np.zeros((251, bw, 3), np.uint8)
+        x0, y0 = (bw - cfg["CAR_WIDTH"]) // 2, (251 - cfg["CAR_HEIGHT"]) // 2
+        car[y0:y0 + cfg["CAR_HEIGHT"], x0:x0 + cfg["CAR_WIDTH"]] = np.random.default_rng(3).integers(0, 256, (cfg["CAR_HEIGHT"], cfg["CAR_WIDTH"], 3), dtype=np.uint8)
+    got = bev.batch(frames, car)
+    for b in range(3):
+        assert maxdiff(got[b], ref(*frames[b], car)) == 0
+    # and the explicit per-pixel schedule agrees
+    bev1 = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=1)
+    assert np.array_equal(bev1.batch(frames, car), got)
+
+
+def test_frames_that_are_not_dword_multiples_fall_back_to_per_pixel(ffi, SB, oracle):
+    """The plan's aligned 12-byte footprint reads need every frame of a set to start on a 4-byte boundary: 321 x 255 x 3 bytes
+    does not, so AUTO picks the per-pixel schedule and an explicit schedule=2 is refused."""
+    cfg = dict(SMALL_CFG, FRAME_WIDTH=321, FRAME_HEIGHT=255)
     rig = small_rig()
     bev, ref = make_pair(SB, oracle, rig, cfg, True, False, 0)
     assert bev.plan_info()["schedule"] == 1 and not bev.plan_info()["plan_usable"]
@@ -271,6 +297,27 @@ def test_incalibrator_undistort_config2(ffi, oracle):
         assert np.array_equal(got[i], oracle.remap(imgs[i], m1, m2))
     assert np.array_equal(cal.undistort(imgs[0]), got[0])
     a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE = 1280, 1024, 0.5, 1
+
+
+def test_incalibrator_undistort_width_not_a_multiple_of_4(ffi, oracle):
+    """cv2.remap through the tile plan with a destination pitch that is not a multiple of 4 pixels (padded rows + compaction)."""
+    from cameracalibration_amd.IntrinsicCalibration import InCalibrator
+
+    a = InCalibrator.get_args()
+    keep = (a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE)
+    try:
+        for fw, fh in [(322, 250), (318, 252)]:
+            a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE = fw, fh, 0.6, 1
+            K, D = W.undistort_calibration()
+            K = np.diag([fw / 1280.0, fh / 960.0, 1.0]) @ K
+            cal = InCalibrator("fisheye")
+            data = cal.set_calibration(K, D)
+            imgs = np.random.default_rng(8).integers(0, 256, (5, fh, fw, 3), dtype=np.uint8)
+            got = cal.undistort_batch(imgs)
+            for i in range(5):
+                assert np.array_equal(got[i], oracle.remap(imgs[i], data.map1, data.map2)), (fw, fh, i)
+    finally:
+        a.FRAME_WIDTH, a.FRAME_HEIGHT, a.FOCAL_SCALE, a.SIZE_SCALE = keep
 
 
 def test_incalibrator_on_reference_image(ffi, oracle, repo_rig):

@@ -16,15 +16,20 @@ BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 -
   bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
 python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
 cd /tmp && export TMPDIR=/tmp
-for w in direct_stitch_b256 blend_balance_b256 undistort_b64; do
+for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k; do
   rm -rf /tmp/kt_$w
   timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
+  case $w in blend_b256|blend_4k) continue;; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c
     timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1
     cp $(find /tmp/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${w}_$c.csv 2>/dev/null
   done
 done
+# per-class times of config 3: the same step launched class by class (BEVW_PLAN_ONELAUNCH=0)
+rm -rf /tmp/kt_classes
+BEVW_PLAN_ONELAUNCH=0 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_classes -- python $R/bench.py --workload direct_stitch_b256 --steps 10 --warmup 2 --no-cpu-baseline > /tmp/kt_classes.log 2>&1
+cp $(find /tmp/kt_classes -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_direct_stitch_b256_per_class.csv
 cd $R
 python tools/summarize_pmc.py $O
