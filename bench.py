@@ -376,7 +376,11 @@ def main():
 
     traffic, traffic_source = measured_traffic(a.workload, batch)
     # per-step durations from the marks: the median is robust against the one-off hiccups a 13 ms region is exposed to
-    laps = sorted(tbetween(i, i + 1) for i in range(a.steps))
+    laps = [tbetween(i, i + 1) for i in range(a.steps)]
+    if os.environ.get("BEVW_BENCH_DUMP_STEPS") and d.rank == 0:   # per-step trace for clock / drift studies (tools/r02/)
+        with open(os.environ["BEVW_BENCH_DUMP_STEPS"], "w") as fh:
+            fh.write("\n".join("%.5f" % x for x in laps) + "\n")
+    laps = sorted(laps)
     lap_median = d.max(laps[len(laps) // 2] if len(laps) % 2 else 0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2]))
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbevwarp.so")
 SOURCES = ["bevwarp.hip"]
-HEADERS = ["bevw_device.h", "bevw_kernels.h", "bevw_plan.h", os.path.join("..", "..", "include", "bevwarp.h")]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "bevwarp.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
          "-Wno-pass-failed", "-Wno-inline-asm"]
 

@@ -77,7 +77,7 @@ __device__ inline int pair_distinct(const uint32_t *cand, uint32_t use, uint32_t
 // of its two pair entries.
 __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict__ plan, uint32_t *__restrict__ hdr, int ntiles,
                                                          uint32_t row_bytes, uint32_t set_bytes, uint2 *__restrict__ plan_pr,
-                                                         uint32_t *__restrict__ gsrc)
+                                                         uint32_t *__restrict__ gsrc, int LX)
 {
     constexpr int kMax = kPairMaxRounds * 64;   // groups per step, whole-tile staging
     constexpr int kMaxSlice = kPairSliceRounds * 64;
@@ -146,7 +146,29 @@ __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict_
         write_src(0, count, kPairMaxRounds);
         for (int k = 0; k < 8; ++k) rewrite(k, count);
     } else {
-        // sliced: pixel slot j of every lane has its own group list (single-contributor tiles: <= 2 groups per pixel)
+        // sliced: four slices of 64 pixels, each with its own group list (single-contributor tiles: <= 2 groups per pixel).
+        // A slice is a COMPACT piece of the tile -- pixels 64 s .. 64 s + 63 in row-major order (two rows of a 32 x 8 tile),
+        // lane l computing pixel 64 s + l -- so that the slices touch disjoint source rows; with "pixel slot j of every lane"
+        // every slice re-requested most of the tile's lines (160 against 83 distinct lines per tile-frame on config 3).
+        // The kernel brings the four pixels of a lane back to store order through LDS (plan_pair_body, SLICES == 4).
+        {
+            const int W = 4 * LX, LY = 64 / LX;
+            const bool transposed = (h & kHdrTransposed) != 0;
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int pix = 64 * sidx + lane, x = pix % W, y = pix / W;
+                const int src_lane = transposed ? (x >> 2) * LY + y : y * LX + (x >> 2);
+                e[sidx] = ent[x & 3][src_lane];
+                e[4 + sidx] = make_uint2(0u, 0u);
+            }
+            __syncthreads();
+            for (int k = 0; k < 8; ++k) {
+                uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu;
+                if (e[k].y & kMetaValid) { c0 = e[k].x / 12u; c1 = c0 + gpr; }
+                cand[lane * 16 + 2 * k] = c0;
+                cand[lane * 16 + 2 * k + 1] = c1;
+            }
+            __syncthreads();
+        }
         int worst = 0;
         for (int j = 0; j < 4; ++j) {
             __syncthreads();
@@ -234,7 +256,8 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
     const uint32_t ooff = ((uint32_t)y * a.pitch + x0) * 3;
     const uint32_t ooff_masked = inimg ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: not written
-    constexpr int kWavePatch = (SLICES == 1 ? ROUNDS : kPairSliceRounds) * kPairRoundBytes;   // LDS this class needs per wave
+    // LDS this class needs per wave: the staged rounds, and 1 KB for the slice -> store order exchange of the sliced class
+    constexpr int kWavePatch = SLICES == 1 ? ROUNDS * kPairRoundBytes : kPairSliceRounds * kPairRoundBytes + 1024;
     uint8_t *const patch = lds + wave * kWavePatch;
     const uint2 *const pw = reinterpret_cast<const uint2 *>(patch);
 
@@ -371,39 +394,39 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
             for (int u = 0; u < D; ++u) frame(b + u, u);
         }
     } else {
-        // step = (frame, slice j): pixel slot j of all lanes; ring slot = slice parity
+        // step = (frame, slice j): lane l computes pixel 64 j + l of the tile (row-major); ring slot = slice parity
+        uint32_t *const xch = reinterpret_cast<uint32_t *>(patch + kPairSliceRounds * kPairRoundBytes);
+        const int xrd = ly_ * (4 * LX) + 4 * lx_;   // the lane's 4 stored pixels in row-major pixel order
         issue(b_begin, 0, 0);
         issue(b_begin, 1, 1);
         land(0);
 #pragma unroll 1
         for (int b = b_begin; b < b_end; ++b) {
-            uint32_t acc[4][3];
             uint32_t P[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 issue(j < 2 ? b : b + 1, (j + 2) & 3, j & 1);
                 if (kFast) {
-                    pixel(0, j, acc[j]);
+                    uint32_t acc[3];
+                    pixel(0, j, acc);
+                    P[j] = acc_to_px(acc);
                 } else {
                     int px[3];
                     contrib(0, j, px);
                     P[j] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
                 }
+                xch[64 * j + lane] = P[j];
                 land((j & 1) ^ 1);
             }
+            const uint4 q = *reinterpret_cast<const uint4 *>(xch + xrd);   // same wave: LDS operations complete in order
+            P[0] = q.x; P[1] = q.y; P[2] = q.z; P[3] = q.w;
             uint32_t d0, d1, d2;
-            if (kFast && !car_any) {
-                pack_accs(acc, d0, d1, d2);
+            if (kFast) {
+                if (car_any) add_car(P, car0, car1, car2);
             } else {
-                if (kFast) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) P[j] = acc_to_px(acc[j]);
-                    add_car(P, car0, car1, car2);
-                } else {
-                    finish(b, P);
-                }
-                pack_pixels(P, d0, d1, d2);
+                finish(b, P);
             }
+            pack_pixels(P, d0, d1, d2);
             store(b, d0, d1, d2);
         }
     }
@@ -414,7 +437,7 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
 template <int LX, int NSLOT, bool BLEND, bool SUMS, int SLICES, int ROUNDS>
 __global__ void __launch_bounds__(256) k_plan_pair(PlanArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * (SLICES == 1 ? ROUNDS : kPairSliceRounds) * kPairRoundBytes];
+    __shared__ __attribute__((aligned(16))) uint8_t patch[4 * (SLICES == 1 ? ROUNDS * kPairRoundBytes : kPairSliceRounds * kPairRoundBytes + 1024)];
     plan_pair_body<LX, NSLOT, BLEND, SUMS, SLICES, ROUNDS>(a, blockIdx.x, patch);
 }
 

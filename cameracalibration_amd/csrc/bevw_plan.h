@@ -71,8 +71,18 @@ struct Plan {
     void *list_pr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int n_pr[6] = {0, 0, 0, 0, 0, 0};
 
-    void *list_rp_single = nullptr, *list_rp_double = nullptr;
-    int n_rp_single = 0, n_rp_double = 0;
+    void *list_rp_single = nullptr, *list_rp_double = nullptr, *list_rp_empty = nullptr;
+    int n_rp_single = 0, n_rp_double = 0, n_rp_empty = 0;
+    // block-staged variant (bevw_block.h): 64 x 32 block tiles compiled on the host; their base tiles are in none of the
+    // pr / rp lists
+    void *bt_entries = nullptr, *bt_gsrc = nullptr, *bt_pos = nullptr;
+    void *list_bt[2] = {nullptr, nullptr};   // block tiles with 1 / 2 rounds of 512 groups
+    int n_bt[2] = {0, 0};
+    int n_bt_tiles = 0;                      // base tiles they cover
+    // the block-staged classes run on a second stream next to the per-wave classes (fork / join with two events): the two
+    // grids fill each other's tails
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool paired_ok = false;
 };
 
@@ -423,6 +433,10 @@ struct PlanArgs {
     const uint32_t *gsrc;        // group source offsets [ntiles][kPairRounds][64]
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
     int nlist;
+    // block-staged classes (bevw_block.h): tile_list holds block-tile ids, ngroups = nlist
+    const uint2 *bt_entries;
+    const uint32_t *bt_gsrc;
+    const uint32_t *bt_pos;
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -718,6 +732,7 @@ __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a) { plan_empty_bo
 
 }  // namespace bevw
 #include "bevw_pair.h"
+#include "bevw_block.h"
 namespace bevw {
 
 // Every tile class of a step in ONE launch: the class kernels write disjoint tiles and never depend on each other, but
@@ -792,10 +807,13 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 static inline void plan_release(Plan &p)
 {
     void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5],
-                    p.list_rp_single, p.list_rp_double,
+                    p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt[0], p.list_bt[1],
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p.ev_fork) (void)hipEventDestroy(p.ev_fork);
+    if (p.ev_join) (void)hipEventDestroy(p.ev_join);
+    if (p.aux) (void)hipStreamDestroy(p.aux);
     p = Plan();
 }
 
@@ -810,7 +828,7 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
                                          int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
-                                         int ncams = 4)
+                                         int ncams = 4, bool block_tiles = true)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -862,13 +880,50 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if ((e = hipMalloc(&p.gsrc, (size_t)p.ntiles * kPairSrcSlots * 64 * sizeof(uint32_t))) != hipSuccess) return e;
         hipLaunchKernelGGL(k_plan_pair_build, dim3(p.ntiles), dim3(64), 0, st, static_cast<const uint2 *>(p.entries),
                            static_cast<uint32_t *>(p.hdr), p.ntiles, (uint32_t)fw * 3, (uint32_t)((size_t)fw * fh * 3 * ncams),
-                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc));
+                           static_cast<uint2 *>(p.entries_pr), static_cast<uint32_t *>(p.gsrc), lx);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         p.paired_ok = true;
     }
     std::vector<uint32_t> hdr((size_t)p.ntiles);
     if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;
+    // block tiles (bevw_block.h): compiled on the host from the LUTs; claimed base tiles get kHdrBlock in the host copy
+    if (block_tiles && p.paired_ok && lx == 8) {
+        const size_t bpx = (size_t)bw * bh;
+        std::vector<int16_t> h1[4];
+        std::vector<uint16_t> h2[4];
+        std::vector<uint8_t> hm[4];
+        for (int c = 0; c < ncams; ++c) {
+            h1[c].resize(bpx * 2); h2[c].resize(bpx); hm[c].resize(bpx);
+            if ((e = hipMemcpy(h1[c].data(), T.lut1[c], bpx * 4, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            if ((e = hipMemcpy(h2[c].data(), T.lut2[c], bpx * 2, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+            if ((e = hipMemcpy(hm[c].data(), T.mask[c], bpx, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+        }
+        BlockPlanHost bp;
+        std::vector<uint32_t> hdr_bt = hdr;
+        block_compile(h1, h2, hm, ncams, fw, fh, bw, bh, p.tiles_x, p.tiles_y, hdr_bt, bp);
+        // worth two more launches only when the block tiles take a good part of the work (the 4K rig: 18 of 4166 tiles)
+        size_t claimed = 0, busy = 0;
+        for (size_t t = 0; t < hdr.size(); ++t) {
+            if (hdr[t] & kHdrEmpty) continue;
+            ++busy;
+            if (hdr_bt[t] & kHdrBlock) ++claimed;
+        }
+        if (!bp.pos.empty() && claimed * 4 >= busy) {
+            hdr.swap(hdr_bt);
+            if ((e = hipMalloc(&p.bt_entries, bp.entries.size() * sizeof(uint2))) != hipSuccess) return e;
+            if ((e = hipMemcpy(p.bt_entries, bp.entries.data(), bp.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
+            if ((e = plan_upload_list(bp.gsrc, &p.bt_gsrc)) != hipSuccess) return e;
+            if ((e = plan_upload_list(bp.pos, &p.bt_pos)) != hipSuccess) return e;
+            for (int r = 0; r < 2; ++r) {
+                p.n_bt[r] = (int)bp.list[r].size();
+                if ((e = plan_upload_list(bp.list[r], &p.list_bt[r])) != hipSuccess) return e;
+            }
+            if ((e = hipStreamCreateWithFlags(&p.aux, hipStreamNonBlocking)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
+            if ((e = hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
+        }
+    }
     // classify tiles (order kept): slow > empty > double > single
     std::vector<uint32_t> ls, ld, lw, le;
     for (int t = 0; t < p.ntiles; ++t) {
@@ -905,9 +960,12 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     };
     order(ls); order(ld); order(lw);
     {
-        std::vector<uint32_t> pr[6], rs, rd;
-        for (uint32_t t : ls) { if (hdr[t] & kHdrPaired) pr[(hdr[t] >> 8) & 3u].push_back(t); else rs.push_back(t); }
+        std::vector<uint32_t> pr[6], rs, rd, re;
+        for (uint32_t t : ls) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else if (hdr[t] & kHdrPaired) pr[(hdr[t] >> 8) & 3u].push_back(t); else rs.push_back(t); }
         for (uint32_t t : ld) { if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 1u)].push_back(t); else rd.push_back(t); }
+        for (uint32_t t : le) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else re.push_back(t); }
+        p.n_rp_empty = (int)re.size();
+        if ((e = plan_upload_list(re, &p.list_rp_empty)) != hipSuccess) return e;
         for (int c = 0; c < 6; ++c) {
             p.n_pr[c] = (int)pr[c].size();
             if ((e = plan_upload_list(pr[c], &p.list_pr[c])) != hipSuccess) return e;
@@ -951,11 +1009,13 @@ __global__ void k_plan_unpad(const uint8_t *__restrict__ src, int bw, int pitch,
 // xcd_map: 1 = an XCD owns whole batch chunks; staged: 0 = gather classes only (k_plan_lean), 1 = pair-staged classes
 // (bevw_pair.h) for every tile that has a pair plan; one_launch: 1 = all tile classes of a step in one kernel
 // (k_plan_all), 0 = one launch per class
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; };
+// two_streams: 1 = the block-staged classes run on the plan's second stream, concurrently with the per-wave classes (measured:
+// no consistent gain on config 3, a loss on the short undistort step -- profiles/r02/sweeps.log; off)
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int two_streams = 0; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, bool staged, bool one_launch)
+                                        bool sums, bool staged, bool one_launch, bool two_streams)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -980,8 +1040,10 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     // the sparse rest, which stays on the gather kernel (k_plan_lean)
     void *l_single = staged ? p.list_rp_single : p.list_single;
     void *l_double = staged ? p.list_rp_double : p.list_double;
+    void *l_empty = staged ? p.list_rp_empty : p.list_empty;
     const int n_single = staged ? p.n_rp_single : p.n_single;
     const int n_double = staged ? p.n_rp_double : p.n_double;
+    const int n_empty = staged ? p.n_rp_empty : p.n_empty;
 #define BEVW_LAUNCH_CLASS(KERNEL, NS, SHMEM, ...)                                                                  \
     do {                                                                                                            \
         const dim3 grid(grid_blocks());                                                                             \
@@ -992,6 +1054,31 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         if ((e = hipGetLastError()) != hipSuccess) return e;                                                        \
     } while (0)
 #define BEVW_COMMA ,
+    // block-staged classes first: their blocks (8 waves, one barrier per frame) run longest
+    const bool fork = staged && two_streams && p.aux && (p.n_bt[0] || p.n_bt[1]);
+    hipStream_t sb = fork ? p.aux : st;
+    if (fork) {
+        if ((e = hipEventRecord(p.ev_fork, st)) != hipSuccess) return e;
+        if ((e = hipStreamWaitEvent(p.aux, p.ev_fork, 0)) != hipSuccess) return e;
+    }
+    if (staged) {
+        for (int r = 1; r >= 0; --r) {
+            if (!p.n_bt[r]) continue;
+            a.tile_list = static_cast<const uint32_t *>(p.list_bt[r]); a.nlist = p.n_bt[r]; a.ngroups = p.n_bt[r];
+            const dim3 grid(grid_blocks()), block8(512);
+#define BEVW_LAUNCH_BLOCK(R)                                                                                            \
+    do {                                                                                                                 \
+        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true, R>), grid, block8, 0, sb, a);                    \
+        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false, R>), grid, block8, 0, sb, a);                      \
+        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true, R>), grid, block8, 0, sb, a);                       \
+        else hipLaunchKernelGGL((k_plan_block<false, false, R>), grid, block8, 0, sb, a);                                \
+    } while (0)
+            if (r == 1) BEVW_LAUNCH_BLOCK(2); else BEVW_LAUNCH_BLOCK(1);
+#undef BEVW_LAUNCH_BLOCK
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+    }
+    if (fork && (e = hipEventRecord(p.ev_join, p.aux)) != hipSuccess) return e;
     if (staged && one_launch) {
         PlanAllArgs q;
         q.a = a;
@@ -1000,7 +1087,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         // (profiles/r01_sweeps.log, profiles/r02/sweeps.log)
         struct Cls { int kind; void *list; int n; };
         const Cls cls[] = {{8, p.list_pr[3], p.n_pr[3]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
-                           {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]}, {2, p.list_empty, p.n_empty}};
+                           {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]}, {2, l_empty, n_empty}};
         uint32_t at = 0;
         int np = 0;
         for (const Cls &c : cls) {
@@ -1032,8 +1119,8 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         if (staged && p.n_pr[3]) { set_list(p.list_pr[3], p.n_pr[3]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 4 BEVW_COMMA 2); }
         if (staged && p.n_pr[4]) { set_list(p.list_pr[4], p.n_pr[4]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
         if (staged && p.n_pr[5]) { set_list(p.list_pr[5], p.n_pr[5]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
-        if (p.n_empty) {
-            set_list(p.list_empty, p.n_empty);
+        if (n_empty) {
+            set_list(l_empty, n_empty);
             hipLaunchKernelGGL((k_plan_empty<LX>), dim3((unsigned)(a.ngroups * a.nchunks)), block, 0, st, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
@@ -1042,6 +1129,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     }
 #undef BEVW_LAUNCH_CLASS
 #undef BEVW_COMMA
+    if (fork && (e = hipStreamWaitEvent(st, p.ev_join, 0)) != hipSuccess) return e;
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
         const dim3 grid(grid_blocks());
@@ -1088,6 +1176,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.tile_list = nullptr; a.nlist = p.ntiles;
     a.plan_pr = static_cast<const uint2 *>(p.entries_pr);
     a.gsrc = static_cast<const uint32_t *>(p.gsrc);
+    a.bt_entries = static_cast<const uint2 *>(p.bt_entries);
+    a.bt_gsrc = static_cast<const uint32_t *>(p.bt_gsrc);
+    a.bt_pos = static_cast<const uint32_t *>(p.bt_pos);
     // pair-staged schedule: needs 4-byte aligned frame sets (dword-addressed group loads) and is not combined with the
     // per-tap luminance kernel
     const bool use_staged = !balance && tune.lean && tune.staged && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0;
@@ -1110,9 +1201,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

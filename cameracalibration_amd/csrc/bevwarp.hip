@@ -69,7 +69,9 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     static const int inter_env = [] { const char *s = getenv("BEVW_PLAN_INTERLEAVE"); return s ? atoi(s) : 1; }();
     static const int colmajor_env = [] { const char *s = getenv("BEVW_PLAN_COLMAJOR"); return s ? atoi(s) : 1; }();
     static const int super_env = [] { const char *s = getenv("BEVW_PLAN_SUPER"); return s ? atoi(s) : 1; }();
-    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams);
+    static const int block_env = [] { const char *s = getenv("BEVW_PLAN_BLOCK"); return s ? atoi(s) : 1; }();   // block tiles (bevw_block.h)
+    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
+                                   block_env != 0);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -85,6 +87,7 @@ static const PlanTuning &plan_tuning()
         if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_ONELAUNCH")) t.one_launch = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_TWOSTREAMS")) t.two_streams = atoi(s);
         return t;
     }();
     return tune;
@@ -1130,7 +1133,8 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
     if (plan_tuning().staged && h->plan.paired_ok) {
-        for (int c = 0; c < 6; ++c) info[5] += h->plan.n_pr[c];   // tiles on the pair-staged schedule (bevw_pair.h)
+        for (int c = 0; c < 6; ++c) info[5] += h->plan.n_pr[c];   // tiles on the pair-staged schedules (bevw_pair.h, bevw_block.h)
+        info[5] += h->plan.n_bt_tiles;
         info[6] = h->plan.n_rp_single + h->plan.n_rp_double;      // single / double tiles left on the L1-gather kernels
     } else {
         info[6] = h->plan.n_single + h->plan.n_double;
