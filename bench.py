@@ -298,6 +298,8 @@ def main():
                  "table_build_s": round(t_build, 3), "cameras_per_rank": len(gen.cams), "camera_groups": units_world,
                  "part_boxes": [list(b) for b in gen.boxes],
                  "transport": "single rank" if d.world == 1 else "rccl (native: ncclAllGather + grouped ncclSend/ncclRecv on the engine stream)"}
+        if os.environ.get("BEVW_BENCH_PTRS"):   # placement study (profiles/r02/sweeps.log: per-process spread)
+            extra["ptrs"] = {"in": hex(d_in.ptr), "out": hex(d_out.ptr)}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     elif w["kind"] == "bev":
@@ -323,6 +325,8 @@ def main():
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
                  "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3),
                  "tiles": {"staged": info["tiles_staged"], "gather": info["tiles_gather"], "border": info["tiles_border"]}}
+        if os.environ.get("BEVW_BENCH_PTRS"):   # placement study (profiles/r02/sweeps.log: per-process spread)
+            extra["ptrs"] = {"in": hex(d_in.ptr), "out": hex(d_out.ptr)}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     else:

@@ -183,7 +183,7 @@ __device__ __forceinline__ void plan_block_body(const PlanArgs &a, uint32_t bloc
         const uint8_t *src = a.frames + (size_t)min(b, b_end - 1) * set_bytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[r], 0, 0);
+        for (int r = 0; r < ROUNDS; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[r], 0, kPairLoadAux);
     };
     auto land = [&](int ring) {   // frame parity == ring == patch half
 #pragma unroll
@@ -193,7 +193,7 @@ __device__ __forceinline__ void plan_block_body(const PlanArgs &a, uint32_t bloc
     auto store = [&](int b, uint32_t d0, uint32_t d1, uint32_t d2) {
         uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked, 0, kPairStoreAux);
     };
     constexpr bool kFast = !BLEND && !SUMS;
     auto acc_to_px = [](const uint32_t acc[3]) {

@@ -44,6 +44,15 @@ constexpr int kPairSrcSlots = 8;             // gsrc entries per tile and lane: 
 constexpr int kPairModes = 4;
 constexpr uint32_t kPairNoGroup = 0x80000000u;   // source offset of a lane without a group (frame sets are < 2 GB)
 constexpr uint32_t kBufferWord3 = 0x00020000u;   // raw buffer descriptor, dword 3 (gfx9 family: DATA_FORMAT 32)
+// cache-policy bits of the group loads / tile stores (gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1).  Measured: see
+// profiles/r02/sweeps.log ("cache policy"); the defaults are what ships.
+#ifndef BEVW_LOAD_AUX
+#define BEVW_LOAD_AUX 0
+#endif
+#ifndef BEVW_STORE_AUX
+#define BEVW_STORE_AUX 0
+#endif
+constexpr int kPairLoadAux = BEVW_LOAD_AUX, kPairStoreAux = BEVW_STORE_AUX;
 
 struct __attribute__((packed, aligned(4))) AlignedU4 { uint32_t x, y, z, w; };
 
@@ -302,7 +311,7 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
         const uint8_t *src = a.frames + (size_t)min(b, b_end - 1) * set_bytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[s][r], 0, 0);
+        for (int r = 0; r < ROUNDS; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[s][r], 0, kPairLoadAux);
     };
     auto land = [&](int ring) {
 #pragma unroll
@@ -334,7 +343,7 @@ __device__ __forceinline__ void plan_pair_body(const PlanArgs &a, uint32_t block
         // a frame index past the end of the chunk re-writes the last frame with the same bytes
         uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;
         const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked, 0, kPairStoreAux);
     };
     // contribution of entry (s, j) accumulated onto px (saturating add of the second contributor)
     auto contrib = [&](int s, int j, int px[3]) {

@@ -1055,7 +1055,11 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     } while (0)
 #define BEVW_COMMA ,
     // block-staged classes first: their blocks (8 waves, one barrier per frame) run longest
-    const bool fork = staged && two_streams && p.aux && (p.n_bt[0] || p.n_bt[1]);
+    // (second stream: only when the per-wave side keeps a good part of the work -- on a remap plan every tile is a block tile
+    // and the fork / join events are pure overhead)
+    int n_wave_side = p.n_rp_single + p.n_rp_double;
+    for (int c = 0; c < 6; ++c) n_wave_side += p.n_pr[c];
+    const bool fork = staged && two_streams && p.aux && (p.n_bt[0] || p.n_bt[1]) && n_wave_side * 5 >= p.n_bt_tiles;
     hipStream_t sb = fork ? p.aux : st;
     if (fork) {
         if ((e = hipEventRecord(p.ev_fork, st)) != hipSuccess) return e;
