@@ -18,9 +18,10 @@
 //     flight across it).
 //
 // Block tiles are compiled on the HOST at plan-build time (block_compile: the LUTs come back once, ~30 MB) for the block
-// tiles whose pixels have at most one contributor each, no border footprint, and at most 1024 distinct groups (<= 512:
-// one round, 32 KB of LDS per block; <= 1024: two rounds, 64 KB); their base tiles carry kHdrBlock and leave the per-wave
-// classes.  Sparse block tiles (near the car every pixel samples its own texels), seams and blend overlaps stay on the
+// tiles whose pixels have at most one contributor each, no border footprint, and at most 512 distinct groups (one round
+// = one group per lane of the block, 2 x 16 KB of LDS); their base tiles carry kHdrBlock and leave the per-wave classes.
+// (A second class with two rounds -- <= 1024 groups, 64 KB, 2 blocks per CU -- and block tiles with two contributors per
+// pixel were built and measured no faster than the per-wave classes they replaced: profiles/r02/sweeps.log.)  Sparse block tiles (near the car every pixel samples its own texels), seams and blend overlaps stay on the
 // per-wave pair classes.
 #pragma once
 #include <algorithm>
@@ -32,14 +33,14 @@ constexpr uint32_t kHdrBlock = 1024u;          // base tile belongs to a block t
 constexpr int kBlockW = 64, kBlockH = 32;      // block tile in pixels = 2 x 4 base tiles of 32 x 8
 constexpr int kBlockWaves = 8;
 constexpr int kBlockRoundGroups = kBlockWaves * 64;              // groups per round: one per lane of the block
-constexpr int kBlockMaxRounds = 2;
+constexpr int kBlockMaxRounds = 1;   // rounds of 512 groups per block tile (a 2-round class, 64 KB of LDS, measured no faster: sweeps.log)
 constexpr int kBlockRoundBytes = kBlockWaves * kPairRoundBytes;  // 16 KB of pair entries per round
 
 struct BlockPlanHost {
     std::vector<uint2> entries;      // [nbt][8 waves][4 pixel slots][64 lanes]
-    std::vector<uint32_t> gsrc;      // [nbt][2 rounds][8 waves][64 lanes]
+    std::vector<uint32_t> gsrc;      // [nbt][rounds][8 waves][64 lanes]
     std::vector<uint32_t> pos;       // [nbt]  block-tile x | y << 16
-    std::vector<uint32_t> list[kBlockMaxRounds];   // block tiles by rounds (1, 2)
+    std::vector<uint32_t> list[kBlockMaxRounds];   // block tiles by rounds
 };
 
 // Host-side plan compiler of the block tiles.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers
@@ -97,7 +98,7 @@ static inline void block_compile(const std::vector<int16_t> lut1[4], const std::
             keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
             const int count = (int)keys.size();
             if (count == 0 || count > kBlockMaxRounds * kBlockRoundGroups) continue;
-            const int rounds = count <= kBlockRoundGroups ? 1 : 2;
+            const int rounds = (count + kBlockRoundGroups - 1) / kBlockRoundGroups;
             const uint32_t id = (uint32_t)out.pos.size();
             out.pos.push_back((uint32_t)bx | ((uint32_t)by << 16));
             out.list[rounds - 1].push_back(id);

@@ -147,9 +147,9 @@ __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict_
     const int count = pair_distinct(cand, 0xffffu, list, kMax, lane);
     __syncthreads();
     if (count == 0) return;
-    // two-contributor tiles (seams, blend overlaps) have pair classes for <= 128 groups; the few sparser ones stay on the
-    // gather class
-    if ((h & kHdrSecond) && count > 128) return;
+    // two-contributor tiles (seams, blend overlaps) have pair classes for <= 256 groups (whole-tile staging in 1 / 2 / 4
+    // rounds); the few sparser ones stay on the gather class
+    if ((h & kHdrSecond) && count > kMax) return;
     if (count <= kMax) {
         mode = count <= 64 ? 0 : (count <= 128 ? 1 : 2);
         write_src(0, count, kPairMaxRounds);

@@ -67,17 +67,18 @@ struct Plan {
     void *entries_pr = nullptr;  // uint2[ntiles][8][64]: x = LDS byte address of the pair entry of row 0 | row 1 << 16, y = meta
     void *gsrc = nullptr;        // uint32[ntiles][8][64]: per-lane source offset of the group of [slice][round]
     // pair classes: single-contributor tiles by mode (whole-tile 1 / 2 / 4 rounds, sliced), then two-contributor tiles
-    // (whole-tile 1 / 2 rounds)
-    void *list_pr[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int n_pr[6] = {0, 0, 0, 0, 0, 0};
+    // (whole-tile 1 / 2 / 4 rounds)
+    static constexpr int kPairClasses = 7;
+    void *list_pr[kPairClasses] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_pr[kPairClasses] = {0, 0, 0, 0, 0, 0, 0};
 
     void *list_rp_single = nullptr, *list_rp_double = nullptr, *list_rp_empty = nullptr;
     int n_rp_single = 0, n_rp_double = 0, n_rp_empty = 0;
     // block-staged variant (bevw_block.h): 64 x 32 block tiles compiled on the host; their base tiles are in none of the
     // pr / rp lists
     void *bt_entries = nullptr, *bt_gsrc = nullptr, *bt_pos = nullptr;
-    void *list_bt[2] = {nullptr, nullptr};   // block tiles with 1 / 2 rounds of 512 groups
-    int n_bt[2] = {0, 0};
+    void *list_bt = nullptr;                 // block-tile ids
+    int n_bt = 0;
     int n_bt_tiles = 0;                      // base tiles they cover
     // the block-staged classes run on a second stream next to the per-wave classes (fork / join with two events): the two
     // grids fill each other's tails
@@ -740,7 +741,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 8;   // classes of one merged launch
+constexpr int kPlanAllMax = 9;   // classes of one merged launch
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -748,7 +749,7 @@ struct PlanAllArgs {
     int ngroups[kPlanAllMax];
     uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
     // launch position -> class: 2 empty, 3 gather single, 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced),
-    // 9, 10 pair-staged double (1 / 2 rounds)
+    // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds)
     int kind[kPlanAllMax];
     int n;                             // launch positions in use
 };
@@ -772,6 +773,7 @@ __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
         case 8: plan_pair_body<LX, 1, BLEND, SUMS, 4, 2>(a, id, stage_0); break;
         case 9: plan_pair_body<LX, 2, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
         case 10: plan_pair_body<LX, 2, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
+        case 11: plan_pair_body<LX, 2, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
         // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
@@ -806,8 +808,8 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5],
-                    p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt[0], p.list_bt[1],
+    void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5], p.list_pr[6],
+                    p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt,
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -915,10 +917,8 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
             if ((e = hipMemcpy(p.bt_entries, bp.entries.data(), bp.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
             if ((e = plan_upload_list(bp.gsrc, &p.bt_gsrc)) != hipSuccess) return e;
             if ((e = plan_upload_list(bp.pos, &p.bt_pos)) != hipSuccess) return e;
-            for (int r = 0; r < 2; ++r) {
-                p.n_bt[r] = (int)bp.list[r].size();
-                if ((e = plan_upload_list(bp.list[r], &p.list_bt[r])) != hipSuccess) return e;
-            }
+            p.n_bt = (int)bp.list[0].size();
+            if ((e = plan_upload_list(bp.list[0], &p.list_bt)) != hipSuccess) return e;
             if ((e = hipStreamCreateWithFlags(&p.aux, hipStreamNonBlocking)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
             if ((e = hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
@@ -960,13 +960,13 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     };
     order(ls); order(ld); order(lw);
     {
-        std::vector<uint32_t> pr[6], rs, rd, re;
+        std::vector<uint32_t> pr[Plan::kPairClasses], rs, rd, re;
         for (uint32_t t : ls) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else if (hdr[t] & kHdrPaired) pr[(hdr[t] >> 8) & 3u].push_back(t); else rs.push_back(t); }
-        for (uint32_t t : ld) { if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 1u)].push_back(t); else rd.push_back(t); }
+        for (uint32_t t : ld) { if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 3u)].push_back(t); else rd.push_back(t); }
         for (uint32_t t : le) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else re.push_back(t); }
         p.n_rp_empty = (int)re.size();
         if ((e = plan_upload_list(re, &p.list_rp_empty)) != hipSuccess) return e;
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < Plan::kPairClasses; ++c) {
             p.n_pr[c] = (int)pr[c].size();
             if ((e = plan_upload_list(pr[c], &p.list_pr[c])) != hipSuccess) return e;
         }
@@ -1058,29 +1058,21 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     // (second stream: only when the per-wave side keeps a good part of the work -- on a remap plan every tile is a block tile
     // and the fork / join events are pure overhead)
     int n_wave_side = p.n_rp_single + p.n_rp_double;
-    for (int c = 0; c < 6; ++c) n_wave_side += p.n_pr[c];
-    const bool fork = staged && two_streams && p.aux && (p.n_bt[0] || p.n_bt[1]) && n_wave_side * 5 >= p.n_bt_tiles;
+    for (int c = 0; c < Plan::kPairClasses; ++c) n_wave_side += p.n_pr[c];
+    const bool fork = staged && two_streams && p.aux && p.n_bt && n_wave_side * 5 >= p.n_bt_tiles;
     hipStream_t sb = fork ? p.aux : st;
     if (fork) {
         if ((e = hipEventRecord(p.ev_fork, st)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(p.aux, p.ev_fork, 0)) != hipSuccess) return e;
     }
-    if (staged) {
-        for (int r = 1; r >= 0; --r) {
-            if (!p.n_bt[r]) continue;
-            a.tile_list = static_cast<const uint32_t *>(p.list_bt[r]); a.nlist = p.n_bt[r]; a.ngroups = p.n_bt[r];
-            const dim3 grid(grid_blocks()), block8(512);
-#define BEVW_LAUNCH_BLOCK(R)                                                                                            \
-    do {                                                                                                                 \
-        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true, R>), grid, block8, 0, sb, a);                    \
-        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false, R>), grid, block8, 0, sb, a);                      \
-        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true, R>), grid, block8, 0, sb, a);                       \
-        else hipLaunchKernelGGL((k_plan_block<false, false, R>), grid, block8, 0, sb, a);                                \
-    } while (0)
-            if (r == 1) BEVW_LAUNCH_BLOCK(2); else BEVW_LAUNCH_BLOCK(1);
-#undef BEVW_LAUNCH_BLOCK
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-        }
+    if (staged && p.n_bt) {
+        a.tile_list = static_cast<const uint32_t *>(p.list_bt); a.nlist = p.n_bt; a.ngroups = p.n_bt;
+        const dim3 grid(grid_blocks()), block8(512);
+        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true, 1>), grid, block8, 0, sb, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false, 1>), grid, block8, 0, sb, a);
+        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true, 1>), grid, block8, 0, sb, a);
+        else hipLaunchKernelGGL((k_plan_block<false, false, 1>), grid, block8, 0, sb, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (fork && (e = hipEventRecord(p.ev_join, p.aux)) != hipSuccess) return e;
     if (staged && one_launch) {
@@ -1090,7 +1082,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         // tiles, then the shorter pair classes, then the empty tiles), so that the short blocks fill the tail of the grid
         // (profiles/r01_sweeps.log, profiles/r02/sweeps.log)
         struct Cls { int kind; void *list; int n; };
-        const Cls cls[] = {{8, p.list_pr[3], p.n_pr[3]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
+        const Cls cls[] = {{8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
                            {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]}, {2, l_empty, n_empty}};
         uint32_t at = 0;
         int np = 0;
@@ -1123,6 +1115,7 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         if (staged && p.n_pr[3]) { set_list(p.list_pr[3], p.n_pr[3]); BEVW_LAUNCH_CLASS(k_plan_pair, 1, 0, BEVW_COMMA 4 BEVW_COMMA 2); }
         if (staged && p.n_pr[4]) { set_list(p.list_pr[4], p.n_pr[4]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 1); }
         if (staged && p.n_pr[5]) { set_list(p.list_pr[5], p.n_pr[5]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 2); }
+        if (staged && p.n_pr[6]) { set_list(p.list_pr[6], p.n_pr[6]); BEVW_LAUNCH_CLASS(k_plan_pair, 2, 0, BEVW_COMMA 1 BEVW_COMMA 4); }
         if (n_empty) {
             set_list(l_empty, n_empty);
             hipLaunchKernelGGL((k_plan_empty<LX>), dim3((unsigned)(a.ngroups * a.nchunks)), block, 0, st, a);

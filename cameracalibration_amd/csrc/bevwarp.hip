@@ -1133,7 +1133,7 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
     if (plan_tuning().staged && h->plan.paired_ok) {
-        for (int c = 0; c < 6; ++c) info[5] += h->plan.n_pr[c];   // tiles on the pair-staged schedules (bevw_pair.h, bevw_block.h)
+        for (int c = 0; c < Plan::kPairClasses; ++c) info[5] += h->plan.n_pr[c];   // tiles on the pair-staged schedules (bevw_pair.h, bevw_block.h)
         info[5] += h->plan.n_bt_tiles;
         info[6] = h->plan.n_rp_single + h->plan.n_rp_double;      // single / double tiles left on the L1-gather kernels
     } else {

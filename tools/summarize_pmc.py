@@ -26,8 +26,8 @@ try:
     CAL = json.load(open(os.path.join(ROOT, "profiles", "pmc_calibration.json")))["factors"]
 except (OSError, ValueError, KeyError):
     CAL = None
-GROUP_LOADERS = ("k_plan_all", "k_plan_pair", "k_plan_spatial")   # pair-staged stitch kernels
-PER_STEP = ("k_plan_all", "k_plan_staged", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
+GROUP_LOADERS = ("k_plan_all", "k_plan_pair", "k_plan_block")   # pair-staged stitch kernels
+PER_STEP = ("k_plan_all", "k_plan_block", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
 
 
 def kernel_sums(path):
