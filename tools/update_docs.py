@@ -1,40 +1,40 @@
-"""Rewrite the measured tables of DESIGN.md / BASELINE.md / README.md from profiles/r01_final/bench_*.json and
-profiles/hbm_traffic.json (run after tools/collect_profiles.sh and copying its output into profiles/)."""
+"""Regenerate the measured blocks of DESIGN.md / BASELINE.md / README.md (between `<!-- name:begin -->` / `<!-- name:end -->`
+markers) from profiles/r02_final/bench_*.json, the rocprofv3 kernel statistics and profiles/hbm_traffic.json.  Run after
+tools/collect_profiles.sh and copying its output into profiles/r02_final/."""
 import csv
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r01_final")
+P = os.path.join(ROOT, "profiles", "r02_final")
 W = ["direct_stitch_b256", "blend_b256", "blend_balance_b256", "undistort_b64", "blend_4k"]
 d = {w: json.load(open(os.path.join(P, "bench_%s.json" % w))) for w in W}
 t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
 ALG = {"direct_stitch_b256": 5532357 * 256, "blend_balance_b256": 22585476 * 256, "undistort_b64": 5421912 * 64}
+R01 = {"direct_stitch_b256": "0.65-0.67 ms, 0.26-0.27 (driver: 0.263)", "blend_b256": "0.739 ms", "blend_balance_b256": "2.311 ms",
+       "undistort_b64": "0.157 ms", "blend_4k": "0.242 ms"}
 
 
 def fmt(v):
     return format(round(v), ",")
 
 
-def cpu(w):
-    return d[w]["cpu_baseline"]["value"]
-
-
-def ratio(w):
-    return (t[w]["fetch_bytes"] + t[w]["write_bytes"]) / ALG[w]
-
-
-def kernel_avg_us():
-    with open(os.path.join(P, "rocprofv3_kernel_stats_direct_stitch_b256.csv")) as fh:
-        for r in csv.DictReader(fh):
-            if "k_plan_all" in r["Name"]:
-                return float(r["AverageNs"]) / 1e3
-    return float("nan")
-
-
-def replace_between(s, start, end, new):
-    i0, i1 = s.index(start), s.index(end)
+def between(s, name, new):
+    a, b = "<!-- %s:begin -->" % name, "<!-- %s:end -->" % name
+    i0, i1 = s.index(a) + len(a), s.index(b)
     return s[:i0] + new + s[i1:]
+
+
+def step_kernels(w):
+    """[(short name, average us)] of the per-step stitch kernels of workload w, launch order"""
+    out = []
+    with open(os.path.join(P, "rocprofv3_kernel_stats_%s.csv" % w)) as fh:
+        for r in csv.DictReader(fh):
+            n = r["Name"]
+            if any(k in n for k in ("k_plan_block", "k_plan_all", "k_plan_lean")):
+                out.append((n.split("(")[0].replace("void bevw::", ""), float(r["AverageNs"]) / 1e3))
+    order = {"k_plan_block": 0, "k_plan_all": 1, "k_plan_lean": 2}
+    return sorted(out, key=lambda kv: order[kv[0].split("<")[0]])
 
 
 def design():
@@ -43,27 +43,30 @@ def design():
 
     def row(name, w, unit):
         x, main = d[w], w == "direct_stitch_b256"
-        v, fr = fmt(x["value"]) + " " + unit, "%.3f" % x["roofline"]["frac"]
-        return "| %s | %s | %.3f | %s | %.1f %s (%d) | %dx |" % (name, "**" + v + "**" if main else v, x["roofline"]["kernel_ms"],
-                                                                "**" + fr + "**" if main else fr, cpu(w), unit,
-                                                                x["cpu_baseline"]["cores"], round(x["value"] / cpu(w)))
+        r, c = x["roofline"], x["cpu_baseline"]
+        v = fmt(x["value"]) + " " + unit
+        fr = "%.3f" % r["frac"]
+        return "| %s | %s | %.3f, %.3f | %s | %s / %s %s | %s |" % (
+            name, "**" + v + "**" if main else v, r["kernel_ms"], r["kernel_ms_median"],
+            ("**" + fr + "** (this run's buffer placement; see below)") if main else fr,
+            format(round(c["value"], 1), ","), format(round(c["value_1_thread"], 1), ","), unit, R01[w])
     rows = [row("config 3 direct stitch, batch 256", "direct_stitch_b256", "frames/s"), row("blend only, batch 256", "blend_b256", "frames/s"),
             row("config 4 blend + balance, batch 256", "blend_balance_b256", "frames/s"), row("config 2 undistort, batch 64", "undistort_b64", "images/s"),
             row("config 5 geometry (4K blend, 1 GPU, batch 32)", "blend_4k", "frames/s")]
-    ds, bb, ud = t["direct_stitch_b256"], t["blend_balance_b256"], t["undistort_b64"]
-    text = "\n".join(rows) + "\n\n" + (
-        "The numbers move by up to +-5 %% from box to box (config 3 between 353 k and 402 k frames/s over this round's runs of the same\n"
-        "kernels); the table is one `tools/collect_profiles.sh` run on one box.\n\n"
-        "rocprofv3 agrees with the HIP-event numbers: the step is ONE kernel, `k_plan_all<8,false,false>`, whose average in\n"
-        "`rocprofv3_kernel_stats_direct_stitch_b256.csv` is %.0f us against `roofline.kernel_ms` = %.3f ms of the un-profiled run\n"
-        "(per class, from the per-class launches of an earlier build: staged singles 299 us, gather singles 283 us, seam classes\n"
-        "37 + 27 us, empty tiles 21 us). HBM traffic per launch (`rocprofv3_pmc_hbm_traffic.md`, separate FETCH_SIZE / WRITE_SIZE\n"
-        "passes): config 3 %.0f + %.0f MB = %.2f x the 1.416 GB algorithmic bytes; config 2 %.0f + %.0f MB = %.2f x; config 4\n"
-        "%.0f + %.0f MB = %.2f x the gather-twice accounting (the built store-and-rescale schedule writes the pre-gain BEV and the\n"
-        "luminance-shifted texel groups once more) -- the kernels do not waste bandwidth, they under-use it.\n\n") % (
-        kernel_avg_us(), d["direct_stitch_b256"]["roofline"]["kernel_ms"], ds["fetch_bytes"] / 1e6, ds["write_bytes"] / 1e6, ratio("direct_stitch_b256"),
-        ud["fetch_bytes"] / 1e6, ud["write_bytes"] / 1e6, ratio("undistort_b64"), bb["fetch_bytes"] / 1e6, bb["write_bytes"] / 1e6, ratio("blend_balance_b256"))
-    s = replace_between(s, "| config 3 direct stitch, batch 256 | **", "Round-1 progression of config 3", text)
+    hdr = ("| Workload | units/s | ms / step (mean, median) | roofline frac | CPU oracle %d threads / 1 thread | round 1 |\n|---|---|---|---|---|---|\n"
+           % d["direct_stitch_b256"]["cpu_baseline"]["cores"])
+    s = between(s, "measured-table", "\n" + hdr + "\n".join(rows) + "\n")
+    ks = step_kernels("direct_stitch_b256")
+    s = between(s, "rocprof-sum", "`profiles/r02_final/rocprofv3_kernel_stats_direct_stitch_b256.csv` agrees: %s = %.0f us (%s) against `kernel_ms` %.3f." % (
+        " + ".join("%.1f" % us for _, us in ks), sum(us for _, us in ks), ", ".join("`%s`" % n.split("<")[0] for n, _ in ks),
+        d["direct_stitch_b256"]["roofline"]["kernel_ms"]))
+
+    def tr(w):
+        x = t[w]
+        return x["fetch_bytes"] / 1e6, x["write_bytes"] / 1e6, (x["fetch_bytes"] + x["write_bytes"]) / ALG[w]
+    a3, a2, a4 = tr("direct_stitch_b256"), tr("undistort_b64"), tr("blend_balance_b256")
+    s = between(s, "traffic", "config 3 %s + %s MB = %.2f x the 1.416 GB algorithmic bytes; config 2 %s + %s MB = %.2f x; config 4 %s + %s MB = %.2f x the "
+                              "gather-twice accounting." % (fmt(a3[0]), fmt(a3[1]), a3[2], fmt(a2[0]), fmt(a2[1]), a2[2], fmt(a4[0]), fmt(a4[1]), a4[2]))
     open(p, "w").write(s)
 
 
@@ -71,18 +74,24 @@ def baseline():
     p = os.path.join(ROOT, "BASELINE.md")
     s = open(p).read()
     x = d
-    new = ("| CPU oracle (reference op order, OpenMP), config 3 direct stitch | %.1f frames/s | 16 threads of the GPU box's host | `bench.py` `cpu_baseline`, kind \"port\" (cv2 itself is not installable) |\n"
-           "| CPU oracle, blend only / config 4 blend+balance / config 2 undistort | %.1f / %.1f frames/s / %s images/s | 16 threads | same |\n"
-           "| MI355X, config 3 direct stitch, batch 256 | **%s frames/s** (%.3f ms per launch) | 1 GPU | roofline frac %.3f of 8 TB/s on compulsory bytes; measured HBM traffic %.2fx compulsory; 353 k - 402 k across boxes |\n"
+    c = lambda w: x[w]["cpu_baseline"]
+    tr = t["direct_stitch_b256"]
+    new = ("\n| Measured here (round 2, `profiles/r02_final/`) | units/s | cores / GPUs | notes |\n|---|---|---|---|\n"
+           "| CPU oracle (reference op order, -O3 -march=native, OpenMP), config 3 direct stitch | %.1f frames/s (%.1f on 1 thread) | %d threads of the GPU box's host | `bench.py` `cpu_baseline`, kind \"port\" (cv2 itself is not installable) |\n"
+           "| CPU oracle, blend only / config 4 blend+balance / config 2 undistort | %.1f / %.1f frames/s / %s images/s | %d threads | same |\n"
+           "| MI355X, config 3 direct stitch, batch 256 | **%s frames/s** (%.3f ms per step) | 1 GPU | roofline frac %.3f of 8 TB/s on compulsory bytes; measured HBM traffic %.2fx compulsory (calibrated counters); 0.53-0.62 ms for the same build depending on buffer placement (DESIGN.md section 4) |\n"
            "| MI355X, blend only, batch 256 | %s frames/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 4 blend + balance, batch 256 | %s frames/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 2 undistort, batch 64 | %s images/s | 1 GPU | frac %.3f |\n"
-           "| MI355X, config 5 geometry (4K blend) on one GPU, batch 32 | %s frames/s | 1 GPU | frac %.3f; the camera-per-GPU form (`bench.py --workload blend_4k_camera_shard`) is built and bit-exact, its RCCL transport unmeasured (1-GPU boxes) |\n") % (
-        cpu("direct_stitch_b256"), cpu("blend_b256"), cpu("blend_balance_b256"), fmt(cpu("undistort_b64")),
-        fmt(x["direct_stitch_b256"]["value"]), x["direct_stitch_b256"]["roofline"]["kernel_ms"], x["direct_stitch_b256"]["roofline"]["frac"], ratio("direct_stitch_b256"),
+           "| MI355X, config 5 geometry (4K blend) on one GPU, batch 32 | %s frames/s | 1 GPU | frac %.3f; the camera-per-GPU form (`bench.py --workload blend_4k_camera_shard`) is built and bit-exact, its RCCL layer exercised world-1 only (1-GPU boxes) |\n"
+           "| Achievable HBM rates (`tools/hbm_stream.hip`, `profiles/r02/hbm_stream.log`) | stream read 6.4, write 5.9, copy 5.35, 9 : 16 read : write mix 5.16 TB/s; random 64-byte gather 3.56, 128-byte 5.9 TB/s | 1 GPU | the stitch moves 2.1 GB per config-3 step at 3.4-4.0 TB/s |\n") % (
+        c("direct_stitch_b256")["value"], c("direct_stitch_b256")["value_1_thread"], c("direct_stitch_b256")["cores"],
+        c("blend_b256")["value"], c("blend_balance_b256")["value"], fmt(c("undistort_b64")["value"]), c("blend_b256")["cores"],
+        fmt(x["direct_stitch_b256"]["value"]), x["direct_stitch_b256"]["roofline"]["kernel_ms"], x["direct_stitch_b256"]["roofline"]["frac"],
+        (tr["fetch_bytes"] + tr["write_bytes"]) / ALG["direct_stitch_b256"],
         fmt(x["blend_b256"]["value"]), x["blend_b256"]["roofline"]["frac"], fmt(x["blend_balance_b256"]["value"]), x["blend_balance_b256"]["roofline"]["frac"],
         fmt(x["undistort_b64"]["value"]), x["undistort_b64"]["roofline"]["frac"], fmt(x["blend_4k"]["value"]), x["blend_4k"]["roofline"]["frac"])
-    s = replace_between(s, "| CPU oracle (reference op order, OpenMP), config 3 direct stitch |", "| Achievable HBM ceiling", new)
+    s = between(s, "measured-rows", new)
     open(p, "w").write(s)
 
 
@@ -90,12 +99,16 @@ def readme():
     p = os.path.join(ROOT, "README.md")
     s = open(p).read()
     x = d
-    new = ("* 1 MI355X, batch 256, 4 x 1280x960 -> 1080x1080: **%.1f k stitched frames/s** direct (%.0f %% of the 8 TB/s roofline on\n"
-           "  compulsory bytes), %d k blend, %d k blend+balance, %d k undistort images/s, %d k frames/s on the 4K rig; CPU oracle on 16\n"
-           "  host threads: %.0f frames/s.  Details, profiles and the bound analysis: `DESIGN.md`, `profiles/`.\n\n") % (
+    new = ("\n* 1 MI355X, batch 256, 4 x 1280x960 -> 1080x1080, `profiles/r02_final/` (one run; the same build measures 0.53-0.62 ms per step\n"
+           "  depending on where the batch buffers land physically): **%.1f k stitched frames/s** direct (%.0f %% of the 8 TB/s roofline on compulsory\n"
+           "  bytes), %d k blend, %d k blend+balance, %d k undistort images/s, %d k frames/s on the 4K rig; CPU oracle on %d host threads:\n"
+           "  %.0f frames/s (%.0f on one).  The driver's own round-1 run measured 379,472 frames/s (frac 0.264).  Details, profiles and the bound\n"
+           "  analysis: `DESIGN.md`, `profiles/`.\n") % (
         x["direct_stitch_b256"]["value"] / 1e3, x["direct_stitch_b256"]["roofline"]["frac"] * 100, round(x["blend_b256"]["value"] / 1e3),
-        round(x["blend_balance_b256"]["value"] / 1e3), round(x["undistort_b64"]["value"] / 1e3), round(x["blend_4k"]["value"] / 1e3), cpu("direct_stitch_b256"))
-    s = replace_between(s, "* 1 MI355X, batch 256", "Build: `python __graft_entry__.py`", new)
+        round(x["blend_balance_b256"]["value"] / 1e3), round(x["undistort_b64"]["value"] / 1e3), round(x["blend_4k"]["value"] / 1e3),
+        x["direct_stitch_b256"]["cpu_baseline"]["cores"], x["direct_stitch_b256"]["cpu_baseline"]["value"],
+        x["direct_stitch_b256"]["cpu_baseline"]["value_1_thread"])
+    s = between(s, "measured", new)
     open(p, "w").write(s)
 
 
