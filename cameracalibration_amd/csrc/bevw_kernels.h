@@ -282,29 +282,33 @@ __global__ void k_warp_perspective(const uint8_t *__restrict__ src, int sw, int 
 }
 
 // sum of V = max(B,G,R) over one frame; np.mean(v) = sum / N exactly in fp64 (surroundBEV.py:64-67).
-// grid = (blocks_per_frame, n_frames); each lane eats 16-byte vectors (16 B = 5.33 texels, so work on 48-byte groups).
+// grid = (blocks_per_frame, n_frames).  A lane eats 12-byte pieces (4 whole texels, one global_load_dwordx3): consecutive lanes read
+// consecutive pieces, so every wave instruction covers 768 contiguous bytes, and 4 pieces per lane are in flight per trip.
+// vec_ok: the frames are 4-byte aligned and a whole number of dwords.
+struct __attribute__((packed, aligned(4))) VsumPiece { uint32_t x, y, z; };
+__device__ __forceinline__ unsigned vsum_piece(const VsumPiece &p)
+{
+    // texels (B G R): bytes 0..2 | 3..5 | 6..8 | 9..11 of x y z
+    const unsigned t1 = __builtin_amdgcn_alignbyte(p.y, p.x, 3), t2 = __builtin_amdgcn_alignbyte(p.z, p.y, 2), t3 = p.z >> 8;
+    auto v = [](unsigned t) { return max(t & 255u, max((t >> 8) & 255u, (t >> 16) & 255u)); };
+    return v(p.x) + v(t1) + v(t2) + v(t3);
+}
 __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, int vec_ok,
                        unsigned long long *__restrict__ sums)
 {
     const uint8_t *f = frames + (size_t)blockIdx.y * frame_bytes;
-    const size_t ngroups = vec_ok ? frame_bytes / 48 : 0;  // 16 texels per 48-byte group (needs 16-byte aligned frames)
-    const uint4 *f4 = reinterpret_cast<const uint4 *>(f);
+    const size_t npieces = vec_ok ? frame_bytes / 12 : 0;
+    const VsumPiece *fp = reinterpret_cast<const VsumPiece *>(f);
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (size_t)gridDim.x * blockDim.x;
     unsigned acc = 0;
-    for (size_t gidx = tid; gidx < ngroups; gidx += nthreads) {
-        uint4 a = f4[gidx * 3], b = f4[gidx * 3 + 1], c = f4[gidx * 3 + 2];
-        const unsigned wds[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int b0 = t * 3;
-            unsigned v0 = (wds[b0 >> 2] >> ((b0 & 3) * 8)) & 255;
-            unsigned v1 = (wds[(b0 + 1) >> 2] >> (((b0 + 1) & 3) * 8)) & 255;
-            unsigned v2 = (wds[(b0 + 2) >> 2] >> (((b0 + 2) & 3) * 8)) & 255;
-            acc += max(v0, max(v1, v2));
-        }
+    size_t i = tid;
+    for (; i + 3 * nthreads < npieces; i += 4 * nthreads) {
+        const VsumPiece a = fp[i], b = fp[i + nthreads], c = fp[i + 2 * nthreads], d = fp[i + 3 * nthreads];
+        acc += vsum_piece(a) + vsum_piece(b) + vsum_piece(c) + vsum_piece(d);
     }
-    // texels not covered by whole groups
-    for (size_t t = ngroups * 16 + tid; t * 3 + 2 < frame_bytes; t += nthreads)
+    for (; i < npieces; i += nthreads) acc += vsum_piece(fp[i]);
+    // texels not covered by whole pieces
+    for (size_t t = npieces * 4 + tid; t * 3 + 2 < frame_bytes; t += nthreads)
         acc += max((unsigned)f[t * 3], max((unsigned)f[t * 3 + 1], (unsigned)f[t * 3 + 2]));
     __shared__ unsigned long long part[16];
     unsigned long long s = wave_sum_u64(acc);
@@ -313,7 +317,7 @@ __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, i
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
-        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[i];
+        for (int i2 = 0; i2 < (int)(blockDim.x >> 6); ++i2) t += part[i2];
         atomicAdd(&sums[blockIdx.y], t);
     }
 }

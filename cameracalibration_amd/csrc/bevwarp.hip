@@ -846,7 +846,7 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
     const size_t frame_bytes = (size_t)fw * fh * 3;
     HIP_TRY(hipMemsetAsync(d_vsums, 0, sizeof(unsigned long long) * 4 * (size_t)nsets, st));
     const int nframes = nsets * 4;
-    const int vec_ok = (frame_bytes % 16 == 0 && ((uintptr_t)d_frames & 15u) == 0) ? 1 : 0;   // k_vsum's uint4 loads
+    const int vec_ok = (frame_bytes % 4 == 0 && ((uintptr_t)d_frames & 3u) == 0) ? 1 : 0;   // k_vsum's 12-byte loads
     int bpf = 2048 / (nframes > 0 ? nframes : 1);
     if (bpf < 8) bpf = 8;
     if (bpf > 256) bpf = 256;
@@ -1285,7 +1285,7 @@ int bevw_shard_vsums_device(bevw_handle *h, const void *d_frames, int batch, voi
     const size_t frame_bytes = (size_t)c.frame_width * c.frame_height * 3;
     const int nframes = batch * h->shard_n;
     HIP_TRY(hipMemsetAsync(d_vsums, 0, sizeof(unsigned long long) * (size_t)nframes, h->stream));
-    const int vec_ok = (frame_bytes % 16 == 0 && ((uintptr_t)d_frames & 15u) == 0) ? 1 : 0;
+    const int vec_ok = (frame_bytes % 4 == 0 && ((uintptr_t)d_frames & 3u) == 0) ? 1 : 0;
     int bpf = 2048 / nframes;
     if (bpf < 8) bpf = 8;
     if (bpf > 256) bpf = 256;
