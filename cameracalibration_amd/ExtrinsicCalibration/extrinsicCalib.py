@@ -31,7 +31,7 @@ parser.add_argument('-path', '--INPUT_PATH', default='./data/', type=str, help='
 parser.add_argument('-bw', '--BORAD_WIDTH', default=7, type=int, help='Chess Board Width (corners number)')
 parser.add_argument('-bh', '--BORAD_HEIGHT', default=6, type=int, help='Chess Board Height (corners number)')
 parser.add_argument('-size', '--SCALED_SIZE', default=10, type=int, help='Scaled Chess Board Square Size (image pixel)')
-args, _unknown = parser.parse_known_args()
+args, _unknown = parser.parse_known_args(_ffi.own_argv(parser))
 
 
 class CenterImage:

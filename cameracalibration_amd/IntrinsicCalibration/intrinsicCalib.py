@@ -32,7 +32,7 @@ parser.add_argument('-fw', '--FRAME_WIDTH', default=1280, type=int, help='Camera
 parser.add_argument('-fh', '--FRAME_HEIGHT', default=1024, type=int, help='Camera Frame Height')
 parser.add_argument('-fs', '--FOCAL_SCALE', default=0.5, type=float, help='Camera Undistort Focal Scale')
 parser.add_argument('-ss', '--SIZE_SCALE', default=1, type=float, help='Camera Undistort Size Scale')
-args, _unknown = parser.parse_known_args()
+args, _unknown = parser.parse_known_args(_ffi.own_argv(parser))
 
 
 class CalibData:

@@ -45,7 +45,7 @@ parser.add_argument('-fs', '--FOCAL_SCALE', default=1, type=float, help='Camera 
 parser.add_argument('-ss', '--SIZE_SCALE', default=2, type=float, help='Camera Undistort Size Scale')
 parser.add_argument('-blend', '--BLEND_FLAG', default=False, type=bool, help='Blend BEV Image (Ture/False)')
 parser.add_argument('-balance', '--BALANCE_FLAG', default=False, type=bool, help='Balance BEV Image (Ture/False)')
-args, _unknown = parser.parse_known_args()
+args, _unknown = parser.parse_known_args(_ffi.own_argv(parser))
 
 FRAME_WIDTH = args.FRAME_WIDTH
 FRAME_HEIGHT = args.FRAME_HEIGHT
@@ -289,7 +289,11 @@ class BevGenerator:
     """
 
     def __init__(self, blend=args.BLEND_FLAG, balance=args.BALANCE_FLAG, *, rig=None, device=0,
-                 schedule=_ffi.SCHED_AUTO):
+                 schedule=_ffi.SCHED_AUTO, projection='lut'):
+        """blend / balance: as in the reference (surroundBEV.py:283).  Additive keywords: rig ({name: (K, D, H)} instead of the
+        data directory), device, schedule, and projection -- 'lut' (default: the reference's table-driven path, bit-exact against
+        the oracle) or 'analytic' (inverse homography + fisheye model evaluated per frame and pixel in fp64, no tables; not the
+        reference's fixed-point arithmetic -- see bevw_set_projection in include/bevwarp.h)."""
         self.init_args()
         if rig is None:
             self.cameras = [Camera('front'), Camera('back'), Camera('left'), Camera('right')]
@@ -300,6 +304,11 @@ class BevGenerator:
         self.device = device
         self._engine = _Engine([(c.camera_mat, c.dist_coeff, c.homography) for c in self.cameras], blend, balance,
                                device, schedule)
+        if projection not in ('lut', 'analytic'):
+            raise Exception("projection should be lut/analytic")
+        self.projection = projection
+        if projection == 'analytic':
+            check(lib().bevw_set_projection(self._engine.h, _ffi.PROJ_ANALYTIC))
         for i, cam in enumerate(self.cameras):
             cam._attach(self._engine, i)
         cls = BlendMask if self.blend else Mask

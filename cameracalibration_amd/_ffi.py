@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so
 ABI_VERSION = 1
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
+PROJ_LUT, PROJ_ANALYTIC = 0, 1   # bevw_set_projection
 COMPAT_FILLPOLY, COMPAT_ADDWEIGHTED = 0, 1   # bevw_set_compat keys (include/bevwarp.h)
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "bevw_get_lut": (_i, [_vp, _i, _vp, _vp]),
     "bevw_get_mask": (_i, [_vp, _i, _vp]),
     "bevw_plan_info": (_i, [_vp, _vp]),
+    "bevw_set_projection": (_i, [_vp, _i]),
     "bevw_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "bevw_run_device": (_i, [_vp, _vp, _i, _vp, _vp]),
     "bevw_run_cameras": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -155,6 +157,27 @@ def f64(a, n) -> np.ndarray:
     out = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1)[:n])
     if out.size != n:
         raise Exception(f"expected {n} float64 values, got {out.size}")
+    return out
+
+
+def own_argv(parser, argv=None):
+    """The tokens of argv that are EXACTLY one of `parser`'s option strings (plus their value).  The mirror modules parse their
+    flags at import time like the reference does (surroundBEV.py:6-17); argparse prefix-matches single-dash options (a foreign
+    `-s` is taken for `-ss`) and would abort the host program, so only exact matches are handed to it."""
+    import sys
+
+    argv = list(sys.argv[1:] if argv is None else argv)
+    opts = parser._option_string_actions
+    out, i = [], 0
+    while i < len(argv):
+        tok = argv[i]
+        key = tok.split("=", 1)[0]
+        if key in opts:
+            out.append(tok)
+            if "=" not in tok and opts[key].nargs != 0 and i + 1 < len(argv):
+                out.append(argv[i + 1])
+                i += 1
+        i += 1
     return out
 
 

@@ -420,6 +420,120 @@ __global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, int fh, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Analytic projection (BASELINE north star): the same stitch WITHOUT look-up tables.  Per frame and
+// BEV pixel: inverse homography -> undistorted pixel -> fisheye model (the formulas of cv2.fisheye.initUndistortRectifyMap,
+// k_fisheye_map above) -> raw frame position, fp64; bilinear interpolation of the four texels in fp64, round half to even.
+// This is NOT the reference's arithmetic (the reference samples through two fixed-point tables, quantised to 1/32 pixel
+// twice -- the LUT quirk); it is what those tables approximate, judged against the table path by PSNR
+// (tests/test_analytic.py).  Masks, blend weights, the luminance round trip on the taps, the saturating sums, the white
+// balance and the car are the reference's, shared with k_stitch_pp.  Pixels whose undistorted position falls outside the
+// undistorted image contribute 0 (warp_homography of an image has BORDER_CONSTANT 0 there).
+// grid = (ceil(bw / 256), bh, batch)
+struct AnalyticRig {
+    double Minv[4][9];          // inverse homographies (BEV -> undistorted image)
+    double fx[4], fy[4], cx[4], cy[4];     // K
+    double d[4][4];             // D
+    double nfx[4], nfy[4], ncx[4], ncy[4]; // K' of the undistorted image (get_camera_mat_dst)
+    int uw, uh;                 // undistorted image size
+};
+
+template <bool BAL>
+__device__ __forceinline__ void analytic_px(const uint8_t *__restrict__ src, int fw, int fh, const AnalyticRig &R, int c, int x, int y,
+                                            int out[3], int delta, const int *sdiv, const int *hdiv)
+{
+    out[0] = out[1] = out[2] = 0;
+    const double *M = R.Minv[c];
+    const double X = M[0] * x + M[1] * y + M[2], Y = M[3] * x + M[4] * y + M[5], Wd = M[6] * x + M[7] * y + M[8];
+    if (Wd == 0.0) return;
+    const double u = X / Wd, v = Y / Wd;
+    if (!(u >= 0.0 && u <= (double)(R.uw - 1) && v >= 0.0 && v <= (double)(R.uh - 1))) return;
+    const double xn = (u - R.ncx[c]) / R.nfx[c], yn = (v - R.ncy[c]) / R.nfy[c];
+    const double r = sqrt(xn * xn + yn * yn);
+    const double theta = atan(r);
+    const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t4 * t4;
+    const double theta_d = theta * (1 + R.d[c][0] * t2 + R.d[c][1] * t4 + R.d[c][2] * t6 + R.d[c][3] * t8);
+    const double scale = (r == 0) ? 1.0 : theta_d / r;
+    const double px = R.fx[c] * xn * scale + R.cx[c], py = R.fy[c] * yn * scale + R.cy[c];
+    if (!(px > -1.0 && px < (double)fw && py > -1.0 && py < (double)fh)) return;   // the whole footprint is outside
+    const double fpx = floor(px), fpy = floor(py);
+    const int sx = (int)fpx, sy = (int)fpy;
+    const double ax = px - fpx, ay = py - fpy;
+    double t[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int tx = sx + (q & 1), ty = sy + (q >> 1);
+        if ((unsigned)tx < (unsigned)fw && (unsigned)ty < (unsigned)fh) {
+            const uint8_t *p = src + ((size_t)ty * fw + tx) * 3;
+            int b = p[0], g = p[1], rr = p[2];
+            if (BAL) luminance_shift_px(b, g, rr, delta, sdiv, hdiv);
+            t[q][0] = b; t[q][1] = g; t[q][2] = rr;
+        } else {
+            t[q][0] = t[q][1] = t[q][2] = 0.0;   // BORDER_CONSTANT 0 per tap
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double top = (1.0 - ax) * t[0][k] + ax * t[1][k], bot = (1.0 - ax) * t[2][k] + ax * t[3][k];
+        out[k] = sat_u8(rne_d((1.0 - ay) * top + ay * bot));
+    }
+}
+
+template <bool BLEND, bool BAL>
+__global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh,
+                                  const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
+                                  const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
+                                  uint8_t *__restrict__ out)
+{
+    __shared__ int sdiv[256], hdiv[256];
+    __shared__ unsigned long long part[3][4];
+    if (BAL) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+        __syncthreads();
+    }
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    const int b = blockIdx.z;
+    const size_t frame_bytes = (size_t)fw * fh * 3;
+    int acc[3] = {0, 0, 0};
+    if (x < bw) {
+        const size_t o = (size_t)y * bw + x;
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {
+            const int m = T.mask[c][o];
+            if (m == 0) continue;
+            const uint8_t *src = frames + ((size_t)b * 4 + c) * frame_bytes;
+            int v[3];
+            analytic_px<BAL>(src, fw, fh, R, c, x, y, v, BAL ? deltas[b * 4 + c] : 0, sdiv, hdiv);
+            if (BLEND) {
+                const float wgt = blend_weight_f32(m);
+                v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
+            }
+            acc[0] = min(255, acc[0] + v[0]); acc[1] = min(255, acc[1] + v[1]); acc[2] = min(255, acc[2] + v[2]);
+        }
+        uint8_t *d = out + ((size_t)b * bw * bh + o) * 3;
+        if (!BAL && car != nullptr) {
+            acc[0] = min(255, acc[0] + car[o * 3]); acc[1] = min(255, acc[1] + car[o * 3 + 1]);
+            acc[2] = min(255, acc[2] + car[o * 3 + 2]);
+        }
+        d[0] = (uint8_t)acc[0]; d[1] = (uint8_t)acc[1]; d[2] = (uint8_t)acc[2];
+    }
+    if (BAL) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            unsigned s = wave_sum_u32((unsigned)acc[k]);
+            if (lane == 0) part[k][wv] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            unsigned long long t = 0;
+            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[threadIdx.x][i];
+            atomicAdd(&chsums[b * 3 + threadIdx.x], t);
+        }
+    }
+}
+
 // per-channel sums of a batch of images (color_balance as an exported helper). grid = (blocks, batch)
 __global__ void k_channel_sums(const uint8_t *__restrict__ img, size_t npx, unsigned long long *__restrict__ chsums)
 {

@@ -776,6 +776,8 @@ struct bevw_handle {
     DevBuf in, out, car, tmp;
     Plan plan;
     int schedule_in_use = BEVW_SCHED_PER_PIXEL;
+    int projection = BEVW_PROJ_LUT;   // bevw_set_projection
+    AnalyticRig arig;                 // filled by bevw_build
     // camera-per-GPU mode: the cameras this handle owns (shard_n == 0: all four, the ordinary BevGenerator)
     int shard_n = 0;
     int shard_cams[4] = {0, 1, 2, 3};
@@ -839,6 +841,37 @@ static int stitch_per_pixel(bevw_handle *h, const uint8_t *d_frames, int batch, 
     return launch_check("k_stitch_pp");
 }
 
+// BEVW_PROJ_ANALYTIC: the per-pixel stitch with the projection evaluated per frame (k_stitch_analytic)
+static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
+{
+    const bevw_config &c = h->cfg;
+    StitchTables T;
+    for (int i = 0; i < 4; ++i) {
+        T.lut1[i] = h->lut1[i].as<int16_t>();
+        T.lut2[i] = h->lut2[i].as<uint16_t>();
+        T.mask[i] = h->mask[i].as<uint8_t>();
+    }
+    const int *deltas = h->deltas.as<int>();
+    const HsvTables *tab = h->hsv.as<HsvTables>();
+    unsigned long long *chs = h->chsums.as<unsigned long long>();
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        dim3 grid((c.bev_width + 255) / 256, c.bev_height, nb), block(256);
+        const uint8_t *fr = d_frames + (size_t)b0 * 4 * c.frame_width * c.frame_height * 3;
+        uint8_t *o = d_out + (size_t)b0 * c.bev_width * c.bev_height * 3;
+#define LAUNCH_AN(BL, BA)                                                                                                   \
+        hipLaunchKernelGGL((k_stitch_analytic<BL, BA>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
+                           c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car,                        \
+                           chs ? chs + b0 * 3 : nullptr, o)
+        if (c.blend && c.balance) LAUNCH_AN(true, true);
+        else if (c.blend) LAUNCH_AN(true, false);
+        else if (c.balance) LAUNCH_AN(false, true);
+        else LAUNCH_AN(false, false);
+#undef LAUNCH_AN
+    }
+    return launch_check("k_stitch_analytic");
+}
+
 // luminance statistics of a batch of 4-camera sets -> deltas[batch][4]
 static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, int fw, int fh, unsigned long long *d_vsums,
                            int *d_deltas)
@@ -877,7 +910,9 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
     // balance schedule of the tile plan: 1 = shift the sampled band of the raw frames once (k_lum_band), then the lean
     // kernels; 0 = luminance round trip per fetched texel inside the generic kernel
     static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
-    if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok) {
+    if (h->projection == BEVW_PROJ_ANALYTIC) {
+        BEVW_TRY(stitch_analytic(h, d_frames, batch, d_car, d_out));
+    } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok) {
         const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
         BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
         hipError_t e = plan_lum_band(h->plan, h->stream, d_frames, h->tmp.as<uint8_t>(), batch, h->deltas.as<int>(),
@@ -976,6 +1011,11 @@ int bevw_build(bevw_handle *h)
         BEVW_TRY(build_fisheye_maps(st, h->K[c], h->D[c], Kd, uw, uh, h->und1[c].as<int16_t>(), h->und2[c].as<uint16_t>()));
         Mat3 Minv;
         invert3x3(h->H[c], Minv.m);
+        for (int k = 0; k < 9; ++k) h->arig.Minv[c][k] = Minv.m[k];
+        h->arig.fx[c] = h->K[c][0]; h->arig.fy[c] = h->K[c][4]; h->arig.cx[c] = h->K[c][2]; h->arig.cy[c] = h->K[c][5];
+        for (int k = 0; k < 4; ++k) h->arig.d[c][k] = h->D[c][k];
+        h->arig.nfx[c] = Kd[0]; h->arig.nfy[c] = Kd[4]; h->arig.ncx[c] = Kd[2]; h->arig.ncy[c] = Kd[5];
+        h->arig.uw = uw; h->arig.uh = uh;
         hipLaunchKernelGGL(k_bev_lut, dim3((bw + 255) / 256, bh), dim3(256), 0, st, Minv, h->und1[c].as<int16_t>(),
                            h->und2[c].as<uint16_t>(), uw, uh, bw, bh, persp_block_width(bw, bh), h->lut1[c].as<int16_t>(),
                            h->lut2[c].as<uint16_t>());
@@ -1122,6 +1162,15 @@ int bevw_get_mask(bevw_handle *h, int cam, uint8_t *mask)
     HIP_TRY(hipMemcpy(mask, h->mask[cam].p, (size_t)h->cfg.bev_width * h->cfg.bev_height, hipMemcpyDeviceToHost));
     return BEVW_OK;
 }
+int bevw_set_projection(bevw_handle *h, int mode)
+{
+    if (!h) return fail(BEVW_E_INVALID, "null handle");
+    if (mode != BEVW_PROJ_LUT && mode != BEVW_PROJ_ANALYTIC) return fail(BEVW_E_INVALID, "unknown projection mode %d", mode);
+    if (mode == BEVW_PROJ_ANALYTIC && h->shard_n) return fail(BEVW_E_INVALID, "analytic projection is not available on camera-shard handles");
+    h->projection = mode;
+    return BEVW_OK;
+}
+
 int bevw_plan_info(bevw_handle *h, int32_t info[8])
 {
     BEVW_TRY(need_built(h));

@@ -103,6 +103,15 @@ void bevw_destroy(bevw_handle *h);
 int bevw_get_undistort_map(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2); /* Camera.undistort_maps */
 int bevw_get_lut(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2);           /* Camera.bev_maps       */
 int bevw_get_mask(bevw_handle *h, int cam, uint8_t *mask);  /* Mask.mask / BlendMask.mask (u8, before /255.0)   */
+/* Projection mode of bevw_run* (BASELINE.json north_star: "inverts H and applies the K/D fisheye model per output
+ * pixel").  BEVW_PROJ_LUT (default) is the reference's path: the tables Camera.__init__ builds (surroundBEV.py:82-102) compiled into
+ * the contributor plan -- bit-exact against the oracle.  BEVW_PROJ_ANALYTIC evaluates inverse homography + fisheye model per frame and
+ * pixel in fp64 and interpolates the four texels in fp64: no tables, not the reference's fixed-point arithmetic; judged against the
+ * table path by PSNR (tests/test_analytic.py).  Masks, blend weights, balance and the car are unchanged.  Call before or after
+ * bevw_build; not available on camera-shard handles. */
+#define BEVW_PROJ_LUT 0
+#define BEVW_PROJ_ANALYTIC 1
+int bevw_set_projection(bevw_handle *h, int mode);
 int bevw_plan_info(bevw_handle *h, int32_t info[8]);        /* [0] max contributors/pixel, [1] plan usable, [2] schedule in use */
 
 /* ---- BevGenerator.__call__ (surroundBEV.py:312-325) ------------------------------------------------------ */
