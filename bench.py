@@ -47,6 +47,12 @@ WORKLOADS = {
                           metric="fisheye undistort remap images/sec (1280x960 u8)"),
     "blend_4k": dict(kind="bev", cfg="4K", blend=True, balance=False, batch=32, unit="frames/s",
                      metric="stitched BEV frames/sec (4-cam 3840x2160->1080x1080, blend)"),
+    # the table-free projection mode: per-frame inverse homography + fisheye model, fp32 / fp64; same algorithmic
+    # bytes as config 3, so the roofline line shows what evaluating the projection per frame costs against the table path
+    "direct_stitch_analytic_f32_b64": dict(kind="bev", cfg="S", blend=False, balance=False, batch=64, unit="frames/s", projection="analytic_f32",
+                                           metric="stitched BEV frames/sec (4-cam 1280x960->1080x1080, analytic fp32 projection per frame)"),
+    "direct_stitch_analytic_f64_b64": dict(kind="bev", cfg="S", blend=False, balance=False, batch=64, unit="frames/s", projection="analytic",
+                                           metric="stitched BEV frames/sec (4-cam 1280x960->1080x1080, analytic fp64 projection per frame)"),
     # BASELINE config 5 in its camera-per-GPU form: ranks own cameras, parts travel over RCCL
     # send/recv, the stitch rank rotates.  1, 2 or a multiple of 4 ranks; every group of 4 ranks is a replica.
     "blend_4k_camera_shard": dict(kind="camera", cfg="4K", blend=True, balance=False, batch=32, unit="frames/s",
@@ -311,7 +317,8 @@ def main():
         for k, v in cfg.items():
             setattr(ns, k, v)
         t_build = time.perf_counter()
-        bev = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=rig, device=dev, schedule=sched)
+        bev = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=rig, device=dev, schedule=sched,
+                              projection=w.get("projection", "lut"))
         t_build = time.perf_counter() - t_build
         fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
         unique = W.synthetic_frames(a.unique_sets, fw, fh, seed=W.SEED + d.rank)

@@ -292,8 +292,8 @@ class BevGenerator:
                  schedule=_ffi.SCHED_AUTO, projection='lut'):
         """blend / balance: as in the reference (surroundBEV.py:283).  Additive keywords: rig ({name: (K, D, H)} instead of the
         data directory), device, schedule, and projection -- 'lut' (default: the reference's table-driven path, bit-exact against
-        the oracle) or 'analytic' (inverse homography + fisheye model evaluated per frame and pixel in fp64, no tables; not the
-        reference's fixed-point arithmetic -- see bevw_set_projection in include/bevwarp.h)."""
+        the oracle) 'analytic' (inverse homography + fisheye model evaluated per frame and pixel in fp64, no tables; not the
+        reference's fixed-point arithmetic -- see bevw_set_projection in include/bevwarp.h) or 'analytic_f32' (the same in fp32)."""
         self.init_args()
         if rig is None:
             self.cameras = [Camera('front'), Camera('back'), Camera('left'), Camera('right')]
@@ -304,11 +304,12 @@ class BevGenerator:
         self.device = device
         self._engine = _Engine([(c.camera_mat, c.dist_coeff, c.homography) for c in self.cameras], blend, balance,
                                device, schedule)
-        if projection not in ('lut', 'analytic'):
-            raise Exception("projection should be lut/analytic")
+        modes = {'lut': _ffi.PROJ_LUT, 'analytic': _ffi.PROJ_ANALYTIC, 'analytic_f32': _ffi.PROJ_ANALYTIC_F32}
+        if projection not in modes:
+            raise Exception("projection should be lut/analytic/analytic_f32")
         self.projection = projection
-        if projection == 'analytic':
-            check(lib().bevw_set_projection(self._engine.h, _ffi.PROJ_ANALYTIC))
+        if projection != 'lut':
+            check(lib().bevw_set_projection(self._engine.h, modes[projection]))
         for i, cam in enumerate(self.cameras):
             cam._attach(self._engine, i)
         cls = BlendMask if self.blend else Mask

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so
 ABI_VERSION = 1
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
-PROJ_LUT, PROJ_ANALYTIC = 0, 1   # bevw_set_projection
+PROJ_LUT, PROJ_ANALYTIC, PROJ_ANALYTIC_F32 = 0, 1, 2   # bevw_set_projection
 COMPAT_FILLPOLY, COMPAT_ADDWEIGHTED = 0, 1   # bevw_set_compat keys (include/bevwarp.h)
 
 

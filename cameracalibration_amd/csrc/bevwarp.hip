@@ -860,9 +860,14 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
         const uint8_t *fr = d_frames + (size_t)b0 * 4 * c.frame_width * c.frame_height * 3;
         uint8_t *o = d_out + (size_t)b0 * c.bev_width * c.bev_height * 3;
 #define LAUNCH_AN(BL, BA)                                                                                                   \
-        hipLaunchKernelGGL((k_stitch_analytic<BL, BA>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                           c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car,                        \
-                           chs ? chs + b0 * 3 : nullptr, o)
+        do {                                                                                                                 \
+            if (h->projection == BEVW_PROJ_ANALYTIC_F32)                                                                     \
+                hipLaunchKernelGGL((k_stitch_analytic<BL, BA, float>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
+                                   c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
+            else                                                                                                             \
+                hipLaunchKernelGGL((k_stitch_analytic<BL, BA, double>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
+                                   c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
+        } while (0)
         if (c.blend && c.balance) LAUNCH_AN(true, true);
         else if (c.blend) LAUNCH_AN(true, false);
         else if (c.balance) LAUNCH_AN(false, true);
@@ -910,7 +915,7 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
     // balance schedule of the tile plan: 1 = shift the sampled band of the raw frames once (k_lum_band), then the lean
     // kernels; 0 = luminance round trip per fetched texel inside the generic kernel
     static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
-    if (h->projection == BEVW_PROJ_ANALYTIC) {
+    if (h->projection != BEVW_PROJ_LUT) {
         BEVW_TRY(stitch_analytic(h, d_frames, batch, d_car, d_out));
     } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok) {
         const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
@@ -1165,8 +1170,8 @@ int bevw_get_mask(bevw_handle *h, int cam, uint8_t *mask)
 int bevw_set_projection(bevw_handle *h, int mode)
 {
     if (!h) return fail(BEVW_E_INVALID, "null handle");
-    if (mode != BEVW_PROJ_LUT && mode != BEVW_PROJ_ANALYTIC) return fail(BEVW_E_INVALID, "unknown projection mode %d", mode);
-    if (mode == BEVW_PROJ_ANALYTIC && h->shard_n) return fail(BEVW_E_INVALID, "analytic projection is not available on camera-shard handles");
+    if (mode != BEVW_PROJ_LUT && mode != BEVW_PROJ_ANALYTIC && mode != BEVW_PROJ_ANALYTIC_F32) return fail(BEVW_E_INVALID, "unknown projection mode %d", mode);
+    if (mode != BEVW_PROJ_LUT && h->shard_n) return fail(BEVW_E_INVALID, "analytic projection is not available on camera-shard handles");
     h->projection = mode;
     return BEVW_OK;
 }

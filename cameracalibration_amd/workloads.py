@@ -128,4 +128,6 @@ ALGORITHMIC_BYTES = {
     "blend_balance_b256": 22_585_476,  # config 4: V-mean pass 14,745,600 + 2 x touched 2,170,338 + out 3,499,200
     "blend_4k": 11_810_991,            # config 5 (blend only): touched 8,311,791 + out 3,499,200
     "blend_4k_camera_shard": 11_810_991,  # same frames, camera per GPU (exchange bytes are overhead, not counted)
+    "direct_stitch_analytic_f32_b64": 5_532_357,   # config 3's bytes: the analytic modes touch (nearly) the same texels
+    "direct_stitch_analytic_f64_b64": 5_532_357,
 }

@@ -110,7 +110,8 @@ int bevw_get_mask(bevw_handle *h, int cam, uint8_t *mask);  /* Mask.mask / Blend
  * table path by PSNR (tests/test_analytic.py).  Masks, blend weights, balance and the car are unchanged.  Call before or after
  * bevw_build; not available on camera-shard handles. */
 #define BEVW_PROJ_LUT 0
-#define BEVW_PROJ_ANALYTIC 1
+#define BEVW_PROJ_ANALYTIC 1       /* fp64 projection and interpolation: equals its NumPy specification (oracle/np_analytic.py) */
+#define BEVW_PROJ_ANALYTIC_F32 2   /* the same formulas in fp32: ~3x faster, held against the fp64 mode by PSNR */
 int bevw_set_projection(bevw_handle *h, int mode);
 int bevw_plan_info(bevw_handle *h, int32_t info[8]);        /* [0] max contributors/pixel, [1] plan usable, [2] schedule in use */
 

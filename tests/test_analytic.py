@@ -103,3 +103,20 @@ def test_hip_analytic_with_balance_runs_and_stays_close_to_the_table_path(ffi, S
     assert psnr(lut, ana) > 28.0
     with pytest.raises(Exception, match="projection should be lut/analytic"):
         SB.BevGenerator(rig=repo_rig.rig, projection='exact')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blend", [False, True])
+def test_hip_analytic_f32_against_fp64(ffi, SB, oracle, repo_rig, blend):
+    """fp32 projection (positions good to ~1e-4 pixel) against the fp64 mode: judged by PSNR and max difference, not byte for byte"""
+    cfg = dict(oracle.DEFAULT_CFG)
+    a = SB.BevGenerator.get_args()
+    for k, v in cfg.items():
+        setattr(a, k, v)
+    frames = [repo_rig.image(n) for n in oracle.CAMERAS]
+    f64 = SB.BevGenerator(blend=blend, rig=repo_rig.rig, projection='analytic')(*frames)
+    f32 = SB.BevGenerator(blend=blend, rig=repo_rig.rig, projection='analytic_f32')(*frames)
+    d = np.abs(f64.astype(np.int32) - f32.astype(np.int32))
+    print("analytic fp32 vs fp64, blend=%s: PSNR %.1f dB, %.2f %% identical, max %d LSB" % (blend, psnr(f64, f32), 100 * (d == 0).mean(), int(d.max())))
+    assert psnr(f64, f32) > 55.0
+    assert (d == 0).mean() > 0.97
