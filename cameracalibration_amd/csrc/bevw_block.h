@@ -129,10 +129,15 @@ static inline void block_compile(const std::vector<int16_t> lut1[4], const std::
 // s_barrier that waits for this wave's LDS traffic only: the register prefetch (vmcnt) and the stores stay in flight
 __device__ __forceinline__ void block_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// one block of 8 waves: block tile from the class list, frames of the chunk.  lds: 2 x ROUNDS x 16 KB.
-template <bool BLEND, bool SUMS, int ROUNDS>
+// one block: block tile from the class list, frames of the chunk.  lds: 2 x 16 KB.
+// NSUB 1: 8 waves, wave w owns rows 4w .. 4w+3 (k_plan_block, 512 threads).  NSUB 2: 4 waves, wave w owns rows 4w .. 4w+3 and
+// 16+4w .. 16+4w+3 -- two groups, eight pixels and two stores per lane and frame -- so that the block tile fits the 256-thread blocks
+// of the merged launch (k_plan_all).
+template <bool BLEND, bool SUMS, int NSUB>
 __device__ __forceinline__ void plan_block_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
 {
+    static_assert(NSUB == 1 || NSUB == 2, "8 or 4 waves per block tile");
+    constexpr int kWaves = kBlockWaves / NSUB;
     uint32_t chunk, group;
     if (!plan_block_map(a, block_id, chunk, group)) return;   // uniform over the block
     if ((int)group >= a.nlist) return;
@@ -141,60 +146,62 @@ __device__ __forceinline__ void plan_block_body(const PlanArgs &a, uint32_t bloc
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bx = (int)(pos & 0xffffu), by = (int)(pos >> 16);
-    const int x0 = bx * kBlockW + (lane & 15) * 4, y = by * kBlockH + wave * 4 + (lane >> 4);
-    const bool inimg = x0 < a.bw && y < a.bh;
+    const int x0 = bx * kBlockW + (lane & 15) * 4;
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
-    const uint32_t ooff = ((uint32_t)y * a.pitch + x0) * 3;
-    const uint32_t ooff_masked = inimg ? ooff : kPairNoGroup;
-    constexpr int kHalf = ROUNDS * kBlockRoundBytes;   // one frame's patch
+    constexpr int kHalf = kBlockRoundBytes;   // one frame's patch
 
-    uint32_t i0[4], i1[4], wxa[4], wxb[4], wy[4];
-    float wf[4];
+    uint32_t i0[NSUB][4], i1[NSUB][4], wxa[NSUB][4], wy[NSUB][4], gs[NSUB], ooff[NSUB], ooff_masked[NSUB];
+    uint32_t car[NSUB][3];
+    float wf[NSUB][4];
+    int sum_tile[NSUB];
+    bool sum_plain;
+    uint32_t car_or = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint2 e = a.bt_entries[(((size_t)bt * kBlockWaves + wave) * 4 + j) * 64 + lane];
-        const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
-        const bool valid = e.y & kMetaValid;
-        i0[j] = (e.x & 0xffffu) >> 3; i1[j] = e.x >> 19;
-        wxa[j] = valid ? ((32 - fx) | (fx << 8)) : 0u;
-        wxb[j] = wxa[j] << 16;
-        wy[j] = ((32 - fy) << 6) | (fy << 22);
-        wf[j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
-    }
-    uint32_t gs[ROUNDS];
+    for (int s = 0; s < NSUB; ++s) {
+        const int vw = wave + kWaves * s;   // the wave of the 8-wave layout this sub-tile belongs to
+        const int y = by * kBlockH + vw * 4 + (lane >> 4);
+        const bool inimg = x0 < a.bw && y < a.bh;
+        ooff[s] = ((uint32_t)y * a.pitch + x0) * 3;
+        ooff_masked[s] = inimg ? ooff[s] : kPairNoGroup;
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) gs[r] = a.bt_gsrc[(((size_t)bt * kBlockMaxRounds + r) * kBlockWaves + wave) * 64 + lane];
-    uint32_t car0 = 0, car1 = 0, car2 = 0;
-    if (!SUMS && a.car != nullptr && inimg) {
-        const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff);
-        car0 = cp[0]; car1 = cp[1]; car2 = cp[2];
+        for (int j = 0; j < 4; ++j) {
+            const uint2 e = a.bt_entries[(((size_t)bt * kBlockWaves + vw) * 4 + j) * 64 + lane];
+            const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
+            const bool valid = e.y & kMetaValid;
+            i0[s][j] = (e.x & 0xffffu) >> 3; i1[s][j] = e.x >> 19;
+            wxa[s][j] = valid ? ((32 - fx) | (fx << 8)) : 0u;   // zero x weights: an absent entry contributes exactly 0
+            wy[s][j] = ((32 - fy) << 6) | (fy << 22);
+            wf[s][j] = BLEND ? blend_weight_f32((int)((e.y >> 10) & 255)) : 1.f;
+        }
+        gs[s] = a.bt_gsrc[((size_t)bt * kBlockWaves + vw) * 64 + lane];
+        car[s][0] = car[s][1] = car[s][2] = 0;
+        if (!SUMS && a.car != nullptr && inimg) {
+            const uint32_t *cp = reinterpret_cast<const uint32_t *>(a.car + ooff[s]);
+            car[s][0] = cp[0]; car[s][1] = cp[1]; car[s][2] = cp[2];
+        }
+        car_or |= car[s][0] | car[s][1] | car[s][2];
+        // balance: sub-tile vw owns the channel-sum slot of base tile vw of the block tile (only the per-frame total is used); where
+        // that base tile does not exist (right / bottom edge) it adds into the first one (plan_stitch_impl zeroes psums)
+        const int sum_tx = 2 * bx + (vw & 1), sum_ty = 4 * by + (vw >> 1);
+        const bool sum_own = sum_tx < a.tiles_x && sum_ty * a.tiles_x + sum_tx < a.ntiles;
+        sum_tile[s] = sum_own ? sum_ty * a.tiles_x + sum_tx : 4 * by * a.tiles_x + 2 * bx;
     }
-    const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
-    // balance: wave w owns the channel-sum slot of base tile w of the block tile (only the per-frame total is used); where
-    // that base tile does not exist (right / bottom edge) it adds into the first one (plan_stitch_impl zeroes psums)
-    const int sum_tx = 2 * bx + (wave & 1), sum_ty = 4 * by + (wave >> 1);
-    const bool sum_own = sum_tx < a.tiles_x && sum_ty * a.tiles_x + sum_tx < a.ntiles;
-    const bool sum_plain = 2 * bx + 1 < a.tiles_x && (4 * by + 3) * a.tiles_x + 2 * bx + 1 < a.ntiles;   // all 8 base tiles exist
-    const int sum_tile = sum_own ? sum_ty * a.tiles_x + sum_tx : 4 * by * a.tiles_x + 2 * bx;
+    sum_plain = 2 * bx + 1 < a.tiles_x && (4 * by + 3) * a.tiles_x + 2 * bx + 1 < a.ntiles;   // all 8 base tiles exist
+    const bool car_any = __builtin_amdgcn_ballot_w64(car_or != 0) != 0;
 
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
     constexpr int D = 2;
-    pair_u32x4 pf[D][ROUNDS];
+    pair_u32x4 pf[D][NSUB];
     auto issue = [&](int b, int ring) {
         const uint8_t *src = a.frames + (size_t)min(b, b_end - 1) * set_bytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[r], 0, kPairLoadAux);
+        for (int s = 0; s < NSUB; ++s) pf[ring][s] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[s], 0, kPairLoadAux);
     };
     auto land = [&](int ring) {   // frame parity == ring == patch half
 #pragma unroll
-        for (int r = 0; r < ROUNDS; ++r)
-            pair_convert_store(pf[ring][r], lds + ring * kHalf + (r * kBlockWaves + wave) * kPairRoundBytes, lane);
-    };
-    auto store = [&](int b, uint32_t d0, uint32_t d1, uint32_t d2) {
-        uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-        __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked, 0, kPairStoreAux);
+        for (int s = 0; s < NSUB; ++s)
+            pair_convert_store(pf[ring][s], lds + ring * kHalf + (wave + kWaves * s) * kPairRoundBytes, lane);
     };
     constexpr bool kFast = !BLEND && !SUMS;
     auto acc_to_px = [](const uint32_t acc[3]) {
@@ -203,47 +210,56 @@ __device__ __forceinline__ void plan_block_body(const PlanArgs &a, uint32_t bloc
     auto frame = [&](int b, int ring) {
         const uint2 *const pw = reinterpret_cast<const uint2 *>(lds + ring * kHalf);
         issue(b + D, ring);   // the ring slot of frame b was converted one step ago
-        uint32_t acc[4][3];
+        uint32_t d[NSUB][3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bilinear_pairs(pw[i0[j]], pw[i1[j]], wxa[j], wxb[j], wy[j], acc[j]);
-        uint32_t d0, d1, d2;
-        if (kFast && !car_any) {
-            pack_accs(acc, d0, d1, d2);
-        } else {
-            uint32_t P[4];
+        for (int s = 0; s < NSUB; ++s) {
+            uint32_t acc[4][3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (BLEND) {
-                    uint32_t px = 0;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) px |= (uint32_t)(int)((float)((acc[j][k] >> 16) & 255u) * wf[j]) << (8 * k);
-                    P[j] = px;
-                } else {
-                    P[j] = acc_to_px(acc[j]);
-                }
-            }
-            if (SUMS) {
-                uint32_t sb = 0, sg = 0, sr = 0;
+            for (int j = 0; j < 4; ++j) bilinear_pairs(pw[i0[s][j]], pw[i1[s][j]], wxa[s][j], wxa[s][j] << 16, wy[s][j], acc[j]);
+            if (kFast && !car_any) {
+                pack_accs(acc, d[s][0], d[s][1], d[s][2]);
+            } else {
+                uint32_t P[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
-                    sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
-                    sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
-                }
-                uint32_t bg = sb | (sg << 16);
+                    if (BLEND) {
+                        uint32_t px = 0;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
-                if (lane == 0 && b < b_end) {
-                    uint32_t *ps = a.psums + ((size_t)b * a.ntiles + sum_tile) * 3;
-                    if (sum_plain) { ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr; }
-                    else { atomicAdd(ps + 0, bg & 0xffffu); atomicAdd(ps + 1, bg >> 16); atomicAdd(ps + 2, sr); }
+                        for (int k = 0; k < 3; ++k) px |= (uint32_t)(int)((float)((acc[j][k] >> 16) & 255u) * wf[s][j]) << (8 * k);
+                        P[j] = px;
+                    } else {
+                        P[j] = acc_to_px(acc[j]);
+                    }
                 }
+                if (SUMS) {
+                    uint32_t sb = 0, sg = 0, sr = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sb = __builtin_amdgcn_udot4(P[j], 0x00000001u, sb, false);
+                        sg = __builtin_amdgcn_udot4(P[j], 0x00000100u, sg, false);
+                        sr = __builtin_amdgcn_udot4(P[j], 0x00010000u, sr, false);
+                    }
+                    uint32_t bg = sb | (sg << 16);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
+                    if (lane == 0 && b < b_end) {
+                        uint32_t *ps = a.psums + ((size_t)b * a.ntiles + sum_tile[s]) * 3;
+                        if (sum_plain) { ps[0] = bg & 0xffffu; ps[1] = bg >> 16; ps[2] = sr; }
+                        else { atomicAdd(ps + 0, bg & 0xffffu); atomicAdd(ps + 1, bg >> 16); atomicAdd(ps + 2, sr); }
+                    }
+                }
+                if (car_any) add_car(P, car[s][0], car[s][1], car[s][2]);
+                pack_pixels(P, d[s][0], d[s][1], d[s][2]);
             }
-            if (car_any) add_car(P, car0, car1, car2);
-            pack_pixels(P, d0, d1, d2);
         }
         land(ring ^ 1);       // frame b+1 into the other half: nobody reads it before the barrier
-        store(b, d0, d1, d2);
+        {
+            uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
+#pragma unroll
+            for (int s = 0; s < NSUB; ++s)
+                __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d[s][0], d[s][1], d[s][2]}, ro, (int)ooff_masked[s], 0, kPairStoreAux);
+        }
         block_lds_barrier();  // half[ring ^ 1] complete for everybody; half[ring] free for frame b+2
     };
 #pragma unroll
@@ -257,11 +273,12 @@ __device__ __forceinline__ void plan_block_body(const PlanArgs &a, uint32_t bloc
     }
 }
 
-template <bool BLEND, bool SUMS, int ROUNDS>
+// the block-staged class as a kernel of its own: 8 waves per block tile (per-class launches: BEVW_PLAN_ONELAUNCH=0)
+template <bool BLEND, bool SUMS>
 __global__ void __launch_bounds__(512) k_plan_block(PlanArgs a)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[2 * ROUNDS * kBlockRoundBytes];
-    plan_block_body<BLEND, SUMS, ROUNDS>(a, blockIdx.x, patch);
+    __shared__ __attribute__((aligned(16))) uint8_t patch[2 * kBlockRoundBytes];
+    plan_block_body<BLEND, SUMS, 1>(a, blockIdx.x, patch);
 }
 
 }  // namespace bevw

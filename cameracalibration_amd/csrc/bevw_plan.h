@@ -741,7 +741,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 9;   // classes of one merged launch
+constexpr int kPlanAllMax = 10;   // classes of one merged launch
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -749,7 +749,7 @@ struct PlanAllArgs {
     int ngroups[kPlanAllMax];
     uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
     // launch position -> class: 2 empty, 3 gather single, 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced),
-    // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds)
+    // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds), 12 block-staged (bevw_block.h, 4 waves per block tile)
     int kind[kPlanAllMax];
     int n;                             // launch positions in use
 };
@@ -774,6 +774,7 @@ __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
         case 9: plan_pair_body<LX, 2, BLEND, SUMS, 1, 1>(a, id, stage_0); break;
         case 10: plan_pair_body<LX, 2, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
         case 11: plan_pair_body<LX, 2, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
+        case 12: plan_block_body<BLEND, SUMS, 2>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
         // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
@@ -1009,13 +1010,14 @@ __global__ void k_plan_unpad(const uint8_t *__restrict__ src, int bw, int pitch,
 // xcd_map: 1 = an XCD owns whole batch chunks; staged: 0 = gather classes only (k_plan_lean), 1 = pair-staged classes
 // (bevw_pair.h) for every tile that has a pair plan; one_launch: 1 = all tile classes of a step in one kernel
 // (k_plan_all), 0 = one launch per class
+// bt_merged: 1 = the block tiles are a class of the merged launch (4 waves per block tile), 0 = their own 8-wave kernel first
 // two_streams: 1 = the block-staged classes run on the plan's second stream, concurrently with the per-wave classes (measured:
 // no consistent gain on config 3, a loss on the short undistort step -- profiles/r02/sweeps.log; off)
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int two_streams = 0; };
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int two_streams = 0; int bt_merged = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, bool staged, bool one_launch, bool two_streams)
+                                        bool sums, bool staged, bool one_launch, bool two_streams, bool bt_in_merged_launch)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1059,19 +1061,20 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     // and the fork / join events are pure overhead)
     int n_wave_side = p.n_rp_single + p.n_rp_double;
     for (int c = 0; c < Plan::kPairClasses; ++c) n_wave_side += p.n_pr[c];
-    const bool fork = staged && two_streams && p.aux && p.n_bt && n_wave_side * 5 >= p.n_bt_tiles;
+    const bool fork = staged && two_streams && p.aux && p.n_bt && n_wave_side * 5 >= p.n_bt_tiles && !(one_launch && bt_in_merged_launch);
     hipStream_t sb = fork ? p.aux : st;
     if (fork) {
         if ((e = hipEventRecord(p.ev_fork, st)) != hipSuccess) return e;
         if ((e = hipStreamWaitEvent(p.aux, p.ev_fork, 0)) != hipSuccess) return e;
     }
-    if (staged && p.n_bt) {
+    const bool bt_merged = staged && one_launch && bt_in_merged_launch && p.n_bt > 0;   // block tiles as a class of k_plan_all (4 waves each)
+    if (staged && p.n_bt && !bt_merged) {
         a.tile_list = static_cast<const uint32_t *>(p.list_bt); a.nlist = p.n_bt; a.ngroups = p.n_bt;
         const dim3 grid(grid_blocks()), block8(512);
-        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true, 1>), grid, block8, 0, sb, a);
-        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false, 1>), grid, block8, 0, sb, a);
-        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true, 1>), grid, block8, 0, sb, a);
-        else hipLaunchKernelGGL((k_plan_block<false, false, 1>), grid, block8, 0, sb, a);
+        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true>), grid, block8, 0, sb, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false>), grid, block8, 0, sb, a);
+        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true>), grid, block8, 0, sb, a);
+        else hipLaunchKernelGGL((k_plan_block<false, false>), grid, block8, 0, sb, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (fork && (e = hipEventRecord(p.ev_join, p.aux)) != hipSuccess) return e;
@@ -1082,14 +1085,14 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         // tiles, then the shorter pair classes, then the empty tiles), so that the short blocks fill the tail of the grid
         // (profiles/r01_sweeps.log, profiles/r02/sweeps.log)
         struct Cls { int kind; void *list; int n; };
-        const Cls cls[] = {{8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
+        const Cls cls[] = {{12, p.list_bt, bt_merged ? p.n_bt : 0}, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
                            {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]}, {2, l_empty, n_empty}};
         uint32_t at = 0;
         int np = 0;
         for (const Cls &c : cls) {
             if (!c.n) continue;
             q.kind[np] = c.kind;
-            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = (c.n + 3) / 4;
+            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = c.kind == 12 ? c.n : (c.n + 3) / 4;
             q.start[np] = at;
             a.ngroups = q.ngroups[np];
             const unsigned nblk = c.kind == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
@@ -1198,9 +1201,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0, tune.bt_merged != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0, tune.bt_merged != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0, tune.bt_merged != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {
