@@ -80,10 +80,6 @@ struct Plan {
     void *list_bt = nullptr;                 // block-tile ids
     int n_bt = 0;
     int n_bt_tiles = 0;                      // base tiles they cover
-    // the block-staged classes run on a second stream next to the per-wave classes (fork / join with two events): the two
-    // grids fill each other's tails
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool paired_ok = false;
 };
 
@@ -814,9 +810,6 @@ static inline void plan_release(Plan &p)
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
-    if (p.ev_fork) (void)hipEventDestroy(p.ev_fork);
-    if (p.ev_join) (void)hipEventDestroy(p.ev_join);
-    if (p.aux) (void)hipStreamDestroy(p.aux);
     p = Plan();
 }
 
@@ -920,9 +913,6 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
             if ((e = plan_upload_list(bp.pos, &p.bt_pos)) != hipSuccess) return e;
             p.n_bt = (int)bp.list[0].size();
             if ((e = plan_upload_list(bp.list[0], &p.list_bt)) != hipSuccess) return e;
-            if ((e = hipStreamCreateWithFlags(&p.aux, hipStreamNonBlocking)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&p.ev_fork, hipEventDisableTiming)) != hipSuccess) return e;
-            if ((e = hipEventCreateWithFlags(&p.ev_join, hipEventDisableTiming)) != hipSuccess) return e;
         }
     }
     // classify tiles (order kept): slow > empty > double > single
@@ -1011,13 +1001,11 @@ __global__ void k_plan_unpad(const uint8_t *__restrict__ src, int bw, int pitch,
 // (bevw_pair.h) for every tile that has a pair plan; one_launch: 1 = all tile classes of a step in one kernel
 // (k_plan_all), 0 = one launch per class
 // bt_merged: 1 = the block tiles are a class of the merged launch (4 waves per block tile), 0 = their own 8-wave kernel first
-// two_streams: 1 = the block-staged classes run on the plan's second stream, concurrently with the per-wave classes (measured:
-// no consistent gain on config 3, a loss on the short undistort step -- profiles/r02/sweeps.log; off)
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int two_streams = 0; int bt_merged = 1; };
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int bt_merged = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, bool staged, bool one_launch, bool two_streams, bool bt_in_merged_launch)
+                                        bool sums, bool staged, bool one_launch, bool bt_in_merged_launch)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1057,27 +1045,17 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     } while (0)
 #define BEVW_COMMA ,
     // block-staged classes first: their blocks (8 waves, one barrier per frame) run longest
-    // (second stream: only when the per-wave side keeps a good part of the work -- on a remap plan every tile is a block tile
-    // and the fork / join events are pure overhead)
-    int n_wave_side = p.n_rp_single + p.n_rp_double;
-    for (int c = 0; c < Plan::kPairClasses; ++c) n_wave_side += p.n_pr[c];
-    const bool fork = staged && two_streams && p.aux && p.n_bt && n_wave_side * 5 >= p.n_bt_tiles && !(one_launch && bt_in_merged_launch);
-    hipStream_t sb = fork ? p.aux : st;
-    if (fork) {
-        if ((e = hipEventRecord(p.ev_fork, st)) != hipSuccess) return e;
-        if ((e = hipStreamWaitEvent(p.aux, p.ev_fork, 0)) != hipSuccess) return e;
-    }
+    // (running the block class on a second stream next to the per-wave classes was measured: no consistent gain, profiles/r02/sweeps.log)
     const bool bt_merged = staged && one_launch && bt_in_merged_launch && p.n_bt > 0;   // block tiles as a class of k_plan_all (4 waves each)
     if (staged && p.n_bt && !bt_merged) {
         a.tile_list = static_cast<const uint32_t *>(p.list_bt); a.nlist = p.n_bt; a.ngroups = p.n_bt;
         const dim3 grid(grid_blocks()), block8(512);
-        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true>), grid, block8, 0, sb, a);
-        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false>), grid, block8, 0, sb, a);
-        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true>), grid, block8, 0, sb, a);
-        else hipLaunchKernelGGL((k_plan_block<false, false>), grid, block8, 0, sb, a);
+        if (blend && sums) hipLaunchKernelGGL((k_plan_block<true, true>), grid, block8, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_block<true, false>), grid, block8, 0, st, a);
+        else if (sums) hipLaunchKernelGGL((k_plan_block<false, true>), grid, block8, 0, st, a);
+        else hipLaunchKernelGGL((k_plan_block<false, false>), grid, block8, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (fork && (e = hipEventRecord(p.ev_join, p.aux)) != hipSuccess) return e;
     if (staged && one_launch) {
         PlanAllArgs q;
         q.a = a;
@@ -1129,7 +1107,6 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     }
 #undef BEVW_LAUNCH_CLASS
 #undef BEVW_COMMA
-    if (fork && (e = hipStreamWaitEvent(st, p.ev_join, 0)) != hipSuccess) return e;
     if (p.n_slow) {
         set_list(p.list_slow, p.n_slow);
         const dim3 grid(grid_blocks());
@@ -1201,9 +1178,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0, tune.bt_merged != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0, tune.bt_merged != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.two_streams != 0, tune.bt_merged != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

@@ -87,7 +87,6 @@ static const PlanTuning &plan_tuning()
         if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_ONELAUNCH")) t.one_launch = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_TWOSTREAMS")) t.two_streams = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_BT_MERGED")) t.bt_merged = atoi(s);
         return t;
     }();
