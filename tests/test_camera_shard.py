@@ -113,6 +113,37 @@ def test_hip_shards_combine_to_the_full_stitch(oracle, blend, balance):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bw", [250, 249])
+def test_hip_shards_with_a_bev_width_that_is_not_a_multiple_of_4(oracle, bw):
+    """camera shards on the padded-pitch tile plan (Plan::pitch): boxes, packing and the combine take the byte-granular paths"""
+    from cameracalibration_amd.SurroundBirdEyeView import cameraShard as CS
+
+    cfg = dict(SC.CFG, BEV_WIDTH=bw, BEV_HEIGHT=251)
+    SC.apply_cfg(cfg)
+    try:
+        CS._sb.BevGenerator.init_args(None)
+        rig_list = [SC.rig()[n] for n in SC.W.CAMERA_NAMES]
+        frames, car = SC.frames(batch=2, cfg=cfg), SC.car(cfg)
+        for blend, balance in [(True, False), (True, True)]:
+            ref = oracle.RefBevGenerator(SC.rig(), cfg, blend=blend, balance=balance)
+            want = np.stack([ref(*frames[b], car=car) for b in range(frames.shape[0])])
+            for part in ([(0, 1), (2, 3)], [(0,), (1,), (2,), (3,)]):
+                engines = [CS.HipShardEngine(rig_list, cams, blend, balance) for cams in part]
+                all_vsums = None
+                if balance:
+                    all_vsums = np.zeros((frames.shape[0], 4), np.uint64)
+                    for e in engines:
+                        all_vsums[:, list(e.cams)] = e.vsums(np.ascontiguousarray(frames[:, list(e.cams)]))
+                parts = [e.partial(np.ascontiguousarray(frames[:, list(e.cams)]), all_vsums) for e in engines]
+                got = engines[-1].combine(parts, [e.box for e in engines], car)
+                assert np.array_equal(got, want), "bw %d partition %s: %d bytes differ" % (bw, part, np.count_nonzero(got != want))
+                for e in engines:
+                    e.close()
+    finally:
+        SC.apply_cfg()
+
+
+@pytest.mark.gpu
 def test_hip_shard_box_and_errors():
     from cameracalibration_amd import _ffi
     from cameracalibration_amd.SurroundBirdEyeView import cameraShard as CS
