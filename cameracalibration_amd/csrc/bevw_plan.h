@@ -7,7 +7,9 @@
 // fractions, u8 mask/weight, camera}.  One wave64 owns a (4*LX) x (64/LX) pixel tile (4 horizontally adjacent
 // pixels per lane = one 12-byte store), loads its slice of the plan ONCE into registers, and then loops over the
 // frames of its batch chunk.  Address, weight and mask arithmetic is hoisted out of the batch loop; the fixed-point
-// bilinear runs on v_dot4_u32_u8 / v_dot2_u32_u16.  Two ways to get the texels, chosen per tile when the plan is built:
+// bilinear runs on v_dot4_u32_u8 / v_dot2_u32_u16.  Three ways to get the texels, chosen per tile when the plan is built:
+//   * block-staged (bevw_block.h, round 2): 2 x 4 base tiles form a 64 x 32 block tile whose footprint is staged ONCE per
+//     frame into a patch all waves of the block share (dense single-contributor regions: 71 % of the tiles of config 3);
 //   * pair-staged (bevw_pair.h, round 2): the tile's source texels are fetched in row-run groups, turned ONCE into
 //     dot-product-ready texel pairs in a wave-private LDS patch, and every pixel reads two 8-byte pair entries;
 //   * gather (plan_gather_tile): the schedule of round 1 for what cannot be pair-staged (frame widths that are not a
