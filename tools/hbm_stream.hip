@@ -55,6 +55,28 @@ __global__ void __launch_bounds__(256) k_stream_copy(const uint4 *__restrict__ s
         for (int u = 0; u < U; ++u) dst[base + (size_t)u * 256 + threadIdx.x] = v[u];
     }
 }
+// copy variants (--copy): nontemporal accesses, and every block owning ONE contiguous piece of the buffers
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) k_stream_copy_blocked(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const size_t per = n16 / gridDim.x, span = (size_t)U * 256;
+    const size_t b0 = (size_t)blockIdx.x * per;
+    for (size_t base = b0; base + span <= b0 + per; base += span) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint4 *p = src + base + (size_t)u * 256 + threadIdx.x;
+            if (NT) { v[u].x = __builtin_nontemporal_load(&p->x); v[u].y = __builtin_nontemporal_load(&p->y); v[u].z = __builtin_nontemporal_load(&p->z); v[u].w = __builtin_nontemporal_load(&p->w); }
+            else v[u] = *p;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint4 *q = dst + base + (size_t)u * 256 + threadIdx.x;
+            if (NT) { __builtin_nontemporal_store(v[u].x, &q->x); __builtin_nontemporal_store(v[u].y, &q->y); __builtin_nontemporal_store(v[u].z, &q->z); __builtin_nontemporal_store(v[u].w, &q->w); }
+            else *q = v[u];
+        }
+    }
+}
 // R streaming reads per W streaming writes, every lane alike.  `nit` iterations per block.
 template <int R, int W>
 __global__ void __launch_bounds__(256) k_mix(const uint4 *__restrict__ src, uint4 *__restrict__ dst, int nit, uint32_t *__restrict__ sink)
@@ -166,6 +188,19 @@ int main(int argc, char **argv)
     CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&sink, 64));
     CK(hipMemset(a, 1, bytes)); CK(hipMemset(b, 2, bytes));
     float ms;
+    if (argc > 1 && !strcmp(argv[1], "--copy")) {
+        // the guide quotes 6.29 TB/s for a float4 copy (read + written bytes): which copy shape gets there?
+#define COPYB(U, G, NT)                                                                                                             \
+        ms = timeit([&] { hipLaunchKernelGGL((k_stream_copy_blocked<U, NT>), dim3(G), dim3(256), 0, 0, a, b, n16); });              \
+        report("copy, contiguous piece per block U=" #U " grid=" #G " nt=" #NT, ms, (double)bytes, (double)bytes)
+        COPYB(4, 2048, false); COPYB(4, 2048, true); COPYB(8, 2048, false); COPYB(8, 2048, true); COPYB(8, 8192, false); COPYB(8, 8192, true);
+        COPYB(4, 16384, false); COPYB(4, 16384, true);
+        ms = timeit([&] { hipLaunchKernelGGL((k_stream_copy<8>), dim3(8192), dim3(256), 0, 0, a, b, n16); });
+        report("copy, interleaved blocks U=8 grid=8192", ms, (double)bytes, (double)bytes);
+        ms = timeit([&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); });
+        report("hipMemcpyAsync device to device", ms, (double)bytes, (double)bytes);
+        return 0;
+    }
 #define STREAM(U, G)                                                                                                                \
     ms = timeit([&] { hipLaunchKernelGGL((k_stream_read<U>), dim3(G), dim3(256), 0, 0, a, n16, sink); });                           \
     report("stream read  U=" #U " grid=" #G, ms, (double)bytes, 0);                                                                 \
