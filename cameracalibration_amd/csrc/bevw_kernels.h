@@ -439,17 +439,19 @@ struct AnalyticRig {
 };
 
 // F = double: the specification's arithmetic (oracle/np_analytic.py).  F = float: the same formulas in fp32 (atanf, sqrtf; positions good
-// to ~1e-4 pixel), ~3x faster; held against the fp64 result by PSNR, not byte for byte.
-template <bool BAL, typename F>
-__device__ __forceinline__ void analytic_px(const uint8_t *__restrict__ src, int fw, int fh, const AnalyticRig &R, int c, int x, int y,
-                                            int out[3], int delta, const int *sdiv, const int *hdiv)
+// to ~1e-4 pixel), faster; held against the fp64 result by PSNR, not byte for byte.
+template <typename F>
+struct AnalyticTap { int sx, sy; F ax, ay; };   // raw-frame footprint of one (pixel, camera): top-left texel and the fractions
+
+// BEV pixel (x, y) of camera c -> footprint; false when the pixel samples nothing (outside the undistorted image or the frame)
+template <typename F>
+__device__ __forceinline__ bool analytic_project(const AnalyticRig &R, int c, int x, int y, int fw, int fh, AnalyticTap<F> &t)
 {
-    out[0] = out[1] = out[2] = 0;
     const double *M = R.Minv[c];
     const F X = (F)M[0] * x + (F)M[1] * y + (F)M[2], Y = (F)M[3] * x + (F)M[4] * y + (F)M[5], Wd = (F)M[6] * x + (F)M[7] * y + (F)M[8];
-    if (Wd == (F)0) return;
+    if (Wd == (F)0) return false;
     const F u = X / Wd, v = Y / Wd;
-    if (!(u >= (F)0 && u <= (F)(R.uw - 1) && v >= (F)0 && v <= (F)(R.uh - 1))) return;
+    if (!(u >= (F)0 && u <= (F)(R.uw - 1) && v >= (F)0 && v <= (F)(R.uh - 1))) return false;
     const F xn = (u - (F)R.ncx[c]) / (F)R.nfx[c], yn = (v - (F)R.ncy[c]) / (F)R.nfy[c];
     const F r = sqrt(xn * xn + yn * yn);
     const F theta = atan(r);
@@ -457,32 +459,43 @@ __device__ __forceinline__ void analytic_px(const uint8_t *__restrict__ src, int
     const F theta_d = theta * ((F)1 + (F)R.d[c][0] * t2 + (F)R.d[c][1] * t4 + (F)R.d[c][2] * t6 + (F)R.d[c][3] * t8);
     const F scale = (r == (F)0) ? (F)1 : theta_d / r;
     const F px = (F)R.fx[c] * xn * scale + (F)R.cx[c], py = (F)R.fy[c] * yn * scale + (F)R.cy[c];
-    if (!(px > (F)-1 && px < (F)fw && py > (F)-1 && py < (F)fh)) return;   // the whole footprint is outside
+    if (!(px > (F)-1 && px < (F)fw && py > (F)-1 && py < (F)fh)) return false;   // the whole footprint is outside
     const F fpx = floor(px), fpy = floor(py);
-    const int sx = (int)fpx, sy = (int)fpy;
-    const F ax = px - fpx, ay = py - fpy;
+    t.sx = (int)fpx; t.sy = (int)fpy;
+    t.ax = px - fpx; t.ay = py - fpy;
+    return true;
+}
+
+// bilinear interpolation of the footprint in F, BORDER_CONSTANT 0 per tap, round half to even
+template <bool BAL, typename F>
+__device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src, int fw, int fh, const AnalyticTap<F> &tp, int out[3], int delta,
+                                                const int *sdiv, const int *hdiv)
+{
     F t[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int tx = sx + (q & 1), ty = sy + (q >> 1);
+        const int tx = tp.sx + (q & 1), ty = tp.sy + (q >> 1);
         if ((unsigned)tx < (unsigned)fw && (unsigned)ty < (unsigned)fh) {
             const uint8_t *p = src + ((size_t)ty * fw + tx) * 3;
             int b = p[0], g = p[1], rr = p[2];
             if (BAL) luminance_shift_px(b, g, rr, delta, sdiv, hdiv);
             t[q][0] = (F)b; t[q][1] = (F)g; t[q][2] = (F)rr;
         } else {
-            t[q][0] = t[q][1] = t[q][2] = (F)0;   // BORDER_CONSTANT 0 per tap
+            t[q][0] = t[q][1] = t[q][2] = (F)0;
         }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const F top = ((F)1 - ax) * t[0][k] + ax * t[1][k], bot = ((F)1 - ax) * t[2][k] + ax * t[3][k];
-        out[k] = sat_u8(rne_d((double)(((F)1 - ay) * top + ay * bot)));
+        const F top = ((F)1 - tp.ax) * t[0][k] + tp.ax * t[1][k], bot = ((F)1 - tp.ax) * t[2][k] + tp.ax * t[3][k];
+        out[k] = sat_u8(rne_d((double)(((F)1 - tp.ay) * top + tp.ay * bot)));
     }
 }
 
+// grid = (ceil(bw / 256), bh, ceil(batch / kAnalyticFrames)): a thread evaluates the projection of its pixel once per call and samples
+// kAnalyticFrames frames with it (the calibration of a handle is the same for every frame of a call; no table ever reaches memory)
+constexpr int kAnalyticFrames = 8;
 template <bool BLEND, bool BAL, typename F>
-__global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh,
+__global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh, int batch,
                                   const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                                   const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
                                   uint8_t *__restrict__ out)
@@ -495,43 +508,63 @@ __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, in
     }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
-    const int b = blockIdx.z;
+    const int b_begin = blockIdx.z * kAnalyticFrames, b_end = min(batch, b_begin + kAnalyticFrames);
     const size_t frame_bytes = (size_t)fw * fh * 3;
-    int acc[3] = {0, 0, 0};
+    const size_t o = (size_t)y * bw + (x < bw ? x : 0);
+    AnalyticTap<F> tap[4];
+    int cam[4], msk[4], n = 0;
     if (x < bw) {
-        const size_t o = (size_t)y * bw + x;
 #pragma unroll 1
         for (int c = 0; c < 4; ++c) {
             const int m = T.mask[c][o];
             if (m == 0) continue;
-            const uint8_t *src = frames + ((size_t)b * 4 + c) * frame_bytes;
-            int v[3];
-            analytic_px<BAL, F>(src, fw, fh, R, c, x, y, v, BAL ? deltas[b * 4 + c] : 0, sdiv, hdiv);
-            if (BLEND) {
-                const float wgt = blend_weight_f32(m);
-                v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
-            }
-            acc[0] = min(255, acc[0] + v[0]); acc[1] = min(255, acc[1] + v[1]); acc[2] = min(255, acc[2] + v[2]);
+            AnalyticTap<F> t;
+            if (!analytic_project<F>(R, c, x, y, fw, fh, t)) continue;   // contributes 0
+            // (the slots are filled in camera order, as the reference adds front, back, left, right)
+            if (n == 0) { tap[0] = t; cam[0] = c; msk[0] = m; }
+            else if (n == 1) { tap[1] = t; cam[1] = c; msk[1] = m; }
+            else if (n == 2) { tap[2] = t; cam[2] = c; msk[2] = m; }
+            else { tap[3] = t; cam[3] = c; msk[3] = m; }
+            ++n;
         }
-        uint8_t *d = out + ((size_t)b * bw * bh + o) * 3;
-        if (!BAL && car != nullptr) {
-            acc[0] = min(255, acc[0] + car[o * 3]); acc[1] = min(255, acc[1] + car[o * 3 + 1]);
-            acc[2] = min(255, acc[2] + car[o * 3 + 2]);
-        }
-        d[0] = (uint8_t)acc[0]; d[1] = (uint8_t)acc[1]; d[2] = (uint8_t)acc[2];
     }
-    if (BAL) {
-        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll 1
+    for (int b = b_begin; b < b_end; ++b) {
+        int acc[3] = {0, 0, 0};
+        if (x < bw) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            unsigned s = wave_sum_u32((unsigned)acc[k]);
-            if (lane == 0) part[k][wv] = s;
+            for (int k = 0; k < 4; ++k) {
+                if (k >= n) break;
+                const uint8_t *src = frames + ((size_t)b * 4 + cam[k]) * frame_bytes;
+                int v[3];
+                analytic_sample<BAL, F>(src, fw, fh, tap[k], v, BAL ? deltas[b * 4 + cam[k]] : 0, sdiv, hdiv);
+                if (BLEND) {
+                    const float wgt = blend_weight_f32(msk[k]);
+                    v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
+                }
+                acc[0] = min(255, acc[0] + v[0]); acc[1] = min(255, acc[1] + v[1]); acc[2] = min(255, acc[2] + v[2]);
+            }
+            uint8_t *d = out + ((size_t)b * bw * bh + o) * 3;
+            if (!BAL && car != nullptr) {
+                acc[0] = min(255, acc[0] + car[o * 3]); acc[1] = min(255, acc[1] + car[o * 3 + 1]);
+                acc[2] = min(255, acc[2] + car[o * 3 + 2]);
+            }
+            d[0] = (uint8_t)acc[0]; d[1] = (uint8_t)acc[1]; d[2] = (uint8_t)acc[2];
         }
-        __syncthreads();
-        if (threadIdx.x < 3) {
-            unsigned long long t = 0;
-            for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[threadIdx.x][i];
-            atomicAdd(&chsums[b * 3 + threadIdx.x], t);
+        if (BAL) {
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            __syncthreads();   // part[] of the previous frame has been consumed
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                unsigned s = wave_sum_u32((unsigned)acc[k]);
+                if (lane == 0) part[k][wv] = s;
+            }
+            __syncthreads();
+            if (threadIdx.x < 3) {
+                unsigned long long t = 0;
+                for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += part[threadIdx.x][i];
+                atomicAdd(&chsums[b * 3 + threadIdx.x], t);
+            }
         }
     }
 }

@@ -841,7 +841,7 @@ static int stitch_per_pixel(bevw_handle *h, const uint8_t *d_frames, int batch, 
     return launch_check("k_stitch_pp");
 }
 
-// BEVW_PROJ_ANALYTIC: the per-pixel stitch with the projection evaluated per frame (k_stitch_analytic)
+// BEVW_PROJ_ANALYTIC(_F32): the per-pixel stitch with the projection evaluated in the kernel (k_stitch_analytic)
 static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
 {
     const bevw_config &c = h->cfg;
@@ -854,19 +854,20 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
     const int *deltas = h->deltas.as<int>();
     const HsvTables *tab = h->hsv.as<HsvTables>();
     unsigned long long *chs = h->chsums.as<unsigned long long>();
-    for (int b0 = 0; b0 < batch; b0 += 65535) {
-        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-        dim3 grid((c.bev_width + 255) / 256, c.bev_height, nb), block(256);
+    const int per_launch = 65535 * kAnalyticFrames;
+    for (int b0 = 0; b0 < batch; b0 += per_launch) {
+        const int nb = batch - b0 < per_launch ? batch - b0 : per_launch;
+        dim3 grid((c.bev_width + 255) / 256, c.bev_height, (nb + kAnalyticFrames - 1) / kAnalyticFrames), block(256);
         const uint8_t *fr = d_frames + (size_t)b0 * 4 * c.frame_width * c.frame_height * 3;
         uint8_t *o = d_out + (size_t)b0 * c.bev_width * c.bev_height * 3;
 #define LAUNCH_AN(BL, BA)                                                                                                   \
         do {                                                                                                                 \
             if (h->projection == BEVW_PROJ_ANALYTIC_F32)                                                                     \
                 hipLaunchKernelGGL((k_stitch_analytic<BL, BA, float>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                                   c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
+                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
             else                                                                                                             \
                 hipLaunchKernelGGL((k_stitch_analytic<BL, BA, double>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                                   c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
+                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
         } while (0)
         if (c.blend && c.balance) LAUNCH_AN(true, true);
         else if (c.blend) LAUNCH_AN(true, false);
