@@ -774,6 +774,7 @@ struct bevw_handle {
     DevBuf und1[4], und2[4], lut1[4], lut2[4], mask[4];
     DevBuf hsv, vsums, deltas, chsums;
     DevBuf in, out, car, tmp;
+    DevBuf pre;           // balance: the pre-gain BEV (the gain pass runs out of place)
     Plan plan;
     int schedule_in_use = BEVW_SCHED_PER_PIXEL;
     int projection = BEVW_PROJ_LUT;   // bevw_set_projection
@@ -916,6 +917,7 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
     // balance schedule of the tile plan: 1 = shift the sampled band of the raw frames once (k_lum_band), then the lean
     // kernels; 0 = luminance round trip per fetched texel inside the generic kernel
     static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
+    uint8_t *gain_in = d_out;   // where the pre-gain BEV is written (the gain pass is in place unless stated otherwise)
     if (h->projection != BEVW_PROJ_LUT) {
         BEVW_TRY(stitch_analytic(h, d_frames, batch, d_car, d_out));
     } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok) {
@@ -924,8 +926,13 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         hipError_t e = plan_lum_band(h->plan, h->stream, d_frames, h->tmp.as<uint8_t>(), batch, h->deltas.as<int>(),
                                      h->hsv.as<HsvTables>());
         if (e != hipSuccess) return fail(BEVW_E_HIP, "k_lum_band launch failed: %s", hipGetErrorString(e));
+        // the gain pass reads the pre-gain BEV from a buffer of its own instead of rewriting the output in place: a read stream
+        // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
+        // one more BEV batch of HBM (0.9 GB at batch 256)
+        static const int oop = [] { const char *s = getenv("BEVW_GAIN_OOP"); return s ? atoi(s) : 1; }();
+        if (oop && npx % 4 == 0) { BEVW_TRY(h->pre.reserve(npx * 3 * (size_t)batch)); gain_in = h->pre.as<uint8_t>(); }
         BEVW_TRY(plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr,
-                             h->chsums.as<unsigned long long>(), d_out, true));
+                             h->chsums.as<unsigned long long>(), gain_in, true));
     } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4) {
         BEVW_TRY(plan_stitch(h->plan, h->stream, d_frames, batch, c.blend != 0, c.balance != 0, h->deltas.as<int>(),
                              h->hsv.as<HsvTables>(), d_car, h->chsums.as<unsigned long long>(), d_out));
@@ -936,7 +943,7 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         for (int b0 = 0; b0 < batch; b0 += 65535) {
             const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
             if (npx % 4 == 0 && aligned4)
-                hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
+                hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, gain_in + (size_t)b0 * npx * 3, npx,
                                    h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3, 32u,
                                    (uint32_t)nb, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
             else
@@ -1124,7 +1131,7 @@ void bevw_destroy(bevw_handle *h)
             h->und1[c].release(); h->und2[c].release(); h->lut1[c].release(); h->lut2[c].release(); h->mask[c].release();
         }
         h->hsv.release(); h->vsums.release(); h->deltas.release(); h->chsums.release(); h->sdeltas.release();
-        h->in.release(); h->out.release(); h->car.release(); h->tmp.release();
+        h->in.release(); h->out.release(); h->car.release(); h->tmp.release(); h->pre.release();
         plan_release(h->plan);
         h->laps.release();
         if (h->ev0) (void)hipEventDestroy(h->ev0);
