@@ -15,6 +15,8 @@ oracle/bevoracle.c or oracle/np_twin.py:
   fisheye maps (A.1)       inverse consistency: the map's target point is pushed back through an independent numerical
                            inverse of the distortion polynomial (scipy.optimize.brentq) and must land on the pixel it came from.
   BGR->HSV (A.7)           skimage.color.rgb2hsv from the image's conda python 3.9 (when present): |dH| <= 1, |dS| <= 1, V exact.
+  HSV->BGR (A.7)           skimage.color.hsv2rgb in float64: the 8-bit result is its rounding (<= 0.5 LSB).
+  resize (A.10)            skimage.transform.resize(order=1) where both sampling conventions coincide, scipy at cv2's own positions elsewhere.
 
 These are evidence ABOUT the restatement, reported as measured differences; they are not the parity oracle.
 """
@@ -177,3 +179,63 @@ def test_bgr2hsv_against_skimage(oracle, tmp_path):
     dH = np.minimum(dH, 180.0 - dH)[chroma]
     assert dH.max() <= 1.0 + 1e-9
     print("BGR2HSV vs skimage: max |dH| %.3f (of 180), max |dS| %.3f (of 255), V exact, %d colours" % (dH.max(), dS.max(), len(bgr)))
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason="no conda python with scikit-image in this image")
+def test_hsv2bgr_against_skimage(oracle, tmp_path):
+    """cv2.cvtColor(HSV2BGR) on 8U (surroundBEV.py:76): the float path H * 2 deg, S / 255, V / 255 -> BGR * 255 rounded."""
+    rng = np.random.default_rng(6)
+    hsv = np.stack([rng.integers(0, 180, 60000), rng.integers(0, 256, 60000), rng.integers(0, 256, 60000)], axis=1).astype(np.uint8)
+    np.save(tmp_path / "hsv.npy", hsv)
+    code = ("import numpy as np, sys\nfrom skimage.color import hsv2rgb\n"
+            "hsv = np.load(sys.argv[1]).astype(np.float64)\n"
+            "rgb = hsv2rgb(np.stack([hsv[:, 0] / 180.0, hsv[:, 1] / 255.0, hsv[:, 2] / 255.0], axis=1)[None])[0]\n"
+            "np.save(sys.argv[2], rgb)\n")
+    r = subprocess.run([CONDA, "-c", code, str(tmp_path / "hsv.npy"), str(tmp_path / "rgb.npy")], capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("skimage not usable")
+    ref = np.load(tmp_path / "rgb.npy")[:, ::-1] * 255.0          # -> BGR, 0..255 float
+    mine = oracle.hsv2bgr(hsv.reshape(1, -1, 3)).reshape(-1, 3).astype(np.float64)
+    d = np.abs(mine - ref)
+    print("HSV2BGR vs skimage: max |diff| %.3f LSB, mean %.3f over %d colours" % (d.max(), d.mean(), len(hsv)))
+    assert d.max() <= 0.5 + 1e-3          # the float result rounded to the nearest integer
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason="no conda python with scikit-image in this image")
+@pytest.mark.parametrize("f", [0.5, 2.0])
+def test_resize_linear_against_skimage(oracle, repo_rig, tmp_path, f):
+    """cv2.resize INTER_LINEAR (ScaleImage.__call__, extrinsicCalib.py:125): half-pixel centres, edge replication, 11-bit fixed-point
+    weights -- against skimage.transform.resize(order=1) in float64.  Only for factors where the output size is exactly f x the input:
+    cv2 samples with scale 1 / fx, skimage with input size / output size, and the two drift apart when f * size is rounded (x0.8 on 512
+    columns: up to half a pixel) -- those factors are held against scipy at cv2's own sample positions below."""
+    img = repo_rig.image("front")[200:520, 300:812]
+    got = oracle.resize_linear(img, f, f).astype(np.float64)
+    np.save(tmp_path / "img.npy", img)
+    code = ("import numpy as np, sys\nfrom skimage.transform import resize\n"
+            "img = np.load(sys.argv[1]).astype(np.float64)\n"
+            "out = resize(img, (int(sys.argv[3]), int(sys.argv[4])), order=1, mode='edge', anti_aliasing=False, preserve_range=True)\n"
+            "np.save(sys.argv[2], out)\n")
+    r = subprocess.run([CONDA, "-c", code, str(tmp_path / "img.npy"), str(tmp_path / "out.npy"), str(got.shape[0]), str(got.shape[1])],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("skimage not usable")
+    ref = np.load(tmp_path / "out.npy")
+    d = np.abs(got - ref)
+    print("resize x%.1f vs skimage order=1: max |diff| %.2f LSB, mean %.3f" % (f, d.max(), d.mean()))
+    assert d.mean() < 0.3 and d.max() <= 1.0   # rounding (0.25 on average) + the 11-bit weight quantisation
+
+
+@pytest.mark.parametrize("f", [0.37, 0.8, 1.6, 3.3])
+def test_resize_linear_against_scipy_at_cv2_positions(oracle, repo_rig, f):
+    """the same interpolation at the positions cv2 documents for fx-driven resizes -- source x = (dst x + 0.5) / fx - 0.5, clamped to the
+    image (edge replication) -- through scipy's order-1 interpolator in float64"""
+    img = repo_rig.image("front")[200:520, 300:812]
+    got = oracle.resize_linear(img, f, f).astype(np.float64)
+    dh, dw = got.shape[:2]
+    ys = np.clip((np.arange(dh) + 0.5) / f - 0.5, 0, img.shape[0] - 1)
+    xs = np.clip((np.arange(dw) + 0.5) / f - 0.5, 0, img.shape[1] - 1)
+    yy, xx = np.meshgrid(ys, xs, indexing="ij")
+    ref = np.stack([ndimage.map_coordinates(img[..., c].astype(np.float64), [yy, xx], order=1, mode="nearest") for c in range(3)], axis=-1)
+    d = np.abs(got - ref)
+    print("resize x%.2f vs scipy at cv2's positions: max |diff| %.2f LSB, mean %.3f" % (f, d.max(), d.mean()))
+    assert d.mean() < 0.3 and d.max() <= 1.0
