@@ -739,7 +739,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 10;   // classes of one merged launch
+constexpr int kPlanAllMax = 10;   // classes of one merged launch (launch positions in use)
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -1065,8 +1065,16 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         // tiles, then the shorter pair classes, then the empty tiles), so that the short blocks fill the tail of the grid
         // (profiles/r01_sweeps.log, profiles/r02/sweeps.log)
         struct Cls { int kind; void *list; int n; };
-        const Cls cls[] = {{12, p.list_bt, bt_merged ? p.n_bt : 0}, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single}, {10, p.list_pr[5], p.n_pr[5]},
-                           {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]}, {2, l_empty, n_empty}};
+        // launch order: the per-wave classes with the longest-running blocks first (sliced and 4-round tiles ... 1-round tiles), the block
+        // tiles behind them when the per-wave side holds a good part of the work (config 3 / blend: -1 % against block tiles first; a remap
+        // plan is nearly all block tiles and they go first: +2.5 % otherwise), the empty tiles last (profiles/r02/sweeps.log, run49)
+        int n_wave_side = n_single + n_double;
+        for (int c = 0; c < Plan::kPairClasses; ++c) n_wave_side += p.n_pr[c];
+        const bool bt_last = n_wave_side * 5 >= p.n_bt_tiles;
+        const Cls bt_cls = {12, p.list_bt, bt_merged ? p.n_bt : 0}, none = {12, nullptr, 0};
+        const Cls cls[] = {bt_last ? none : bt_cls, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single},
+                           {10, p.list_pr[5], p.n_pr[5]}, {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]},
+                           bt_last ? bt_cls : none, {2, l_empty, n_empty}};
         uint32_t at = 0;
         int np = 0;
         for (const Cls &c : cls) {
