@@ -79,6 +79,8 @@ struct Plan {
     // block-staged variant (bevw_block.h): 64 x 32 block tiles compiled on the host; their base tiles are in none of the
     // pr / rp lists
     void *bt_entries = nullptr, *bt_gsrc = nullptr, *bt_pos = nullptr;
+    void *sm_entries = nullptr, *sm_gsrc = nullptr, *sm_pos = nullptr, *list_sm = nullptr;   // seam block tiles (bevw_block.h)
+    int n_sm = 0;
     void *list_bt = nullptr;                 // block-tile ids
     int n_bt = 0;
     int n_bt_tiles = 0;                      // base tiles they cover
@@ -436,6 +438,10 @@ struct PlanArgs {
     const uint2 *bt_entries;
     const uint32_t *bt_gsrc;
     const uint32_t *bt_pos;
+    // seam block tiles (64 x 16, two contributors)
+    const uint2 *sm_entries;
+    const uint32_t *sm_gsrc;
+    const uint32_t *sm_pos;
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -739,7 +745,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 10;   // classes of one merged launch (launch positions in use)
+constexpr int kPlanAllMax = 12;   // classes of one merged launch (launch positions in use)
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -773,6 +779,7 @@ __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
         case 10: plan_pair_body<LX, 2, BLEND, SUMS, 1, 2>(a, id, stage_0); break;
         case 11: plan_pair_body<LX, 2, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
         case 12: plan_block_body<BLEND, SUMS, 2>(a, id, stage_0); break;
+        case 13: plan_seam_body<BLEND, SUMS>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
         // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
@@ -808,7 +815,7 @@ __global__ void k_reduce_psums(const uint32_t *__restrict__ psums, int ntiles, u
 static inline void plan_release(Plan &p)
 {
     void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5], p.list_pr[6],
-                    p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt,
+                    p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt, p.sm_entries, p.sm_gsrc, p.sm_pos, p.list_sm,
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -826,7 +833,7 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
                                          int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
-                                         int ncams = 4, bool block_tiles = true)
+                                         int ncams = 4, bool block_tiles = true, bool seam_tiles = true)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -900,6 +907,8 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         BlockPlanHost bp;
         std::vector<uint32_t> hdr_bt = hdr;
         block_compile(h1, h2, hm, ncams, fw, fh, bw, bh, p.tiles_x, p.tiles_y, hdr_bt, bp);
+        SeamPlanHost sp;
+        if (seam_tiles) seam_compile(h1, h2, hm, ncams, fw, fh, bw, bh, p.tiles_x, p.tiles_y, hdr_bt, sp);
         // worth two more launches only when the block tiles take a good part of the work (the 4K rig: 18 of 4166 tiles)
         size_t claimed = 0, busy = 0;
         for (size_t t = 0; t < hdr.size(); ++t) {
@@ -915,6 +924,14 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
             if ((e = plan_upload_list(bp.pos, &p.bt_pos)) != hipSuccess) return e;
             p.n_bt = (int)bp.list[0].size();
             if ((e = plan_upload_list(bp.list[0], &p.list_bt)) != hipSuccess) return e;
+            if (!sp.pos.empty()) {
+                if ((e = hipMalloc(&p.sm_entries, sp.entries.size() * sizeof(uint2))) != hipSuccess) return e;
+                if ((e = hipMemcpy(p.sm_entries, sp.entries.data(), sp.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
+                if ((e = plan_upload_list(sp.gsrc, &p.sm_gsrc)) != hipSuccess) return e;
+                if ((e = plan_upload_list(sp.pos, &p.sm_pos)) != hipSuccess) return e;
+                if ((e = plan_upload_list(sp.list, &p.list_sm)) != hipSuccess) return e;
+                p.n_sm = (int)sp.list.size();
+            }
         }
     }
     // classify tiles (order kept): slow > empty > double > single
@@ -955,7 +972,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     {
         std::vector<uint32_t> pr[Plan::kPairClasses], rs, rd, re;
         for (uint32_t t : ls) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else if (hdr[t] & kHdrPaired) pr[(hdr[t] >> 8) & 3u].push_back(t); else rs.push_back(t); }
-        for (uint32_t t : ld) { if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 3u)].push_back(t); else rd.push_back(t); }
+        for (uint32_t t : ld) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else if (hdr[t] & kHdrPaired) pr[4 + ((hdr[t] >> 8) & 3u)].push_back(t); else rd.push_back(t); }
         for (uint32_t t : le) { if (hdr[t] & kHdrBlock) ++p.n_bt_tiles; else re.push_back(t); }
         p.n_rp_empty = (int)re.size();
         if ((e = plan_upload_list(re, &p.list_rp_empty)) != hipSuccess) return e;
@@ -1058,6 +1075,15 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else hipLaunchKernelGGL((k_plan_block<false, false>), grid, block8, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (staged && p.n_sm && !one_launch) {   // the seam block tiles as a launch of their own (per-class mode)
+        a.tile_list = static_cast<const uint32_t *>(p.list_sm); a.nlist = p.n_sm; a.ngroups = p.n_sm;
+        const dim3 grid(grid_blocks());
+        if (blend && sums) hipLaunchKernelGGL((k_plan_seam<true, true>), grid, block, 0, st, a);
+        else if (blend) hipLaunchKernelGGL((k_plan_seam<true, false>), grid, block, 0, st, a);
+        else if (sums) hipLaunchKernelGGL((k_plan_seam<false, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_plan_seam<false, false>), grid, block, 0, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (staged && one_launch) {
         PlanAllArgs q;
         q.a = a;
@@ -1073,14 +1099,14 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         const bool bt_last = n_wave_side * 5 >= p.n_bt_tiles;
         const Cls bt_cls = {12, p.list_bt, bt_merged ? p.n_bt : 0}, none = {12, nullptr, 0};
         const Cls cls[] = {bt_last ? none : bt_cls, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single},
-                           {10, p.list_pr[5], p.n_pr[5]}, {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]}, {5, p.list_pr[0], p.n_pr[0]},
-                           bt_last ? bt_cls : none, {2, l_empty, n_empty}};
+                           {10, p.list_pr[5], p.n_pr[5]}, {13, p.list_sm, p.n_sm}, {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]},
+                           {5, p.list_pr[0], p.n_pr[0]}, bt_last ? bt_cls : none, {2, l_empty, n_empty}};
         uint32_t at = 0;
         int np = 0;
         for (const Cls &c : cls) {
             if (!c.n) continue;
             q.kind[np] = c.kind;
-            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = c.kind == 12 ? c.n : (c.n + 3) / 4;
+            q.list[np] = static_cast<const uint32_t *>(c.list); q.nlist[np] = c.n; q.ngroups[np] = c.kind >= 12 ? c.n : (c.n + 3) / 4;
             q.start[np] = at;
             a.ngroups = q.ngroups[np];
             const unsigned nblk = c.kind == 2 ? (unsigned)(a.ngroups * a.nchunks) : grid_blocks();
@@ -1166,6 +1192,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.bt_entries = static_cast<const uint2 *>(p.bt_entries);
     a.bt_gsrc = static_cast<const uint32_t *>(p.bt_gsrc);
     a.bt_pos = static_cast<const uint32_t *>(p.bt_pos);
+    a.sm_entries = static_cast<const uint2 *>(p.sm_entries);
+    a.sm_gsrc = static_cast<const uint32_t *>(p.sm_gsrc);
+    a.sm_pos = static_cast<const uint32_t *>(p.sm_pos);
     // pair-staged schedule: needs 4-byte aligned frame sets (dword-addressed group loads) and is not combined with the
     // per-tap luminance kernel
     const bool use_staged = !balance && tune.lean && tune.staged && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0;
