@@ -20,9 +20,11 @@
 // Block tiles are compiled on the HOST at plan-build time (block_compile: the LUTs come back once, ~30 MB) for the block
 // tiles whose pixels have at most one contributor each, no border footprint, and at most 512 distinct groups (one round
 // = one group per lane of the block, 2 x 16 KB of LDS); their base tiles carry kHdrBlock and leave the per-wave classes.
-// (A second class with two rounds -- <= 1024 groups, 64 KB, 2 blocks per CU -- and block tiles with two contributors per
-// pixel were built and measured no faster than the per-wave classes they replaced: profiles/r02/sweeps.log.)  Sparse block tiles (near the car every pixel samples its own texels), seams and blend overlaps stay on the
-// per-wave pair classes.
+// (A second class with two rounds -- <= 1024 groups, 64 KB, 2 blocks per CU -- and full 8-wave block tiles with two contributors
+// per pixel were built and measured no faster than the per-wave classes they replaced: profiles/r02/sweeps.log.)
+// Seams and blend overlaps get SEAM block tiles instead: 64 x 16 pixels, 4 waves, two contributors per pixel sharing one 512-group
+// patch (seam_compile / plan_seam_body below; only as a class of the merged launch's 256-thread blocks, and not for balance handles).
+// Sparse block tiles (near the car every pixel samples its own texels) stay on the per-wave pair classes.
 #pragma once
 #include <algorithm>
 #include <vector>
