@@ -84,7 +84,7 @@ def baseline():
     new = ("\n| Measured here (round 2, `profiles/r02_final/`) | units/s | cores / GPUs | notes |\n|---|---|---|---|\n"
            "| CPU oracle (reference op order, -O3 -march=native, OpenMP), config 3 direct stitch | %.1f frames/s (%.1f on 1 thread) | %d threads of the GPU box's host | `bench.py` `cpu_baseline`, kind \"port\" (cv2 itself is not installable) |\n"
            "| CPU oracle, blend only / config 4 blend+balance / config 2 undistort | %.1f / %.1f frames/s / %s images/s | %d threads | same |\n"
-           "| MI355X, config 3 direct stitch, batch 256 | **%s frames/s** (%.3f ms per step) | 1 GPU | roofline frac %.3f of 8 TB/s on compulsory bytes; measured HBM traffic %.2fx compulsory (calibrated counters); 0.53-0.62 ms for the same build depending on buffer placement (DESIGN.md section 4) |\n"
+           "| MI355X, config 3 direct stitch, batch 256 | **%s frames/s** (%.3f ms per step) | 1 GPU | roofline frac %.3f of 8 TB/s on compulsory bytes; measured HBM traffic %.2fx compulsory (calibrated counters); 0.51-0.62 ms for the same build depending on buffer placement (DESIGN.md section 4) |\n"
            "| MI355X, blend only, batch 256 | %s frames/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 4 blend + balance, batch 256 | %s frames/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 2 undistort, batch 64 | %s images/s | 1 GPU | frac %.3f |\n"
@@ -104,7 +104,7 @@ def readme():
     p = os.path.join(ROOT, "README.md")
     s = open(p).read()
     x = d
-    new = ("\n* 1 MI355X, batch 256, 4 x 1280x960 -> 1080x1080, `profiles/r02_final/` (one run; the same build measures 0.53-0.62 ms per step\n"
+    new = ("\n* 1 MI355X, batch 256, 4 x 1280x960 -> 1080x1080, `profiles/r02_final/` (one run; the same build measures 0.51-0.62 ms per step\n"
            "  depending on where the batch buffers land physically): **%.1f k stitched frames/s** direct (%.0f %% of the 8 TB/s roofline on compulsory\n"
            "  bytes), %d k blend, %d k blend+balance, %d k undistort images/s, %d k frames/s on the 4K rig; CPU oracle on %d host threads:\n"
            "  %.0f frames/s (%.0f on one).  The driver's own round-1 run measured 379,472 frames/s (frac 0.264).  Details, profiles and the bound\n"
