@@ -9,6 +9,57 @@
 
 namespace bevw {
 
+// ---- byte-permute / dot-product instructions of the staged stitch kernels, callable from host code as well ----------
+// On the device these are the gfx950 instructions themselves (v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16).
+// The host versions restate the instructions bit for bit; they exist ONLY so that tests/native/unit_emulate.cpp can run
+// the kernels' per-lane arithmetic and the plan compiler's output on a CPU (no product path ever calls them on the host).
+__host__ __device__ __forceinline__ uint32_t px_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+    const uint64_t v = ((uint64_t)hi << 32) | lo;   // byte s of {hi, lo}: 0..3 = lo, 4..7 = hi; 0x0c = 0x00, >= 0x0d = 0xff
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t s = (sel >> (8 * i)) & 255u;
+        uint32_t b;
+        if (s < 8) b = (uint32_t)(v >> (8 * s)) & 255u;
+        else if (s < 12) b = ((v >> (16 * (s - 8) + 15)) & 1u) ? 255u : 0u;   // sign of bytes 1, 3, 5, 7
+        else b = s == 12 ? 0u : 255u;
+        r |= b << (8 * i);
+    }
+    return r;
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t px_alignbyte(uint32_t hi, uint32_t lo, uint32_t n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, n);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (n & 3u)));
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t px_dot4(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_udot4(a, b, c, false);
+#else
+    for (int i = 0; i < 4; ++i) c += ((a >> (8 * i)) & 255u) * ((b >> (8 * i)) & 255u);
+    return c;
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t px_dot2(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    union { uint32_t u; us2 v; } x, y;
+    x.u = a; y.u = b;
+    return __builtin_amdgcn_udot2(x.v, y.v, c, false);
+#else
+    return c + (a & 0xffffu) * (b & 0xffffu) + (a >> 16) * (b >> 16);
+#endif
+}
+
 constexpr int kQBits = 5;          // INTER_BITS
 constexpr int kQOne = 32;          // INTER_TAB_SIZE
 constexpr int kQTab2 = 1024;       // INTER_TAB_SIZE2
@@ -204,7 +255,7 @@ __device__ __forceinline__ void remap_f32_px(const T *__restrict__ src, int sw, 
 }
 
 // ---- BlendMask weight: (img * float32(mask / 255.0)).astype(uint8)  (surroundBEV.py:187-188, 279-280) -------
-__device__ __forceinline__ float blend_weight_f32(int mask_u8) { return (float)((double)mask_u8 / 255.0); }
+__host__ __device__ __forceinline__ float blend_weight_f32(int mask_u8) { return (float)((double)mask_u8 / 255.0); }
 __device__ __forceinline__ int blend_mul(int v, float w) { return (int)((float)v * w); }  // truncation
 
 // ---- wave64 / block reductions for the balance statistics --------------------------------------------------

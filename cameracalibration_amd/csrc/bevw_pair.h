@@ -201,44 +201,46 @@ __global__ void __launch_bounds__(64) k_plan_pair_build(const uint2 *__restrict_
 
 typedef uint32_t pair_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t pair_u32x3 __attribute__((ext_vector_type(3)));
-// 16 source bytes (texels 4g .. 4g+4 of one row) -> the four pair entries, stored for lane `lane` of round patch `rp`
+// 16 source bytes (texels 4g .. 4g+4 of one row) -> the four pair entries: A = pairs 0, 1, B = pairs 2, 3
+__host__ __device__ __forceinline__ void pair_convert(uint32_t dx, uint32_t dy, uint32_t dz, uint32_t dw, uint4 &A, uint4 &B)
+{
+    A.x = px_perm(dy, dx, 0x04010300u);   // pair 0: b0 b1 g0 g1   (source bytes 0 3 1 4)
+    A.y = px_perm(dy, dx, 0x0c0c0502u);   //         r0 r1 0 0     (2 5)
+    A.z = px_perm(dy, dx, 0x07040603u);   // pair 1: bytes 3 6 4 7
+    A.w = px_perm(dz, dy, 0x0c0c0401u);   //         5 8
+    B.x = px_perm(dz, dy, 0x06030502u);   // pair 2: bytes 6 9 7 10
+    B.y = px_perm(dz, dz, 0x0c0c0300u);   //         8 11
+    B.z = px_perm(dw, dz, 0x05020401u);   // pair 3: bytes 9 12 10 13
+    B.w = px_perm(dw, dz, 0x0c0c0603u);   //         11 14
+}
+// ... stored for lane `lane` of round patch `rp`
 __device__ __forceinline__ void pair_convert_store(const pair_u32x4 &d, uint8_t *rp, int lane)
 {
     uint4 A, B;
-    A.x = __builtin_amdgcn_perm(d.y, d.x, 0x04010300u);   // pair 0: b0 b1 g0 g1   (source bytes 0 3 1 4)
-    A.y = __builtin_amdgcn_perm(d.y, d.x, 0x0c0c0502u);   //         r0 r1 0 0     (2 5)
-    A.z = __builtin_amdgcn_perm(d.y, d.x, 0x07040603u);   // pair 1: bytes 3 6 4 7
-    A.w = __builtin_amdgcn_perm(d.z, d.y, 0x0c0c0401u);   //         5 8
-    B.x = __builtin_amdgcn_perm(d.z, d.y, 0x06030502u);   // pair 2: bytes 6 9 7 10
-    B.y = __builtin_amdgcn_perm(d.z, d.z, 0x0c0c0300u);   //         8 11
-    B.z = __builtin_amdgcn_perm(d.w, d.z, 0x05020401u);   // pair 3: bytes 9 12 10 13
-    B.w = __builtin_amdgcn_perm(d.w, d.z, 0x0c0c0603u);   //         11 14
+    pair_convert(d.x, d.y, d.z, d.w, A, B);
     reinterpret_cast<uint4 *>(rp)[lane] = A;
     reinterpret_cast<uint4 *>(rp + 1024)[lane] = B;
 }
 
 // one pixel from its two pair entries: accumulators with the result byte in bits 16..23 (as bilinear_rows_b2)
-__device__ __forceinline__ void bilinear_pairs(uint2 q0, uint2 q1, uint32_t wxa, uint32_t wxb, uint32_t wy64, uint32_t acc[3])
+__host__ __device__ __forceinline__ void bilinear_pairs(uint2 q0, uint2 q1, uint32_t wxa, uint32_t wxb, uint32_t wy64, uint32_t acc[3])
 {
-    const uint32_t hb0 = __builtin_amdgcn_udot4(q0.x, wxa, 0u, false), hb1 = __builtin_amdgcn_udot4(q1.x, wxa, 0u, false);
-    const uint32_t hg0 = __builtin_amdgcn_udot4(q0.x, wxb, 0u, false), hg1 = __builtin_amdgcn_udot4(q1.x, wxb, 0u, false);
-    const uint32_t hr0 = __builtin_amdgcn_udot4(q0.y, wxa, 0u, false), hr1 = __builtin_amdgcn_udot4(q1.y, wxa, 0u, false);
-    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    union { uint32_t u; us2 v; } pb, pg, pr, w;
-    pb.u = hb0 | (hb1 << 16); pg.u = hg0 | (hg1 << 16); pr.u = hr0 | (hr1 << 16); w.u = wy64;
-    acc[0] = __builtin_amdgcn_udot2(pb.v, w.v, 32768u, false);
-    acc[1] = __builtin_amdgcn_udot2(pg.v, w.v, 32768u, false);
-    acc[2] = __builtin_amdgcn_udot2(pr.v, w.v, 32768u, false);
+    const uint32_t hb0 = px_dot4(q0.x, wxa, 0u), hb1 = px_dot4(q1.x, wxa, 0u);
+    const uint32_t hg0 = px_dot4(q0.x, wxb, 0u), hg1 = px_dot4(q1.x, wxb, 0u);
+    const uint32_t hr0 = px_dot4(q0.y, wxa, 0u), hr1 = px_dot4(q1.y, wxa, 0u);
+    acc[0] = px_dot2(hb0 | (hb1 << 16), wy64, 32768u);
+    acc[1] = px_dot2(hg0 | (hg1 << 16), wy64, 32768u);
+    acc[2] = px_dot2(hr0 | (hr1 << 16), wy64, 32768u);
 }
 
 // 12 accumulators (result byte in bits 16..23) of a lane's 4 pixels -> the 12 output bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
-__device__ __forceinline__ void pack_accs(const uint32_t acc[4][3], uint32_t &d0, uint32_t &d1, uint32_t &d2)
+__host__ __device__ __forceinline__ void pack_accs(const uint32_t acc[4][3], uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {
     // perm(hi, lo, sel): byte 2 of lo = index 2, byte 2 of hi = index 6; the two halves of each output dword have zeros
     // where the other half has data: combine with v_or_b32 (a 2.5-clk VOP2)
-    d0 = __builtin_amdgcn_perm(acc[1][0], acc[0][2], 0x06020c0cu) | __builtin_amdgcn_perm(acc[0][1], acc[0][0], 0x0c0c0602u);
-    d1 = __builtin_amdgcn_perm(acc[2][1], acc[2][0], 0x06020c0cu) | __builtin_amdgcn_perm(acc[1][2], acc[1][1], 0x0c0c0602u);
-    d2 = __builtin_amdgcn_perm(acc[3][2], acc[3][1], 0x06020c0cu) | __builtin_amdgcn_perm(acc[3][0], acc[2][2], 0x0c0c0602u);
+    d0 = px_perm(acc[1][0], acc[0][2], 0x06020c0cu) | px_perm(acc[0][1], acc[0][0], 0x0c0c0602u);
+    d1 = px_perm(acc[2][1], acc[2][0], 0x06020c0cu) | px_perm(acc[1][2], acc[1][1], 0x0c0c0602u);
+    d2 = px_perm(acc[3][2], acc[3][1], 0x06020c0cu) | px_perm(acc[3][0], acc[2][2], 0x0c0c0602u);
 }
 
 // one wave: tile from the class list, frames of the chunk.  lds: the block's patches, 4 x (rounds per step x 2 KB).

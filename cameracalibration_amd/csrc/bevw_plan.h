@@ -84,6 +84,12 @@ struct Plan {
     void *list_bt = nullptr;                 // block-tile ids
     int n_bt = 0;
     int n_bt_tiles = 0;                      // base tiles they cover
+    // unit schedule (bevw_unit.h): k-d partition compiled on the host; their base tiles are in none of the pr / rp lists either
+    void *un_desc = nullptr, *un_entries = nullptr, *un_gsrc = nullptr;
+    static constexpr int kUnitLists = 4;
+    void *list_un[kUnitLists] = {nullptr, nullptr, nullptr, nullptr};
+    int n_un[kUnitLists] = {0, 0, 0, 0};
+    size_t un_lines = 0, un_sectors = 0;     // request arithmetic of the partition (per frame)
     bool paired_ok = false;
 };
 
@@ -137,23 +143,22 @@ __device__ __forceinline__ void quad_exchange(uint32_t P[4], uint32_t *xp_wave, 
 }
 
 // 4 pixel dwords (B | G << 8 | R << 16) -> the 12 output bytes
-__device__ __forceinline__ void pack_pixels(const uint32_t P[4], uint32_t &d0, uint32_t &d1, uint32_t &d2)
+__host__ __device__ __forceinline__ void pack_pixels(const uint32_t P[4], uint32_t &d0, uint32_t &d1, uint32_t &d2)
 {
-    d0 = __builtin_amdgcn_perm(P[1], P[0], 0x04020100u);
-    d1 = __builtin_amdgcn_perm(P[2], P[1], 0x05040201u);
-    d2 = __builtin_amdgcn_perm(P[3], P[2], 0x06050402u);
+    d0 = px_perm(P[1], P[0], 0x04020100u);
+    d1 = px_perm(P[2], P[1], 0x05040201u);
+    d2 = px_perm(P[3], P[2], 0x06050402u);
 }
 
 // saturating add of the car sprite (12 bytes c0 c1 c2 at the lane's store position) onto 4 pixel dwords
-__device__ __forceinline__ void add_car(uint32_t P[4], uint32_t c0, uint32_t c1, uint32_t c2)
+__host__ __device__ __forceinline__ void add_car(uint32_t P[4], uint32_t c0, uint32_t c1, uint32_t c2)
 {
-    const uint32_t C[4] = {c0 & 0xffffffu, __builtin_amdgcn_alignbyte(c1, c0, 3) & 0xffffffu,
-                           __builtin_amdgcn_alignbyte(c2, c1, 2) & 0xffffffu, c2 >> 8};
+    const uint32_t C[4] = {c0 & 0xffffffu, px_alignbyte(c1, c0, 3) & 0xffffffu, px_alignbyte(c2, c1, 2) & 0xffffffu, c2 >> 8};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const uint32_t b = min(255u, (P[j] & 255u) + (C[j] & 255u));
-        const uint32_t g = min(255u, ((P[j] >> 8) & 255u) + ((C[j] >> 8) & 255u));
-        const uint32_t r = min(255u, ((P[j] >> 16) & 255u) + ((C[j] >> 16) & 255u));
+        const uint32_t sb = (P[j] & 255u) + (C[j] & 255u), sg = ((P[j] >> 8) & 255u) + ((C[j] >> 8) & 255u);
+        const uint32_t sr = ((P[j] >> 16) & 255u) + ((C[j] >> 16) & 255u);
+        const uint32_t b = sb < 255u ? sb : 255u, g = sg < 255u ? sg : 255u, r = sr < 255u ? sr : 255u;
         P[j] = b | (g << 8) | (r << 16);
     }
 }
@@ -416,6 +421,8 @@ __device__ __forceinline__ void eval_entry(const uint8_t *__restrict__ fb, const
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
+struct UnitDesc;   // bevw_unit.h
+
 struct PlanArgs {
     const uint8_t *frames;
     const uint2 *plan;
@@ -442,6 +449,10 @@ struct PlanArgs {
     const uint2 *sm_entries;
     const uint32_t *sm_gsrc;
     const uint32_t *sm_pos;
+    // units (bevw_unit.h): tile_list holds unit ids, ngroups = nlist
+    const UnitDesc *un_desc;
+    const uint2 *un_entries;
+    const uint32_t *un_gsrc;
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -738,6 +749,7 @@ __global__ void __launch_bounds__(1024) k_plan_empty(PlanArgs a) { plan_empty_bo
 }  // namespace bevw
 #include "bevw_pair.h"
 #include "bevw_block.h"
+#include "bevw_unit.h"
 namespace bevw {
 
 // Every tile class of a step in ONE launch: the class kernels write disjoint tiles and never depend on each other, but
@@ -745,7 +757,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 12;   // classes of one merged launch (launch positions in use)
+constexpr int kPlanAllMax = 16;   // classes of one merged launch (launch positions in use)
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -753,15 +765,19 @@ struct PlanAllArgs {
     int ngroups[kPlanAllMax];
     uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
     // launch position -> class: 2 empty, 3 gather single, 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced),
-    // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds), 12 block-staged (bevw_block.h, 4 waves per block tile)
+    // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds), 12 block-staged (bevw_block.h, 4 waves per block tile), 13 seam block tiles,
+    // 14 .. 17 units (bevw_unit.h, class = kind - 14)
     int kind[kPlanAllMax];
     int n;                             // launch positions in use
 };
 
 // The two-contributor classes set the register budget (~140 VGPRs, 3 workgroups per CU); measured, the single-contributor
 // classes lose nothing at that occupancy (profiles/r01_sweeps.log: two launches split by register budget are slower).
+#ifndef BEVW_PLAN_ALL_WAVES
+#define BEVW_PLAN_ALL_WAVES 3   // waves per SIMD the merged kernel is compiled for (168 VGPRs: 3 blocks of 32 KB per CU; 4 spills 2 registers)
+#endif
 template <int LX, bool BLEND, bool SUMS>
-__global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BEVW_PLAN_ALL_WAVES, BEVW_PLAN_ALL_WAVES))) k_plan_all(PlanAllArgs q)
 {
     __shared__ __attribute__((aligned(16))) uint8_t stage_0[4 * kPairPatch];
     int pos = 0;
@@ -780,6 +796,10 @@ __global__ void __launch_bounds__(256) k_plan_all(PlanAllArgs q)
         case 11: plan_pair_body<LX, 2, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
         case 12: plan_block_body<BLEND, SUMS, 2>(a, id, stage_0); break;
         case 13: plan_seam_body<BLEND, SUMS>(a, id, stage_0); break;
+        case 14: plan_unit_body<SUMS, kUnitClassNQ[0], kUnitClassGR[0]>(a, id, stage_0); break;
+        case 15: plan_unit_body<SUMS, kUnitClassNQ[1], kUnitClassGR[1]>(a, id, stage_0); break;
+        case 16: plan_unit_body<SUMS, kUnitClassNQ[2], kUnitClassGR[2]>(a, id, stage_0); break;
+        case 17: plan_unit_body<SUMS, kUnitClassNQ[3], kUnitClassGR[3]>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
         // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
@@ -816,6 +836,7 @@ static inline void plan_release(Plan &p)
 {
     void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5], p.list_pr[6],
                     p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt, p.sm_entries, p.sm_gsrc, p.sm_pos, p.list_sm,
+                    p.un_desc, p.un_entries, p.un_gsrc, p.list_un[0], p.list_un[1], p.list_un[2], p.list_un[3],
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -833,7 +854,8 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
                                          int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
-                                         int ncams = 4, bool block_tiles = true, bool seam_tiles = true)
+                                         int ncams = 4, bool block_tiles = true, bool seam_tiles = true, bool units = true,
+                                         const UnitTuning &unit_tune = UnitTuning())
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -904,9 +926,31 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
             if ((e = hipMemcpy(h2[c].data(), T.lut2[c], bpx * 2, hipMemcpyDeviceToHost)) != hipSuccess) return e;
             if ((e = hipMemcpy(hm[c].data(), T.mask[c], bpx, hipMemcpyDeviceToHost)) != hipSuccess) return e;
         }
+        // units (bevw_unit.h) first: they take every single-contributor base tile without border footprints; block tiles are the
+        // round-2 schedule for the same tiles and are compiled only when the units are switched off
+        bool have_units = false;
+        if (units) {
+            UnitPlanHost up;
+            std::vector<uint32_t> hdr_un = hdr;
+            unit_compile(h1, h2, hm, ncams, fw, fh, bw, bh, (bw + 3) & ~3, p.tiles_x, p.tiles_y, hdr_un, up, unit_tune);
+            if (!up.desc.empty()) {
+                have_units = true;
+                hdr.swap(hdr_un);
+                if ((e = hipMalloc(&p.un_desc, up.desc.size() * sizeof(UnitDesc))) != hipSuccess) return e;
+                if ((e = hipMemcpy(p.un_desc, up.desc.data(), up.desc.size() * sizeof(UnitDesc), hipMemcpyHostToDevice)) != hipSuccess) return e;
+                if ((e = hipMalloc(&p.un_entries, up.entries.size() * sizeof(uint2))) != hipSuccess) return e;
+                if ((e = hipMemcpy(p.un_entries, up.entries.data(), up.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
+                if ((e = plan_upload_list(up.gsrc, &p.un_gsrc)) != hipSuccess) return e;
+                for (int c = 0; c < kUnitClasses; ++c) {
+                    p.n_un[c] = (int)up.list[c].size();
+                    if ((e = plan_upload_list(up.list[c], &p.list_un[c])) != hipSuccess) return e;
+                }
+                p.un_lines = up.lines; p.un_sectors = up.sectors;
+            }
+        }
         BlockPlanHost bp;
         std::vector<uint32_t> hdr_bt = hdr;
-        block_compile(h1, h2, hm, ncams, fw, fh, bw, bh, p.tiles_x, p.tiles_y, hdr_bt, bp);
+        if (!have_units) block_compile(h1, h2, hm, ncams, fw, fh, bw, bh, p.tiles_x, p.tiles_y, hdr_bt, bp);
         SeamPlanHost sp;
         if (seam_tiles) seam_compile(h1, h2, hm, ncams, fw, fh, bw, bh, p.tiles_x, p.tiles_y, hdr_bt, sp);
         // worth two more launches only when the block tiles take a good part of the work (the 4K rig: 18 of 4166 tiles)
@@ -916,14 +960,16 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
             ++busy;
             if (hdr_bt[t] & kHdrBlock) ++claimed;
         }
-        if (!bp.pos.empty() && claimed * 4 >= busy) {
+        if (have_units || (!bp.pos.empty() && claimed * 4 >= busy)) {
             hdr.swap(hdr_bt);
-            if ((e = hipMalloc(&p.bt_entries, bp.entries.size() * sizeof(uint2))) != hipSuccess) return e;
-            if ((e = hipMemcpy(p.bt_entries, bp.entries.data(), bp.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
-            if ((e = plan_upload_list(bp.gsrc, &p.bt_gsrc)) != hipSuccess) return e;
-            if ((e = plan_upload_list(bp.pos, &p.bt_pos)) != hipSuccess) return e;
-            p.n_bt = (int)bp.list[0].size();
-            if ((e = plan_upload_list(bp.list[0], &p.list_bt)) != hipSuccess) return e;
+            if (!bp.pos.empty()) {
+                if ((e = hipMalloc(&p.bt_entries, bp.entries.size() * sizeof(uint2))) != hipSuccess) return e;
+                if ((e = hipMemcpy(p.bt_entries, bp.entries.data(), bp.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
+                if ((e = plan_upload_list(bp.gsrc, &p.bt_gsrc)) != hipSuccess) return e;
+                if ((e = plan_upload_list(bp.pos, &p.bt_pos)) != hipSuccess) return e;
+                p.n_bt = (int)bp.list[0].size();
+                if ((e = plan_upload_list(bp.list[0], &p.list_bt)) != hipSuccess) return e;
+            }
             if (!sp.pos.empty()) {
                 if ((e = hipMalloc(&p.sm_entries, sp.entries.size() * sizeof(uint2))) != hipSuccess) return e;
                 if ((e = hipMemcpy(p.sm_entries, sp.entries.data(), sp.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
@@ -1075,6 +1121,18 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         else hipLaunchKernelGGL((k_plan_block<false, false>), grid, block8, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    if (staged && !one_launch) {             // the unit classes as launches of their own (per-class mode)
+#define BEVW_LAUNCH_UNIT(C)                                                                                                                  \
+    if (p.n_un[C]) {                                                                                                                         \
+        a.tile_list = static_cast<const uint32_t *>(p.list_un[C]); a.nlist = p.n_un[C]; a.ngroups = p.n_un[C];                               \
+        const dim3 grid(grid_blocks());                                                                                                      \
+        if (sums) hipLaunchKernelGGL((k_plan_unit<true, kUnitClassNQ[C], kUnitClassGR[C]>), grid, block, 0, st, a);                          \
+        else hipLaunchKernelGGL((k_plan_unit<false, kUnitClassNQ[C], kUnitClassGR[C]>), grid, block, 0, st, a);                              \
+        if ((e = hipGetLastError()) != hipSuccess) return e;                                                                                 \
+    }
+        BEVW_LAUNCH_UNIT(2) BEVW_LAUNCH_UNIT(3) BEVW_LAUNCH_UNIT(1) BEVW_LAUNCH_UNIT(0)
+#undef BEVW_LAUNCH_UNIT
+    }
     if (staged && p.n_sm && !one_launch) {   // the seam block tiles as a launch of their own (per-class mode)
         a.tile_list = static_cast<const uint32_t *>(p.list_sm); a.nlist = p.n_sm; a.ngroups = p.n_sm;
         const dim3 grid(grid_blocks());
@@ -1098,7 +1156,9 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         for (int c = 0; c < Plan::kPairClasses; ++c) n_wave_side += p.n_pr[c];
         const bool bt_last = n_wave_side * 5 >= p.n_bt_tiles;
         const Cls bt_cls = {12, p.list_bt, bt_merged ? p.n_bt : 0}, none = {12, nullptr, 0};
-        const Cls cls[] = {bt_last ? none : bt_cls, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single},
+        // units (bevw_unit.h) in front: they hold the bulk of the step; the classes with 4 rounds of groups run longest
+        const Cls cls[] = {{16, p.list_un[2], p.n_un[2]}, {17, p.list_un[3], p.n_un[3]}, {15, p.list_un[1], p.n_un[1]}, {14, p.list_un[0], p.n_un[0]},
+                           bt_last ? none : bt_cls, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single},
                            {10, p.list_pr[5], p.n_pr[5]}, {13, p.list_sm, p.n_sm}, {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]},
                            {5, p.list_pr[0], p.n_pr[0]}, bt_last ? bt_cls : none, {2, l_empty, n_empty}};
         uint32_t at = 0;
@@ -1195,6 +1255,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.sm_entries = static_cast<const uint2 *>(p.sm_entries);
     a.sm_gsrc = static_cast<const uint32_t *>(p.sm_gsrc);
     a.sm_pos = static_cast<const uint32_t *>(p.sm_pos);
+    a.un_desc = static_cast<const UnitDesc *>(p.un_desc);
+    a.un_entries = static_cast<const uint2 *>(p.un_entries);
+    a.un_gsrc = static_cast<const uint32_t *>(p.un_gsrc);
     // pair-staged schedule: needs 4-byte aligned frame sets (dword-addressed group loads) and is not combined with the
     // per-tap luminance kernel
     const bool use_staged = !balance && tune.lean && tune.staged && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0;

@@ -1,0 +1,498 @@
+// bevw_unit.h -- the UNIT schedule of the tile plan (included by bevw_plan.h after bevw_block.h; round 3).
+//
+// Why.  The stitch is bound by the NUMBER of vector-L1 -> L2 requests.  Round 2's schedule paid, per
+// frame of BASELINE config 3, ~61 k source-line requests (13 k for the dense 64 x 32 block tiles, 48 k for the per-wave
+// 32 x 8 classes that hold the 29 % of the tiles no block tile could take: every one of those waves fetches the lines of
+// its own small footprint) and 75 k write requests (rows of 96 / 192 bytes straddle 64-byte sectors).  The floor of the
+// geometry is 22 k + 55 k.  A UNIT is what the plan compiler makes of that arithmetic:
+//
+//   * the BEV is cut by a k-d partition into rectangles of <= 4096 pixels (up to 256 pixels wide) whose distinct source
+//     texel groups fit ONE LDS patch of <= 1024 groups (32 KB of pair entries) -- wide and flat where the BEV x axis runs
+//     along source rows (front / back cameras), narrow and tall where the BEV y axis does (left / right), small where every
+//     pixel samples its own texels (near the car).  A split is made only when a rectangle does not fit, and in the direction
+//     that costs fewer source lines + write sectors (counted on the CPU from the LUTs: unit_compile below);
+//   * one block of 4 waves owns a unit for the frames of its batch chunk: per frame every lane loads up to GR texel groups
+//     (buffer_load_dwordx4, ascending list, masked lanes touch no memory), converts them ONCE into pair entries
+//     (bevw_pair.h) in the block's patch, and then interpolates up to NQ pixel quads from it;
+//   * a wave-store writes the longest row runs the unit's width allows: one run of 768 contiguous bytes for a 256-pixel
+//     wide unit, two of 384 for 128 (13.0 / 13.9 write requests per 256 pixels instead of 15.5 / 19.1).
+//
+// Classes (NQ quads per lane x GR rounds of 256 groups): dense far field (4, 1) and (4, 2) -- double-buffered patch, ONE
+// barrier per frame, as the block tiles of round 2; mid and near field (2, 4) and (1, 4) -- the patch takes the whole 32 KB,
+// two barriers per frame.  (A (4, 4) class needs 163 VGPRs = 3 waves per SIMD for every class of the merged launch; without
+// it the partition pays 1.5 % more requests and every class stays below 128.)  Units are classes of the merged launch
+// (k_plan_all: 256 threads, 32 KB).
+// Base tiles with a two-contributor pixel (seams, blend overlaps), a blend weight below 255, a frame-border footprint or no
+// contributor at all keep their round-2 classes: a unit never stores a quad of such a base tile (kMetaSkip).  Every unit
+// pixel therefore has weight 255 = 1.0f exactly, and the kernel needs no blend variant: trunc(f32(v) * 1.0f) == v.
+//
+// The plan is compiled on the HOST (unit_compile); tests/native/unit_emulate.cpp runs the same compiler and the per-lane
+// arithmetic below (unit_emulate) on a CPU, so the indexing of this file is checked without a GPU.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace bevw {
+
+constexpr uint32_t kMetaSkip = 1u << 22;     // on pixel slot 0 of a quad: the quad's base tile belongs to another class -> not stored
+constexpr int kUnitWaves = 4;
+constexpr int kUnitThreads = kUnitWaves * 64;
+constexpr int kUnitMaxNQ = 4;                // pixel quads per lane
+constexpr int kUnitMaxGR = 4;                // rounds of kUnitThreads groups
+constexpr int kUnitMaxGroups = kUnitMaxGR * kUnitThreads;        // 1024 groups = 32 KB of pair entries
+constexpr int kUnitMaxWidth = 256;           // pixels: 64 quads = one wave-store per row
+constexpr int kUnitClasses = 4;
+constexpr int kUnitClassNQ[kUnitClasses] = {4, 4, 2, 1};
+constexpr int kUnitClassGR[kUnitClasses] = {1, 2, 4, 4};
+
+// unit descriptor: 8 dwords, read with scalar loads
+struct UnitDesc {
+    uint32_t pos;        // x0 | y0 << 16 (pixels)
+    uint32_t shape;      // w | h << 16 (pixels; w a multiple of 4)
+    uint32_t ent_off;    // entries of the unit start at un_entries[ent_off * 64]
+    uint32_t gs_off;     // group offsets of the unit start at un_gsrc[gs_off * kUnitThreads]
+    uint32_t lq;         // log2 of the lanes per row (quads per row rounded up to a power of two, >= 4)
+    uint32_t sum_tile;   // balance: psums slot (a base tile owned by this unit)
+    uint32_t groups;     // distinct groups (diagnostics)
+    uint32_t pixels;     // contributing pixels (diagnostics)
+};
+
+// lane -> quad of the unit: slot `sidx` (0 .. 4 NQ - 1) covers 64 >> lq consecutive rows of (1 << lq) quads
+__host__ __device__ __forceinline__ void unit_quad(uint32_t lq, int sidx, int lane, int &qx, int &row)
+{
+    qx = lane & ((1 << lq) - 1);
+    row = sidx * (64 >> lq) + (lane >> lq);
+}
+// slot index of (wave, quad slot j): rows are dealt to the waves round-robin, so the waves of a block work on neighbouring rows
+__host__ __device__ __forceinline__ int unit_slot(int wave, int j) { return j * kUnitWaves + wave; }
+// LDS byte address of pair k (0..3) of group slot s inside a frame's patch: round r = s >> 8 and wave w = (s >> 6) & 3 load it,
+// pairs 0, 1 of all lanes in the first KB of the (round, wave) patch, pairs 2, 3 in the second (pair_convert_store)
+__host__ __device__ __forceinline__ uint32_t unit_lds_addr(uint32_t slot, uint32_t k)
+{
+    return (slot >> 6) * (uint32_t)kPairRoundBytes + (k >> 1) * 1024u + (slot & 63u) * 16u + (k & 1u) * 8u;
+}
+
+struct UnitPlanHost {
+    std::vector<UnitDesc> desc;
+    std::vector<uint2> entries;                // per unit: [4 NQ slots][4 pixels][64 lanes]
+    std::vector<uint32_t> gsrc;                // per unit: [GR rounds][256 lanes]
+    std::vector<uint32_t> list[kUnitClasses];  // unit ids by class
+    size_t claimed_tiles = 0;
+    // request arithmetic of the compiled partition (per frame): distinct 128-byte source lines, 64-byte write sectors
+    size_t lines = 0, sectors = 0;
+};
+
+struct UnitTuning {
+    int max_groups = kUnitMaxGroups;
+    int root_w = 256, root_h = 64;   // the k-d partition starts from cells of this size
+    int min_w = 16;                  // narrowest unit (pixels)
+};
+
+// Host-side plan compiler of the units.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers (32 x 8 tiles,
+// tiles_x per row) as k_plan_build / k_plan_pair_build left them; base tiles claimed by a unit get kHdrBlock.  `pitch` = pixels per
+// output row (bw rounded up to 4).  The contributor rule is k_plan_build's.
+static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::vector<uint16_t> lut2[4], const std::vector<uint8_t> mask[4],
+                                int ncams, int fw, int fh, int bw, int bh, int pitch, int tiles_x, int tiles_y, std::vector<uint32_t> &hdr,
+                                UnitPlanHost &out, const UnitTuning &tune = UnitTuning())
+{
+    const uint32_t frame_bytes = (uint32_t)fw * fh * 3, gpr = (uint32_t)fw / 4;
+    const size_t set_bytes = (size_t)frame_bytes * ncams;
+    constexpr uint32_t kNone = 0xffffffffu;
+    // ---- per pixel: footprint offset + meta of the (only) contributor; base tiles a unit may own ---------------------------
+    std::vector<uint8_t> own((size_t)tiles_x * tiles_y, 0);
+    for (size_t t = 0; t < own.size(); ++t) own[t] = (hdr[t] & (kHdrSlow | kHdrSecond | kHdrEmpty | kHdrBlock)) ? 0 : 1;
+    std::vector<uint32_t> poff((size_t)pitch * bh, kNone), pmeta((size_t)pitch * bh, 0u);
+    for (int y = 0; y < bh; ++y)
+        for (int x = 0; x < bw; ++x) {
+            const size_t t = (size_t)(y / 8) * tiles_x + x / 32;
+            if (!own[t]) continue;
+            const size_t o = (size_t)y * bw + x;
+            for (int c = 0; c < ncams; ++c) {
+                const uint32_t m = mask[c][o];
+                if (m == 0) continue;
+                const int sx = lut1[c][o * 2], sy = lut1[c][o * 2 + 1];
+                if (sx >= fw || sx + 1 < 0 || sy >= fh || sy + 1 < 0) continue;   // whole footprint outside: adds 0
+                const uint32_t off = (uint32_t)c * frame_bytes + ((uint32_t)sy * fw + sx) * 3;
+                if ((size_t)(off / 12u + gpr) * 12u + 16u > set_bytes) { own[t] = 2; break; }   // the last group's 16-byte window would overrun
+                if (m != 255u) { own[t] = 2; break; }                                            // a blend weight: the tile keeps its blend-aware class
+                poff[(size_t)y * pitch + x] = off;
+                pmeta[(size_t)y * pitch + x] = (lut2[c][o] & (kQTab2 - 1)) | (m << 10) | ((uint32_t)c << 18) | kMetaValid;
+                break;   // single-contributor tiles: the first contributor is the only one
+            }
+        }
+    for (int y = 0; y < bh; ++y)      // base tiles dropped for an overrun: their pixels leave the units
+        for (int x = 0; x < bw; ++x)
+            if (own[(size_t)(y / 8) * tiles_x + x / 32] != 1) poff[(size_t)y * pitch + x] = kNone;
+    auto owned = [&](int x, int y) { return x < bw && y < bh && own[(size_t)(y / 8) * tiles_x + x / 32] == 1; };
+
+    // ---- request arithmetic of a rectangle: distinct groups, distinct 128-byte lines, contributing pixels -------------------
+    std::vector<uint32_t> gstamp(set_bytes / 12 + 2, 0u), lstamp(set_bytes / 128 + 2, 0u);
+    uint32_t stamp = 0;
+    struct Stats { int groups, lines, pixels, quads; };
+    auto cell_stats = [&](int x0, int y0, int w, int h) {
+        Stats s = {0, 0, 0, 0};
+        ++stamp;
+        for (int y = y0; y < y0 + h; ++y)
+            for (int x = x0; x < x0 + w; ++x) {
+                if ((x & 3) == 0 && owned(x, y)) ++s.quads;
+                const uint32_t off = poff[(size_t)y * pitch + x];
+                if (off == kNone) continue;
+                ++s.pixels;
+                for (uint32_t r = 0; r < 2; ++r) {
+                    const uint32_t k = off / 12u + r * gpr;
+                    if (gstamp[k] == stamp) continue;
+                    gstamp[k] = stamp;
+                    ++s.groups;
+                    const uint32_t a = k * 12u;
+                    for (uint32_t l = a >> 7; l <= (a + 15u) >> 7; ++l)
+                        if (lstamp[l] != stamp) { lstamp[l] = stamp; ++s.lines; }
+                }
+            }
+        return s;
+    };
+    auto write_sectors = [&](int x0, int y0, int w, int h) {   // 64-byte sectors the row runs of the rectangle touch
+        long n = 0;
+        for (int y = y0; y < y0 + h; ++y) {
+            const long a0 = ((long)y * pitch + x0) * 3, a1 = ((long)y * pitch + x0 + w) * 3;
+            n += (a1 - 1) / 64 - a0 / 64 + 1;
+        }
+        return n;
+    };
+    auto lanes_log2 = [](int w) { int lq = 2; while ((4 << lq) < w) ++lq; return lq; };   // quads per row rounded up to 4 .. 64 lanes
+    auto slots_needed = [&](int w, int h) { const int rps = 64 >> lanes_log2(w); return (h + rps - 1) / rps; };
+
+    // ---- emit one unit ---------------------------------------------------------------------------------------------------------
+    std::vector<uint32_t> keys;
+    auto emit = [&](int x0, int y0, int w, int h, const Stats &st) {
+        keys.clear();
+        for (int y = y0; y < y0 + h; ++y)
+            for (int x = x0; x < x0 + w; ++x) {
+                const uint32_t off = poff[(size_t)y * pitch + x];
+                if (off == kNone) continue;
+                keys.push_back(off / 12u);
+                keys.push_back(off / 12u + gpr);
+            }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        const int count = (int)keys.size();
+        const int lq = lanes_log2(w), slots = slots_needed(w, h);
+        // class: the cheapest (NQ, GR) that holds the unit (cost ~ 4 pixels x 14 VALU per quad slot, 8 v_perm + 2 ds_write per round)
+        int cls = -1, best = 1 << 30;
+        for (int c = 0; c < kUnitClasses; ++c) {
+            if (kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < count) continue;
+            const int cost = kUnitClassNQ[c] * 64 + kUnitClassGR[c] * 14;
+            if (cost < best) { best = cost; cls = c; }
+        }
+        if (cls < 0) return false;
+        const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls];
+        UnitDesc d;
+        d.pos = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        d.shape = (uint32_t)w | ((uint32_t)h << 16);
+        d.ent_off = (uint32_t)(out.entries.size() / 64);
+        d.gs_off = (uint32_t)(out.gsrc.size() / kUnitThreads);
+        d.lq = (uint32_t)lq;
+        d.sum_tile = 0;
+        d.groups = (uint32_t)count;
+        d.pixels = (uint32_t)st.pixels;
+        auto slot_of = [&](uint32_t key) { return (uint32_t)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin()); };
+        const size_t e0 = out.entries.size();
+        out.entries.resize(e0 + (size_t)NQ * kUnitWaves * 4 * 64, make_uint2(0u, 0u));
+        bool have_sum_tile = false;
+        for (int sidx = 0; sidx < NQ * kUnitWaves; ++sidx)
+            for (int lane = 0; lane < 64; ++lane) {
+                int qx, row;
+                unit_quad((uint32_t)lq, sidx, lane, qx, row);
+                const int x = x0 + 4 * qx, y = y0 + row;
+                uint2 *e = out.entries.data() + e0 + (size_t)sidx * 4 * 64 + lane;   // pixel p at e[p * 64]
+                if (4 * qx >= w || row >= h) continue;            // lane without a quad: zero entries, masked in the kernel
+                if (!owned(x, y)) { e[0].y = kMetaSkip; continue; }
+                if (!have_sum_tile) { d.sum_tile = (uint32_t)((y / 8) * tiles_x + x / 32); have_sum_tile = true; }
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t off = poff[(size_t)y * pitch + x + p];
+                    if (off == kNone) continue;
+                    const uint32_t key = off / 12u, pk = (off - key * 12u) / 3u;
+                    e[p * 64] = make_uint2(unit_lds_addr(slot_of(key), pk) | (unit_lds_addr(slot_of(key + gpr), pk) << 16),
+                                           pmeta[(size_t)y * pitch + x + p]);
+                }
+            }
+        const size_t g0 = out.gsrc.size();
+        out.gsrc.resize(g0 + (size_t)GR * kUnitThreads, kPairNoGroup);
+        for (int s = 0; s < count; ++s) out.gsrc[g0 + s] = keys[(size_t)s] * 12u;
+        out.list[cls].push_back((uint32_t)out.desc.size());
+        out.desc.push_back(d);
+        out.lines += (size_t)st.lines;
+        out.sectors += (size_t)write_sectors(x0, y0, w, h);
+        return true;
+    };
+
+    // ---- k-d partition -----------------------------------------------------------------------------------------------------------
+    struct Cell { int x0, y0, w, h; };
+    std::vector<Cell> stack;
+    const int root_w = std::min(tune.root_w, kUnitMaxWidth);
+    for (int y0 = 0; y0 < bh; y0 += tune.root_h)
+        for (int x0 = 0; x0 < pitch; x0 += root_w) stack.push_back({x0, y0, std::min(root_w, pitch - x0), std::min(tune.root_h, bh - y0)});
+    std::reverse(stack.begin(), stack.end());   // pop in row-major order: neighbouring units are neighbours in the class lists
+    while (!stack.empty()) {
+        const Cell c = stack.back();
+        stack.pop_back();
+        const Stats st = cell_stats(c.x0, c.y0, c.w, c.h);
+        if (st.quads == 0) continue;              // nothing a unit owns in here
+        bool fits = false;   // some class holds the rectangle
+        for (int k = 0; k < kUnitClasses; ++k)
+            fits = fits || (st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
+        if (fits && emit(c.x0, c.y0, c.w, c.h, st)) continue;
+        // split: rows at a multiple of the rows per wave-slot, columns at a multiple of 16 pixels; the cheaper cut wins
+        long best = -1;
+        Cell a = c, b = c;
+        const int rps = 64 >> lanes_log2(c.w);
+        if (c.h > 1) {
+            int h2 = (c.h + 1) / 2;
+            h2 = std::min(c.h - 1, (h2 + rps - 1) / rps * rps);
+            const Stats s0 = cell_stats(c.x0, c.y0, c.w, h2), s1 = cell_stats(c.x0, c.y0 + h2, c.w, c.h - h2);
+            best = (long)s0.lines + s1.lines;
+            a = {c.x0, c.y0, c.w, h2};
+            b = {c.x0, c.y0 + h2, c.w, c.h - h2};
+        }
+        if (c.w > tune.min_w) {
+            const int w2 = std::min(c.w - 4, (c.w / 2 + 15) / 16 * 16);
+            const Stats s0 = cell_stats(c.x0, c.y0, w2, c.h), s1 = cell_stats(c.x0 + w2, c.y0, c.w - w2, c.h);
+            const long cost = (long)s0.lines + s1.lines + write_sectors(c.x0, c.y0, w2, c.h) + write_sectors(c.x0 + w2, c.y0, c.w - w2, c.h) -
+                              write_sectors(c.x0, c.y0, c.w, c.h);
+            if (best < 0 || cost < best) {
+                best = cost;
+                a = {c.x0, c.y0, w2, c.h};
+                b = {c.x0 + w2, c.y0, c.w - w2, c.h};
+            }
+        }
+        if (best < 0) {
+            // one row of the narrowest width that still does not fit (cannot happen: 4 quads x 4 pixels x 2 groups): leave the
+            // pixels to the per-wave classes
+            for (int y = c.y0; y < c.y0 + c.h; ++y)
+                for (int x = c.x0; x < c.x0 + c.w; ++x)
+                    if (owned(x, y)) own[(size_t)(y / 8) * tiles_x + x / 32] = 3;
+            continue;
+        }
+        stack.push_back(b);
+        stack.push_back(a);
+    }
+    // a base tile dropped late (own == 3) may already be referenced by emitted units of other cells only through skip flags that
+    // were computed while it was still owned: such a partition is unusable -> compile nothing (callers fall back to round 2's classes)
+    for (uint8_t o : own)
+        if (o == 3) { out = UnitPlanHost(); return; }
+    for (size_t t = 0; t < own.size(); ++t)
+        if (own[t] == 1) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// CPU emulation of one unit and one frame: the per-lane steps of plan_unit_body in program order (group loads -> pair conversion
+// -> patch -> pixel interpolation -> 12-byte stores), with the same helpers.  Test infrastructure (tests/native/unit_emulate.cpp).
+// ---------------------------------------------------------------------------------------------------------------------------------
+static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, const uint8_t *frame_set, size_t set_bytes,
+                                const uint8_t *car, int pitch, uint8_t *out_img, uint32_t sums[3] = nullptr, std::vector<uint8_t> *written = nullptr)
+{
+    const UnitDesc &d = up.desc[unit];
+    const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls];
+    std::vector<uint8_t> patch((size_t)kUnitMaxGR * kUnitWaves * kPairRoundBytes, 0xcd);
+    for (int r = 0; r < GR; ++r)
+        for (int tid = 0; tid < kUnitThreads; ++tid) {
+            const uint32_t off = up.gsrc[((size_t)d.gs_off + r) * kUnitThreads + tid];
+            uint32_t w[4] = {0, 0, 0, 0};   // a masked lane's buffer load returns zeros
+            if (off != kPairNoGroup && (size_t)off + 16 <= set_bytes) memcpy(w, frame_set + off, 16);
+            uint4 A, B;
+            pair_convert(w[0], w[1], w[2], w[3], A, B);
+            uint8_t *rp = patch.data() + (size_t)(r * kUnitWaves + (tid >> 6)) * kPairRoundBytes;
+            memcpy(rp + (size_t)(tid & 63) * 16, &A, 16);
+            memcpy(rp + 1024 + (size_t)(tid & 63) * 16, &B, 16);
+        }
+    const int ux = (int)(d.pos & 0xffffu), uy = (int)(d.pos >> 16), uw = (int)(d.shape & 0xffffu), uh = (int)(d.shape >> 16);
+    for (int wave = 0; wave < kUnitWaves; ++wave)
+        for (int j = 0; j < NQ; ++j)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int sidx = unit_slot(wave, j);
+                int qx, row;
+                unit_quad(d.lq, sidx, lane, qx, row);
+                const uint2 *e = up.entries.data() + ((size_t)d.ent_off + (size_t)sidx * 4) * 64 + lane;
+                uint32_t acc[4][3];
+                for (int p = 0; p < 4; ++p) {
+                    const uint2 en = e[p * 64];
+                    const uint32_t fx = en.y & 31, fy = (en.y >> 5) & 31;
+                    const bool valid = en.y & kMetaValid;
+                    const uint32_t wxa = valid ? ((32 - fx) | (fx << 8)) : 0u, wy = ((32 - fy) << 6) | (fy << 22);
+                    uint2 q0, q1;
+                    memcpy(&q0, patch.data() + (en.x & 0xffffu), 8);
+                    memcpy(&q1, patch.data() + (en.x >> 16), 8);
+                    bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc[p]);
+                    if (sums)
+                        for (int k = 0; k < 3; ++k) sums[k] += (acc[p][k] >> 16) & 255u;
+                }
+                if (4 * qx >= uw || row >= uh || (e[0].y & kMetaSkip)) continue;   // the lane's store is masked
+                uint32_t o[3];
+                const size_t ooff = ((size_t)(uy + row) * pitch + ux + 4 * qx) * 3;
+                if (car) {
+                    uint32_t P[4], c[3];
+                    for (int p = 0; p < 4; ++p) P[p] = ((acc[p][0] >> 16) & 255u) | (((acc[p][1] >> 16) & 255u) << 8) | (((acc[p][2] >> 16) & 255u) << 16);
+                    memcpy(c, car + ooff, 12);
+                    add_car(P, c[0], c[1], c[2]);
+                    pack_pixels(P, o[0], o[1], o[2]);
+                } else {
+                    pack_accs(acc, o[0], o[1], o[2]);
+                }
+                memcpy(out_img + ooff, o, 12);
+                if (written) for (int k = 0; k < 4; ++k) ++(*written)[(size_t)(uy + row) * pitch + ux + 4 * qx + k];
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// device side
+// ---------------------------------------------------------------------------------------------------------------------------------
+// one block of 4 waves: unit from the class list, frames of the chunk.  lds: 32 KB.
+// GR <= 2: the frame's patch (GR x 8 KB) is double-buffered -- frame b+1 is converted into the other half while frame b is
+// interpolated, one s_barrier per frame.  GR == 4: one patch; conversion and interpolation are separated by two barriers per frame.
+// The groups of the next TWO frames are in flight in registers in both cases.  Register budget: 16 registers per quad slot
+// (LDS indices and weights of 4 pixels) + 8 per round of groups in flight; nothing else lives across the frame loop -- the car
+// sprite is re-read per frame by the few units that lie under it.
+template <bool SUMS, int NQ, int GR>
+__device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
+{
+    static_assert(NQ >= 1 && NQ <= kUnitMaxNQ && GR >= 1 && GR <= kUnitMaxGR, "unit class");
+    uint32_t chunk, group;
+    if (!plan_block_map(a, block_id, chunk, group)) return;   // uniform over the block
+    if ((int)group >= a.nlist) return;
+    const uint32_t unit = __builtin_amdgcn_readfirstlane(a.tile_list[group]);
+    const uint32_t *dp = reinterpret_cast<const uint32_t *>(a.un_desc + unit);
+    const uint32_t pos = __builtin_amdgcn_readfirstlane(dp[0]), shape = __builtin_amdgcn_readfirstlane(dp[1]);
+    const uint32_t ent_off = __builtin_amdgcn_readfirstlane(dp[2]), gs_off = __builtin_amdgcn_readfirstlane(dp[3]);
+    const uint32_t lq = __builtin_amdgcn_readfirstlane(dp[4]), sum_tile = __builtin_amdgcn_readfirstlane(dp[5]);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ux = (int)(pos & 0xffffu), uy = (int)(pos >> 16), uw = (int)(shape & 0xffffu), uh = (int)(shape >> 16);
+    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
+    constexpr int kPatch = GR * kUnitWaves * kPairRoundBytes;   // one frame's pair entries
+    constexpr bool DB = 2 * kPatch <= kUnitMaxGroups * 32;      // both halves fit the block's 32 KB
+
+    uint32_t i0[NQ][4], i1[NQ][4], wxa[NQ][4], wy[NQ][4], gs[GR], ooff_masked[NQ];
+    const bool with_car = !SUMS && a.car != nullptr;
+    const __amdgpu_buffer_rsrc_t rcar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(with_car ? a.car : a.out), 0,
+                                                                          with_car ? (uint32_t)img_bytes : 0u, kBufferWord3);
+    uint32_t car_or = 0;
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int sidx = unit_slot(wave, j);
+        int qx, row;
+        unit_quad(lq, sidx, lane, qx, row);
+        const uint32_t ooff = ((uint32_t)(uy + row) * a.pitch + ux + 4 * qx) * 3;
+        bool store = 4 * qx < uw && row < uh;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint2 e = a.un_entries[((size_t)ent_off + sidx * 4 + p) * 64 + lane];
+            if (p == 0 && (e.y & kMetaSkip)) store = false;
+            const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
+            const bool valid = e.y & kMetaValid;
+            i0[j][p] = (e.x & 0xffffu) >> 3; i1[j][p] = e.x >> 19;
+            wxa[j][p] = valid ? ((32 - fx) | (fx << 8)) : 0u;   // zero x weights: an absent entry contributes exactly 0
+            wy[j][p] = ((32 - fy) << 6) | (fy << 22);
+        }
+        ooff_masked[j] = store ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: neither read (car) nor written
+        const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
+        car_or |= c.x | c.y | c.z;
+    }
+#pragma unroll
+    for (int r = 0; r < GR; ++r) gs[r] = a.un_gsrc[((size_t)gs_off + r) * kUnitThreads + threadIdx.x];
+    const bool car_any = __builtin_amdgcn_ballot_w64(car_or != 0) != 0;
+
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    constexpr int D = 2;
+    pair_u32x4 pf[D][GR];
+    auto issue = [&](int b, int ring) {
+        const uint8_t *src = a.frames + (size_t)min(b, b_end - 1) * set_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
+#pragma unroll
+        for (int r = 0; r < GR; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[r], 0, kPairLoadAux);
+    };
+    auto land = [&](int ring) {   // the groups of ring slot `ring` -> the patch half of that frame
+#pragma unroll
+        for (int r = 0; r < GR; ++r)
+            pair_convert_store(pf[ring][r], lds + (DB ? ring * kPatch : 0) + (r * kUnitWaves + wave) * kPairRoundBytes, lane);
+    };
+    auto acc_to_px = [](const uint32_t acc[3]) {
+        return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
+    };
+    auto frame = [&](int b, int ring) {
+        if (!DB) {
+            land(ring);            // every wave finished reading the previous frame: barrier at the end of its step
+            block_lds_barrier();
+        }
+        const uint2 *const pw = reinterpret_cast<const uint2 *>(lds + (DB ? ring * kPatch : 0));
+        issue(b + D, ring);        // the ring slot of frame b has been converted
+        uint32_t d[NQ][3];
+        uint32_t tb = 0, tg = 0, tr = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            uint32_t acc[4][3];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) bilinear_pairs(pw[i0[j][p]], pw[i1[j][p]], wxa[j][p], wxa[j][p] << 16, wy[j][p], acc[p]);
+            if (!SUMS && !car_any) {
+                pack_accs(acc, d[j][0], d[j][1], d[j][2]);
+            } else {
+                uint32_t P[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) P[p] = acc_to_px(acc[p]);
+                if (SUMS) {
+                    // a lane's 4 pixels sum to <= 1020 per channel and a wave to <= 65280: B and G travel packed through the butterfly
+                    uint32_t sb = 0, sg = 0, sr = 0;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        sb = __builtin_amdgcn_udot4(P[p], 0x00000001u, sb, false);
+                        sg = __builtin_amdgcn_udot4(P[p], 0x00000100u, sg, false);
+                        sr = __builtin_amdgcn_udot4(P[p], 0x00010000u, sr, false);
+                    }
+                    uint32_t bg = sb | (sg << 16);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
+                    tb += bg & 0xffffu; tg += bg >> 16; tr += sr;
+                }
+                if (car_any) {     // uniform over the wave; the sprite is not kept in registers across the frame loop
+                    const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
+                    add_car(P, c.x, c.y, c.z);
+                }
+                pack_pixels(P, d[j][0], d[j][1], d[j][2]);
+            }
+        }
+        if (SUMS && lane == 0 && b < b_end) {
+            // skipped quads and lanes without a quad have zero entries: they add 0.  psums is zeroed per call (plan_stitch_impl)
+            uint32_t *ps = a.psums + ((size_t)b * a.ntiles + sum_tile) * 3;
+            atomicAdd(ps + 0, tb); atomicAdd(ps + 1, tg); atomicAdd(ps + 2, tr);
+        }
+        if (DB) land(ring ^ 1);    // frame b+1 into the other half: nobody reads it before the barrier
+        {
+            uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+                __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+        }
+        block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
+    };
+#pragma unroll
+    for (int u = 0; u < D; ++u) issue(b_begin + u, u);
+    if (DB) {
+        land(0);
+        block_lds_barrier();
+    }
+#pragma unroll 1
+    for (int b = b_begin; b < b_end; b += D) {
+#pragma unroll
+        for (int u = 0; u < D; ++u) frame(b + u, u);
+    }
+}
+
+// the unit classes as kernels of their own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit the per-class profiles are taken on)
+template <bool SUMS, int NQ, int GR>
+__global__ void __launch_bounds__(kUnitThreads) k_plan_unit(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
+    plan_unit_body<SUMS, NQ, GR>(a, blockIdx.x, patch);
+}
+
+}  // namespace bevw

@@ -71,8 +71,17 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     static const int super_env = [] { const char *s = getenv("BEVW_PLAN_SUPER"); return s ? atoi(s) : 1; }();
     static const int block_env = [] { const char *s = getenv("BEVW_PLAN_BLOCK"); return s ? atoi(s) : 1; }();   // block tiles (bevw_block.h)
     static const int seam_env = [] { const char *s = getenv("BEVW_PLAN_SEAM"); return s ? atoi(s) : 1; }();      // seam block tiles
+    static const int unit_env = [] { const char *s = getenv("BEVW_PLAN_UNITS"); return s ? atoi(s) : 1; }();     // unit schedule (bevw_unit.h)
+    static const UnitTuning unit_tune = [] {
+        UnitTuning t;
+        if (const char *s = getenv("BEVW_UNIT_GROUPS")) t.max_groups = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_ROOT_W")) t.root_w = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_ROOT_H")) t.root_h = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_MIN_W")) t.min_w = atoi(s);
+        return t;
+    }();
     hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
-                                   block_env != 0, seam_tiles && seam_env != 0);
+                                   block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, unit_tune);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }

@@ -1,0 +1,217 @@
+// Host-only check of the unit schedule (cameracalibration_amd/csrc/bevw_unit.h) -- runs without a GPU.
+//
+// The plan compiler (unit_compile) and a CPU emulation of the kernel body (unit_emulate: the per-lane steps of plan_unit_body with
+// the kernels' own pair / dot-product helpers, whose host versions restate the gfx950 instructions) are run on
+//   * synthetic LUTs (no arguments): a smooth map with a two-contributor stripe, a hole, a border stripe and a sparse corner, or
+//   * real tables and frames handed over in a file (tests/test_unit_schedule.py: the oracle's LUTs of a bench rig),
+// and every pixel a unit stores is compared with the fixed-point bilinear formula of cv2.remap evaluated directly from the LUT
+// (surroundBEV.py:116-117; INTER_LINEAR, 5-bit x 5-bit weights, (sum + 512) >> 10).  Also checked: every quad of a claimed base tile
+// is stored exactly once, no quad of an unclaimed base tile is touched, group lists are ascending and inside the frame set.
+//
+// file mode: unit_emulate <in> <out>
+//   in : int32 fw fh bw bh ncams nframes has_car | per camera: int16 lut1[bh][bw][2], uint16 lut2[bh][bw], uint8 mask[bh][bw]
+//        | uint8 frames[nframes][ncams][fh][fw][3] | uint8 car[bh][bw][3] if has_car
+//   out: int32 nunits claimed_tiles lines sectors | uint8 written[bh][bw] | uint8 image[nframes][bh][bw][3] (unwritten pixels 0)
+#include <cstdio>
+#include <cstdlib>
+#include <hip/hip_runtime.h>
+
+#include "../../cameracalibration_amd/csrc/bevw_plan.h"
+
+using namespace bevw;
+
+#define CHECK(c, ...) do { if (!(c)) { fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); return 1; } } while (0)
+
+struct Rig {
+    int fw, fh, bw, bh, ncams, nframes;
+    std::vector<int16_t> l1[4];
+    std::vector<uint16_t> l2[4];
+    std::vector<uint8_t> mk[4];
+    std::vector<uint8_t> frames, car;
+};
+
+// base-tile headers as k_plan_build leaves them (bevw_plan.h): second contributor / border footprint / empty
+static std::vector<uint32_t> host_headers(const Rig &r, int tiles_x, int tiles_y)
+{
+    std::vector<uint32_t> hdr((size_t)tiles_x * tiles_y, 0u);
+    std::vector<int> any(hdr.size(), 0);
+    const uint32_t frame_bytes = (uint32_t)r.fw * r.fh * 3;
+    for (int y = 0; y < r.bh; ++y)
+        for (int x = 0; x < r.bw; ++x) {
+            const size_t o = (size_t)y * r.bw + x, t = (size_t)(y / 8) * tiles_x + x / 32;
+            int count = 0;
+            for (int c = 0; c < r.ncams; ++c) {
+                if (r.mk[c][o] == 0) continue;
+                const int sx = r.l1[c][o * 2], sy = r.l1[c][o * 2 + 1];
+                if (sx >= r.fw || sx + 1 < 0 || sy >= r.fh || sy + 1 < 0) continue;
+                const bool interior = (unsigned)sx < (unsigned)(r.fw - 1) && (unsigned)sy < (unsigned)(r.fh - 1);
+                const uint32_t toff = ((uint32_t)sy * r.fw + sx) * 3;
+                if (!(interior && (toff & ~3u) + (uint32_t)r.fw * 3 + 12 <= frame_bytes)) hdr[t] |= kHdrSlow;
+                ++count;
+            }
+            if (count > 1) hdr[t] |= kHdrSecond;
+            if (count > 0) any[t] = 1;
+        }
+    for (size_t t = 0; t < hdr.size(); ++t)
+        if (!any[t]) hdr[t] |= kHdrEmpty;
+    return hdr;
+}
+
+static int expected_px(const Rig &r, int b, int x, int y, int out[3])
+{
+    out[0] = out[1] = out[2] = 0;
+    const size_t o = (size_t)y * r.bw + x;
+    for (int c = 0; c < r.ncams; ++c) {
+        if (r.mk[c][o] == 0) continue;
+        const int sx = r.l1[c][o * 2], sy = r.l1[c][o * 2 + 1];
+        if (sx >= r.fw || sx + 1 < 0 || sy >= r.fh || sy + 1 < 0) continue;
+        const int fx = r.l2[c][o] & 31, fy = (r.l2[c][o] >> 5) & 31;
+        const uint8_t *f = r.frames.data() + ((size_t)b * r.ncams + c) * r.fw * r.fh * 3;
+        for (int k = 0; k < 3; ++k) {
+            const int p00 = f[((size_t)sy * r.fw + sx) * 3 + k], p01 = f[((size_t)sy * r.fw + sx + 1) * 3 + k];
+            const int p10 = f[((size_t)(sy + 1) * r.fw + sx) * 3 + k], p11 = f[((size_t)(sy + 1) * r.fw + sx + 1) * 3 + k];
+            out[k] = ((p00 * (32 - fx) + p01 * fx) * (32 - fy) + (p10 * (32 - fx) + p11 * fx) * fy + 512) >> 10;
+        }
+        return 1;
+    }
+    return 0;
+}
+
+static int run(const Rig &r, const char *out_path)
+{
+    CHECK(r.bw % 4 == 0, "this check handles BEV widths that are a multiple of 4");
+    const int tiles_x = (r.bw + 31) / 32, tiles_y = (r.bh + 7) / 8, pitch = r.bw;
+    std::vector<uint32_t> hdr0 = host_headers(r, tiles_x, tiles_y), hdr = hdr0;
+    UnitPlanHost up;
+    unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up);
+    CHECK(!up.desc.empty(), "no unit compiled");
+    const size_t set_bytes = (size_t)r.fw * r.fh * 3 * r.ncams;
+    size_t claimed = 0;
+    for (size_t t = 0; t < hdr.size(); ++t) {
+        if (hdr[t] & kHdrBlock) {
+            ++claimed;
+            CHECK(!(hdr0[t] & (kHdrSlow | kHdrSecond | kHdrEmpty)), "base tile %zu claimed although it is slow / double / empty", t);
+        }
+    }
+    CHECK(claimed == up.claimed_tiles, "claimed tiles %zu != %zu", claimed, up.claimed_tiles);
+    // group lists
+    std::vector<int> cls_of(up.desc.size(), -1);
+    for (int c = 0; c < kUnitClasses; ++c)
+        for (uint32_t u : up.list[c]) { CHECK(cls_of[u] < 0, "unit %u in two classes", u); cls_of[u] = c; }
+    for (size_t u = 0; u < up.desc.size(); ++u) {
+        CHECK(cls_of[u] >= 0, "unit %zu in no class", u);
+        const UnitDesc &d = up.desc[u];
+        const int GR = kUnitClassGR[cls_of[u]], NQ = kUnitClassNQ[cls_of[u]];
+        const uint32_t *gs = up.gsrc.data() + (size_t)d.gs_off * kUnitThreads;
+        CHECK((int)d.groups <= GR * kUnitThreads, "unit %zu: %u groups in a class of %d", u, d.groups, GR * kUnitThreads);
+        for (int s = 0; s < GR * kUnitThreads; ++s) {
+            if (s >= (int)d.groups) { CHECK(gs[s] == kPairNoGroup, "unit %zu: group list has a tail", u); continue; }
+            CHECK(gs[s] % 12 == 0 && (size_t)gs[s] + 16 <= set_bytes, "unit %zu: group %d out of the frame set", u, s);
+            CHECK(s == 0 || gs[s] > gs[s - 1], "unit %zu: groups not ascending at %d", u, s);
+        }
+        const int w = (int)(d.shape & 0xffffu), h = (int)(d.shape >> 16);
+        CHECK(w % 4 == 0 && w <= kUnitMaxWidth && (4 << d.lq) >= w && ((h + (64 >> d.lq) - 1) / (64 >> d.lq)) <= NQ * kUnitWaves, "unit %zu: %d x %d does not fit its class", u, w, h);
+    }
+    // emulate every unit on every frame
+    std::vector<uint8_t> img((size_t)r.nframes * pitch * r.bh * 3, 0), written((size_t)pitch * r.bh, 0);
+    for (int b = 0; b < r.nframes; ++b) {
+        std::vector<uint8_t> wr((size_t)pitch * r.bh, 0);
+        for (size_t u = 0; u < up.desc.size(); ++u)
+            unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.car.empty() ? nullptr : r.car.data(), pitch,
+                         img.data() + (size_t)b * pitch * r.bh * 3, nullptr, &wr);
+        if (b == 0) written = wr;
+        size_t bad = 0;
+        for (int y = 0; y < r.bh; ++y)
+            for (int x = 0; x < r.bw; ++x) {
+                const bool cl = (hdr[(size_t)(y / 8) * tiles_x + x / 32] & kHdrBlock) != 0;
+                CHECK(wr[(size_t)y * pitch + x] == (cl ? 1 : 0), "pixel (%d, %d) stored %d times (claimed %d)", x, y, wr[(size_t)y * pitch + x], (int)cl);
+                if (!cl) continue;
+                int e[3];
+                expected_px(r, b, x, y, e);
+                for (int k = 0; k < 3; ++k) {
+                    int v = e[k];
+                    if (!r.car.empty()) v = std::min(255, v + r.car[((size_t)y * r.bw + x) * 3 + k]);
+                    const int got = img[(((size_t)b * r.bh + y) * pitch + x) * 3 + k];
+                    if (got != v && bad++ < 5) fprintf(stderr, "frame %d pixel (%d, %d) channel %d: %d, expected %d\n", b, x, y, k, got, v);
+                }
+            }
+        CHECK(bad == 0, "%zu wrong bytes in frame %d", bad, b);
+    }
+    // sums of the balance variant against the image
+    {
+        uint32_t sums[3] = {0, 0, 0};
+        std::vector<uint8_t> tmp((size_t)pitch * r.bh * 3, 0);
+        for (size_t u = 0; u < up.desc.size(); ++u) unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data(), set_bytes, nullptr, pitch, tmp.data(), sums);
+        unsigned long long want[3] = {0, 0, 0};
+        for (int y = 0; y < r.bh; ++y)
+            for (int x = 0; x < r.bw; ++x)
+                if (hdr[(size_t)(y / 8) * tiles_x + x / 32] & kHdrBlock) {
+                    int e[3];
+                    expected_px(r, 0, x, y, e);
+                    for (int k = 0; k < 3; ++k) want[k] += e[k];
+                }
+        for (int k = 0; k < 3; ++k) CHECK(sums[k] == want[k], "channel sum %d: %u, expected %llu", k, sums[k], want[k]);
+    }
+    printf("unit schedule ok: %zu units (classes", up.desc.size());
+    for (int c = 0; c < kUnitClasses; ++c) printf(" %dx%d:%zu", kUnitClassNQ[c], kUnitClassGR[c], up.list[c].size());
+    printf("), %zu of %zu base tiles claimed, %zu source lines + %zu write sectors per frame\n", claimed, hdr.size(), up.lines, up.sectors);
+    if (out_path) {
+        FILE *f = fopen(out_path, "wb");
+        CHECK(f, "cannot write %s", out_path);
+        const int32_t head[4] = {(int32_t)up.desc.size(), (int32_t)claimed, (int32_t)up.lines, (int32_t)up.sectors};
+        fwrite(head, 4, 4, f);
+        fwrite(written.data(), 1, written.size(), f);
+        fwrite(img.data(), 1, img.size(), f);
+        fclose(f);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    Rig r;
+    if (argc >= 2) {
+        FILE *f = fopen(argv[1], "rb");
+        CHECK(f, "cannot read %s", argv[1]);
+        int32_t head[7];
+        CHECK(fread(head, 4, 7, f) == 7, "short header");
+        r.fw = head[0]; r.fh = head[1]; r.bw = head[2]; r.bh = head[3]; r.ncams = head[4]; r.nframes = head[5];
+        const size_t npx = (size_t)r.bw * r.bh;
+        for (int c = 0; c < r.ncams; ++c) {
+            r.l1[c].resize(npx * 2); r.l2[c].resize(npx); r.mk[c].resize(npx);
+            CHECK(fread(r.l1[c].data(), 2, npx * 2, f) == npx * 2 && fread(r.l2[c].data(), 2, npx, f) == npx && fread(r.mk[c].data(), 1, npx, f) == npx, "short tables");
+        }
+        r.frames.resize((size_t)r.nframes * r.ncams * r.fw * r.fh * 3);
+        CHECK(fread(r.frames.data(), 1, r.frames.size(), f) == r.frames.size(), "short frames");
+        if (head[6]) { r.car.resize(npx * 3); CHECK(fread(r.car.data(), 1, r.car.size(), f) == r.car.size(), "short car"); }
+        fclose(f);
+        return run(r, argc >= 3 ? argv[2] : nullptr);
+    }
+    // synthetic rig: two cameras, 520 x 300 frames, 328 x 150 BEV (partial tiles at the right / bottom edge)
+    r.fw = 520; r.fh = 300; r.bw = 328; r.bh = 150; r.ncams = 2; r.nframes = 2;
+    const size_t npx = (size_t)r.bw * r.bh;
+    for (int c = 0; c < 2; ++c) { r.l1[c].resize(npx * 2); r.l2[c].resize(npx); r.mk[c].assign(npx, 0); }
+    for (int y = 0; y < r.bh; ++y)
+        for (int x = 0; x < r.bw; ++x) {
+            const size_t o = (size_t)y * r.bw + x;
+            // camera 0: dense on the left (3/4 texel per pixel), sparse towards the right (up to 3 texels per pixel, rows 2 apart)
+            const int sx0 = x < 160 ? x * 3 / 4 + 3 : 123 + (x - 160) * 2 + (y & 1), sy0 = x < 160 ? y * 3 / 4 + 5 : y * 2 - 3;
+            r.l1[0][o * 2] = (int16_t)sx0; r.l1[0][o * 2 + 1] = (int16_t)sy0;
+            r.l2[0][o] = (uint16_t)(((x * 7 + y) & 31) | (((y * 5 + x) & 31) << 5));
+            r.mk[0][o] = 255;
+            // camera 1: a rotated view (BEV y runs along source x) that takes over in a stripe of columns 96 .. 135 with an overlap at 96 .. 103
+            r.l1[1][o * 2] = (int16_t)(400 - y); r.l1[1][o * 2 + 1] = (int16_t)(x / 2 + 20);
+            r.l2[1][o] = (uint16_t)(((x * 3) & 31) | (((y * 11) & 31) << 5));
+            if (x >= 96 && x < 136) { r.mk[1][o] = 255; if (x >= 104) r.mk[0][o] = 0; }
+        }
+    for (int y = 40; y < 56; ++y) for (int x = 192; x < 256; ++x) r.mk[0][(size_t)y * r.bw + x] = 0;    // a hole (empty base tiles)
+    for (int y = 100; y < 108; ++y) for (int x = 0; x < 32; ++x) r.mk[0][(size_t)y * r.bw + x] = 200;   // a blend weight: not a unit's tile
+    r.frames.resize((size_t)r.nframes * r.ncams * r.fw * r.fh * 3);
+    uint32_t seed = 12345u;
+    for (uint8_t &v : r.frames) { seed = seed * 1664525u + 1013904223u; v = (uint8_t)(seed >> 24); }
+    if (run(r, nullptr)) return 1;
+    // once more with a car sprite over part of the image
+    r.car.assign(npx * 3, 0);
+    for (int y = 30; y < 90; ++y) for (int x = 50; x < 210; ++x) for (int k = 0; k < 3; ++k) r.car[((size_t)y * r.bw + x) * 3 + k] = (uint8_t)(x + 2 * y + 40 * k);
+    return run(r, nullptr);
+}

@@ -1,0 +1,112 @@
+"""The unit schedule (cameracalibration_amd/csrc/bevw_unit.h) checked WITHOUT a GPU.
+
+tests/native/unit_emulate.cpp is compiled with hipcc (only its host part runs): it runs the host-side plan compiler (unit_compile:
+k-d partition of the BEV into units, group lists, LDS pair addresses) and a CPU emulation of the kernel body that uses the kernels' own
+pair-conversion / dot-product helpers (their host versions restate v_perm_b32 / v_dot4_u32_u8 / v_dot2_u32_u16), and compares every
+stored pixel with cv2.remap's fixed-point formula evaluated from the LUT.  Here it is driven with
+  * its built-in synthetic rig (two cameras, seam, hole, blend weight, sparse corner, car sprite), and
+  * the oracle's tables of the bench rigs (BASELINE config 3 direct / blend, the 4K rig, the undistort map): the pixels the units store
+    must equal the oracle's BevGenerator output byte for byte, and the partition's request arithmetic must stay at the level DESIGN.md
+    section 4 quotes."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from cameracalibration_amd import workloads as W
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def exe(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("unit") / "unit_emulate")
+    hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    cmd = [hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-inline-asm",
+           "-Wno-unused-result", os.path.join(ROOT, "tests", "native", "unit_emulate.cpp"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return out
+
+
+def test_units_on_synthetic_tables(exe):
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("unit schedule ok") == 2   # without and with a car sprite
+
+
+def _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh):
+    """luts: [(int16 [bh,bw,2], uint16 [bh,bw])], masks: [uint8 [bh,bw]], frames: uint8 [n, ncams, fh, fw, 3]"""
+    inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<7i", fw, fh, bw, bh, len(luts), frames.shape[0], int(car is not None)))
+        for (m1, m2), mk in zip(luts, masks):
+            f.write(np.ascontiguousarray(m1, np.int16).tobytes())
+            f.write(np.ascontiguousarray(m2, np.uint16).tobytes())
+            f.write(np.ascontiguousarray(mk, np.uint8).tobytes())
+        f.write(np.ascontiguousarray(frames, np.uint8).tobytes())
+        if car is not None:
+            f.write(np.ascontiguousarray(car, np.uint8).tobytes())
+    r = subprocess.run([exe, inp, outp], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = open(outp, "rb").read()
+    nunits, claimed, lines, sectors = struct.unpack("<4i", raw[:16])
+    written = np.frombuffer(raw, np.uint8, bw * bh, 16).reshape(bh, bw)
+    img = np.frombuffer(raw, np.uint8, frames.shape[0] * bh * bw * 3, 16 + bw * bh).reshape(frames.shape[0], bh, bw, 3)
+    return dict(units=nunits, claimed=claimed, lines=lines, sectors=sectors, written=written, img=img, log=r.stdout)
+
+
+def _mask2d(m):
+    return m[..., 0] if m.ndim == 3 else m
+
+
+@pytest.mark.parametrize("name,cfg,rig,blend,max_requests", [
+    # requests per frame = distinct source lines + write sectors of the partition; round 2's schedule paid ~136 k on config 3
+    ("config3_direct", W.CONFIG_S, W.rig_s, False, 108_000),
+    ("config3_blend", W.CONFIG_S, W.rig_s, True, None),
+    ("rig_4k_blend", W.CONFIG_4K, W.rig_4k, True, None),
+])
+def test_units_on_bench_rigs_match_the_oracle(exe, tmp_path, name, cfg, rig, blend, max_requests):
+    O.build()
+    gen = O.RefBevGenerator(rig(), cfg, blend=blend, balance=False)
+    fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+    frames = W.synthetic_frames(1, fw, fh, kind="random")
+    rng = np.random.default_rng(7)
+    car = np.zeros((bh, bw, 3), np.uint8)
+    cw, ch = cfg["CAR_WIDTH"], cfg["CAR_HEIGHT"]
+    x0, y0 = (bw - cw) // 2 - 20, (bh - ch) // 2 - 20          # a sprite that overlaps the trapezoids by 20 pixels
+    car[y0:y0 + ch + 40, x0:x0 + cw + 40] = rng.integers(0, 256, (ch + 40, cw + 40, 3), dtype=np.uint8)
+    luts = [cam.bev_maps for cam in gen.cameras]
+    masks = [_mask2d(m) for m in gen.masks]
+    got = _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh)
+    ref = gen(*[frames[0, i] for i in range(4)], car)
+    w = got["written"] == 1
+    assert w.sum() > 0.5 * bw * bh, got["log"]          # the units take the bulk of the image
+    assert np.array_equal(got["img"][0][w], ref[w]), name
+    assert not got["img"][0][~w].any()
+    if max_requests is not None:
+        assert got["lines"] + got["sectors"] <= max_requests, got["log"]
+    print(got["log"].strip())
+
+
+def test_units_on_the_undistort_map_match_the_oracle(exe, tmp_path):
+    """Config 2: cv2.remap through the fisheye undistort maps = a one-camera plan with mask 255 everywhere."""
+    O.build()
+    K, D = W.undistort_calibration()
+    cfg = W.CONFIG_UNDISTORT
+    fw, fh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"]
+    Kd = O.camera_mat_dst(K, fw, fh, cfg["FOCAL_SCALE"], cfg["SIZE_SCALE"])
+    m1, m2 = O.fisheye_init_undistort_rectify_map(K, D, Kd, (int(fw * cfg["SIZE_SCALE"]), int(fh * cfg["SIZE_SCALE"])))
+    img = W.synthetic_frames(1, fw, fh, kind="random")[0, :1]
+    got = _run(exe, tmp_path, [(m1, m2)], [np.full(m1.shape[:2], 255, np.uint8)], img[None], None, fw, fh, m1.shape[1], m1.shape[0])
+    ref = O.remap(img[0], m1, m2)
+    w = got["written"] == 1
+    assert w.sum() > 0.9 * w.size, got["log"]
+    assert np.array_equal(got["img"][0][w], ref[w])
+    print(got["log"].strip())
