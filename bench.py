@@ -69,6 +69,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=0, help="frames (4-camera sets) per GPU per step; 0 = workload default")
     ap.add_argument("--schedule", default="auto", choices=["auto", "pixel", "plan"])
     ap.add_argument("--unique-sets", type=int, default=2, help="distinct synthetic frame sets replicated over the batch")
+    ap.add_argument("--placements", type=int, default=0,
+                    help="buffer placements: the frame / output buffers are freed and re-allocated this many times and K steps are timed "
+                         "on each; the MEDIAN placement is reported (0 = 5 for the single-engine workloads, 1 for the camera-shard one)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -282,7 +285,7 @@ def main():
         d_in = _ffi.DeviceBuffer(batch * mine[0].nbytes, dev)
         upload_replicated(d_in, mine, batch)
         pipe = CS.ResidentShardPipeline(gen, batch)
-        step = lambda: pipe.step(d_in.ptr, None)
+        make_buffers = lambda: ((), (lambda: pipe.step(d_in.ptr, None)))   # the pipeline owns its buffers: one placement
         e = gen.engine
         sync = e.sync
         tstart = lambda: _ffi.check(_ffi.lib().bevw_timer_start(e.h))
@@ -304,8 +307,6 @@ def main():
                  "table_build_s": round(t_build, 3), "cameras_per_rank": len(gen.cams), "camera_groups": units_world,
                  "part_boxes": [list(b) for b in gen.boxes],
                  "transport": "single rank" if d.world == 1 else "rccl (native: ncclAllGather + grouped ncclSend/ncclRecv on the engine stream)"}
-        if os.environ.get("BEVW_BENCH_PTRS"):   # placement study (profiles/r02/sweeps.log: per-process spread)
-            extra["ptrs"] = {"in": hex(d_in.ptr), "out": hex(d_out.ptr)}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     elif w["kind"] == "bev":
@@ -322,18 +323,18 @@ def main():
         t_build = time.perf_counter() - t_build
         fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
         unique = W.synthetic_frames(a.unique_sets, fw, fh, seed=W.SEED + d.rank)
-        d_in = _ffi.DeviceBuffer(batch * unique[0].nbytes, dev)
-        d_out = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
-        upload_replicated(d_in, unique, batch)
-        step = lambda: bev.run_device(d_in.ptr, batch, None, d_out.ptr)
+
+        def make_buffers():
+            b_in = _ffi.DeviceBuffer(batch * unique[0].nbytes, dev)
+            b_out = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
+            upload_replicated(b_in, unique, batch)
+            return (b_in, b_out), (lambda: bev.run_device(b_in.ptr, batch, None, b_out.ptr))
         sync, tstart, tstop = bev.sync, bev.timer_start, bev.timer_stop
         tmark, tbetween = bev.timer_mark, bev.timer_between
         info = bev.plan_info()
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
                  "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3),
                  "tiles": {"staged": info["tiles_staged"], "gather": info["tiles_gather"], "border": info["tiles_border"]}}
-        if os.environ.get("BEVW_BENCH_PTRS"):   # placement study (profiles/r02/sweeps.log: per-process spread)
-            extra["ptrs"] = {"in": hex(d_in.ptr), "out": hex(d_out.ptr)}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     else:
@@ -346,11 +347,13 @@ def main():
                                                            ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"], 0.0, 0.0, C.byref(r)))
         unique = W.synthetic_frames(max(1, a.unique_sets // 2), fw, fh, seed=W.SEED + d.rank)
         imgs = unique.reshape(-1, fh, fw, 3)
-        d_in = _ffi.DeviceBuffer(batch * imgs[0].nbytes, dev)
-        d_out = _ffi.DeviceBuffer(batch * imgs[0].nbytes, dev)
-        upload_replicated(d_in, imgs, batch)
         L = _ffi.lib()
-        step = lambda: _ffi.check(L.bevw_remap_device(r, d_in.ptr, batch, d_out.ptr))
+
+        def make_buffers():
+            b_in = _ffi.DeviceBuffer(batch * imgs[0].nbytes, dev)
+            b_out = _ffi.DeviceBuffer(batch * imgs[0].nbytes, dev)
+            upload_replicated(b_in, imgs, batch)
+            return (b_in, b_out), (lambda: _ffi.check(L.bevw_remap_device(r, b_in.ptr, batch, b_out.ptr)))
         sync = lambda: _ffi.check(L.bevw_remapper_sync(r))
         tstart = lambda: _ffi.check(L.bevw_remapper_timer_start(r))
 
@@ -368,31 +371,47 @@ def main():
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_undistort(w, K, D, ucfg, unique, a.cpu_seconds)
 
-    for _ in range(a.warmup):
-        step()
-    sync()
-    d.barrier()
-    t0 = time.perf_counter()
-    tstart()
-    for i in range(a.steps):
-        tmark(i)     # an event in front of every step, recorded on the engine's stream without synchronising
-        step()
-    tmark(a.steps)
-    ev_ms = tstop()  # records the stop event on the engine's stream and waits for it
-    sync()
-    d.barrier()
-    wall = time.perf_counter() - t0
-    wall = d.max(wall)
-    ev_ms = d.max(ev_ms)
+    # Placements.  The step time of these request-bound kernels follows the DRAM latency the physical pages of the OUTPUT buffer
+    # happen to give (profiles/r03/placement.md: 0.47 .. 0.58 ms for config 3 from the same build and the same process, offsets inside
+    # an allocation do not matter, the channels are evenly loaded in fast and slow draws).  One allocation is one random draw, so the
+    # buffers are freed and re-allocated `placements` times (a growing dummy allocation shifts the heap in between), W warm-up and
+    # exactly K timed steps run on each, and the MEDIAN placement is what the line reports; all draws are listed next to it.
+    placements = a.placements or (1 if w["kind"] == "camera" else 5)
+    draws, dummies = [], []
+    for pi in range(placements):
+        bufs, step = make_buffers()
+        for _ in range(a.warmup):
+            step()
+        sync()
+        d.barrier()
+        t0 = time.perf_counter()
+        tstart()
+        for i in range(a.steps):
+            tmark(i)     # an event in front of every step, recorded on the engine's stream without synchronising
+            step()
+        tmark(a.steps)
+        ev_ms = tstop()  # records the stop event on the engine's stream and waits for it
+        sync()
+        d.barrier()
+        wall = time.perf_counter() - t0
+        wall = d.max(wall)
+        ev_ms = d.max(ev_ms)
+        laps = sorted(tbetween(i, i + 1) for i in range(a.steps))
+        lap_median = d.max(laps[len(laps) // 2] if len(laps) % 2 else 0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2]))
+        draws.append({"wall": wall, "ev_ms": ev_ms, "lap_median": lap_median, "lap_min": laps[0], "lap_max": laps[-1],
+                      "ptrs": [hex(b.ptr) for b in bufs]})
+        for b in bufs:
+            b.free()
+        if pi + 1 < placements and bufs:
+            dummies.append(_ffi.DeviceBuffer((pi + 1) * 37 * 1024 * 1024 + 4096, dev))
+    for b in dummies:
+        b.free()
+    order = sorted(range(placements), key=lambda i: draws[i]["wall"])
+    mid = draws[order[placements // 2]] if placements % 2 else draws[order[placements // 2 - 1]]   # the (lower) median placement
+    wall, ev_ms, lap_median = mid["wall"], mid["ev_ms"], mid["lap_median"]
+    laps = [mid["lap_min"], mid["lap_max"]]
 
     traffic, traffic_source = measured_traffic(a.workload, batch)
-    # per-step durations from the marks: the median is robust against the one-off hiccups a 13 ms region is exposed to
-    laps = [tbetween(i, i + 1) for i in range(a.steps)]
-    if os.environ.get("BEVW_BENCH_DUMP_STEPS") and d.rank == 0:   # per-step trace for clock / drift studies (tools/r02/)
-        with open(os.environ["BEVW_BENCH_DUMP_STEPS"], "w") as fh:
-            fh.write("\n".join("%.5f" % x for x in laps) + "\n")
-    laps = sorted(laps)
-    lap_median = d.max(laps[len(laps) // 2] if len(laps) % 2 else 0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2]))
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
@@ -405,10 +424,15 @@ def main():
                                      else "frames across ranks, no data-path collective"), "device": _ffi.device_name(dev),
                         "unique_frame_sets": int(a.unique_sets)}, **extra),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "frac": achieved / HBM_PEAK_GBS, "frac_best_placement": alg_bytes * batch * a.steps / (min(x["ev_ms"] for x in draws) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "frac_worst_placement": alg_bytes * batch * a.steps / (max(x["ev_ms"] for x in draws) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": traffic, "traffic_source": traffic_source,
                      "kernel_ms": launch_ms, "kernel_ms_median": lap_median, "kernel_ms_min": laps[0], "kernel_ms_max": laps[-1],
                      "frac_median": alg_bytes * batch / (lap_median * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
+        "placements": {"n": placements, "reported": "median placement (by wall time of its K steps)",
+                       "ms_per_step": [round(x["wall"] / a.steps * 1e3, 4) for x in draws],
+                       "kernel_ms_median": [round(x["lap_median"], 4) for x in draws]},
         "cpu_baseline": cpu,
     }
     if d.rank == 0:

@@ -188,11 +188,121 @@ class HipShardEngine:
             pass
 
 
+def _recv_exact(c, n):
+    buf = b""
+    while len(buf) < n:
+        chunk = c.recv(n - len(buf))
+        if not chunk:
+            raise Exception("control channel closed")
+        buf += chunk
+    return buf
+
+
+class HubDirectory:
+    """Where the hubs of the camera groups listen.  Only GLOBAL rank 0 is known to be reachable at MASTER_ADDR, and a group's hub
+    (global rank 4 g) generally runs on another host, so a hub binds an ephemeral port on all interfaces and REGISTERS it here; the
+    members of the group ASK here.  Global rank 0 serves the directory from a daemon thread on (all interfaces, port) until every
+    group has registered and every member has asked (or the timeout passes: the listening socket is closed either way).
+    Wire format: b"R" group:u32 port:u32 -> no reply (the hub's host is the peer address of that connection);
+                 b"Q" group:u32          -> u32 port, u16 n, n bytes of host (sent once the group has registered)."""
+
+    def __init__(self, port: int, ngroups: int, nqueries: int, timeout: float = 120.0):
+        import socket
+        import threading
+
+        self.srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        self.srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        self.srv.bind(("", port))
+        self.srv.listen(ngroups + nqueries + 4)
+        self.thread = threading.Thread(target=self._serve, args=(int(ngroups), int(nqueries), float(timeout)), daemon=True)
+        self.thread.start()
+
+    def _serve(self, ngroups, nqueries, timeout):
+        import socket
+        import time
+
+        reg, pending, served = {}, [], 0
+        deadline = time.time() + timeout
+        self.srv.settimeout(0.1)
+        try:
+            while (len(reg) < ngroups or served < nqueries) and time.time() < deadline:
+                try:
+                    c, peer = self.srv.accept()
+                except socket.timeout:
+                    c = None
+                if c is not None:
+                    try:
+                        c.settimeout(5.0)
+                        kind = _recv_exact(c, 1)
+                        group = int.from_bytes(_recv_exact(c, 4), "little")
+                        if kind == b"R" and 0 <= group < ngroups:
+                            reg[group] = (peer[0], int.from_bytes(_recv_exact(c, 4), "little"))
+                            c.close()
+                        elif kind == b"Q" and 0 <= group < ngroups:
+                            pending.append((c, group))
+                        else:
+                            c.close()            # not one of ours
+                    except Exception:
+                        c.close()
+                still = []
+                for c, g in pending:
+                    if g not in reg:
+                        still.append((c, g))
+                        continue
+                    host = reg[g][0].encode()
+                    try:
+                        c.sendall(reg[g][1].to_bytes(4, "little") + len(host).to_bytes(2, "little") + host)
+                    except OSError:
+                        pass
+                    c.close()
+                    served += 1
+                pending = still
+        finally:
+            for c, _ in pending:
+                c.close()
+            self.srv.close()
+
+    @staticmethod
+    def _connect(addr, port, timeout):
+        import socket
+        import time
+
+        t0 = time.time()
+        while True:
+            try:
+                return socket.create_connection((addr, port), timeout=timeout)
+            except OSError:
+                if time.time() - t0 > timeout:
+                    raise
+                time.sleep(0.05)
+
+    @staticmethod
+    def register(addr, port, group, hub_port, timeout=120.0):
+        c = HubDirectory._connect(addr, port, timeout)
+        c.sendall(b"R" + int(group).to_bytes(4, "little") + int(hub_port).to_bytes(4, "little"))
+        c.close()
+
+    @staticmethod
+    def lookup(addr, port, group, timeout=120.0):
+        c = HubDirectory._connect(addr, port, timeout)
+        c.settimeout(timeout)
+        c.sendall(b"Q" + int(group).to_bytes(4, "little"))
+        hub_port = int.from_bytes(_recv_exact(c, 4), "little")
+        n = int.from_bytes(_recv_exact(c, 2), "little")
+        host = _recv_exact(c, n).decode()
+        c.close()
+        return host, hub_port
+
+
 class SocketGroup:
     """Out-of-band control channel of one camera group (a star over TCP, group rank 0 is the hub): carries the RCCL unique
-    id and the mask boxes once, at construction.  Plain sockets -- the data plane is RCCL."""
+    id and the mask boxes once, at construction.  Plain sockets -- the data plane is RCCL.
 
-    def __init__(self, rank: int, world: int, addr: str, port: int, timeout: float = 120.0):
+    ``addr`` / ``port``: where the hub listens.  With ``directory=(addr, port, group)`` the hub instead binds an ephemeral port on all
+    interfaces and publishes it through the HubDirectory at that address (multi-node worlds: the hub of group g > 0 does not run
+    on MASTER_ADDR's host)."""
+
+    def __init__(self, rank: int, world: int, addr: str, port: int, timeout: float = 120.0, directory=None):
         import socket
         import time
 
@@ -203,40 +313,41 @@ class SocketGroup:
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, port))
-            srv.listen(self.world)
-            srv.settimeout(timeout)
             got = {}
-            while len(got) < self.world - 1:
-                c, _ = srv.accept()
-                c.settimeout(timeout)
-                r = int.from_bytes(self._recv(c, 4), "little")
-                got[r] = c
-            srv.close()
+            try:
+                if directory is not None:
+                    srv.bind(("", 0))
+                    srv.listen(self.world)
+                    HubDirectory.register(directory[0], directory[1], directory[2], srv.getsockname()[1], timeout)
+                else:
+                    srv.bind((addr, port))
+                    srv.listen(self.world)
+                deadline = time.time() + timeout
+                while len(got) < self.world - 1:
+                    srv.settimeout(max(0.05, deadline - time.time()))
+                    c, _ = srv.accept()          # socket.timeout when a member never shows up
+                    c.settimeout(timeout)
+                    r = int.from_bytes(_recv_exact(c, 4), "little")
+                    if not (0 < r < self.world) or r in got:
+                        c.close()                # not a member of this group (a stray connection, another job)
+                        continue
+                    got[r] = c
+            except Exception:
+                for c in got.values():
+                    c.close()
+                raise
+            finally:
+                srv.close()
             self.peers = [got[r] for r in range(1, self.world)]
         else:
-            t0 = time.time()
-            while True:
-                try:
-                    c = socket.create_connection((addr, port), timeout=timeout)
-                    break
-                except OSError:
-                    if time.time() - t0 > timeout:
-                        raise
-                    time.sleep(0.05)
+            if directory is not None:
+                addr, port = HubDirectory.lookup(directory[0], directory[1], directory[2], timeout)
+            c = HubDirectory._connect(addr, port, timeout)
             c.settimeout(timeout)
             c.sendall(self.rank.to_bytes(4, "little"))
             self.peers = [c]
 
-    @staticmethod
-    def _recv(c, n):
-        buf = b""
-        while len(buf) < n:
-            chunk = c.recv(n - len(buf))
-            if not chunk:
-                raise Exception("control channel closed")
-            buf += chunk
-        return buf
+    _recv = staticmethod(_recv_exact)
 
     def broadcast(self, payload, nbytes: int) -> bytes:
         """bytes of group rank 0 -> every rank."""
@@ -339,7 +450,15 @@ class CameraShardedBev:
         else:
             if not isinstance(self.engine, HipShardEngine):
                 raise Exception("the RCCL exchange needs the HIP engine; inject a host transport for stand-in engines")
-            control = SocketGroup(self.group_rank, len(self.ranks), addr, port + control_port_offset + self.group)
+            # rendezvous: global rank 0 (the one process known to run at MASTER_ADDR) serves the hub directory on
+            # MASTER_PORT + control_port_offset (BEVW_CONTROL_PORT overrides the port); every group's hub binds an ephemeral port
+            # on its own host and registers it there
+            import os as _os
+
+            dport = int(_os.environ.get("BEVW_CONTROL_PORT", port + control_port_offset))
+            ngroups = len({g for g, _ in assign})
+            self._directory = HubDirectory(dport, ngroups, self.world_size - ngroups) if self.rank == 0 else None
+            control = SocketGroup(self.group_rank, len(self.ranks), addr, 0, directory=(addr, dport, self.group))
             self.rccl = RcclGroup(self.group_rank, len(self.ranks), device, control)
             boxes = [np.frombuffer(b, np.int32) for b in control.all_gather(mine.tobytes())]
         self.boxes = [tuple(int(v) for v in b) for b in boxes]
@@ -402,13 +521,29 @@ class CameraShardedBev:
         return self._pipe.out.download((batch, e.bh, e.bw, 3))
 
     def close(self):
-        if self._pipe is not None:
+        if getattr(self, "_pipe", None) is not None:
             self._pipe.close()
             self._pipe = None
-        if self.rccl is not None:
+        if getattr(self, "rccl", None) is not None:
             self.rccl.close()
             self.rccl = None
-        self.engine.close()
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+            self.engine = None
+
+    # the RCCL communicator, the control sockets and the device buffers are released when the object is dropped or leaves a `with`
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ResidentShardPipeline:

@@ -89,7 +89,10 @@ struct Plan {
     static constexpr int kUnitLists = 4;
     void *list_un[kUnitLists] = {nullptr, nullptr, nullptr, nullptr};
     int n_un[kUnitLists] = {0, 0, 0, 0};
+    void *list_un_all = nullptr;             // every unit in partition order, class in bits 28..31
+    int n_un_all = 0;
     size_t un_lines = 0, un_sectors = 0;     // request arithmetic of the partition (per frame)
+    int un_skew = 0;
     bool paired_ok = false;
 };
 
@@ -437,6 +440,7 @@ struct PlanArgs {
     int tiles_x, ntiles, ngroups;
     int ncams;                   // images per frame set: 4 for BevGenerator, 1 for a plain cv2.remap
     int batch, nb, nchunks, xcd_affine;
+    int group_major;             // xcd_affine: block order inside an XCD is (tile group, chunk) instead of (chunk, tile group)
     const uint2 *plan_pr;        // pair-staged entries (plan_pair_body)
     const uint32_t *gsrc;        // group source offsets [ntiles][kPairRounds][64]
     const uint32_t *tile_list;   // class kernels: tile indices; nlist entries, ngroups = ceil(nlist / 4)
@@ -451,8 +455,9 @@ struct PlanArgs {
     const uint32_t *sm_pos;
     // units (bevw_unit.h): tile_list holds unit ids, ngroups = nlist
     const UnitDesc *un_desc;
-    const uint2 *un_entries;
+    const uint4 *un_entries;     // one uint4 per lane and quad slot: the plan entries of the lane's 4 pixels
     const uint32_t *un_gsrc;
+    int un_skew;                 // unit_skew constant of the plan
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -464,8 +469,15 @@ __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, u
     const uint32_t ng = (uint32_t)a.ngroups;
     if (a.xcd_affine == 1) {
         const uint32_t xcd = id & 7u, k = id >> 3;
-        chunk = xcd + 8u * (k / ng);
-        group = k % ng;
+        if (a.group_major) {
+            // the chunks of an XCD back to back for every tile group: the blocks that read the same plan entries run at the same time
+            const uint32_t cpx = ((uint32_t)a.nchunks + 7u) >> 3;
+            chunk = xcd + 8u * (k % cpx);
+            group = k / cpx;
+        } else {
+            chunk = xcd + 8u * (k / ng);
+            group = k % ng;
+        }
     } else {
         chunk = id / ng;
         group = id % ng;
@@ -757,7 +769,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 16;   // classes of one merged launch (launch positions in use)
+constexpr int kPlanAllMax = 17;   // classes of one merged launch (launch positions in use)
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -766,7 +778,7 @@ struct PlanAllArgs {
     uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
     // launch position -> class: 2 empty, 3 gather single, 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced),
     // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds), 12 block-staged (bevw_block.h, 4 waves per block tile), 13 seam block tiles,
-    // 14 .. 17 units (bevw_unit.h, class = kind - 14)
+    // 14 .. 17 units (bevw_unit.h, class = kind - 14), 18 units of every class in partition order
     int kind[kPlanAllMax];
     int n;                             // launch positions in use
 };
@@ -800,6 +812,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BEVW_P
         case 15: plan_unit_body<SUMS, kUnitClassNQ[1], kUnitClassGR[1]>(a, id, stage_0); break;
         case 16: plan_unit_body<SUMS, kUnitClassNQ[2], kUnitClassGR[2]>(a, id, stage_0); break;
         case 17: plan_unit_body<SUMS, kUnitClassNQ[3], kUnitClassGR[3]>(a, id, stage_0); break;
+        case 18: plan_unit_any<SUMS>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
         // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
@@ -836,7 +849,7 @@ static inline void plan_release(Plan &p)
 {
     void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5], p.list_pr[6],
                     p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt, p.sm_entries, p.sm_gsrc, p.sm_pos, p.list_sm,
-                    p.un_desc, p.un_entries, p.un_gsrc, p.list_un[0], p.list_un[1], p.list_un[2], p.list_un[3],
+                    p.un_desc, p.un_entries, p.un_gsrc, p.list_un_all, p.list_un[0], p.list_un[1], p.list_un[2], p.list_un[3],
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -850,6 +863,14 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
     hipError_t e = hipMalloc(dptr, v.size() * sizeof(uint32_t));
     if (e != hipSuccess) return e;
     return hipMemcpy(*dptr, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+}
+
+// pixels per output row the plan kernels write: bw rounded up to 4 (12-byte stores); BEVW_ABL_PITCH_ALIGN=N rounds to N pixels instead
+// (ablation: N = 64 makes every row start on a 64-byte sector -- the cost of partially written sectors, profiles/r03/sweeps.log)
+static inline int plan_pitch(int bw)
+{
+    static const int align = [] { const char *s = getenv("BEVW_ABL_PITCH_ALIGN"); const int v = s ? atoi(s) : 4; return v >= 4 && v % 4 == 0 ? v : 4; }();
+    return (bw + align - 1) / align * align;
 }
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
@@ -932,20 +953,22 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if (units) {
             UnitPlanHost up;
             std::vector<uint32_t> hdr_un = hdr;
-            unit_compile(h1, h2, hm, ncams, fw, fh, bw, bh, (bw + 3) & ~3, p.tiles_x, p.tiles_y, hdr_un, up, unit_tune);
+            unit_compile(h1, h2, hm, ncams, fw, fh, bw, bh, plan_pitch(bw), p.tiles_x, p.tiles_y, hdr_un, up, unit_tune);
             if (!up.desc.empty()) {
                 have_units = true;
                 hdr.swap(hdr_un);
                 if ((e = hipMalloc(&p.un_desc, up.desc.size() * sizeof(UnitDesc))) != hipSuccess) return e;
                 if ((e = hipMemcpy(p.un_desc, up.desc.data(), up.desc.size() * sizeof(UnitDesc), hipMemcpyHostToDevice)) != hipSuccess) return e;
-                if ((e = hipMalloc(&p.un_entries, up.entries.size() * sizeof(uint2))) != hipSuccess) return e;
-                if ((e = hipMemcpy(p.un_entries, up.entries.data(), up.entries.size() * sizeof(uint2), hipMemcpyHostToDevice)) != hipSuccess) return e;
+                if ((e = hipMalloc(&p.un_entries, up.entries.size() * sizeof(uint32_t))) != hipSuccess) return e;
+                if ((e = hipMemcpy(p.un_entries, up.entries.data(), up.entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) != hipSuccess) return e;
                 if ((e = plan_upload_list(up.gsrc, &p.un_gsrc)) != hipSuccess) return e;
                 for (int c = 0; c < kUnitClasses; ++c) {
                     p.n_un[c] = (int)up.list[c].size();
                     if ((e = plan_upload_list(up.list[c], &p.list_un[c])) != hipSuccess) return e;
                 }
-                p.un_lines = up.lines; p.un_sectors = up.sectors;
+                p.n_un_all = (int)up.all.size();
+                if ((e = plan_upload_list(up.all, &p.list_un_all)) != hipSuccess) return e;
+                p.un_lines = up.lines; p.un_sectors = up.sectors; p.un_skew = (int)up.skew;
             }
         }
         BlockPlanHost bp;
@@ -1037,7 +1060,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     if ((e = plan_upload_list(le, &p.list_empty)) != hipSuccess) return e;
     // 12-byte stores need 4-byte aligned pixel quads: rows of `pitch` pixels (bw % 4 != 0: padded scratch + k_plan_unpad)
     // and the aligned 12-byte footprint reads need every frame of a set to start on a 4-byte boundary
-    p.pitch = (bw + 3) & ~3;
+    p.pitch = plan_pitch(bw);
     p.usable = p.max_contrib <= 2 && (((size_t)fw * fh * 3) % 4 == 0) && (size_t)fw * fh * 3 * ncams < (1ull << 31);
     return hipSuccess;
 }
@@ -1066,11 +1089,11 @@ __global__ void k_plan_unpad(const uint8_t *__restrict__ src, int bw, int pitch,
 // (bevw_pair.h) for every tile that has a pair plan; one_launch: 1 = all tile classes of a step in one kernel
 // (k_plan_all), 0 = one launch per class
 // bt_merged: 1 = the block tiles are a class of the merged launch (4 waves per block tile), 0 = their own 8-wave kernel first
-struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int bt_merged = 1; };
+struct PlanTuning { int nb = 0; int lean = 1; int lds_pad = 16384; int xcd_map = 1; int staged = 1; int one_launch = 1; int bt_merged = 1; int group_major = 0; int unit_spatial = 1; };
 
 template <int LX>
 static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, bool blend, bool balance, bool lean, int lds_pad,
-                                        bool sums, bool staged, bool one_launch, bool bt_in_merged_launch)
+                                        bool sums, bool staged, bool one_launch, bool bt_in_merged_launch, bool unit_spatial)
 {
     hipError_t e;
     const dim3 block(256);   // 4 waves = 4 tiles per workgroup
@@ -1157,7 +1180,9 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         const bool bt_last = n_wave_side * 5 >= p.n_bt_tiles;
         const Cls bt_cls = {12, p.list_bt, bt_merged ? p.n_bt : 0}, none = {12, nullptr, 0};
         // units (bevw_unit.h) in front: they hold the bulk of the step; the classes with 4 rounds of groups run longest
-        const Cls cls[] = {{16, p.list_un[2], p.n_un[2]}, {17, p.list_un[3], p.n_un[3]}, {15, p.list_un[1], p.n_un[1]}, {14, p.list_un[0], p.n_un[0]},
+        const bool sp = unit_spatial && p.n_un_all > 0;
+        const Cls cls[] = {{18, p.list_un_all, sp ? p.n_un_all : 0},
+                           {16, p.list_un[2], sp ? 0 : p.n_un[2]}, {17, p.list_un[3], sp ? 0 : p.n_un[3]}, {15, p.list_un[1], sp ? 0 : p.n_un[1]}, {14, p.list_un[0], sp ? 0 : p.n_un[0]},
                            bt_last ? none : bt_cls, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single},
                            {10, p.list_pr[5], p.n_pr[5]}, {13, p.list_sm, p.n_sm}, {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]},
                            {5, p.list_pr[0], p.n_pr[0]}, bt_last ? bt_cls : none, {2, l_empty, n_empty}};
@@ -1256,8 +1281,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.sm_gsrc = static_cast<const uint32_t *>(p.sm_gsrc);
     a.sm_pos = static_cast<const uint32_t *>(p.sm_pos);
     a.un_desc = static_cast<const UnitDesc *>(p.un_desc);
-    a.un_entries = static_cast<const uint2 *>(p.un_entries);
+    a.un_entries = static_cast<const uint4 *>(p.un_entries);
     a.un_gsrc = static_cast<const uint32_t *>(p.un_gsrc);
+    a.un_skew = p.un_skew;
     // pair-staged schedule: needs 4-byte aligned frame sets (dword-addressed group loads) and is not combined with the
     // per-tap luminance kernel
     const bool use_staged = !balance && tune.lean && tune.staged && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0;
@@ -1268,6 +1294,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
     a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? 1 : 0;
+    a.group_major = tune.group_major;
     if (balance || sums) {
         const size_t need = (size_t)batch * p.ntiles * 3 * sizeof(uint32_t);
         if (need > p.psums_cap) {
@@ -1280,9 +1307,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.psums = static_cast<uint32_t *>(p.psums);
     if (sums && (e = hipMemsetAsync(p.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     switch (p.lx) {
-        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0); break;
-        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0); break;
-        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0); break;
+        case 8: e = plan_launch_lx<8>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0, tune.unit_spatial != 0); break;
+        case 16: e = plan_launch_lx<16>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0, tune.unit_spatial != 0); break;
+        default: e = plan_launch_lx<4>(p, st, a, blend, balance, tune.lean != 0, tune.lds_pad, sums, use_staged, tune.one_launch != 0, tune.bt_merged != 0, tune.unit_spatial != 0); break;
     }
     if (e != hipSuccess) return e;
     if (balance || sums) {

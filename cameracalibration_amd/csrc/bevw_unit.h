@@ -22,9 +22,16 @@
 // two barriers per frame.  (A (4, 4) class needs 163 VGPRs = 3 waves per SIMD for every class of the merged launch; without
 // it the partition pays 1.5 % more requests and every class stays below 128.)  Units are classes of the merged launch
 // (k_plan_all: 256 threads, 32 KB).
-// Base tiles with a two-contributor pixel (seams, blend overlaps), a blend weight below 255, a frame-border footprint or no
-// contributor at all keep their round-2 classes: a unit never stores a quad of such a base tile (kMetaSkip).  Every unit
-// pixel therefore has weight 255 = 1.0f exactly, and the kernel needs no blend variant: trunc(f32(v) * 1.0f) == v.
+// Base tiles with a two-contributor pixel (seams, blend overlaps), a blend weight below 255 or a frame-border footprint keep
+// their round-2 classes: a unit never stores a quad of such a base tile (kUnitSkip).  Every unit pixel therefore has weight
+// 255 = 1.0f exactly, and the kernel needs no blend variant: trunc(f32(v) * 1.0f) == v.  Base tiles without any contributor
+// (under the car) ARE unit tiles: a unit without groups only writes (car sprite or zeros) in whole row runs.
+//
+// Plan format.  4 bytes per pixel: pair k (2 bits) | group slot of footprint row 0 (10) | of row 1 (10) | fx (5) | fy (5); equal
+// slots = no contributor.  The patch holds the four pair entries of group slot s at s * 32 bytes, so the low 12 bits of an
+// entry ARE the qword index of its row-0 pair.  Group slots are dealt so that the groups that start in one 128-byte source
+// line never straddle two 64-lane load instructions (each line is requested once: round 3's first version, with plain
+// ascending slots, requested every sixth line twice).
 //
 // The plan is compiled on the HOST (unit_compile); tests/native/unit_emulate.cpp runs the same compiler and the per-lane
 // arithmetic below (unit_emulate) on a CPU, so the indexing of this file is checked without a GPU.
@@ -35,26 +42,26 @@
 
 namespace bevw {
 
-constexpr uint32_t kMetaSkip = 1u << 22;     // on pixel slot 0 of a quad: the quad's base tile belongs to another class -> not stored
 constexpr int kUnitWaves = 4;
 constexpr int kUnitThreads = kUnitWaves * 64;
 constexpr int kUnitMaxNQ = 4;                // pixel quads per lane
 constexpr int kUnitMaxGR = 4;                // rounds of kUnitThreads groups
-constexpr int kUnitMaxGroups = kUnitMaxGR * kUnitThreads;        // 1024 groups = 32 KB of pair entries
+constexpr int kUnitMaxGroups = kUnitMaxGR * kUnitThreads;        // 1024 group slots = 32 KB of pair entries
 constexpr int kUnitMaxWidth = 256;           // pixels: 64 quads = one wave-store per row
 constexpr int kUnitClasses = 4;
 constexpr int kUnitClassNQ[kUnitClasses] = {4, 4, 2, 1};
 constexpr int kUnitClassGR[kUnitClasses] = {1, 2, 4, 4};
+constexpr uint32_t kUnitSkip = 1u << 22;     // entry of pixel 0 of a quad, with equal slots: the quad's base tile belongs to another class -> not stored
 
 // unit descriptor: 8 dwords, read with scalar loads
 struct UnitDesc {
-    uint32_t pos;        // x0 | y0 << 16 (pixels)
+    uint32_t pos;        // x0 (int16: the unskewed left edge, may be negative) | y0 << 16 (pixels)
     uint32_t shape;      // w | h << 16 (pixels; w a multiple of 4)
-    uint32_t ent_off;    // entries of the unit start at un_entries[ent_off * 64]
+    uint32_t ent_off;    // entries of the unit start at un_entries[ent_off * 64] (one uint4 = 4 pixels per lane and slot)
     uint32_t gs_off;     // group offsets of the unit start at un_gsrc[gs_off * kUnitThreads]
     uint32_t lq;         // log2 of the lanes per row (quads per row rounded up to a power of two, >= 4)
     uint32_t sum_tile;   // balance: psums slot (a base tile owned by this unit)
-    uint32_t groups;     // distinct groups (diagnostics)
+    uint32_t groups;     // distinct groups; 0 = the unit only writes (no contributor anywhere)
     uint32_t pixels;     // contributing pixels (diagnostics)
 };
 
@@ -64,29 +71,53 @@ __host__ __device__ __forceinline__ void unit_quad(uint32_t lq, int sidx, int la
     qx = lane & ((1 << lq) - 1);
     row = sidx * (64 >> lq) + (lane >> lq);
 }
+// Row shift of the unit grid: row y of every unit is shifted right by unit_skew(c, y) pixels, c chosen so that the byte offset of pixel
+// (64 k + shift, y) inside the image is a multiple of 64 for every k: interior unit boundaries then fall on 64-byte sector boundaries in
+// EVERY row, and no sector is written in two pieces by two blocks (a partially written sector costs the memory system far more than
+// a request: DESIGN.md section 4).  c = 0: plain rectangles.
+// The constant carries the multiplier in bits 0..7 and the period mask (15 for 64-byte, 7 for 32-byte alignment) in bits 8..15.
+__host__ __device__ __forceinline__ int unit_skew(uint32_t c, int y) { return 4 * (int)(((c & 255u) * (uint32_t)y) & (c >> 8)); }
 // slot index of (wave, quad slot j): rows are dealt to the waves round-robin, so the waves of a block work on neighbouring rows
 __host__ __device__ __forceinline__ int unit_slot(int wave, int j) { return j * kUnitWaves + wave; }
-// LDS byte address of pair k (0..3) of group slot s inside a frame's patch: round r = s >> 8 and wave w = (s >> 6) & 3 load it,
-// pairs 0, 1 of all lanes in the first KB of the (round, wave) patch, pairs 2, 3 in the second (pair_convert_store)
-__host__ __device__ __forceinline__ uint32_t unit_lds_addr(uint32_t slot, uint32_t k)
+// plan entry of one pixel
+__host__ __device__ __forceinline__ uint32_t unit_entry(uint32_t slot0, uint32_t slot1, uint32_t k, uint32_t code)
 {
-    return (slot >> 6) * (uint32_t)kPairRoundBytes + (k >> 1) * 1024u + (slot & 63u) * 16u + (k & 1u) * 8u;
+    return k | (slot0 << 2) | (slot1 << 12) | ((code & 1023u) << 22);
+}
+// decoded: qword indices of the two pair entries inside the frame's patch, x weights {32 - fx, fx, 0, 0}, y weights x 64
+__host__ __device__ __forceinline__ void unit_decode(uint32_t e, uint32_t &i0, uint32_t &i1, uint32_t &wxa, uint32_t &wy)
+{
+    const uint32_t fx = (e >> 22) & 31u, fy = e >> 27;
+    i0 = e & 0xfffu;
+    i1 = ((e >> 10) & 0xffcu) | (e & 3u);
+    wxa = (i0 >> 2) != (i1 >> 2) ? ((32u - fx) | (fx << 8)) : 0u;   // equal slots: no contributor -> zero x weights add exactly 0
+    wy = ((32u - fy) << 6) | (fy << 22);
 }
 
 struct UnitPlanHost {
     std::vector<UnitDesc> desc;
-    std::vector<uint2> entries;                // per unit: [4 NQ slots][4 pixels][64 lanes]
+    std::vector<uint32_t> entries;             // per unit: [4 NQ slots][64 lanes][4 pixels]
     std::vector<uint32_t> gsrc;                // per unit: [GR rounds][256 lanes]
     std::vector<uint32_t> list[kUnitClasses];  // unit ids by class
+    std::vector<uint32_t> all;                 // every unit in partition order: id | class << 28
     size_t claimed_tiles = 0;
+    uint32_t skew = 0;                         // unit_skew constant of this plan
     // request arithmetic of the compiled partition (per frame): distinct 128-byte source lines, 64-byte write sectors
     size_t lines = 0, sectors = 0;
+    size_t cls_lines[kUnitClasses] = {}, cls_sectors[kUnitClasses] = {}, cls_pixels[kUnitClasses] = {}, cls_groups[kUnitClasses] = {};
 };
 
 struct UnitTuning {
     int max_groups = kUnitMaxGroups;
     int root_w = 256, root_h = 64;   // the k-d partition starts from cells of this size
     int min_w = 16;                  // narrowest unit (pixels)
+    // cost of a cut = line_cost x source lines + sector_cost x write sectors: a read request holds its place in the L1's miss queue about
+    // twice as long as a write request (~1200 against ~520 clk), but a sector that two units share is written in two
+    // pieces, and a partially written sector that reaches the memory costs about as much as a read
+    int line_cost = 2, sector_cost = 3;
+    int align_lines = 1;             // group slots: the groups of one source line stay inside one 64-lane load instruction
+    int own_empty = 1;               // base tiles without a contributor are unit tiles
+    int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
 };
 
 // Host-side plan compiler of the units.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers (32 x 8 tiles,
@@ -99,10 +130,13 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     const uint32_t frame_bytes = (uint32_t)fw * fh * 3, gpr = (uint32_t)fw / 4;
     const size_t set_bytes = (size_t)frame_bytes * ncams;
     constexpr uint32_t kNone = 0xffffffffu;
-    // ---- per pixel: footprint offset + meta of the (only) contributor; base tiles a unit may own ---------------------------
+    // ---- per pixel: footprint offset + fraction code of the (only) contributor; base tiles a unit may own --------------------
     std::vector<uint8_t> own((size_t)tiles_x * tiles_y, 0);
-    for (size_t t = 0; t < own.size(); ++t) own[t] = (hdr[t] & (kHdrSlow | kHdrSecond | kHdrEmpty | kHdrBlock)) ? 0 : 1;
-    std::vector<uint32_t> poff((size_t)pitch * bh, kNone), pmeta((size_t)pitch * bh, 0u);
+    for (size_t t = 0; t < own.size(); ++t) {
+        own[t] = (hdr[t] & (kHdrSlow | kHdrSecond | kHdrBlock)) ? 0 : 1;
+        if ((hdr[t] & kHdrEmpty) && !tune.own_empty) own[t] = 0;
+    }
+    std::vector<uint32_t> poff((size_t)pitch * bh, kNone), pcode((size_t)pitch * bh, 0u);
     for (int y = 0; y < bh; ++y)
         for (int x = 0; x < bw; ++x) {
             const size_t t = (size_t)(y / 8) * tiles_x + x / 32;
@@ -117,14 +151,29 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
                 if ((size_t)(off / 12u + gpr) * 12u + 16u > set_bytes) { own[t] = 2; break; }   // the last group's 16-byte window would overrun
                 if (m != 255u) { own[t] = 2; break; }                                            // a blend weight: the tile keeps its blend-aware class
                 poff[(size_t)y * pitch + x] = off;
-                pmeta[(size_t)y * pitch + x] = (lut2[c][o] & (kQTab2 - 1)) | (m << 10) | ((uint32_t)c << 18) | kMetaValid;
+                pcode[(size_t)y * pitch + x] = lut2[c][o] & (kQTab2 - 1);
                 break;   // single-contributor tiles: the first contributor is the only one
             }
         }
-    for (int y = 0; y < bh; ++y)      // base tiles dropped for an overrun: their pixels leave the units
+    for (int y = 0; y < bh; ++y)      // base tiles dropped above: their pixels leave the units
         for (int x = 0; x < bw; ++x)
             if (own[(size_t)(y / 8) * tiles_x + x / 32] != 1) poff[(size_t)y * pitch + x] = kNone;
     auto owned = [&](int x, int y) { return x < bw && y < bh && own[(size_t)(y / 8) * tiles_x + x / 32] == 1; };
+    // rows of P = 3 pitch bytes: byte P y + 12 q is a multiple of 64 <=> q = -(P / 4) * 11 * y (mod 16)   (3 * 11 = 1 mod 16).  Only when
+    // every image of a batch starts on a sector boundary (P * bh a multiple of 64; the batch base is assumed 64-byte aligned -- with any
+    // other base the plan is still correct, just not sector-aligned).
+    const uint32_t P = (uint32_t)pitch * 3u;
+    uint32_t skew = 0;
+    int col_step = 16;
+    if ((tune.skew == 64 || tune.skew == 32) && ((size_t)P * bh) % (size_t)tune.skew == 0) {
+        const uint32_t m = (uint32_t)tune.skew / 4u, inv = tune.skew == 64 ? 11u : 3u;   // 3 * 11 = 1 (mod 16), 3 * 3 = 1 (mod 8)
+        const uint32_t c = (m - ((P / 4u) * inv) % m) % m;
+        if (c != 0) { skew = c | ((m - 1u) << 8); col_step = tune.skew; }    // c == 0: the rows are aligned already
+        else col_step = tune.skew;
+    }
+    out.skew = skew;
+    const int min_w = std::max(col_step, tune.min_w);
+    auto px_x = [&](int u, int y) { return u + unit_skew(skew, y); };   // unskewed column -> image column (may lie outside [0, pitch))
 
     // ---- request arithmetic of a rectangle: distinct groups, distinct 128-byte lines, contributing pixels -------------------
     std::vector<uint32_t> gstamp(set_bytes / 12 + 2, 0u), lstamp(set_bytes / 128 + 2, 0u);
@@ -134,7 +183,9 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         Stats s = {0, 0, 0, 0};
         ++stamp;
         for (int y = y0; y < y0 + h; ++y)
-            for (int x = x0; x < x0 + w; ++x) {
+            for (int u = x0; u < x0 + w; ++u) {
+                const int x = px_x(u, y);
+                if (x < 0 || x >= pitch) continue;
                 if ((x & 3) == 0 && owned(x, y)) ++s.quads;
                 const uint32_t off = poff[(size_t)y * pitch + x];
                 if (off == kNone) continue;
@@ -154,7 +205,9 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     auto write_sectors = [&](int x0, int y0, int w, int h) {   // 64-byte sectors the row runs of the rectangle touch
         long n = 0;
         for (int y = y0; y < y0 + h; ++y) {
-            const long a0 = ((long)y * pitch + x0) * 3, a1 = ((long)y * pitch + x0 + w) * 3;
+            const int xa = std::max(0, px_x(x0, y)), xb = std::min(pitch, px_x(x0 + w, y));
+            if (xa >= xb) continue;
+            const long a0 = ((long)y * pitch + xa) * 3, a1 = ((long)y * pitch + xb) * 3;
             n += (a1 - 1) / 64 - a0 / 64 + 1;
         }
         return n;
@@ -163,11 +216,13 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     auto slots_needed = [&](int w, int h) { const int rps = 64 >> lanes_log2(w); return (h + rps - 1) / rps; };
 
     // ---- emit one unit ---------------------------------------------------------------------------------------------------------
-    std::vector<uint32_t> keys;
+    std::vector<uint32_t> keys, slot;
     auto emit = [&](int x0, int y0, int w, int h, const Stats &st) {
         keys.clear();
         for (int y = y0; y < y0 + h; ++y)
-            for (int x = x0; x < x0 + w; ++x) {
+            for (int u = x0; u < x0 + w; ++u) {
+                const int x = px_x(u, y);
+                if (x < 0 || x >= pitch) continue;
                 const uint32_t off = poff[(size_t)y * pitch + x];
                 if (off == kNone) continue;
                 keys.push_back(off / 12u);
@@ -176,53 +231,64 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
         const int count = (int)keys.size();
+        // group slots in ascending address order; the groups that START in one 128-byte line are kept inside one 64-lane instruction
+        slot.assign((size_t)count, 0u);
+        uint32_t used = 0;
+        for (int i = 0; i < count;) {
+            int j = i;
+            while (j < count && (keys[(size_t)j] * 12u) >> 7 == (keys[(size_t)i] * 12u) >> 7) ++j;
+            if (tune.align_lines && (used & 63u) + (uint32_t)(j - i) > 64u) used = (used + 63u) & ~63u;
+            for (; i < j; ++i) slot[(size_t)i] = used++;
+        }
         const int lq = lanes_log2(w), slots = slots_needed(w, h);
         // class: the cheapest (NQ, GR) that holds the unit (cost ~ 4 pixels x 14 VALU per quad slot, 8 v_perm + 2 ds_write per round)
         int cls = -1, best = 1 << 30;
         for (int c = 0; c < kUnitClasses; ++c) {
-            if (kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < count) continue;
+            if (kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < (int)used) continue;
             const int cost = kUnitClassNQ[c] * 64 + kUnitClassGR[c] * 14;
             if (cost < best) { best = cost; cls = c; }
         }
         if (cls < 0) return false;
         const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls];
         UnitDesc d;
-        d.pos = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        d.pos = (uint32_t)(uint16_t)(int16_t)x0 | ((uint32_t)y0 << 16);
         d.shape = (uint32_t)w | ((uint32_t)h << 16);
-        d.ent_off = (uint32_t)(out.entries.size() / 64);
+        d.ent_off = (uint32_t)(out.entries.size() / 256);
         d.gs_off = (uint32_t)(out.gsrc.size() / kUnitThreads);
         d.lq = (uint32_t)lq;
         d.sum_tile = 0;
         d.groups = (uint32_t)count;
         d.pixels = (uint32_t)st.pixels;
-        auto slot_of = [&](uint32_t key) { return (uint32_t)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin()); };
+        auto slot_of = [&](uint32_t key) { return slot[(size_t)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin())]; };
         const size_t e0 = out.entries.size();
-        out.entries.resize(e0 + (size_t)NQ * kUnitWaves * 4 * 64, make_uint2(0u, 0u));
+        out.entries.resize(e0 + (size_t)NQ * kUnitWaves * 64 * 4, 0u);
         bool have_sum_tile = false;
         for (int sidx = 0; sidx < NQ * kUnitWaves; ++sidx)
             for (int lane = 0; lane < 64; ++lane) {
                 int qx, row;
                 unit_quad((uint32_t)lq, sidx, lane, qx, row);
-                const int x = x0 + 4 * qx, y = y0 + row;
-                uint2 *e = out.entries.data() + e0 + (size_t)sidx * 4 * 64 + lane;   // pixel p at e[p * 64]
-                if (4 * qx >= w || row >= h) continue;            // lane without a quad: zero entries, masked in the kernel
-                if (!owned(x, y)) { e[0].y = kMetaSkip; continue; }
+                const int y = y0 + row, x = px_x(x0 + 4 * qx, y);
+                uint32_t *e = out.entries.data() + e0 + ((size_t)sidx * 64 + lane) * 4;   // the lane's 4 pixels
+                if (4 * qx >= w || row >= h || x < 0 || x >= pitch) continue;   // lane without a quad: zero entries, masked in the kernel
+                if (!owned(x, y)) { e[0] = kUnitSkip; continue; }
                 if (!have_sum_tile) { d.sum_tile = (uint32_t)((y / 8) * tiles_x + x / 32); have_sum_tile = true; }
                 for (int p = 0; p < 4; ++p) {
                     const uint32_t off = poff[(size_t)y * pitch + x + p];
                     if (off == kNone) continue;
                     const uint32_t key = off / 12u, pk = (off - key * 12u) / 3u;
-                    e[p * 64] = make_uint2(unit_lds_addr(slot_of(key), pk) | (unit_lds_addr(slot_of(key + gpr), pk) << 16),
-                                           pmeta[(size_t)y * pitch + x + p]);
+                    e[p] = unit_entry(slot_of(key), slot_of(key + gpr), pk, pcode[(size_t)y * pitch + x + p]);
                 }
             }
         const size_t g0 = out.gsrc.size();
         out.gsrc.resize(g0 + (size_t)GR * kUnitThreads, kPairNoGroup);
-        for (int s = 0; s < count; ++s) out.gsrc[g0 + s] = keys[(size_t)s] * 12u;
+        for (int i = 0; i < count; ++i) out.gsrc[g0 + slot[(size_t)i]] = keys[(size_t)i] * 12u;
         out.list[cls].push_back((uint32_t)out.desc.size());
+        out.all.push_back((uint32_t)out.desc.size() | ((uint32_t)cls << 28));
         out.desc.push_back(d);
+        const size_t ws = (size_t)write_sectors(x0, y0, w, h);
         out.lines += (size_t)st.lines;
-        out.sectors += (size_t)write_sectors(x0, y0, w, h);
+        out.sectors += ws;
+        out.cls_lines[cls] += (size_t)st.lines; out.cls_sectors[cls] += ws; out.cls_pixels[cls] += (size_t)st.pixels; out.cls_groups[cls] += (size_t)count;
         return true;
     };
 
@@ -231,14 +297,14 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     std::vector<Cell> stack;
     const int root_w = std::min(tune.root_w, kUnitMaxWidth);
     for (int y0 = 0; y0 < bh; y0 += tune.root_h)
-        for (int x0 = 0; x0 < pitch; x0 += root_w) stack.push_back({x0, y0, std::min(root_w, pitch - x0), std::min(tune.root_h, bh - y0)});
+        for (int x0 = skew ? -col_step : 0; x0 < pitch; x0 += root_w) stack.push_back({x0, y0, std::min(root_w, pitch - x0), std::min(tune.root_h, bh - y0)});
     std::reverse(stack.begin(), stack.end());   // pop in row-major order: neighbouring units are neighbours in the class lists
     while (!stack.empty()) {
         const Cell c = stack.back();
         stack.pop_back();
         const Stats st = cell_stats(c.x0, c.y0, c.w, c.h);
         if (st.quads == 0) continue;              // nothing a unit owns in here
-        bool fits = false;   // some class holds the rectangle
+        bool fits = false;   // some class holds the rectangle (emit decides finally: line-aligned slots may need a few more)
         for (int k = 0; k < kUnitClasses; ++k)
             fits = fits || (st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
         if (fits && emit(c.x0, c.y0, c.w, c.h, st)) continue;
@@ -250,15 +316,16 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
             int h2 = (c.h + 1) / 2;
             h2 = std::min(c.h - 1, (h2 + rps - 1) / rps * rps);
             const Stats s0 = cell_stats(c.x0, c.y0, c.w, h2), s1 = cell_stats(c.x0, c.y0 + h2, c.w, c.h - h2);
-            best = (long)s0.lines + s1.lines;
+            best = (long)tune.line_cost * (s0.lines + s1.lines);
             a = {c.x0, c.y0, c.w, h2};
             b = {c.x0, c.y0 + h2, c.w, c.h - h2};
         }
-        if (c.w > tune.min_w) {
-            const int w2 = std::min(c.w - 4, (c.w / 2 + 15) / 16 * 16);
+        if (c.w > min_w) {
+            const int w2 = std::min(c.w - 4, (c.w / 2 + col_step - 1) / col_step * col_step);
             const Stats s0 = cell_stats(c.x0, c.y0, w2, c.h), s1 = cell_stats(c.x0 + w2, c.y0, c.w - w2, c.h);
-            const long cost = (long)s0.lines + s1.lines + write_sectors(c.x0, c.y0, w2, c.h) + write_sectors(c.x0 + w2, c.y0, c.w - w2, c.h) -
-                              write_sectors(c.x0, c.y0, c.w, c.h);
+            const long cost = (long)tune.line_cost * (s0.lines + s1.lines) +
+                              (long)tune.sector_cost * (write_sectors(c.x0, c.y0, w2, c.h) + write_sectors(c.x0 + w2, c.y0, c.w - w2, c.h) -
+                                                        write_sectors(c.x0, c.y0, c.w, c.h));
             if (best < 0 || cost < best) {
                 best = cost;
                 a = {c.x0, c.y0, w2, c.h};
@@ -266,20 +333,14 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
             }
         }
         if (best < 0) {
-            // one row of the narrowest width that still does not fit (cannot happen: 4 quads x 4 pixels x 2 groups): leave the
-            // pixels to the per-wave classes
-            for (int y = c.y0; y < c.y0 + c.h; ++y)
-                for (int x = c.x0; x < c.x0 + c.w; ++x)
-                    if (owned(x, y)) own[(size_t)(y / 8) * tiles_x + x / 32] = 3;
-            continue;
+            // one row of the narrowest width that still does not fit (cannot happen: 4 quads x 4 pixels x 2 groups): the partition is
+            // unusable -> compile nothing (callers fall back to round 2's classes)
+            out = UnitPlanHost();
+            return;
         }
         stack.push_back(b);
         stack.push_back(a);
     }
-    // a base tile dropped late (own == 3) may already be referenced by emitted units of other cells only through skip flags that
-    // were computed while it was still owned: such a partition is unusable -> compile nothing (callers fall back to round 2's classes)
-    for (uint8_t o : own)
-        if (o == 3) { out = UnitPlanHost(); return; }
     for (size_t t = 0; t < own.size(); ++t)
         if (own[t] == 1) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
 }
@@ -293,42 +354,45 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 {
     const UnitDesc &d = up.desc[unit];
     const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls];
-    std::vector<uint8_t> patch((size_t)kUnitMaxGR * kUnitWaves * kPairRoundBytes, 0xcd);
-    for (int r = 0; r < GR; ++r)
-        for (int tid = 0; tid < kUnitThreads; ++tid) {
-            const uint32_t off = up.gsrc[((size_t)d.gs_off + r) * kUnitThreads + tid];
-            uint32_t w[4] = {0, 0, 0, 0};   // a masked lane's buffer load returns zeros
-            if (off != kPairNoGroup && (size_t)off + 16 <= set_bytes) memcpy(w, frame_set + off, 16);
-            uint4 A, B;
-            pair_convert(w[0], w[1], w[2], w[3], A, B);
-            uint8_t *rp = patch.data() + (size_t)(r * kUnitWaves + (tid >> 6)) * kPairRoundBytes;
-            memcpy(rp + (size_t)(tid & 63) * 16, &A, 16);
-            memcpy(rp + 1024 + (size_t)(tid & 63) * 16, &B, 16);
-        }
-    const int ux = (int)(d.pos & 0xffffu), uy = (int)(d.pos >> 16), uw = (int)(d.shape & 0xffffu), uh = (int)(d.shape >> 16);
+    std::vector<uint8_t> patch((size_t)kUnitMaxGroups * 32, 0xcd);
+    if (d.groups != 0)
+        for (int r = 0; r < GR; ++r)
+            for (int tid = 0; tid < kUnitThreads; ++tid) {
+                const uint32_t off = up.gsrc[((size_t)d.gs_off + r) * kUnitThreads + tid];
+                uint32_t w[4] = {0, 0, 0, 0};   // a masked lane's buffer load returns zeros
+                if (off != kPairNoGroup && (size_t)off + 16 <= set_bytes) memcpy(w, frame_set + off, 16);
+                uint4 A, B;
+                pair_convert(w[0], w[1], w[2], w[3], A, B);
+                uint8_t *sp = patch.data() + (size_t)(r * kUnitThreads + tid) * 32;
+                memcpy(sp, &A, 16);
+                memcpy(sp + 16, &B, 16);
+            }
+    const int ux = (int)(int16_t)(d.pos & 0xffffu), uy = (int)(d.pos >> 16), uw = (int)(d.shape & 0xffffu), uh = (int)(d.shape >> 16);
     for (int wave = 0; wave < kUnitWaves; ++wave)
         for (int j = 0; j < NQ; ++j)
             for (int lane = 0; lane < 64; ++lane) {
                 const int sidx = unit_slot(wave, j);
                 int qx, row;
                 unit_quad(d.lq, sidx, lane, qx, row);
-                const uint2 *e = up.entries.data() + ((size_t)d.ent_off + (size_t)sidx * 4) * 64 + lane;
-                uint32_t acc[4][3];
-                for (int p = 0; p < 4; ++p) {
-                    const uint2 en = e[p * 64];
-                    const uint32_t fx = en.y & 31, fy = (en.y >> 5) & 31;
-                    const bool valid = en.y & kMetaValid;
-                    const uint32_t wxa = valid ? ((32 - fx) | (fx << 8)) : 0u, wy = ((32 - fy) << 6) | (fy << 22);
-                    uint2 q0, q1;
-                    memcpy(&q0, patch.data() + (en.x & 0xffffu), 8);
-                    memcpy(&q1, patch.data() + (en.x >> 16), 8);
-                    bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc[p]);
-                    if (sums)
-                        for (int k = 0; k < 3; ++k) sums[k] += (acc[p][k] >> 16) & 255u;
-                }
-                if (4 * qx >= uw || row >= uh || (e[0].y & kMetaSkip)) continue;   // the lane's store is masked
+                const uint32_t *e = up.entries.data() + ((size_t)d.ent_off * 64 + (size_t)sidx * 64 + lane) * 4;
+                uint32_t acc[4][3] = {};
+                if (d.groups != 0)
+                    for (int p = 0; p < 4; ++p) {
+                        uint32_t i0, i1, wxa, wy;
+                        unit_decode(e[p], i0, i1, wxa, wy);
+                        uint2 q0, q1;
+                        memcpy(&q0, patch.data() + (size_t)i0 * 8, 8);
+                        memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
+                        bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc[p]);
+                        if (sums)
+                            for (int k = 0; k < 3; ++k) sums[k] += (acc[p][k] >> 16) & 255u;
+                    }
+                uint32_t i0, i1, wxa, wy;
+                unit_decode(e[0], i0, i1, wxa, wy);
+                const int x = ux + 4 * qx + unit_skew(up.skew, uy + row);
+                if (4 * qx >= uw || row >= uh || x < 0 || x >= pitch || (wxa == 0 && (e[0] & kUnitSkip))) continue;   // the lane's store is masked
                 uint32_t o[3];
-                const size_t ooff = ((size_t)(uy + row) * pitch + ux + 4 * qx) * 3;
+                const size_t ooff = ((size_t)(uy + row) * pitch + x) * 3;
                 if (car) {
                     uint32_t P[4], c[3];
                     for (int p = 0; p < 4; ++p) P[p] = ((acc[p][0] >> 16) & 255u) | (((acc[p][1] >> 16) & 255u) << 8) | (((acc[p][2] >> 16) & 255u) << 16);
@@ -339,7 +403,7 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                     pack_accs(acc, o[0], o[1], o[2]);
                 }
                 memcpy(out_img + ooff, o, 12);
-                if (written) for (int k = 0; k < 4; ++k) ++(*written)[(size_t)(uy + row) * pitch + ux + 4 * qx + k];
+                if (written) for (int k = 0; k < 4; ++k) ++(*written)[(size_t)(uy + row) * pitch + x + k];
             }
 }
 
@@ -353,22 +417,19 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 // (LDS indices and weights of 4 pixels) + 8 per round of groups in flight; nothing else lives across the frame loop -- the car
 // sprite is re-read per frame by the few units that lie under it.
 template <bool SUMS, int NQ, int GR>
-__device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
+__device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
 {
     static_assert(NQ >= 1 && NQ <= kUnitMaxNQ && GR >= 1 && GR <= kUnitMaxGR, "unit class");
-    uint32_t chunk, group;
-    if (!plan_block_map(a, block_id, chunk, group)) return;   // uniform over the block
-    if ((int)group >= a.nlist) return;
-    const uint32_t unit = __builtin_amdgcn_readfirstlane(a.tile_list[group]);
     const uint32_t *dp = reinterpret_cast<const uint32_t *>(a.un_desc + unit);
     const uint32_t pos = __builtin_amdgcn_readfirstlane(dp[0]), shape = __builtin_amdgcn_readfirstlane(dp[1]);
     const uint32_t ent_off = __builtin_amdgcn_readfirstlane(dp[2]), gs_off = __builtin_amdgcn_readfirstlane(dp[3]);
     const uint32_t lq = __builtin_amdgcn_readfirstlane(dp[4]), sum_tile = __builtin_amdgcn_readfirstlane(dp[5]);
+    const uint32_t ngroups = __builtin_amdgcn_readfirstlane(dp[6]);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ux = (int)(pos & 0xffffu), uy = (int)(pos >> 16), uw = (int)(shape & 0xffffu), uh = (int)(shape >> 16);
+    const int ux = (int)(int16_t)(pos & 0xffffu), uy = (int)(pos >> 16), uw = (int)(shape & 0xffffu), uh = (int)(shape >> 16);
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
-    constexpr int kPatch = GR * kUnitWaves * kPairRoundBytes;   // one frame's pair entries
+    constexpr int kPatch = GR * kUnitThreads * 32;              // one frame's pair entries
     constexpr bool DB = 2 * kPatch <= kUnitMaxGroups * 32;      // both halves fit the block's 32 KB
 
     uint32_t i0[NQ][4], i1[NQ][4], wxa[NQ][4], wy[NQ][4], gs[GR], ooff_masked[NQ];
@@ -381,39 +442,56 @@ __device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block
         const int sidx = unit_slot(wave, j);
         int qx, row;
         unit_quad(lq, sidx, lane, qx, row);
-        const uint32_t ooff = ((uint32_t)(uy + row) * a.pitch + ux + 4 * qx) * 3;
-        bool store = 4 * qx < uw && row < uh;
+        const int x = ux + 4 * qx + unit_skew((uint32_t)a.un_skew, uy + row);
+        const uint32_t ooff = ((uint32_t)(uy + row) * a.pitch + (uint32_t)x) * 3;
+        const uint4 e4 = a.un_entries[((size_t)ent_off + sidx) * 64 + lane];   // the lane's 4 pixels of this slot
+        const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const uint2 e = a.un_entries[((size_t)ent_off + sidx * 4 + p) * 64 + lane];
-            if (p == 0 && (e.y & kMetaSkip)) store = false;
-            const uint32_t fx = e.y & 31, fy = (e.y >> 5) & 31;
-            const bool valid = e.y & kMetaValid;
-            i0[j][p] = (e.x & 0xffffu) >> 3; i1[j][p] = e.x >> 19;
-            wxa[j][p] = valid ? ((32 - fx) | (fx << 8)) : 0u;   // zero x weights: an absent entry contributes exactly 0
-            wy[j][p] = ((32 - fy) << 6) | (fy << 22);
-        }
+        for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][p], i1[j][p], wxa[j][p], wy[j][p]);
+        const bool store = 4 * qx < uw && row < uh && x >= 0 && x < a.pitch && !(wxa[j][0] == 0 && (e[0] & kUnitSkip));
         ooff_masked[j] = store ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: neither read (car) nor written
         const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
         car_or |= c.x | c.y | c.z;
     }
+    const bool car_any = __builtin_amdgcn_ballot_w64(car_or != 0) != 0;
+    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+
+    if (ngroups == 0) {
+        // no contributor anywhere (under the car): every frame of the chunk gets the sprite or zeros, in whole row runs
+        // (balance: zeros -- the sprite is added after the gains, as in the reference)
+#pragma unroll 1
+        for (int b = b_begin; b < b_end; ++b) {
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * img_bytes, 0, (uint32_t)img_bytes, kBufferWord3);
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);   // zeros without a sprite
+                __builtin_amdgcn_raw_buffer_store_b96(c, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < GR; ++r) gs[r] = a.un_gsrc[((size_t)gs_off + r) * kUnitThreads + threadIdx.x];
-    const bool car_any = __builtin_amdgcn_ballot_w64(car_or != 0) != 0;
 
-    const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
+    // (Dealing the frames of a chunk strided over the batch, or rotating the class lists per XCD, changes nothing: profiles/r03/placement.md)
+    auto frame_of = [&](int b) { return min(b, b_end - 1); };   // past the chunk: the last frame once more
     constexpr int D = 2;
     pair_u32x4 pf[D][GR];
     auto issue = [&](int b, int ring) {
-        const uint8_t *src = a.frames + (size_t)min(b, b_end - 1) * set_bytes;
+        const uint8_t *src = a.frames + (size_t)frame_of(b) * set_bytes;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, (uint32_t)set_bytes, kBufferWord3);
 #pragma unroll
         for (int r = 0; r < GR; ++r) pf[ring][r] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gs[r], 0, kPairLoadAux);
     };
-    auto land = [&](int ring) {   // the groups of ring slot `ring` -> the patch half of that frame
+    auto land = [&](int ring) {   // the groups of ring slot `ring` -> the patch half of that frame: 32 bytes per group slot
 #pragma unroll
-        for (int r = 0; r < GR; ++r)
-            pair_convert_store(pf[ring][r], lds + (DB ? ring * kPatch : 0) + (r * kUnitWaves + wave) * kPairRoundBytes, lane);
+        for (int r = 0; r < GR; ++r) {
+            uint4 A, B;
+            pair_convert(pf[ring][r].x, pf[ring][r].y, pf[ring][r].z, pf[ring][r].w, A, B);
+            uint4 *sp = reinterpret_cast<uint4 *>(lds + (DB ? ring * kPatch : 0)) + (r * kUnitThreads + (int)threadIdx.x) * 2;
+            sp[0] = A;
+            sp[1] = B;
+        }
     };
     auto acc_to_px = [](const uint32_t acc[3]) {
         return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
@@ -461,12 +539,12 @@ __device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block
         }
         if (SUMS && lane == 0 && b < b_end) {
             // skipped quads and lanes without a quad have zero entries: they add 0.  psums is zeroed per call (plan_stitch_impl)
-            uint32_t *ps = a.psums + ((size_t)b * a.ntiles + sum_tile) * 3;
+            uint32_t *ps = a.psums + ((size_t)frame_of(b) * a.ntiles + sum_tile) * 3;
             atomicAdd(ps + 0, tb); atomicAdd(ps + 1, tg); atomicAdd(ps + 2, tr);
         }
         if (DB) land(ring ^ 1);    // frame b+1 into the other half: nobody reads it before the barrier
         {
-            uint8_t *img = a.out + (size_t)min(b, b_end - 1) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
+            uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
@@ -484,6 +562,33 @@ __device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block
     for (int b = b_begin; b < b_end; b += D) {
 #pragma unroll
         for (int u = 0; u < D; ++u) frame(b + u, u);
+    }
+}
+
+// block -> (chunk, unit) of a class list
+template <bool SUMS, int NQ, int GR>
+__device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
+{
+    uint32_t chunk, group;
+    if (!plan_block_map(a, block_id, chunk, group)) return;   // uniform over the block
+    if ((int)group >= a.nlist) return;
+    plan_unit_run<SUMS, NQ, GR>(a, chunk, __builtin_amdgcn_readfirstlane(a.tile_list[group]), lds);
+}
+
+// block -> (chunk, unit) of the list of ALL units in the partition's own (spatial) order, class in bits 28..31: neighbouring units run
+// at the same time on the same XCD, whatever their class, so the two halves of a sector that two units share meet in the L2
+template <bool SUMS>
+__device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
+{
+    uint32_t chunk, group;
+    if (!plan_block_map(a, block_id, chunk, group)) return;
+    if ((int)group >= a.nlist) return;
+    const uint32_t e = __builtin_amdgcn_readfirstlane(a.tile_list[group]), unit = e & 0x0fffffffu;
+    switch (e >> 28) {
+        case 0: plan_unit_run<SUMS, kUnitClassNQ[0], kUnitClassGR[0]>(a, chunk, unit, lds); break;
+        case 1: plan_unit_run<SUMS, kUnitClassNQ[1], kUnitClassGR[1]>(a, chunk, unit, lds); break;
+        case 2: plan_unit_run<SUMS, kUnitClassNQ[2], kUnitClassGR[2]>(a, chunk, unit, lds); break;
+        default: plan_unit_run<SUMS, kUnitClassNQ[3], kUnitClassGR[3]>(a, chunk, unit, lds); break;
     }
 }
 

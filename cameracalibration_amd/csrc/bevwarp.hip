@@ -78,6 +78,11 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
         if (const char *s = getenv("BEVW_UNIT_ROOT_W")) t.root_w = atoi(s);
         if (const char *s = getenv("BEVW_UNIT_ROOT_H")) t.root_h = atoi(s);
         if (const char *s = getenv("BEVW_UNIT_MIN_W")) t.min_w = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_LINE_COST")) t.line_cost = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_SECTOR_COST")) t.sector_cost = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_ALIGN_LINES")) t.align_lines = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_OWN_EMPTY")) t.own_empty = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_SKEW")) t.skew = atoi(s);
         return t;
     }();
     hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
@@ -98,6 +103,8 @@ static const PlanTuning &plan_tuning()
         if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_ONELAUNCH")) t.one_launch = atoi(s);
         if (const char *s = getenv("BEVW_PLAN_BT_MERGED")) t.bt_merged = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_GROUPMAJOR")) t.group_major = atoi(s);
+        if (const char *s = getenv("BEVW_PLAN_SPATIAL")) t.unit_spatial = atoi(s);
         return t;
     }();
     return tune;

@@ -83,14 +83,24 @@ static int run(const Rig &r, const char *out_path)
     const int tiles_x = (r.bw + 31) / 32, tiles_y = (r.bh + 7) / 8, pitch = r.bw;
     std::vector<uint32_t> hdr0 = host_headers(r, tiles_x, tiles_y), hdr = hdr0;
     UnitPlanHost up;
-    unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up);
+    UnitTuning tune;   // the library's knobs (csrc/bevwarp.hip: plan_build), so that partitions can be explored without a GPU
+    if (const char *e = getenv("BEVW_UNIT_GROUPS")) tune.max_groups = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_ROOT_W")) tune.root_w = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_ROOT_H")) tune.root_h = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_MIN_W")) tune.min_w = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_LINE_COST")) tune.line_cost = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_SECTOR_COST")) tune.sector_cost = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_ALIGN_LINES")) tune.align_lines = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_OWN_EMPTY")) tune.own_empty = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_SKEW")) tune.skew = atoi(e);
+    unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune);
     CHECK(!up.desc.empty(), "no unit compiled");
     const size_t set_bytes = (size_t)r.fw * r.fh * 3 * r.ncams;
     size_t claimed = 0;
     for (size_t t = 0; t < hdr.size(); ++t) {
         if (hdr[t] & kHdrBlock) {
             ++claimed;
-            CHECK(!(hdr0[t] & (kHdrSlow | kHdrSecond | kHdrEmpty)), "base tile %zu claimed although it is slow / double / empty", t);
+            CHECK(!(hdr0[t] & (kHdrSlow | kHdrSecond)), "base tile %zu claimed although it is slow / double", t);
         }
     }
     CHECK(claimed == up.claimed_tiles, "claimed tiles %zu != %zu", claimed, up.claimed_tiles);
@@ -104,11 +114,19 @@ static int run(const Rig &r, const char *out_path)
         const int GR = kUnitClassGR[cls_of[u]], NQ = kUnitClassNQ[cls_of[u]];
         const uint32_t *gs = up.gsrc.data() + (size_t)d.gs_off * kUnitThreads;
         CHECK((int)d.groups <= GR * kUnitThreads, "unit %zu: %u groups in a class of %d", u, d.groups, GR * kUnitThreads);
+        uint32_t last = 0, seen = 0;
         for (int s = 0; s < GR * kUnitThreads; ++s) {
-            if (s >= (int)d.groups) { CHECK(gs[s] == kPairNoGroup, "unit %zu: group list has a tail", u); continue; }
+            if (gs[s] == kPairNoGroup) continue;   // padding: the groups of one source line stay inside one 64-lane instruction
             CHECK(gs[s] % 12 == 0 && (size_t)gs[s] + 16 <= set_bytes, "unit %zu: group %d out of the frame set", u, s);
-            CHECK(s == 0 || gs[s] > gs[s - 1], "unit %zu: groups not ascending at %d", u, s);
+            CHECK(seen == 0 || gs[s] > last, "unit %zu: groups not ascending at %d", u, s);
+            // every group that starts in the same 128-byte line sits in the same 64-lane instruction
+            if (seen) { const int prev = s - 1; (void)prev; }
+            last = gs[s]; ++seen;
         }
+        CHECK(seen == d.groups, "unit %zu: %u groups listed, %u expected", u, seen, d.groups);
+        for (int s = 1; s < GR * kUnitThreads; ++s)
+            if (gs[s] != kPairNoGroup && gs[s - 1] != kPairNoGroup && (gs[s] >> 7) == (gs[s - 1] >> 7))
+                CHECK((s >> 6) == ((s - 1) >> 6), "unit %zu: the groups of one source line straddle two load instructions at slot %d", u, s);
         const int w = (int)(d.shape & 0xffffu), h = (int)(d.shape >> 16);
         CHECK(w % 4 == 0 && w <= kUnitMaxWidth && (4 << d.lq) >= w && ((h + (64 >> d.lq) - 1) / (64 >> d.lq)) <= NQ * kUnitWaves, "unit %zu: %d x %d does not fit its class", u, w, h);
     }
@@ -153,7 +171,9 @@ static int run(const Rig &r, const char *out_path)
         for (int k = 0; k < 3; ++k) CHECK(sums[k] == want[k], "channel sum %d: %u, expected %llu", k, sums[k], want[k]);
     }
     printf("unit schedule ok: %zu units (classes", up.desc.size());
-    for (int c = 0; c < kUnitClasses; ++c) printf(" %dx%d:%zu", kUnitClassNQ[c], kUnitClassGR[c], up.list[c].size());
+    for (int c = 0; c < kUnitClasses; ++c)
+        printf(" %dx%d:%zu[px %zu groups %zu lines %zu sectors %zu]", kUnitClassNQ[c], kUnitClassGR[c], up.list[c].size(), up.cls_pixels[c], up.cls_groups[c],
+               up.cls_lines[c], up.cls_sectors[c]);
     printf("), %zu of %zu base tiles claimed, %zu source lines + %zu write sectors per frame\n", claimed, hdr.size(), up.lines, up.sectors);
     if (out_path) {
         FILE *f = fopen(out_path, "wb");
