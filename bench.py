@@ -72,6 +72,10 @@ def parse_args():
     ap.add_argument("--placements", type=int, default=0,
                     help="buffer placements: the frame / output buffers are freed and re-allocated this many times and K steps are timed "
                          "on each; the MEDIAN placement is reported (0 = 5 for the single-engine workloads, 1 for the camera-shard one)")
+    ap.add_argument("--output-pitch", default="aligned", choices=["aligned", "dense"],
+                    help="row pitch of the device-resident BEV images (bevw_set_output_pitch): aligned = rows of whole 64-byte sectors "
+                         "(1080 -> 1088 pixels, cv::cuda::GpuMat style), dense = the reference's host layout; the other layout is measured "
+                         "too and reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -268,6 +272,7 @@ def main():
     cpu = None
 
     units_world = d.world   # ranks that each contribute `batch` units per step
+    other_layout = None     # (name, harness factory) of the second device-image layout of the BEV workloads
     if w["kind"] == "camera":
         cfg, rig = W.CONFIG_4K, W.rig_4k()
         from cameracalibration_amd.SurroundBirdEyeView import cameraShard as CS, surroundBEV as SB
@@ -317,24 +322,35 @@ def main():
         ns = SB.BevGenerator.get_args()
         for k, v in cfg.items():
             setattr(ns, k, v)
-        t_build = time.perf_counter()
-        bev = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=rig, device=dev, schedule=sched,
-                              projection=w.get("projection", "lut"))
-        t_build = time.perf_counter() - t_build
         fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
         unique = W.synthetic_frames(a.unique_sets, fw, fh, seed=W.SEED + d.rank)
+        proj = w.get("projection", "lut")
+        layouts = [a.output_pitch, "dense" if a.output_pitch == "aligned" else "aligned"] if proj == "lut" else ["dense"]
 
-        def make_buffers():
-            b_in = _ffi.DeviceBuffer(batch * unique[0].nbytes, dev)
-            b_out = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
-            upload_replicated(b_in, unique, batch)
-            return (b_in, b_out), (lambda: bev.run_device(b_in.ptr, batch, None, b_out.ptr))
-        sync, tstart, tstop = bev.sync, bev.timer_start, bev.timer_stop
-        tmark, tbetween = bev.timer_mark, bev.timer_between
+        def engine(layout):
+            t0 = time.perf_counter()
+            g = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=rig, device=dev, schedule=sched, projection=proj,
+                                output_pitch=layout)
+            return g, time.perf_counter() - t0
+
+        def harness(g):
+            def make_buffers():
+                b_in = _ffi.DeviceBuffer(batch * unique[0].nbytes, dev)
+                b_out = _ffi.DeviceBuffer(batch * bh * g.out_pitch * 3, dev)
+                upload_replicated(b_in, unique, batch)
+                return (b_in, b_out), (lambda: g.run_device(b_in.ptr, batch, None, b_out.ptr))
+            return make_buffers, g.sync, g.timer_start, g.timer_stop, g.timer_mark, g.timer_between
+        bev, t_build = engine(layouts[0])
+        make_buffers, sync, tstart, tstop, tmark, tbetween = harness(bev)
+        if len(layouts) > 1:
+            other_layout = (layouts[1], lambda: harness(engine(layouts[1])[0]))
         info = bev.plan_info()
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
                  "schedule": {1: "per_pixel", 2: "tile_plan"}[info["schedule"]], "table_build_s": round(t_build, 3),
-                 "tiles": {"staged": info["tiles_staged"], "gather": info["tiles_gather"], "border": info["tiles_border"]}}
+                 "tiles": {"staged": info["tiles_staged"], "gather": info["tiles_gather"], "border": info["tiles_border"]},
+                 "output_layout": ("device images [B][%d][%d][3] u8: rows padded to whole 64-byte sectors (bevw_set_output_pitch; host entry "
+                                   "points return dense arrays, rows compacted inside the D2H copy)" % (bh, bev.out_pitch)) if bev.out_pitch != bw
+                 else "device images [B][%d][%d][3] u8, dense (the reference's host layout)" % (bh, bw)}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_bev(w, cfg, rig, unique, a.cpu_seconds)
     else:
@@ -377,39 +393,50 @@ def main():
     # buffers are freed and re-allocated `placements` times (a growing dummy allocation shifts the heap in between), W warm-up and
     # exactly K timed steps run on each, and the MEDIAN placement is what the line reports; all draws are listed next to it.
     placements = a.placements or (1 if w["kind"] == "camera" else 5)
-    draws, dummies = [], []
-    for pi in range(placements):
-        bufs, step = make_buffers()
-        for _ in range(a.warmup):
-            step()
-        sync()
-        d.barrier()
-        t0 = time.perf_counter()
-        tstart()
-        for i in range(a.steps):
-            tmark(i)     # an event in front of every step, recorded on the engine's stream without synchronising
-            step()
-        tmark(a.steps)
-        ev_ms = tstop()  # records the stop event on the engine's stream and waits for it
-        sync()
-        d.barrier()
-        wall = time.perf_counter() - t0
-        wall = d.max(wall)
-        ev_ms = d.max(ev_ms)
-        laps = sorted(tbetween(i, i + 1) for i in range(a.steps))
-        lap_median = d.max(laps[len(laps) // 2] if len(laps) % 2 else 0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2]))
-        draws.append({"wall": wall, "ev_ms": ev_ms, "lap_median": lap_median, "lap_min": laps[0], "lap_max": laps[-1],
-                      "ptrs": [hex(b.ptr) for b in bufs]})
-        for b in bufs:
+
+    def measure(make_buffers, sync, tstart, tstop, tmark, tbetween):
+        draws, dummies = [], []
+        for pi in range(placements):
+            bufs, step = make_buffers()
+            for _ in range(a.warmup):
+                step()
+            sync()
+            d.barrier()
+            t0 = time.perf_counter()
+            tstart()
+            for i in range(a.steps):
+                tmark(i)     # an event in front of every step, recorded on the engine's stream without synchronising
+                step()
+            tmark(a.steps)
+            ev_ms = tstop()  # records the stop event on the engine's stream and waits for it
+            sync()
+            d.barrier()
+            wall = time.perf_counter() - t0
+            wall = d.max(wall)
+            ev_ms = d.max(ev_ms)
+            laps = sorted(tbetween(i, i + 1) for i in range(a.steps))
+            lap_median = d.max(laps[len(laps) // 2] if len(laps) % 2 else 0.5 * (laps[len(laps) // 2 - 1] + laps[len(laps) // 2]))
+            draws.append({"wall": wall, "ev_ms": ev_ms, "lap_median": lap_median, "lap_min": laps[0], "lap_max": laps[-1]})
+            for b in bufs:
+                b.free()
+            if pi + 1 < placements and bufs:
+                dummies.append(_ffi.DeviceBuffer((pi + 1) * 37 * 1024 * 1024 + 4096, dev))
+        for b in dummies:
             b.free()
-        if pi + 1 < placements and bufs:
-            dummies.append(_ffi.DeviceBuffer((pi + 1) * 37 * 1024 * 1024 + 4096, dev))
-    for b in dummies:
-        b.free()
-    order = sorted(range(placements), key=lambda i: draws[i]["wall"])
-    mid = draws[order[placements // 2]] if placements % 2 else draws[order[placements // 2 - 1]]   # the (lower) median placement
+        order = sorted(range(placements), key=lambda i: draws[i]["wall"])
+        mid = draws[order[placements // 2]] if placements % 2 else draws[order[placements // 2 - 1]]   # the (lower) median placement
+        return mid, draws
+
+    mid, draws = measure(make_buffers, sync, tstart, tstop, tmark, tbetween)
     wall, ev_ms, lap_median = mid["wall"], mid["ev_ms"], mid["lap_median"]
     laps = [mid["lap_min"], mid["lap_max"]]
+    other = None
+    if other_layout is not None:
+        o_mid, o_draws = measure(*other_layout[1]())
+        other = {"output_layout": other_layout[0], "ms_per_step": o_mid["wall"] / a.steps * 1e3, "kernel_ms_median": o_mid["lap_median"],
+                 "value": batch * units_world * a.steps / o_mid["wall"],
+                 "frac": alg_bytes * batch * a.steps / (o_mid["ev_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "placements_ms_per_step": [round(x["wall"] / a.steps * 1e3, 4) for x in o_draws]}
 
     traffic, traffic_source = measured_traffic(a.workload, batch)
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
@@ -433,6 +460,7 @@ def main():
         "placements": {"n": placements, "reported": "median placement (by wall time of its K steps)",
                        "ms_per_step": [round(x["wall"] / a.steps * 1e3, 4) for x in draws],
                        "kernel_ms_median": [round(x["lap_median"], 4) for x in draws]},
+        "other_output_layout": other,
         "cpu_baseline": cpu,
     }
     if d.rank == 0:

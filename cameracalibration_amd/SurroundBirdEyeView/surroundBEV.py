@@ -104,7 +104,7 @@ def _snapshot_config(blend=False, balance=False, device=0, schedule=_ffi.SCHED_A
 class _Engine:
     """Owns one bevw_handle (4 cameras + masks on the device)."""
 
-    def __init__(self, rig, blend, balance, device, schedule):
+    def __init__(self, rig, blend, balance, device, schedule, output_pitch=0):
         _ffi.require_device()
         self.cfg = _snapshot_config(blend, balance, device, schedule)
         h = C.c_void_p()
@@ -113,6 +113,8 @@ class _Engine:
         try:
             for i, (K, D, H) in enumerate(rig):
                 check(lib().bevw_set_camera(self.h, i, ptr(f64(K, 9)), ptr(f64(D, 4)), ptr(f64(H, 9))))
+            if output_pitch:
+                check(lib().bevw_set_output_pitch(self.h, int(output_pitch)))
             check(lib().bevw_build(self.h))
         except Exception:
             self.close()
@@ -289,11 +291,14 @@ class BevGenerator:
     """
 
     def __init__(self, blend=args.BLEND_FLAG, balance=args.BALANCE_FLAG, *, rig=None, device=0,
-                 schedule=_ffi.SCHED_AUTO, projection='lut'):
+                 schedule=_ffi.SCHED_AUTO, projection='lut', output_pitch='dense'):
         """blend / balance: as in the reference (surroundBEV.py:283).  Additive keywords: rig ({name: (K, D, H)} instead of the
         data directory), device, schedule, and projection -- 'lut' (default: the reference's table-driven path, bit-exact against
         the oracle) 'analytic' (inverse homography + fisheye model evaluated per frame and pixel in fp64, no tables; not the
-        reference's fixed-point arithmetic -- see bevw_set_projection in include/bevwarp.h) or 'analytic_f32' (the same in fp32)."""
+        reference's fixed-point arithmetic -- see bevw_set_projection in include/bevwarp.h) or 'analytic_f32' (the same in fp32);
+        output_pitch -- 'dense' (default), 'aligned' (device-side BEV images get rows of whole 64-byte sectors, cv::cuda::GpuMat style:
+        see bevw_set_output_pitch in include/bevwarp.h) or a number of pixels.  Arrays returned to the host are dense either way; only
+        run_device() callers see the pitch (``out_pitch`` pixels per row of their output buffer)."""
         self.init_args()
         if rig is None:
             self.cameras = [Camera('front'), Camera('back'), Camera('left'), Camera('right')]
@@ -302,8 +307,12 @@ class BevGenerator:
         self.blend = blend
         self.balance = balance
         self.device = device
+        pitch = {'dense': _ffi.PITCH_DENSE, 'aligned': _ffi.PITCH_ALIGNED}.get(output_pitch, output_pitch)
+        if not isinstance(pitch, int):
+            raise Exception("output_pitch should be dense/aligned or a number of pixels")
         self._engine = _Engine([(c.camera_mat, c.dist_coeff, c.homography) for c in self.cameras], blend, balance,
-                               device, schedule)
+                               device, schedule, pitch)
+        self.out_pitch = int(lib().bevw_output_pitch(self._engine.h))   # pixels per row of run_device()'s output images
         modes = {'lut': _ffi.PROJ_LUT, 'analytic': _ffi.PROJ_ANALYTIC, 'analytic_f32': _ffi.PROJ_ANALYTIC_F32}
         if projection not in modes:
             raise Exception("projection should be lut/analytic/analytic_f32")

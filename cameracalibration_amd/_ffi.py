@@ -12,10 +12,11 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
 PROJ_LUT, PROJ_ANALYTIC, PROJ_ANALYTIC_F32 = 0, 1, 2   # bevw_set_projection
+PITCH_DENSE, PITCH_ALIGNED = 0, -1                    # bevw_set_output_pitch
 COMPAT_FILLPOLY, COMPAT_ADDWEIGHTED = 0, 1   # bevw_set_compat keys (include/bevwarp.h)
 
 
@@ -56,6 +57,8 @@ SIGNATURES = {
     "bevw_set_projection": (_i, [_vp, _i]),
     "bevw_run": (_i, [_vp, _vp, _i, _vp, _vp]),
     "bevw_run_device": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "bevw_set_output_pitch": (_i, [_vp, _i]),
+    "bevw_output_pitch": (_i, [_vp]),
     "bevw_run_cameras": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "bevw_camera_undistort": (_i, [_vp, _i, _vp, _i, _vp]),
     "bevw_camera_warp_homography": (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),

@@ -641,13 +641,14 @@ __global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__r
 // Needs npx % 4 == 0 and 4-byte aligned images.  grid = (blocks, batch), block = 256; in place when in == out.
 __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
                                                    const uint8_t *__restrict__ car, uint8_t *out, uint32_t blocks_per_frame,
-                                                   uint32_t nframes, int f32 = 0)
+                                                   uint32_t nframes, int f32 = 0, size_t npx_mean = 0)
 {
     __shared__ uint8_t lut[3][256];
     uint32_t frame, blk;
     if (!xcd_frame_map(blockIdx.x, blocks_per_frame, nframes, frame, blk)) return;   // grid: xcd_frame_grid()
     {
-        const double n = (double)npx;
+        // npx_mean: pixels the channel means are taken over when the images carry padding columns (bevw_set_output_pitch); 0 = npx
+        const double n = (double)(npx_mean ? npx_mean : npx);
         const double B = (double)chsums[frame * 3 + 0] / n, G = (double)chsums[frame * 3 + 1] / n,
                      R = (double)chsums[frame * 3 + 2] / n;
         const double K = (R + G + B) / 3;

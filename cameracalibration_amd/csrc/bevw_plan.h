@@ -49,6 +49,7 @@ struct Plan {
     // so they write rows of `pitch` = bw rounded up to 4 pixels into pad_out and k_plan_unpad compacts them (one more
     // pass over the output instead of the per-pixel schedule)
     int pitch = 0;
+    bool out_pitched = false;    // the caller's output images have rows of `pitch` pixels themselves (bevw_set_output_pitch): no scratch, no compaction
     void *pad_out = nullptr, *pad_car = nullptr;
     size_t pad_cap = 0;
     int *d_max = nullptr;
@@ -865,18 +866,13 @@ static inline hipError_t plan_upload_list(const std::vector<uint32_t> &v, void *
     return hipMemcpy(*dptr, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
 }
 
-// pixels per output row the plan kernels write: bw rounded up to 4 (12-byte stores); BEVW_ABL_PITCH_ALIGN=N rounds to N pixels instead
-// (ablation: N = 64 makes every row start on a 64-byte sector -- the cost of partially written sectors, profiles/r03/sweeps.log)
-static inline int plan_pitch(int bw)
-{
-    static const int align = [] { const char *s = getenv("BEVW_ABL_PITCH_ALIGN"); const int v = s ? atoi(s) : 4; return v >= 4 && v % 4 == 0 ? v : 4; }();
-    return (bw + align - 1) / align * align;
-}
+// pixels per output row the plan kernels write: the caller's pitch (bevw_set_output_pitch), else bw rounded up to 4 (12-byte stores)
+static inline int plan_pitch(int bw, int out_pitch) { return out_pitch > 0 ? out_pitch : (bw + 3) & ~3; }
 
 static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int lx,
                                          int orient = 0, int interleave = 1, bool column_major_transposed = true, int super_tile = 1,
                                          int ncams = 4, bool block_tiles = true, bool seam_tiles = true, bool units = true,
-                                         const UnitTuning &unit_tune = UnitTuning())
+                                         const UnitTuning &unit_tune = UnitTuning(), int out_pitch = 0)
 {
     plan_release(p);
     if (lx != 4 && lx != 8 && lx != 16) lx = kPlanLXDefault;
@@ -953,7 +949,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if (units) {
             UnitPlanHost up;
             std::vector<uint32_t> hdr_un = hdr;
-            unit_compile(h1, h2, hm, ncams, fw, fh, bw, bh, plan_pitch(bw), p.tiles_x, p.tiles_y, hdr_un, up, unit_tune);
+            unit_compile(h1, h2, hm, ncams, fw, fh, bw, bh, plan_pitch(bw, out_pitch), p.tiles_x, p.tiles_y, hdr_un, up, unit_tune);
             if (!up.desc.empty()) {
                 have_units = true;
                 hdr.swap(hdr_un);
@@ -1060,7 +1056,8 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     if ((e = plan_upload_list(le, &p.list_empty)) != hipSuccess) return e;
     // 12-byte stores need 4-byte aligned pixel quads: rows of `pitch` pixels (bw % 4 != 0: padded scratch + k_plan_unpad)
     // and the aligned 12-byte footprint reads need every frame of a set to start on a 4-byte boundary
-    p.pitch = plan_pitch(bw);
+    p.pitch = plan_pitch(bw, out_pitch);
+    p.out_pitched = out_pitch > 0 && out_pitch != bw;
     p.usable = p.max_contrib <= 2 && (((size_t)fw * fh * 3) % 4 == 0) && (size_t)fw * fh * 3 * ncams < (1ull << 31);
     return hipSuccess;
 }
@@ -1252,9 +1249,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.deltas = d_deltas; a.tab = d_tab; a.car = d_car; a.out = d_out;
     a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh;
     a.pitch = p.pitch;
-    const bool padded = p.pitch != p.bw;
+    const bool padded = p.pitch != p.bw, scratch = padded && !p.out_pitched;
     if (padded) {
-        const size_t img = (size_t)p.pitch * p.bh * 3, need = img * (size_t)batch;
+        const size_t img = (size_t)p.pitch * p.bh * 3, need = scratch ? img * (size_t)batch : 0;
         if (need > p.pad_cap) {
             if (p.pad_out) (void)hipFree(p.pad_out);
             p.pad_out = nullptr; p.pad_cap = 0;
@@ -1267,7 +1264,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
                                static_cast<uint8_t *>(p.pad_car));
             a.car = static_cast<const uint8_t *>(p.pad_car);
         }
-        a.out = static_cast<uint8_t *>(p.pad_out);
+        if (scratch) a.out = static_cast<uint8_t *>(p.pad_out);
     }
     a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ngroups = (p.ntiles + 3) / 4;
     a.ncams = p.ncams;
@@ -1316,7 +1313,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, p.ntiles, d_chsums);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (padded) {
+    if (scratch) {
         const size_t rows = (size_t)batch * p.bh;
         for (size_t r0 = 0; r0 < rows; r0 += (size_t)1 << 20) {   // <= 2^20 rows per launch keeps the grid below 2^31 blocks
             const size_t nr = rows - r0 < ((size_t)1 << 20) ? rows - r0 : ((size_t)1 << 20);

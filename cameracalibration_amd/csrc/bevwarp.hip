@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -62,7 +63,8 @@ static int use_device(int device)
     return BEVW_OK;
 }
 
-static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int ncams = 4, bool seam_tiles = true)
+static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int ncams = 4, bool seam_tiles = true,
+                      int out_pitch = 0)
 {
     static const int lx_env = [] { const char *s = getenv("BEVW_PLAN_LX"); return s ? atoi(s) : 0; }();
     static const int orient_env = [] { const char *s = getenv("BEVW_PLAN_ORIENT"); return s ? atoi(s) : 0; }();
@@ -86,7 +88,7 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
         return t;
     }();
     hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
-                                   block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, unit_tune);
+                                   block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, unit_tune, out_pitch);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -213,14 +215,14 @@ static bool host_clip_segment(int w, int h, long long &x1, long long &y1, long l
 // Edge table of cv2.fillPoly for one polygon (XY_SHIFT = 16): slopes come from the image-clipped end points,
 // the y extent from the original ones.  Only scalars are produced here; pixels are written by k_poly_*.
 // OpenCV-version-sensitive choices (include/bevwarp.h: bevw_set_compat); process-wide, read when tables are built / gains applied
-static int g_compat[2] = {1, 1};
+static std::atomic<int> g_compat[2] = {{1}, {1}};   // the DEFAULTS of new handles; a handle snapshots both in bevw_build
 
-static PolyJob make_poly_job(const int (*pts)[2], int npts, int w, int h)
+static PolyJob make_poly_job(const int (*pts)[2], int npts, int w, int h, bool modern)
 {
     PolyJob job;
     memset(&job, 0, sizeof job);
     job.npts = npts;
-    const bool modern = g_compat[BEVW_COMPAT_FILLPOLY] != 0;   // OpenCV >= 4.5.2 edge collection
+    // modern: OpenCV >= 4.5.2 edge collection (BEVW_COMPAT_FILLPOLY)
     job.ceil_left = modern ? 0 : 1;
     for (int i = 0; i < npts; ++i) { job.pts[i][0] = pts[i][0]; job.pts[i][1] = pts[i][1]; }
     const long long HALF = 1 << 15;
@@ -477,14 +479,14 @@ int bevw_set_compat(int key, int value)
 {
     if (key < 0 || key >= 2) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
     if (value != 0 && value != 1) return fail(BEVW_E_INVALID, "compatibility value must be 0 or 1");
-    g_compat[key] = value;
+    g_compat[key].store(value);
     return BEVW_OK;
 }
 
 int bevw_get_compat(int key)
 {
     if (key < 0 || key >= 2) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
-    return g_compat[key];
+    return g_compat[key].load();
 }
 
 const char *bevw_last_error(void) { return g_err; }
@@ -795,6 +797,10 @@ struct bevw_handle {
     Plan plan;
     int schedule_in_use = BEVW_SCHED_PER_PIXEL;
     int projection = BEVW_PROJ_LUT;   // bevw_set_projection
+    int compat[2] = {1, 1};           // bevw_set_compat values at bevw_build: a handle keeps the arithmetic it was built with
+    int pitch_request = BEVW_PITCH_DENSE;   // bevw_set_output_pitch
+    int pitch_px = 0;                 // pixels per row of the device-side BEV images (== bev_width unless a pitch was requested)
+    DevBuf car_pitched;               // the car sprite with rows of pitch_px pixels (gain pass of a pitched handle)
     AnalyticRig arig;                 // filled by bevw_build
     // camera-per-GPU mode: the cameras this handle owns (shard_n == 0: all four, the ordinary BevGenerator)
     int shard_n = 0;
@@ -810,11 +816,11 @@ struct bevw_handle {
     }
 };
 
-static int fill_poly_device(hipStream_t st, const MaskGeometry &g, int cam, bool blend, uint8_t *d_mask)
+static int fill_poly_device(hipStream_t st, const MaskGeometry &g, int cam, bool blend, uint8_t *d_mask, bool modern)
 {
     int pts[8][2];
     const int n = g.polygon(cam, blend, pts);
-    PolyJob job = make_poly_job(pts, n, g.bw, g.bh);
+    PolyJob job = make_poly_job(pts, n, g.bw, g.bh, modern);
     HIP_TRY(hipMemsetAsync(d_mask, 0, (size_t)g.bw * g.bh, st));
     hipLaunchKernelGGL(k_poly_outline, dim3(1), dim3(64), 0, st, job, d_mask, g.bw, g.bh, (uint8_t)255);
     hipLaunchKernelGGL(k_poly_fill, dim3((g.bh + 63) / 64), dim3(64), 0, st, job, d_mask, g.bw, g.bh, (uint8_t)255);
@@ -923,7 +929,12 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
 static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
 {
     const bevw_config &c = h->cfg;
-    const size_t npx = (size_t)c.bev_width * c.bev_height;
+    const size_t npx_true = (size_t)c.bev_width * c.bev_height;
+    const bool pitched = h->pitch_px != c.bev_width;
+    const size_t npx = (size_t)h->pitch_px * c.bev_height;   // pixels per device image, padding columns included
+    if (pitched && (h->projection != BEVW_PROJ_LUT || h->schedule_in_use != BEVW_SCHED_TILE_PLAN ||
+                    ((((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) != 0)))
+        return fail(BEVW_E_INVALID, "an output pitch needs the tile-plan schedule, the table projection and 4-byte aligned buffers");
     if (c.balance) {
         BEVW_TRY(ensure_stats(h, batch));
         BEVW_TRY(luminance_stats(h->stream, d_frames, batch, c.frame_width, c.frame_height,
@@ -947,7 +958,8 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
         // one more BEV batch of HBM (0.9 GB at batch 256)
         static const int oop = [] { const char *s = getenv("BEVW_GAIN_OOP"); return s ? atoi(s) : 1; }();
-        if (oop && npx % 4 == 0) { BEVW_TRY(h->pre.reserve(npx * 3 * (size_t)batch)); gain_in = h->pre.as<uint8_t>(); }
+        // (no room for it: the gain pass runs in place, as before round 2 -- never an error)
+        if (oop && npx % 4 == 0 && h->pre.reserve(npx * 3 * (size_t)batch) == BEVW_OK) gain_in = h->pre.as<uint8_t>();
         BEVW_TRY(plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr,
                              h->chsums.as<unsigned long long>(), gain_in, true));
     } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4) {
@@ -957,16 +969,23 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         BEVW_TRY(stitch_per_pixel(h, d_frames, batch, d_car, d_out));
     }
     if (c.balance) {
+        const uint8_t *gain_car = d_car;
+        if (pitched && d_car) {   // the gain pass walks the image as a flat array: the sprite needs the same row pitch
+            BEVW_TRY(h->car_pitched.reserve(npx * 3));
+            hipLaunchKernelGGL(k_plan_pad, dim3((unsigned)((npx * 3 + 255) / 256)), dim3(256), 0, h->stream, d_car, c.bev_width, h->pitch_px,
+                               c.bev_height, h->car_pitched.as<uint8_t>());
+            gain_car = h->car_pitched.as<uint8_t>();
+        }
         for (int b0 = 0; b0 < batch; b0 += 65535) {
             const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
             if (npx % 4 == 0 && aligned4)
                 hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, gain_in + (size_t)b0 * npx * 3, npx,
-                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3, 32u,
-                                   (uint32_t)nb, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_car, d_out + (size_t)b0 * npx * 3, 32u,
+                                   (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1, npx_true);
             else
                 hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
                                    h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3,
-                                   g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+                                   h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
         }
         BEVW_TRY(launch_check("k_gain"));
     }
@@ -1022,6 +1041,7 @@ int bevw_build(bevw_handle *h)
         if (h->owns(c) && !h->cam_set[c]) return fail(BEVW_E_INVALID, "camera %d has no K/D/H (bevw_set_camera)", c);
     const bevw_config &cfg = h->cfg;
     BEVW_TRY(use_device(cfg.device));
+    for (int k = 0; k < 2; ++k) h->compat[k] = g_compat[k].load();   // later bevw_set_compat calls do not reach this handle
     hipStream_t st = h->stream;
     const int uw = (int)(cfg.frame_width * cfg.size_scale), uh = (int)(cfg.frame_height * cfg.size_scale);
     const int bw = cfg.bev_width, bh = cfg.bev_height;
@@ -1055,13 +1075,13 @@ int bevw_build(bevw_handle *h)
     // Mask / BlendMask (surroundBEV.py:119-280)
     MaskGeometry g{bw, bh, cfg.car_width, cfg.car_height};
     if (!cfg.blend) {
-        for (int c = 0; c < 4; ++c) BEVW_TRY(fill_poly_device(st, g, c, false, h->mask[c].as<uint8_t>()));
+        for (int c = 0; c < 4; ++c) BEVW_TRY(fill_poly_device(st, g, c, false, h->mask[c].as<uint8_t>(), h->compat[BEVW_COMPAT_FILLPOLY] != 0));
     } else {
         DevBuf fresh[4];
         int s = BEVW_OK;
         for (int c = 0; c < 4 && s == BEVW_OK; ++c) {
             s = fresh[c].reserve(bpx);
-            if (s == BEVW_OK) s = fill_poly_device(st, g, c, true, fresh[c].as<uint8_t>());
+            if (s == BEVW_OK) s = fill_poly_device(st, g, c, true, fresh[c].as<uint8_t>(), h->compat[BEVW_COMPAT_FILLPOLY] != 0);
         }
         // BlendMask.__init__ (:165-186): (own mask, other mask, own seam, other seam), two steps per camera
         struct Step { int other; const char *a0, *a1, *b0, *b1; };
@@ -1102,7 +1122,8 @@ int bevw_build(bevw_handle *h)
         T.mask[i] = h->mask[c].as<uint8_t>();
     }
     // (seam block tiles: measured +0.7 % slower under the per-tile channel sums of the balance path, -1.4 .. -1.8 % without: sweeps.log)
-    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams, cfg.balance == 0));
+    h->pitch_px = h->pitch_request == BEVW_PITCH_DENSE ? bw : (h->pitch_request == BEVW_PITCH_ALIGNED ? (bw + 63) / 64 * 64 : h->pitch_request);
+    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams, cfg.balance == 0, h->pitch_px != bw ? h->pitch_px : 0));
     if (h->shard_n) {
         if (!h->plan.usable) return fail(BEVW_E_INVALID, "camera shard needs the tile plan: %d contributors on some pixel", h->plan.max_contrib);
         // bounding box of the owned masks, widened to multiples of 4 pixels in x so that packed rows stay dword aligned
@@ -1128,6 +1149,8 @@ int bevw_build(bevw_handle *h)
         if (x1 > bw) x1 = bw;
         h->shard_box[0] = x0; h->shard_box[1] = y0; h->shard_box[2] = x1; h->shard_box[3] = y1;
     }
+    if (h->pitch_px != bw && (cfg.schedule == BEVW_SCHED_PER_PIXEL || !h->plan.usable))
+        return fail(BEVW_E_INVALID, "an output pitch needs the tile-plan schedule");
     h->schedule_in_use = BEVW_SCHED_PER_PIXEL;
     if (cfg.schedule == BEVW_SCHED_TILE_PLAN) {
         if (!h->plan.usable) return fail(BEVW_E_INVALID, "tile plan unusable: %d contributors on some pixel", h->plan.max_contrib);
@@ -1149,7 +1172,7 @@ void bevw_destroy(bevw_handle *h)
             h->und1[c].release(); h->und2[c].release(); h->lut1[c].release(); h->lut2[c].release(); h->mask[c].release();
         }
         h->hsv.release(); h->vsums.release(); h->deltas.release(); h->chsums.release(); h->sdeltas.release();
-        h->in.release(); h->out.release(); h->car.release(); h->tmp.release(); h->pre.release();
+        h->in.release(); h->out.release(); h->car.release(); h->tmp.release(); h->pre.release(); h->car_pitched.release();
         plan_release(h->plan);
         h->laps.release();
         if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -1223,6 +1246,33 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     return BEVW_OK;
 }
 
+int bevw_set_output_pitch(bevw_handle *h, int pitch_pixels)
+{
+    if (!h) return fail(BEVW_E_INVALID, "null handle");
+    if (h->shard_n) return fail(BEVW_E_INVALID, "an output pitch is not available on camera-shard handles");
+    if (pitch_pixels != BEVW_PITCH_DENSE && pitch_pixels != BEVW_PITCH_ALIGNED &&
+        (pitch_pixels < h->cfg.bev_width || pitch_pixels % 4 != 0 || pitch_pixels > 65532))
+        return fail(BEVW_E_INVALID, "output pitch must be BEVW_PITCH_DENSE, BEVW_PITCH_ALIGNED or a multiple of 4 >= BEV_WIDTH, got %d", pitch_pixels);
+    h->pitch_request = pitch_pixels;
+    h->built = false;
+    return BEVW_OK;
+}
+
+int bevw_output_pitch(bevw_handle *h)
+{
+    if (!h || !h->built) { fail(BEVW_E_INVALID, "bevw_build has not been called"); return BEVW_E_INVALID; }
+    return h->pitch_px;
+}
+
+// [batch * rows][pitch_px][3] on the device -> dense [batch * rows][bw][3] on the host (rows compacted inside the copy)
+static int download_images(bevw_handle *h, uint8_t *out, const void *d_src, size_t rows)
+{
+    const size_t row_bytes = (size_t)h->cfg.bev_width * 3, src_pitch = (size_t)h->pitch_px * 3;
+    if (src_pitch == row_bytes) HIP_TRY(hipMemcpyAsync(out, d_src, row_bytes * rows, hipMemcpyDeviceToHost, h->stream));
+    else HIP_TRY(hipMemcpy2DAsync(out, row_bytes, d_src, src_pitch, row_bytes, rows, hipMemcpyDeviceToHost, h->stream));
+    return BEVW_OK;
+}
+
 int bevw_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_car, void *d_out)
 {
     BEVW_TRY(need_built(h));
@@ -1240,9 +1290,9 @@ int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *ca
     if (batch == 0) return BEVW_OK;
     const bevw_config &c = h->cfg;
     const size_t nin = (size_t)batch * 4 * c.frame_width * c.frame_height * 3;
-    const size_t bev = (size_t)c.bev_width * c.bev_height * 3;
+    const size_t bev = (size_t)c.bev_width * c.bev_height * 3, dbev = (size_t)h->pitch_px * c.bev_height * 3;
     BEVW_TRY(h->in.reserve(nin));
-    BEVW_TRY(h->out.reserve(bev * batch));
+    BEVW_TRY(h->out.reserve(dbev * batch));
     HIP_TRY(hipMemcpyAsync(h->in.p, frames, nin, hipMemcpyHostToDevice, h->stream));
     const uint8_t *d_car = nullptr;
     if (car) {
@@ -1251,7 +1301,7 @@ int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *ca
         d_car = h->car.as<uint8_t>();
     }
     BEVW_TRY(run_device(h, h->in.as<uint8_t>(), batch, d_car, h->out.as<uint8_t>()));
-    HIP_TRY(hipMemcpyAsync(out, h->out.p, bev * batch, hipMemcpyDeviceToHost, h->stream));
+    BEVW_TRY(download_images(h, out, h->out.p, (size_t)batch * c.bev_height));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return BEVW_OK;
 }
@@ -1266,7 +1316,7 @@ int bevw_run_cameras(bevw_handle *h, const uint8_t *front, const uint8_t *back, 
     const bevw_config &c = h->cfg;
     const size_t frame = (size_t)c.frame_width * c.frame_height * 3, bev = (size_t)c.bev_width * c.bev_height * 3;
     BEVW_TRY(h->in.reserve(frame * 4));
-    BEVW_TRY(h->out.reserve(bev));
+    BEVW_TRY(h->out.reserve((size_t)h->pitch_px * c.bev_height * 3));
     const uint8_t *src[4] = {front, back, left, right};
     for (int i = 0; i < 4; ++i)
         HIP_TRY(hipMemcpyAsync(h->in.as<uint8_t>() + frame * i, src[i], frame, hipMemcpyHostToDevice, h->stream));
@@ -1277,7 +1327,7 @@ int bevw_run_cameras(bevw_handle *h, const uint8_t *front, const uint8_t *back, 
         d_car = h->car.as<uint8_t>();
     }
     BEVW_TRY(run_device(h, h->in.as<uint8_t>(), 1, d_car, h->out.as<uint8_t>()));
-    HIP_TRY(hipMemcpyAsync(out, h->out.p, bev, hipMemcpyDeviceToHost, h->stream));
+    BEVW_TRY(download_images(h, out, h->out.p, (size_t)c.bev_height));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return BEVW_OK;
 }
@@ -1590,9 +1640,9 @@ int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_
             hipLaunchKernelGGL(k_channel_sums, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs);
             if (npx % 4 == 0 && dwords)
                 hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o,
-                                   32u, (uint32_t)nb, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+                                   32u, (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
             else hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, o, npx, chs, (const uint8_t *)d_car, o,
-                                    g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+                                    h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
         }
         BEVW_TRY(launch_check("k_channel_sums/k_gain"));
     }
@@ -1670,7 +1720,7 @@ int bevw_color_balance(int device, const uint8_t *images, int batch, int width, 
                                cs.as<unsigned long long>() + (size_t)b0 * 3);
             hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, 0, in.as<uint8_t>() + (size_t)b0 * npx * 3, npx,
                                cs.as<unsigned long long>() + (size_t)b0 * 3, (const uint8_t *)nullptr,
-                               in.as<uint8_t>() + (size_t)b0 * npx * 3, g_compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+                               in.as<uint8_t>() + (size_t)b0 * npx * 3, g_compat[BEVW_COMPAT_ADDWEIGHTED].load() ? 0 : 1);
         }
         s = launch_check("k_channel_sums/k_gain");
     }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BEVW_ABI_VERSION 1
+#define BEVW_ABI_VERSION 2
 
 typedef enum bevw_status {
     BEVW_OK = 0,
@@ -69,7 +69,9 @@ int bevw_abi_version(void);
 
 /* OpenCV-version-sensitive arithmetic behind the reference's cv2 calls.  The reference pins no OpenCV version
  * ("opencv(>=3.4.2)", README.md:14); two of the primitives it calls changed their results across releases, so the choice
- * is a switch (process-wide; set before bevw_build / the run it should affect) instead of a constant:
+ * is a switch instead of a constant.  bevw_set_compat sets the process-wide DEFAULT; a handle takes a snapshot of both values in
+ * bevw_build and keeps it (later calls, or calls from other threads, never change the results of a handle that exists); the stand-alone
+ * bevw_color_balance reads the default at call time:
  *   BEVW_COMPAT_FILLPOLY    cv2.fillPoly (surroundBEV.py:159,234): 1 = OpenCV >= 4.5.2 edge collection (default),
  *                           0 = OpenCV 2.4 .. 4.5.1 (edges between the raw vertices, left span end rounded up)
  *   BEVW_COMPAT_ADDWEIGHTED cv2.addWeighted(ch, k, 0, 0, 0, ch) (surroundBEV.py:52-54): 1 = evaluated in CV_64F (default),
@@ -119,6 +121,19 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8]);        /* [0] max contribut
 /* frames: [batch][4][FH][FW][3]; car: [BH][BW][3] or NULL (already padded, surroundBEV.py:28-41); out: [batch][BH][BW][3] */
 int bevw_run(bevw_handle *h, const uint8_t *frames, int batch, const uint8_t *car, uint8_t *out);
 int bevw_run_device(bevw_handle *h, const void *d_frames, int batch, const void *d_car, void *d_out);
+/* Row pitch of the DEVICE-side BEV images (cv::cuda::GpuMat's `step`; the reference's host arrays, surroundBEV.py:312-325, stay dense).
+ * A 1080-pixel row is 3240 bytes: in a dense image only one row in eight starts on a 64-byte memory sector, every other row run a
+ * kernel block writes starts and ends inside a sector it shares with its neighbour, and partially written sectors are what the
+ * stitch pays most for.  bevw_set_output_pitch (before bevw_build) makes every device image of the handle
+ * [BH][pitch][3] with `pitch_pixels` >= BEV_WIDTH pixels per row: BEVW_PITCH_DENSE (default) = BEV_WIDTH, BEVW_PITCH_ALIGNED = BEV_WIDTH
+ * rounded up to 64 pixels (rows of whole sectors), or an explicit multiple of 4.  With a pitch other than BEV_WIDTH the host entry points
+ * (bevw_run, bevw_run_cameras) still take and return dense arrays -- rows are compacted inside the device-to-host copy -- while
+ * bevw_run_device writes d_out as [batch][BH][bevw_output_pitch()][3] (bytes of the padding columns are unspecified) and still reads a
+ * dense d_car.  Needs the tile-plan schedule; not available on camera-shard handles. */
+#define BEVW_PITCH_DENSE 0
+#define BEVW_PITCH_ALIGNED (-1)
+int bevw_set_output_pitch(bevw_handle *h, int pitch_pixels);
+int bevw_output_pitch(bevw_handle *h);   /* pixels per row of the handle's device images */
 /* The reference's own call shape, bev(front, back, left, right, car) (surroundBEV.py:312, main.py:84): four separate
  * [FH][FW][3] host arrays (no packing copy on the host), one frame set, out [BH][BW][3]. */
 int bevw_run_cameras(bevw_handle *h, const uint8_t *front, const uint8_t *back, const uint8_t *left, const uint8_t *right,
@@ -169,7 +184,7 @@ int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_
  * A communicator spans ONE camera group (1, 2 or 4 ranks; rank order = ascending camera order).  Every call below is
  * enqueued on the handle's own HIP stream: rank-local stitch, exchange and combine need no host synchronisation.
  *   bevw_comm_unique_id  group rank 0 creates the 128-byte id; the caller carries it to the other ranks (any out-of-band
- *                        channel: cameraShard.exchange_unique_id uses a TCP socket, bench.py its launcher's store)
+ *                        channel: cameraShard.RcclGroup broadcasts it over the SocketGroup control channel)
  *   bevw_comm_create     ncclCommInitRank on `device`
  *   bevw_shard_allgather_vsums   balance only: ncclAllGather of the per-frame V sums, laid out as [batch][4]
  *   bevw_shard_gather_parts      grouped ncclSend (non-root) / ncclRecv (root) of the packed mask boxes; d_recv / bytes are

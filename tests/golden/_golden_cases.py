@@ -9,6 +9,10 @@ MODES = [(False, False), (True, False), (False, True), (True, True)]
 RESIZE_FACTORS = (0.37, 0.5, 1.6, 2.0)
 MAIN_CAR = (200, 350)          # main.py:80-81
 PINHOLE_D = (-0.31, 0.12, 0.0015, -0.0007, -0.02)
+# cv2.addWeighted(channel, gain, 0, 0, 0) as color_balance calls it (surroundBEV.py:52-54: src2 is the Python scalar 0, which is what
+# selects the work type inside OpenCV).  Three gains on which a CV_32F and a CV_64F evaluation differ for at least one byte value,
+# applied to the ramp 0..255: the case decides the `addWeighted` switch by itself, independent of any image content.
+ADDWEIGHTED_GAINS = (0.9241071147452891, 1.3978102017483192, 0.7298850131855613)
 
 
 def digest(arr: np.ndarray) -> str:

@@ -82,6 +82,9 @@ def main() -> int:
     for n, out in zip(GC.CAMS, sb.luminance_balance([f.copy() for f in frames])):
         cases["lum_" + n] = out
     cases["color_balance_back"] = sb.color_balance(img["back"].copy())
+    ramp = np.arange(256, dtype=np.uint8).reshape(256, 1)
+    for k, g in enumerate(GC.ADDWEIGHTED_GAINS):      # the call shape of surroundBEV.py:52-54, scalar src2
+        cases["addweighted_scalar_%d" % k] = cv2.addWeighted(ramp, g, 0, 0, 0)
 
     # InCalibrator.undistort geometry (intrinsicCalib.py:90-103 with FOCAL_SCALE 0.5, SIZE_SCALE 1) and the pinhole maps
     K, D = z["front_K"], z["front_D"]

@@ -13,16 +13,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 import _golden_cases as GC  # noqa: E402
 
 PATH = os.environ.get("BEVW_GOLDENS_FILE", os.path.join(ROOT, "tests", "golden", "cv2_goldens.npz"))
-pytestmark = pytest.mark.skipif(not os.path.exists(PATH), reason="no cv2 goldens (tests/golden/make_goldens_with_cv2.py)")
+# BEVW_REQUIRE_GOLDENS=1: whoever has just run make_goldens_with_cv2.py wants a red or a green answer per case, never a skip -- a missing
+# file and a case the file does not hold both FAIL under the flag
+REQUIRE = os.environ.get("BEVW_REQUIRE_GOLDENS", "0") not in ("", "0")
+pytestmark = pytest.mark.skipif(not os.path.exists(PATH) and not REQUIRE, reason="no cv2 goldens (tests/golden/make_goldens_with_cv2.py)")
 
 
 @pytest.fixture(scope="module")
 def goldens():
+    if not os.path.exists(PATH):
+        pytest.fail("BEVW_REQUIRE_GOLDENS is set and %s does not exist (tests/golden/README.md)" % PATH)
     return np.load(PATH)
 
 
 def check(goldens, name, arr):
     if name + "__sha" not in goldens.files:
+        if REQUIRE:
+            pytest.fail("case %s is not in the golden file (regenerate it with the current make_goldens_with_cv2.py)" % name)
         pytest.skip("case %s not in the golden file" % name)
     assert tuple(goldens[name + "__shape"]) == arr.shape, name
     if str(goldens[name + "__sha"]) != GC.digest(arr):
@@ -94,6 +101,27 @@ def test_balance_helpers(goldens, oracle, repo_rig):
     for n, out in zip(GC.CAMS, oracle.luminance_balance(repo_rig.frames())):
         check(goldens, "lum_" + n, out)
     check(goldens, "color_balance_back", oracle.color_balance(repo_rig.image("back")))
+
+
+def test_addweighted_scalar_work_type(goldens, oracle, variants_decided_by_the_goldens):
+    """cv2.addWeighted(ramp, gain, 0, 0, 0) with the scalar second source of surroundBEV.py:52-54 on three gains where a CV_32F and a
+    CV_64F evaluation differ: decides the `addWeighted` switch on its own, whatever the image-based case selected."""
+    ramp = np.repeat(np.arange(256, dtype=np.uint8)[:, None, None], 3, axis=2).copy()    # [256, 1, 3]: one gain per channel
+    hits = {}
+    for v in (1, 0):
+        oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, v)
+        img = ramp.copy()
+        oracle.lib().orc_gain(img.ctypes.data, 256, np.array(GC.ADDWEIGHTED_GAINS, np.float64).ctypes.data)
+        hits[v] = [("addweighted_scalar_%d__sha" % k) in goldens.files and
+                   str(goldens["addweighted_scalar_%d__sha" % k]) == GC.digest(np.ascontiguousarray(img[:, :, k])) for k in range(3)]
+    oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, variants_decided_by_the_goldens.get("addWeighted", 1))
+    if not any(("addweighted_scalar_%d__sha" % k) in goldens.files for k in range(3)):
+        if REQUIRE:
+            pytest.fail("the golden file has no addweighted_scalar_* cases (regenerate it)")
+        pytest.skip("no addweighted_scalar_* cases in the golden file")
+    assert all(hits[1]) or all(hits[0]), "neither work type reproduces cv2.addWeighted with a scalar src2: %s" % hits
+    want = 1 if all(hits[1]) else 0
+    assert variants_decided_by_the_goldens.get("addWeighted", want) == want, "image-based and ramp-based cases disagree on the work type"
 
 
 def test_calibrator_paths(goldens, oracle, repo_rig):

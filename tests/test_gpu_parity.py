@@ -126,6 +126,10 @@ def test_compat_variants_bit_exact(ffi, SB, oracle, fillpoly, addweighted):
         got = bev.batch(frames)
         for b in range(frames.shape[0]):
             assert maxdiff(got[b], ref(*frames[b])) == 0
+        # a handle keeps the values it was built with: flipping the process-wide defaults afterwards does not reach it
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_FILLPOLY, 1 - fillpoly))
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_ADDWEIGHTED, 1 - addweighted))
+        assert np.array_equal(bev.batch(frames), got)
     finally:
         L.bevw_set_compat(ffi.COMPAT_FILLPOLY, 1)
         L.bevw_set_compat(ffi.COMPAT_ADDWEIGHTED, 1)
@@ -570,3 +574,61 @@ def test_incalibrator_normal_pinhole(ffi, oracle, repo_rig):
         m1, m2 = oracle.init_undistort_rectify_map(K, D, Kd, (1280, 1024))
         assert np.array_equal(data.map1, m1) and np.array_equal(data.map2, m2)
         assert np.array_equal(cal.undistort(img), oracle.remap(img, m1, m2))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-side row pitch (bevw_set_output_pitch): rows of whole 64-byte sectors; host results stay dense
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("blend,balance", [(False, False), (True, False), (False, True), (True, True)])
+def test_output_pitch_aligned_config_s(ffi, SB, oracle, blend, balance):
+    """BevGenerator(output_pitch='aligned') on the bench rig (1080-pixel rows -> 1088): the host entry points return the same dense
+    arrays as ever (rows are compacted inside the device-to-host copy), run_device writes [B][BH][1088][3] whose first 1080 columns
+    equal the oracle bit for bit -- all four modes, with a car sprite, batch 5 (a ragged chunk)."""
+    cfg, rig = W.CONFIG_S, W.rig_s()
+    set_args(SB, cfg)
+    bw, bh = cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+    frames = W.synthetic_frames(2, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=W.SEED + 5, kind="random")
+    rng = np.random.default_rng(11)
+    car = np.zeros((bh, bw, 3), np.uint8)
+    car[300:780, 380:700] = rng.integers(0, 256, (480, 320, 3), dtype=np.uint8)
+    bev = SB.BevGenerator(blend=blend, balance=balance, rig=rig, output_pitch='aligned')
+    ref = oracle.RefBevGenerator(rig, cfg, blend=blend, balance=balance)
+    assert bev.out_pitch == 1088 and bev.plan_info()["schedule"] == 2
+    want = [ref(*frames[u], car) for u in range(2)]
+    assert np.array_equal(bev(*frames[0], car), want[0])                       # reference call shape, dense result
+    batch = 5
+    host = bev.batch(np.stack([frames[b % 2] for b in range(batch)]), car)     # host batch, dense result
+    for b in range(batch):
+        assert np.array_equal(host[b], want[b % 2]), "host batch frame %d" % b
+    d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
+    d_car = ffi.DeviceBuffer(car.nbytes).upload(car)
+    d_out = ffi.DeviceBuffer(batch * bh * bev.out_pitch * 3)
+    d_out.fill(0x5A)
+    for b in range(batch):
+        d_in.upload(frames[b % 2], offset=b * frames[0].nbytes)
+    bev.run_device(d_in.ptr, batch, d_car.ptr, d_out.ptr)
+    bev.sync()
+    out = d_out.download((batch, bh, bev.out_pitch, 3))
+    for b in range(batch):
+        assert np.array_equal(out[b, :, :bw], want[b % 2]), "device frame %d" % b
+    for buf in (d_in, d_car, d_out):
+        buf.free()
+
+
+def test_output_pitch_small_rig_and_errors(ffi, SB, oracle):
+    """An explicit pitch on the small rig (248 -> 272 pixels), the dense default, and the refusals: a pitch below the width, not a
+    multiple of 4, or together with the per-pixel schedule."""
+    cfg, rig = SMALL_CFG, small_rig()
+    set_args(SB, cfg)
+    frames = W.synthetic_frames(1, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=3, kind="random")
+    ref = oracle.RefBevGenerator(rig, cfg, blend=True, balance=True)
+    want = ref(*frames[0])
+    for pitch in ('dense', 'aligned', 272):
+        bev = SB.BevGenerator(blend=True, balance=True, rig=rig, output_pitch=pitch)
+        assert bev.out_pitch == {'dense': 248, 'aligned': 256, 272: 272}[pitch]
+        assert np.array_equal(bev(*frames[0]), want), pitch
+    for bad in (244, 250):
+        with pytest.raises(Exception):
+            SB.BevGenerator(rig=rig, output_pitch=bad)
+    with pytest.raises(Exception):
+        SB.BevGenerator(rig=rig, output_pitch='aligned', schedule=ffi.SCHED_PER_PIXEL)
