@@ -87,9 +87,9 @@ struct Plan {
     int n_bt_tiles = 0;                      // base tiles they cover
     // unit schedule (bevw_unit.h): k-d partition compiled on the host; their base tiles are in none of the pr / rp lists either
     void *un_desc = nullptr, *un_entries = nullptr, *un_gsrc = nullptr;
-    static constexpr int kUnitLists = 4;
-    void *list_un[kUnitLists] = {nullptr, nullptr, nullptr, nullptr};
-    int n_un[kUnitLists] = {0, 0, 0, 0};
+    static constexpr int kUnitLists = 7;
+    void *list_un[kUnitLists] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int n_un[kUnitLists] = {0, 0, 0, 0, 0, 0, 0};
     void *list_un_all = nullptr;             // every unit in partition order, class in bits 28..31
     int n_un_all = 0;
     size_t un_lines = 0, un_sectors = 0;     // request arithmetic of the partition (per frame)
@@ -770,7 +770,7 @@ namespace bevw {
 // ~10 us each, five times per step).  Blocks are dealt to the classes in the same order as the separate launches
 // (launch position i owns blocks start[i] .. start[i+1] and runs class kind[i]; every start is a multiple of 8, so a
 // block's XCD is what it was in the separate launch).
-constexpr int kPlanAllMax = 17;   // classes of one merged launch (launch positions in use)
+constexpr int kPlanAllMax = 13;   // classes of one merged launch (launch positions in use)
 struct PlanAllArgs {
     PlanArgs a;
     const uint32_t *list[kPlanAllMax];
@@ -779,7 +779,7 @@ struct PlanAllArgs {
     uint32_t start[kPlanAllMax + 1];   // block ranges in launch order
     // launch position -> class: 2 empty, 3 gather single, 5..8 pair-staged single (whole-tile 1 / 2 / 4 rounds, sliced),
     // 9, 10, 11 pair-staged double (1 / 2 / 4 rounds), 12 block-staged (bevw_block.h, 4 waves per block tile), 13 seam block tiles,
-    // 14 .. 17 units (bevw_unit.h, class = kind - 14), 18 units of every class in partition order
+    // 18 units (bevw_unit.h) of every class in the partition's own order
     int kind[kPlanAllMax];
     int n;                             // launch positions in use
 };
@@ -809,11 +809,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BEVW_P
         case 11: plan_pair_body<LX, 2, BLEND, SUMS, 1, 4>(a, id, stage_0); break;
         case 12: plan_block_body<BLEND, SUMS, 2>(a, id, stage_0); break;
         case 13: plan_seam_body<BLEND, SUMS>(a, id, stage_0); break;
-        case 14: plan_unit_body<SUMS, kUnitClassNQ[0], kUnitClassGR[0]>(a, id, stage_0); break;
-        case 15: plan_unit_body<SUMS, kUnitClassNQ[1], kUnitClassGR[1]>(a, id, stage_0); break;
-        case 16: plan_unit_body<SUMS, kUnitClassNQ[2], kUnitClassGR[2]>(a, id, stage_0); break;
-        case 17: plan_unit_body<SUMS, kUnitClassNQ[3], kUnitClassGR[3]>(a, id, stage_0); break;
-        case 18: plan_unit_any<SUMS>(a, id, stage_0); break;
+        case 18: plan_unit_any<BLEND, SUMS>(a, id, stage_0); break;
         case 2: plan_empty_body<LX>(a, id); break;
         case 3: plan_gather_block<LX, 1, BLEND, SUMS>(a, id, reinterpret_cast<uint32_t *>(stage_0)); break;
         // (the two-contributor gather class -- a handful of sparse seam tiles, 110+ VGPRs -- stays out of the merged kernel: it
@@ -850,7 +846,7 @@ static inline void plan_release(Plan &p)
 {
     void *ptrs[] = {p.entries_pr, p.gsrc, p.list_pr[0], p.list_pr[1], p.list_pr[2], p.list_pr[3], p.list_pr[4], p.list_pr[5], p.list_pr[6],
                     p.list_rp_single, p.list_rp_double, p.list_rp_empty, p.bt_entries, p.bt_gsrc, p.bt_pos, p.list_bt, p.sm_entries, p.sm_gsrc, p.sm_pos, p.list_sm,
-                    p.un_desc, p.un_entries, p.un_gsrc, p.list_un_all, p.list_un[0], p.list_un[1], p.list_un[2], p.list_un[3],
+                    p.un_desc, p.un_entries, p.un_gsrc, p.list_un_all, p.list_un[0], p.list_un[1], p.list_un[2], p.list_un[3], p.list_un[4], p.list_un[5], p.list_un[6],
                     p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_single, p.list_double, p.list_slow, p.list_empty};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -1146,11 +1142,13 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
     if (p.n_un[C]) {                                                                                                                         \
         a.tile_list = static_cast<const uint32_t *>(p.list_un[C]); a.nlist = p.n_un[C]; a.ngroups = p.n_un[C];                               \
         const dim3 grid(grid_blocks());                                                                                                      \
-        if (sums) hipLaunchKernelGGL((k_plan_unit<true, kUnitClassNQ[C], kUnitClassGR[C]>), grid, block, 0, st, a);                          \
-        else hipLaunchKernelGGL((k_plan_unit<false, kUnitClassNQ[C], kUnitClassGR[C]>), grid, block, 0, st, a);                              \
+        if (blend && sums) hipLaunchKernelGGL((k_plan_unit<true, true, C>), grid, block, 0, st, a);                                          \
+        else if (blend) hipLaunchKernelGGL((k_plan_unit<true, false, C>), grid, block, 0, st, a);                                            \
+        else if (sums) hipLaunchKernelGGL((k_plan_unit<false, true, C>), grid, block, 0, st, a);                                             \
+        else hipLaunchKernelGGL((k_plan_unit<false, false, C>), grid, block, 0, st, a);                                                      \
         if ((e = hipGetLastError()) != hipSuccess) return e;                                                                                 \
     }
-        BEVW_LAUNCH_UNIT(2) BEVW_LAUNCH_UNIT(3) BEVW_LAUNCH_UNIT(1) BEVW_LAUNCH_UNIT(0)
+        BEVW_LAUNCH_UNIT(2) BEVW_LAUNCH_UNIT(3) BEVW_LAUNCH_UNIT(4) BEVW_LAUNCH_UNIT(5) BEVW_LAUNCH_UNIT(6) BEVW_LAUNCH_UNIT(1) BEVW_LAUNCH_UNIT(0)
 #undef BEVW_LAUNCH_UNIT
     }
     if (staged && p.n_sm && !one_launch) {   // the seam block tiles as a launch of their own (per-class mode)
@@ -1177,9 +1175,8 @@ static inline hipError_t plan_launch_lx(Plan &p, hipStream_t st, PlanArgs a, boo
         const bool bt_last = n_wave_side * 5 >= p.n_bt_tiles;
         const Cls bt_cls = {12, p.list_bt, bt_merged ? p.n_bt : 0}, none = {12, nullptr, 0};
         // units (bevw_unit.h) in front: they hold the bulk of the step; the classes with 4 rounds of groups run longest
-        const bool sp = unit_spatial && p.n_un_all > 0;
-        const Cls cls[] = {{18, p.list_un_all, sp ? p.n_un_all : 0},
-                           {16, p.list_un[2], sp ? 0 : p.n_un[2]}, {17, p.list_un[3], sp ? 0 : p.n_un[3]}, {15, p.list_un[1], sp ? 0 : p.n_un[1]}, {14, p.list_un[0], sp ? 0 : p.n_un[0]},
+        (void)unit_spatial;   // (class-by-class unit lists exist only as per-class launches: BEVW_PLAN_ONELAUNCH=0)
+        const Cls cls[] = {{18, p.list_un_all, p.n_un_all},
                            bt_last ? none : bt_cls, {8, p.list_pr[3], p.n_pr[3]}, {11, p.list_pr[6], p.n_pr[6]}, {7, p.list_pr[2], p.n_pr[2]}, {3, l_single, n_single},
                            {10, p.list_pr[5], p.n_pr[5]}, {13, p.list_sm, p.n_sm}, {9, p.list_pr[4], p.n_pr[4]}, {6, p.list_pr[1], p.n_pr[1]},
                            {5, p.list_pr[0], p.n_pr[0]}, bt_last ? bt_cls : none, {2, l_empty, n_empty}};

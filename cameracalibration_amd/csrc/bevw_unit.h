@@ -48,16 +48,18 @@ constexpr int kUnitMaxNQ = 4;                // pixel quads per lane
 constexpr int kUnitMaxGR = 4;                // rounds of kUnitThreads groups
 constexpr int kUnitMaxGroups = kUnitMaxGR * kUnitThreads;        // 1024 group slots = 32 KB of pair entries
 constexpr int kUnitMaxWidth = 256;           // pixels: 64 quads = one wave-store per row
-constexpr int kUnitClasses = 4;
-constexpr int kUnitClassNQ[kUnitClasses] = {4, 4, 2, 1};
-constexpr int kUnitClassGR[kUnitClasses] = {1, 2, 4, 4};
+constexpr int kUnitClasses = 7;               // four single-contributor classes, three for units with up to two contributors per pixel
+constexpr int kUnitClassNQ[kUnitClasses] = {4, 4, 2, 1, 2, 1, 1};
+constexpr int kUnitClassGR[kUnitClasses] = {1, 2, 4, 4, 1, 4, 1};
+constexpr int kUnitClassCON[kUnitClasses] = {1, 1, 1, 1, 2, 2, 2};
 constexpr uint32_t kUnitSkip = 1u << 22;     // entry of pixel 0 of a quad, with equal slots: the quad's base tile belongs to another class -> not stored
 
 // unit descriptor: 8 dwords, read with scalar loads
 struct UnitDesc {
     uint32_t pos;        // x0 (int16: the unskewed left edge, may be negative) | y0 << 16 (pixels)
     uint32_t shape;      // w | h << 16 (pixels; w a multiple of 4)
-    uint32_t ent_off;    // entries of the unit start at un_entries[ent_off * 64] (one uint4 = 4 pixels per lane and slot)
+    uint32_t ent_off;    // entries of the unit start at un_entries[ent_off * 64]: per quad slot one uint4 per lane (4 pixels); two-contributor
+                         // classes three (first entries, second entries, the two u8 blend weights of every pixel as w0 | w1 << 8)
     uint32_t gs_off;     // group offsets of the unit start at un_gsrc[gs_off * kUnitThreads]
     uint32_t lq;         // log2 of the lanes per row (quads per row rounded up to a power of two, >= 4)
     uint32_t sum_tile;   // balance: psums slot (a base tile owned by this unit)
@@ -117,6 +119,8 @@ struct UnitTuning {
     int line_cost = 2, sector_cost = 3;
     int align_lines = 1;             // group slots: the groups of one source line stay inside one 64-lane load instruction
     int own_empty = 1;               // base tiles without a contributor are unit tiles
+    int own_double = 1;              // base tiles with a second contributor or a blend weight are unit tiles (classes with two entries per pixel)
+    int wide_double = 1;             // the two-quad class of those units (its blend variant needs 177+ VGPRs: off for blend handles)
     int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
 };
 
@@ -130,35 +134,42 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     const uint32_t frame_bytes = (uint32_t)fw * fh * 3, gpr = (uint32_t)fw / 4;
     const size_t set_bytes = (size_t)frame_bytes * ncams;
     constexpr uint32_t kNone = 0xffffffffu;
-    // ---- per pixel: footprint offset + fraction code of the (only) contributor; base tiles a unit may own --------------------
+    // ---- per pixel: footprint offset, fraction code and weight of up to two contributors; base tiles a unit may own ------------
+    // own: 0 = not a unit tile (border footprints, claimed already), 1 = single-contributor unit tile (every weight 255),
+    //      2 = unit tile with a second contributor or a blend weight somewhere (seams, blend overlaps)
     std::vector<uint8_t> own((size_t)tiles_x * tiles_y, 0);
     for (size_t t = 0; t < own.size(); ++t) {
-        own[t] = (hdr[t] & (kHdrSlow | kHdrSecond | kHdrBlock)) ? 0 : 1;
+        own[t] = (hdr[t] & (kHdrSlow | kHdrBlock)) ? 0 : ((hdr[t] & kHdrSecond) ? (tune.own_double ? 2 : 0) : 1);
         if ((hdr[t] & kHdrEmpty) && !tune.own_empty) own[t] = 0;
     }
-    std::vector<uint32_t> poff((size_t)pitch * bh, kNone), pcode((size_t)pitch * bh, 0u);
+    std::vector<uint32_t> poff[2], pcode[2];
+    std::vector<uint8_t> pmask[2];
+    for (int k = 0; k < 2; ++k) { poff[k].assign((size_t)pitch * bh, kNone); pcode[k].assign((size_t)pitch * bh, 0u); pmask[k].assign((size_t)pitch * bh, 0); }
     for (int y = 0; y < bh; ++y)
         for (int x = 0; x < bw; ++x) {
             const size_t t = (size_t)(y / 8) * tiles_x + x / 32;
             if (!own[t]) continue;
             const size_t o = (size_t)y * bw + x;
+            int count = 0;
             for (int c = 0; c < ncams; ++c) {
                 const uint32_t m = mask[c][o];
                 if (m == 0) continue;
                 const int sx = lut1[c][o * 2], sy = lut1[c][o * 2 + 1];
                 if (sx >= fw || sx + 1 < 0 || sy >= fh || sy + 1 < 0) continue;   // whole footprint outside: adds 0
                 const uint32_t off = (uint32_t)c * frame_bytes + ((uint32_t)sy * fw + sx) * 3;
-                if ((size_t)(off / 12u + gpr) * 12u + 16u > set_bytes) { own[t] = 2; break; }   // the last group's 16-byte window would overrun
-                if (m != 255u) { own[t] = 2; break; }                                            // a blend weight: the tile keeps its blend-aware class
-                poff[(size_t)y * pitch + x] = off;
-                pcode[(size_t)y * pitch + x] = lut2[c][o] & (kQTab2 - 1);
-                break;   // single-contributor tiles: the first contributor is the only one
+                if ((size_t)(off / 12u + gpr) * 12u + 16u > set_bytes || count >= 2) { own[t] = 0; break; }   // the last group's window would overrun
+                if (m != 255u && own[t] == 1) own[t] = tune.own_double ? 2 : 0;                            // a blend weight
+                poff[count][(size_t)y * pitch + x] = off;
+                pcode[count][(size_t)y * pitch + x] = lut2[c][o] & (kQTab2 - 1);
+                pmask[count][(size_t)y * pitch + x] = (uint8_t)m;
+                ++count;
             }
         }
     for (int y = 0; y < bh; ++y)      // base tiles dropped above: their pixels leave the units
         for (int x = 0; x < bw; ++x)
-            if (own[(size_t)(y / 8) * tiles_x + x / 32] != 1) poff[(size_t)y * pitch + x] = kNone;
-    auto owned = [&](int x, int y) { return x < bw && y < bh && own[(size_t)(y / 8) * tiles_x + x / 32] == 1; };
+            if (own[(size_t)(y / 8) * tiles_x + x / 32] == 0) poff[0][(size_t)y * pitch + x] = poff[1][(size_t)y * pitch + x] = kNone;
+    int pass = 1;                     // the kind of base tile the partition pass at hand owns (1: single, 2: double)
+    auto owned = [&](int x, int y) { return x < bw && y < bh && own[(size_t)(y / 8) * tiles_x + x / 32] == pass; };
     // rows of P = 3 pitch bytes: byte P y + 12 q is a multiple of 64 <=> q = -(P / 4) * 11 * y (mod 16)   (3 * 11 = 1 mod 16).  Only when
     // every image of a batch starts on a sector boundary (P * bh a multiple of 64; the batch base is assumed 64-byte aligned -- with any
     // other base the plan is still correct, just not sector-aligned).
@@ -186,47 +197,75 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
             for (int u = x0; u < x0 + w; ++u) {
                 const int x = px_x(u, y);
                 if (x < 0 || x >= pitch) continue;
-                if ((x & 3) == 0 && owned(x, y)) ++s.quads;
-                const uint32_t off = poff[(size_t)y * pitch + x];
-                if (off == kNone) continue;
-                ++s.pixels;
-                for (uint32_t r = 0; r < 2; ++r) {
-                    const uint32_t k = off / 12u + r * gpr;
-                    if (gstamp[k] == stamp) continue;
-                    gstamp[k] = stamp;
-                    ++s.groups;
-                    const uint32_t a = k * 12u;
-                    for (uint32_t l = a >> 7; l <= (a + 15u) >> 7; ++l)
-                        if (lstamp[l] != stamp) { lstamp[l] = stamp; ++s.lines; }
+                if (!owned(x & ~3, y)) continue;
+                if ((x & 3) == 0) ++s.quads;
+                for (int con = 0; con < 2; ++con) {
+                    const uint32_t off = poff[con][(size_t)y * pitch + x];
+                    if (off == kNone) continue;
+                    ++s.pixels;
+                    for (uint32_t r = 0; r < 2; ++r) {
+                        const uint32_t k = off / 12u + r * gpr;
+                        if (gstamp[k] == stamp) continue;
+                        gstamp[k] = stamp;
+                        ++s.groups;
+                        const uint32_t a = k * 12u;
+                        for (uint32_t l = a >> 7; l <= (a + 15u) >> 7; ++l)
+                            if (lstamp[l] != stamp) { lstamp[l] = stamp; ++s.lines; }
+                    }
                 }
             }
         return s;
     };
-    auto write_sectors = [&](int x0, int y0, int w, int h) {   // 64-byte sectors the row runs of the rectangle touch
+    auto write_sectors = [&](int x0, int y0, int w, int h) {   // 64-byte sectors the row runs of the rectangle's OWNED quads touch
         long n = 0;
         for (int y = y0; y < y0 + h; ++y) {
             const int xa = std::max(0, px_x(x0, y)), xb = std::min(pitch, px_x(x0 + w, y));
-            if (xa >= xb) continue;
-            const long a0 = ((long)y * pitch + xa) * 3, a1 = ((long)y * pitch + xb) * 3;
-            n += (a1 - 1) / 64 - a0 / 64 + 1;
+            int run0 = -1;
+            for (int x = xa; x <= xb; x += 4) {
+                const bool in = x < xb && owned(x, y);
+                if (in && run0 < 0) run0 = x;
+                if (!in && run0 >= 0) {
+                    const long a0 = ((long)y * pitch + run0) * 3, a1 = ((long)y * pitch + x) * 3;
+                    n += (a1 - 1) / 64 - a0 / 64 + 1;
+                    run0 = -1;
+                }
+            }
         }
         return n;
+    };
+    // the rectangle shrunk to the bounding box of its owned quads (columns stay on the column grid)
+    auto shrink = [&](int &x0, int &y0, int &w, int &h) {
+        int ya = y0 + h, yb = y0, ua = x0 + w, ub = x0;
+        for (int y = y0; y < y0 + h; ++y)
+            for (int u = x0; u < x0 + w; u += 4) {
+                const int x = px_x(u, y);
+                if (x < 0 || x >= pitch || !owned(x, y)) continue;
+                ya = std::min(ya, y); yb = std::max(yb, y + 1); ua = std::min(ua, u); ub = std::max(ub, u + 4);
+            }
+        if (yb <= ya) return;
+        const int xa = x0 + (ua - x0) / col_step * col_step, xb = std::min(x0 + w, x0 + (ub - x0 + col_step - 1) / col_step * col_step);
+        x0 = xa; w = xb - xa; y0 = ya; h = yb - ya;
     };
     auto lanes_log2 = [](int w) { int lq = 2; while ((4 << lq) < w) ++lq; return lq; };   // quads per row rounded up to 4 .. 64 lanes
     auto slots_needed = [&](int w, int h) { const int rps = 64 >> lanes_log2(w); return (h + rps - 1) / rps; };
 
     // ---- emit one unit ---------------------------------------------------------------------------------------------------------
+    const int root_w = std::min(tune.root_w, kUnitMaxWidth);
+    struct Order { uint64_t key; uint32_t entry; };
+    std::vector<Order> order;       // every unit with its place in the launch order: root cell by root cell, both passes interleaved
     std::vector<uint32_t> keys, slot;
     auto emit = [&](int x0, int y0, int w, int h, const Stats &st) {
         keys.clear();
         for (int y = y0; y < y0 + h; ++y)
             for (int u = x0; u < x0 + w; ++u) {
                 const int x = px_x(u, y);
-                if (x < 0 || x >= pitch) continue;
-                const uint32_t off = poff[(size_t)y * pitch + x];
-                if (off == kNone) continue;
-                keys.push_back(off / 12u);
-                keys.push_back(off / 12u + gpr);
+                if (x < 0 || x >= pitch || !owned(x & ~3, y)) continue;
+                for (int con = 0; con < 2; ++con) {
+                    const uint32_t off = poff[con][(size_t)y * pitch + x];
+                    if (off == kNone) continue;
+                    keys.push_back(off / 12u);
+                    keys.push_back(off / 12u + gpr);
+                }
             }
         std::sort(keys.begin(), keys.end());
         keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
@@ -244,12 +283,13 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         // class: the cheapest (NQ, GR) that holds the unit (cost ~ 4 pixels x 14 VALU per quad slot, 8 v_perm + 2 ds_write per round)
         int cls = -1, best = 1 << 30;
         for (int c = 0; c < kUnitClasses; ++c) {
-            if (kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < (int)used) continue;
+            if (kUnitClassCON[c] != pass || kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < (int)used) continue;
+            if (c == 4 && !tune.wide_double) continue;
             const int cost = kUnitClassNQ[c] * 64 + kUnitClassGR[c] * 14;
             if (cost < best) { best = cost; cls = c; }
         }
         if (cls < 0) return false;
-        const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls];
+        const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], parts = pass == 2 ? 3 : 1;
         UnitDesc d;
         d.pos = (uint32_t)(uint16_t)(int16_t)x0 | ((uint32_t)y0 << 16);
         d.shape = (uint32_t)w | ((uint32_t)h << 16);
@@ -261,29 +301,32 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         d.pixels = (uint32_t)st.pixels;
         auto slot_of = [&](uint32_t key) { return slot[(size_t)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin())]; };
         const size_t e0 = out.entries.size();
-        out.entries.resize(e0 + (size_t)NQ * kUnitWaves * 64 * 4, 0u);
+        out.entries.resize(e0 + (size_t)NQ * kUnitWaves * parts * 64 * 4, 0u);
         bool have_sum_tile = false;
         for (int sidx = 0; sidx < NQ * kUnitWaves; ++sidx)
             for (int lane = 0; lane < 64; ++lane) {
                 int qx, row;
                 unit_quad((uint32_t)lq, sidx, lane, qx, row);
                 const int y = y0 + row, x = px_x(x0 + 4 * qx, y);
-                uint32_t *e = out.entries.data() + e0 + ((size_t)sidx * 64 + lane) * 4;   // the lane's 4 pixels
+                uint32_t *e = out.entries.data() + e0 + (((size_t)sidx * parts) * 64 + lane) * 4;   // the lane's 4 pixels; part k at e + k * 256
                 if (4 * qx >= w || row >= h || x < 0 || x >= pitch) continue;   // lane without a quad: zero entries, masked in the kernel
                 if (!owned(x, y)) { e[0] = kUnitSkip; continue; }
                 if (!have_sum_tile) { d.sum_tile = (uint32_t)((y / 8) * tiles_x + x / 32); have_sum_tile = true; }
-                for (int p = 0; p < 4; ++p) {
-                    const uint32_t off = poff[(size_t)y * pitch + x + p];
-                    if (off == kNone) continue;
-                    const uint32_t key = off / 12u, pk = (off - key * 12u) / 3u;
-                    e[p] = unit_entry(slot_of(key), slot_of(key + gpr), pk, pcode[(size_t)y * pitch + x + p]);
-                }
+                for (int p = 0; p < 4; ++p)
+                    for (int con = 0; con < pass; ++con) {
+                        const uint32_t off = poff[con][(size_t)y * pitch + x + p];
+                        if (off == kNone) continue;
+                        const uint32_t key = off / 12u, pk = (off - key * 12u) / 3u;
+                        e[con * 256 + p] = unit_entry(slot_of(key), slot_of(key + gpr), pk, pcode[con][(size_t)y * pitch + x + p]);
+                        if (pass == 2) e[2 * 256 + p] |= (uint32_t)pmask[con][(size_t)y * pitch + x + p] << (8 * con);
+                    }
             }
         const size_t g0 = out.gsrc.size();
         out.gsrc.resize(g0 + (size_t)GR * kUnitThreads, kPairNoGroup);
         for (int i = 0; i < count; ++i) out.gsrc[g0 + slot[(size_t)i]] = keys[(size_t)i] * 12u;
         out.list[cls].push_back((uint32_t)out.desc.size());
-        out.all.push_back((uint32_t)out.desc.size() | ((uint32_t)cls << 28));
+        order.push_back({((uint64_t)(y0 / tune.root_h) << 48) | ((uint64_t)((x0 + 64) / root_w) << 32) | (uint64_t)order.size(),
+                         (uint32_t)out.desc.size() | ((uint32_t)cls << 28)});
         out.desc.push_back(d);
         const size_t ws = (size_t)write_sectors(x0, y0, w, h);
         out.lines += (size_t)st.lines;
@@ -295,18 +338,21 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     // ---- k-d partition -----------------------------------------------------------------------------------------------------------
     struct Cell { int x0, y0, w, h; };
     std::vector<Cell> stack;
-    const int root_w = std::min(tune.root_w, kUnitMaxWidth);
+    for (pass = 1; pass <= 2; ++pass) {
     for (int y0 = 0; y0 < bh; y0 += tune.root_h)
         for (int x0 = skew ? -col_step : 0; x0 < pitch; x0 += root_w) stack.push_back({x0, y0, std::min(root_w, pitch - x0), std::min(tune.root_h, bh - y0)});
     std::reverse(stack.begin(), stack.end());   // pop in row-major order: neighbouring units are neighbours in the class lists
     while (!stack.empty()) {
-        const Cell c = stack.back();
+        Cell c = stack.back();
         stack.pop_back();
+        shrink(c.x0, c.y0, c.w, c.h);
         const Stats st = cell_stats(c.x0, c.y0, c.w, c.h);
         if (st.quads == 0) continue;              // nothing a unit owns in here
         bool fits = false;   // some class holds the rectangle (emit decides finally: line-aligned slots may need a few more)
         for (int k = 0; k < kUnitClasses; ++k)
-            fits = fits || (st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
+            fits = fits || (kUnitClassCON[k] == pass && !(k == 4 && !tune.wide_double) && st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
+        // a rectangle that is mostly other classes' quads (a seam crossing it diagonally) idles most of its lanes: cut it further
+        if (fits && (long)st.quads * 8 < (long)(c.w / 4) * c.h * 3 && (long)c.w * c.h > 1024) fits = false;
         if (fits && emit(c.x0, c.y0, c.w, c.h, st)) continue;
         // split: rows at a multiple of the rows per wave-slot, columns at a multiple of 16 pixels; the cheaper cut wins
         long best = -1;
@@ -341,19 +387,22 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         stack.push_back(b);
         stack.push_back(a);
     }
+    }
+    std::sort(order.begin(), order.end(), [](const Order &l, const Order &r) { return l.key < r.key; });
+    for (const Order &o : order) out.all.push_back(o.entry);
     for (size_t t = 0; t < own.size(); ++t)
-        if (own[t] == 1) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
+        if (own[t] != 0) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // CPU emulation of one unit and one frame: the per-lane steps of plan_unit_body in program order (group loads -> pair conversion
 // -> patch -> pixel interpolation -> 12-byte stores), with the same helpers.  Test infrastructure (tests/native/unit_emulate.cpp).
 // ---------------------------------------------------------------------------------------------------------------------------------
-static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, const uint8_t *frame_set, size_t set_bytes,
+static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, const uint8_t *frame_set, size_t set_bytes, bool blend,
                                 const uint8_t *car, int pitch, uint8_t *out_img, uint32_t sums[3] = nullptr, std::vector<uint8_t> *written = nullptr)
 {
     const UnitDesc &d = up.desc[unit];
-    const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls];
+    const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], NCON = kUnitClassCON[cls], parts = NCON == 2 ? 3 : 1;
     std::vector<uint8_t> patch((size_t)kUnitMaxGroups * 32, 0xcd);
     if (d.groups != 0)
         for (int r = 0; r < GR; ++r)
@@ -374,18 +423,27 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                 const int sidx = unit_slot(wave, j);
                 int qx, row;
                 unit_quad(d.lq, sidx, lane, qx, row);
-                const uint32_t *e = up.entries.data() + ((size_t)d.ent_off * 64 + (size_t)sidx * 64 + lane) * 4;
-                uint32_t acc[4][3] = {};
+                const uint32_t *e = up.entries.data() + (((size_t)d.ent_off + (size_t)sidx * parts) * 64 + lane) * 4;   // part k at e + k * 256
+                uint32_t P[4] = {0, 0, 0, 0};
                 if (d.groups != 0)
                     for (int p = 0; p < 4; ++p) {
-                        uint32_t i0, i1, wxa, wy;
-                        unit_decode(e[p], i0, i1, wxa, wy);
-                        uint2 q0, q1;
-                        memcpy(&q0, patch.data() + (size_t)i0 * 8, 8);
-                        memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
-                        bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc[p]);
+                        int px[3] = {0, 0, 0};
+                        for (int con = 0; con < NCON; ++con) {
+                            uint32_t i0, i1, wxa, wy, acc[3];
+                            unit_decode(e[con * 256 + p], i0, i1, wxa, wy);
+                            uint2 q0, q1;
+                            memcpy(&q0, patch.data() + (size_t)i0 * 8, 8);
+                            memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
+                            bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc);
+                            const float wf = NCON == 2 ? blend_weight_f32((int)((e[2 * 256 + p] >> (8 * con)) & 255u)) : 1.f;
+                            for (int k = 0; k < 3; ++k) {
+                                const int v = (int)((acc[k] >> 16) & 255u), c = (blend && NCON == 2) ? (int)((float)v * wf) : v;
+                                px[k] = con == 0 ? c : (px[k] + c < 255 ? px[k] + c : 255);
+                            }
+                        }
+                        P[p] = (uint32_t)px[0] | ((uint32_t)px[1] << 8) | ((uint32_t)px[2] << 16);
                         if (sums)
-                            for (int k = 0; k < 3; ++k) sums[k] += (acc[p][k] >> 16) & 255u;
+                            for (int k = 0; k < 3; ++k) sums[k] += (uint32_t)px[k];
                     }
                 uint32_t i0, i1, wxa, wy;
                 unit_decode(e[0], i0, i1, wxa, wy);
@@ -394,14 +452,11 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                 uint32_t o[3];
                 const size_t ooff = ((size_t)(uy + row) * pitch + x) * 3;
                 if (car) {
-                    uint32_t P[4], c[3];
-                    for (int p = 0; p < 4; ++p) P[p] = ((acc[p][0] >> 16) & 255u) | (((acc[p][1] >> 16) & 255u) << 8) | (((acc[p][2] >> 16) & 255u) << 16);
+                    uint32_t c[3];
                     memcpy(c, car + ooff, 12);
                     add_car(P, c[0], c[1], c[2]);
-                    pack_pixels(P, o[0], o[1], o[2]);
-                } else {
-                    pack_accs(acc, o[0], o[1], o[2]);
                 }
+                pack_pixels(P, o[0], o[1], o[2]);
                 memcpy(out_img + ooff, o, 12);
                 if (written) for (int k = 0; k < 4; ++k) ++(*written)[(size_t)(uy + row) * pitch + x + k];
             }
@@ -416,10 +471,14 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 // The groups of the next TWO frames are in flight in registers in both cases.  Register budget: 16 registers per quad slot
 // (LDS indices and weights of 4 pixels) + 8 per round of groups in flight; nothing else lives across the frame loop -- the car
 // sprite is re-read per frame by the few units that lie under it.
-template <bool SUMS, int NQ, int GR>
+// NCON == 2: two plan entries and two blend weights per pixel (seams, blend overlaps): second contribution added with saturation
+// (cv2.add, surroundBEV.py:318-320), weights applied as trunc(f32(v) * w) when BLEND (surroundBEV.py:279-280).
+template <bool BLEND, bool SUMS, int NQ, int GR, int NCON>
 __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
 {
-    static_assert(NQ >= 1 && NQ <= kUnitMaxNQ && GR >= 1 && GR <= kUnitMaxGR, "unit class");
+    static_assert(NQ >= 1 && NQ <= kUnitMaxNQ && GR >= 1 && GR <= kUnitMaxGR && (NCON == 1 || NCON == 2), "unit class");
+    constexpr int kParts = NCON == 2 ? 3 : 1;          // uint4 per lane and quad slot in the plan
+    constexpr bool kWeights = BLEND && NCON == 2;
     const uint32_t *dp = reinterpret_cast<const uint32_t *>(a.un_desc + unit);
     const uint32_t pos = __builtin_amdgcn_readfirstlane(dp[0]), shape = __builtin_amdgcn_readfirstlane(dp[1]);
     const uint32_t ent_off = __builtin_amdgcn_readfirstlane(dp[2]), gs_off = __builtin_amdgcn_readfirstlane(dp[3]);
@@ -432,7 +491,8 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     constexpr int kPatch = GR * kUnitThreads * 32;              // one frame's pair entries
     constexpr bool DB = 2 * kPatch <= kUnitMaxGroups * 32;      // both halves fit the block's 32 KB
 
-    uint32_t i0[NQ][4], i1[NQ][4], wxa[NQ][4], wy[NQ][4], gs[GR], ooff_masked[NQ];
+    uint32_t i0[NQ][NCON][4], i1[NQ][NCON][4], wxa[NQ][NCON][4], wy[NQ][NCON][4], gs[GR], ooff_masked[NQ];
+    float wf[NQ][NCON][4];
     const bool with_car = !SUMS && a.car != nullptr;
     const __amdgpu_buffer_rsrc_t rcar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(with_car ? a.car : a.out), 0,
                                                                           with_car ? (uint32_t)img_bytes : 0u, kBufferWord3);
@@ -444,11 +504,22 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         unit_quad(lq, sidx, lane, qx, row);
         const int x = ux + 4 * qx + unit_skew((uint32_t)a.un_skew, uy + row);
         const uint32_t ooff = ((uint32_t)(uy + row) * a.pitch + (uint32_t)x) * 3;
-        const uint4 e4 = a.un_entries[((size_t)ent_off + sidx) * 64 + lane];   // the lane's 4 pixels of this slot
-        const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+        uint32_t e0 = 0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][p], i1[j][p], wxa[j][p], wy[j][p]);
-        const bool store = 4 * qx < uw && row < uh && x >= 0 && x < a.pitch && !(wxa[j][0] == 0 && (e[0] & kUnitSkip));
+        for (int con = 0; con < NCON; ++con) {
+            const uint4 e4 = a.un_entries[((size_t)ent_off + sidx * kParts + con) * 64 + lane];   // the lane's 4 pixels of this slot
+            const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
+            if (con == 0) e0 = e[0];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][con][p], i1[j][con][p], wxa[j][con][p], wy[j][con][p]);
+        }
+        if (kWeights) {
+            const uint4 w4 = a.un_entries[((size_t)ent_off + sidx * kParts + 2) * 64 + lane];
+            const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { wf[j][0][p] = blend_weight_f32((int)(w[p] & 255u)); wf[j][NCON - 1][p] = blend_weight_f32((int)((w[p] >> 8) & 255u)); }
+        }
+        const bool store = 4 * qx < uw && row < uh && x >= 0 && x < a.pitch && !(wxa[j][0][0] == 0 && (e0 & kUnitSkip));
         ooff_masked[j] = store ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: neither read (car) nor written
         const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
         car_or |= c.x | c.y | c.z;
@@ -509,13 +580,29 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         for (int j = 0; j < NQ; ++j) {
             uint32_t acc[4][3];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) bilinear_pairs(pw[i0[j][p]], pw[i1[j][p]], wxa[j][p], wxa[j][p] << 16, wy[j][p], acc[p]);
-            if (!SUMS && !car_any) {
+            for (int p = 0; p < 4; ++p) bilinear_pairs(pw[i0[j][0][p]], pw[i1[j][0][p]], wxa[j][0][p], wxa[j][0][p] << 16, wy[j][0][p], acc[p]);
+            if (NCON == 1 && !SUMS && !car_any) {
                 pack_accs(acc, d[j][0], d[j][1], d[j][2]);
             } else {
                 uint32_t P[4];
+                if (NCON == 1) {
 #pragma unroll
-                for (int p = 0; p < 4; ++p) P[p] = acc_to_px(acc[p]);
+                    for (int p = 0; p < 4; ++p) P[p] = acc_to_px(acc[p]);
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        uint32_t acc1[3];
+                        bilinear_pairs(pw[i0[j][NCON - 1][p]], pw[i1[j][NCON - 1][p]], wxa[j][NCON - 1][p], wxa[j][NCON - 1][p] << 16, wy[j][NCON - 1][p], acc1);
+                        uint32_t px = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const uint32_t v0 = (acc[p][k] >> 16) & 255u, v1 = (acc1[k] >> 16) & 255u;
+                            const int c0 = kWeights ? (int)((float)v0 * wf[j][0][p]) : (int)v0, c1 = kWeights ? (int)((float)v1 * wf[j][NCON - 1][p]) : (int)v1;
+                            px |= (uint32_t)min(255, c0 + c1) << (8 * k);
+                        }
+                        P[p] = px;
+                    }
+                }
                 if (SUMS) {
                     // a lane's 4 pixels sum to <= 1020 per channel and a wave to <= 65280: B and G travel packed through the butterfly
                     uint32_t sb = 0, sg = 0, sr = 0;
@@ -566,38 +653,42 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 }
 
 // block -> (chunk, unit) of a class list
-template <bool SUMS, int NQ, int GR>
+template <bool BLEND, bool SUMS, int CLS>
 __device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
 {
     uint32_t chunk, group;
     if (!plan_block_map(a, block_id, chunk, group)) return;   // uniform over the block
     if ((int)group >= a.nlist) return;
-    plan_unit_run<SUMS, NQ, GR>(a, chunk, __builtin_amdgcn_readfirstlane(a.tile_list[group]), lds);
+    plan_unit_run<BLEND, SUMS, kUnitClassNQ[CLS], kUnitClassGR[CLS], kUnitClassCON[CLS]>(a, chunk, __builtin_amdgcn_readfirstlane(a.tile_list[group]), lds);
 }
 
 // block -> (chunk, unit) of the list of ALL units in the partition's own (spatial) order, class in bits 28..31: neighbouring units run
 // at the same time on the same XCD, whatever their class, so the two halves of a sector that two units share meet in the L2
-template <bool SUMS>
+template <bool BLEND, bool SUMS>
 __device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
 {
     uint32_t chunk, group;
     if (!plan_block_map(a, block_id, chunk, group)) return;
     if ((int)group >= a.nlist) return;
     const uint32_t e = __builtin_amdgcn_readfirstlane(a.tile_list[group]), unit = e & 0x0fffffffu;
+#define BEVW_UNIT_CASE(C) case C: plan_unit_run<BLEND, SUMS, kUnitClassNQ[C], kUnitClassGR[C], kUnitClassCON[C]>(a, chunk, unit, lds); break;
     switch (e >> 28) {
-        case 0: plan_unit_run<SUMS, kUnitClassNQ[0], kUnitClassGR[0]>(a, chunk, unit, lds); break;
-        case 1: plan_unit_run<SUMS, kUnitClassNQ[1], kUnitClassGR[1]>(a, chunk, unit, lds); break;
-        case 2: plan_unit_run<SUMS, kUnitClassNQ[2], kUnitClassGR[2]>(a, chunk, unit, lds); break;
-        default: plan_unit_run<SUMS, kUnitClassNQ[3], kUnitClassGR[3]>(a, chunk, unit, lds); break;
+        BEVW_UNIT_CASE(0) BEVW_UNIT_CASE(1) BEVW_UNIT_CASE(2) BEVW_UNIT_CASE(3)
+        // class 4 (two quads per lane, two contributors): its blend variant would set the kernel's register budget (177 .. 197 VGPRs);
+        // plans of blend handles are compiled without it (UnitTuning::wide_double)
+        case 4: if (!BLEND) plan_unit_run<false, SUMS, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4]>(a, chunk, unit, lds); break;
+        BEVW_UNIT_CASE(5)
+        default: plan_unit_run<BLEND, SUMS, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6]>(a, chunk, unit, lds); break;
     }
+#undef BEVW_UNIT_CASE
 }
 
 // the unit classes as kernels of their own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit the per-class profiles are taken on)
-template <bool SUMS, int NQ, int GR>
+template <bool BLEND, bool SUMS, int CLS>
 __global__ void __launch_bounds__(kUnitThreads) k_plan_unit(PlanArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
-    plan_unit_body<SUMS, NQ, GR>(a, blockIdx.x, patch);
+    if (!(BLEND && CLS == 4)) plan_unit_body<BLEND && CLS != 4, SUMS, CLS>(a, blockIdx.x, patch);   // (no class-4 units in a blend plan)
 }
 
 }  // namespace bevw

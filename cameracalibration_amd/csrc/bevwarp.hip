@@ -64,7 +64,7 @@ static int use_device(int device)
 }
 
 static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int ncams = 4, bool seam_tiles = true,
-                      int out_pitch = 0)
+                      int out_pitch = 0, bool blend = false)
 {
     static const int lx_env = [] { const char *s = getenv("BEVW_PLAN_LX"); return s ? atoi(s) : 0; }();
     static const int orient_env = [] { const char *s = getenv("BEVW_PLAN_ORIENT"); return s ? atoi(s) : 0; }();
@@ -84,11 +84,17 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
         if (const char *s = getenv("BEVW_UNIT_SECTOR_COST")) t.sector_cost = atoi(s);
         if (const char *s = getenv("BEVW_UNIT_ALIGN_LINES")) t.align_lines = atoi(s);
         if (const char *s = getenv("BEVW_UNIT_OWN_EMPTY")) t.own_empty = atoi(s);
+        if (const char *s = getenv("BEVW_UNIT_OWN_DOUBLE")) t.own_double = atoi(s);
         if (const char *s = getenv("BEVW_UNIT_SKEW")) t.skew = atoi(s);
         return t;
     }();
+    UnitTuning tune = unit_tune;
+    if (blend) tune.wide_double = 0;   // the blend kernels carry no two-quad two-contributor class (bevw_unit.h: plan_unit_any)
+    // balance handles (seam_tiles == false): two-contributor units measured 4 % slower under the per-unit channel sums than the per-wave
+    // pair classes (profiles/r03/sweeps.log), as the seam block tiles of round 2 did
+    if (!seam_tiles && !getenv("BEVW_UNIT_OWN_DOUBLE")) tune.own_double = 0;
     hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
-                                   block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, unit_tune, out_pitch);
+                                   block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, tune, out_pitch);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }
@@ -1123,7 +1129,7 @@ int bevw_build(bevw_handle *h)
     }
     // (seam block tiles: measured +0.7 % slower under the per-tile channel sums of the balance path, -1.4 .. -1.8 % without: sweeps.log)
     h->pitch_px = h->pitch_request == BEVW_PITCH_DENSE ? bw : (h->pitch_request == BEVW_PITCH_ALIGNED ? (bw + 63) / 64 * 64 : h->pitch_request);
-    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams, cfg.balance == 0, h->pitch_px != bw ? h->pitch_px : 0));
+    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams, cfg.balance == 0, h->pitch_px != bw ? h->pitch_px : 0, cfg.blend != 0));
     if (h->shard_n) {
         if (!h->plan.usable) return fail(BEVW_E_INVALID, "camera shard needs the tile plan: %d contributors on some pixel", h->plan.max_contrib);
         // bounding box of the owned masks, widened to multiples of 4 pixels in x so that packed rows stay dword aligned

@@ -9,7 +9,7 @@
 // is stored exactly once, no quad of an unclaimed base tile is touched, group lists are ascending and inside the frame set.
 //
 // file mode: unit_emulate <in> <out>
-//   in : int32 fw fh bw bh ncams nframes has_car | per camera: int16 lut1[bh][bw][2], uint16 lut2[bh][bw], uint8 mask[bh][bw]
+//   in : int32 fw fh bw bh ncams nframes has_car blend | per camera: int16 lut1[bh][bw][2], uint16 lut2[bh][bw], uint8 mask[bh][bw]
 //        | uint8 frames[nframes][ncams][fh][fw][3] | uint8 car[bh][bw][3] if has_car
 //   out: int32 nunits claimed_tiles lines sectors | uint8 written[bh][bw] | uint8 image[nframes][bh][bw][3] (unwritten pixels 0)
 #include <cstdio>
@@ -23,7 +23,7 @@ using namespace bevw;
 #define CHECK(c, ...) do { if (!(c)) { fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); return 1; } } while (0)
 
 struct Rig {
-    int fw, fh, bw, bh, ncams, nframes;
+    int fw, fh, bw, bh, ncams, nframes, blend = 0;
     std::vector<int16_t> l1[4];
     std::vector<uint16_t> l2[4];
     std::vector<uint8_t> mk[4];
@@ -57,12 +57,16 @@ static std::vector<uint32_t> host_headers(const Rig &r, int tiles_x, int tiles_y
     return hdr;
 }
 
+// the reference's arithmetic for one BEV pixel: per camera remap (fixed-point bilinear), mask (direct: select, blend: trunc(f32(v) * f32(m / 255.0)),
+// surroundBEV.py:161-162 / 279-280), saturating adds in camera order (surroundBEV.py:318-320)
 static int expected_px(const Rig &r, int b, int x, int y, int out[3])
 {
     out[0] = out[1] = out[2] = 0;
     const size_t o = (size_t)y * r.bw + x;
+    int n = 0;
     for (int c = 0; c < r.ncams; ++c) {
-        if (r.mk[c][o] == 0) continue;
+        const int m = r.mk[c][o];
+        if (m == 0) continue;
         const int sx = r.l1[c][o * 2], sy = r.l1[c][o * 2 + 1];
         if (sx >= r.fw || sx + 1 < 0 || sy >= r.fh || sy + 1 < 0) continue;
         const int fx = r.l2[c][o] & 31, fy = (r.l2[c][o] >> 5) & 31;
@@ -70,11 +74,13 @@ static int expected_px(const Rig &r, int b, int x, int y, int out[3])
         for (int k = 0; k < 3; ++k) {
             const int p00 = f[((size_t)sy * r.fw + sx) * 3 + k], p01 = f[((size_t)sy * r.fw + sx + 1) * 3 + k];
             const int p10 = f[((size_t)(sy + 1) * r.fw + sx) * 3 + k], p11 = f[((size_t)(sy + 1) * r.fw + sx + 1) * 3 + k];
-            out[k] = ((p00 * (32 - fx) + p01 * fx) * (32 - fy) + (p10 * (32 - fx) + p11 * fx) * fy + 512) >> 10;
+            int v = ((p00 * (32 - fx) + p01 * fx) * (32 - fy) + (p10 * (32 - fx) + p11 * fx) * fy + 512) >> 10;
+            if (r.blend) v = (int)((float)v * (float)((double)m / 255.0));
+            out[k] = std::min(255, out[k] + v);
         }
-        return 1;
+        ++n;
     }
-    return 0;
+    return n;
 }
 
 static int run(const Rig &r, const char *out_path)
@@ -92,6 +98,9 @@ static int run(const Rig &r, const char *out_path)
     if (const char *e = getenv("BEVW_UNIT_SECTOR_COST")) tune.sector_cost = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_ALIGN_LINES")) tune.align_lines = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_OWN_EMPTY")) tune.own_empty = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_OWN_DOUBLE")) tune.own_double = atoi(e);
+    tune.wide_double = r.blend ? 0 : 1;   // as plan_build does for blend handles
+    if (const char *e = getenv("BEVW_UNIT_WIDE_DOUBLE")) tune.wide_double = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_SKEW")) tune.skew = atoi(e);
     unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune);
     CHECK(!up.desc.empty(), "no unit compiled");
@@ -100,7 +109,7 @@ static int run(const Rig &r, const char *out_path)
     for (size_t t = 0; t < hdr.size(); ++t) {
         if (hdr[t] & kHdrBlock) {
             ++claimed;
-            CHECK(!(hdr0[t] & (kHdrSlow | kHdrSecond)), "base tile %zu claimed although it is slow / double", t);
+            CHECK(!(hdr0[t] & kHdrSlow), "base tile %zu claimed although it has border footprints", t);
         }
     }
     CHECK(claimed == up.claimed_tiles, "claimed tiles %zu != %zu", claimed, up.claimed_tiles);
@@ -135,7 +144,7 @@ static int run(const Rig &r, const char *out_path)
     for (int b = 0; b < r.nframes; ++b) {
         std::vector<uint8_t> wr((size_t)pitch * r.bh, 0);
         for (size_t u = 0; u < up.desc.size(); ++u)
-            unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.car.empty() ? nullptr : r.car.data(), pitch,
+            unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.blend != 0, r.car.empty() ? nullptr : r.car.data(), pitch,
                          img.data() + (size_t)b * pitch * r.bh * 3, nullptr, &wr);
         if (b == 0) written = wr;
         size_t bad = 0;
@@ -159,7 +168,7 @@ static int run(const Rig &r, const char *out_path)
     {
         uint32_t sums[3] = {0, 0, 0};
         std::vector<uint8_t> tmp((size_t)pitch * r.bh * 3, 0);
-        for (size_t u = 0; u < up.desc.size(); ++u) unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data(), set_bytes, nullptr, pitch, tmp.data(), sums);
+        for (size_t u = 0; u < up.desc.size(); ++u) unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data(), set_bytes, r.blend != 0, nullptr, pitch, tmp.data(), sums);
         unsigned long long want[3] = {0, 0, 0};
         for (int y = 0; y < r.bh; ++y)
             for (int x = 0; x < r.bw; ++x)
@@ -172,7 +181,7 @@ static int run(const Rig &r, const char *out_path)
     }
     printf("unit schedule ok: %zu units (classes", up.desc.size());
     for (int c = 0; c < kUnitClasses; ++c)
-        printf(" %dx%d:%zu[px %zu groups %zu lines %zu sectors %zu]", kUnitClassNQ[c], kUnitClassGR[c], up.list[c].size(), up.cls_pixels[c], up.cls_groups[c],
+        printf(" %dx%d%s:%zu[px %zu groups %zu lines %zu sectors %zu]", kUnitClassNQ[c], kUnitClassGR[c], kUnitClassCON[c] == 2 ? "d" : "", up.list[c].size(), up.cls_pixels[c], up.cls_groups[c],
                up.cls_lines[c], up.cls_sectors[c]);
     printf("), %zu of %zu base tiles claimed, %zu source lines + %zu write sectors per frame\n", claimed, hdr.size(), up.lines, up.sectors);
     if (out_path) {
@@ -193,9 +202,9 @@ int main(int argc, char **argv)
     if (argc >= 2) {
         FILE *f = fopen(argv[1], "rb");
         CHECK(f, "cannot read %s", argv[1]);
-        int32_t head[7];
-        CHECK(fread(head, 4, 7, f) == 7, "short header");
-        r.fw = head[0]; r.fh = head[1]; r.bw = head[2]; r.bh = head[3]; r.ncams = head[4]; r.nframes = head[5];
+        int32_t head[8];
+        CHECK(fread(head, 4, 8, f) == 8, "short header");
+        r.fw = head[0]; r.fh = head[1]; r.bw = head[2]; r.bh = head[3]; r.ncams = head[4]; r.nframes = head[5]; r.blend = head[7];
         const size_t npx = (size_t)r.bw * r.bh;
         for (int c = 0; c < r.ncams; ++c) {
             r.l1[c].resize(npx * 2); r.l2[c].resize(npx); r.mk[c].resize(npx);
@@ -230,6 +239,9 @@ int main(int argc, char **argv)
     uint32_t seed = 12345u;
     for (uint8_t &v : r.frames) { seed = seed * 1664525u + 1013904223u; v = (uint8_t)(seed >> 24); }
     if (run(r, nullptr)) return 1;
+    r.blend = 1;            // the same tables read as blend weights (the 200 stripe is a real weight now, the overlap columns add two weighted terms)
+    if (run(r, nullptr)) return 1;
+    r.blend = 0;
     // once more with a car sprite over part of the image
     r.car.assign(npx * 3, 0);
     for (int y = 30; y < 90; ++y) for (int x = 50; x < 210; ++x) for (int k = 0; k < 3; ++k) r.car[((size_t)y * r.bw + x) * 3 + k] = (uint8_t)(x + 2 * y + 40 * k);

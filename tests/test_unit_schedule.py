@@ -38,14 +38,14 @@ def exe(tmp_path_factory):
 def test_units_on_synthetic_tables(exe):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("unit schedule ok") == 2   # without and with a car sprite
+    assert r.stdout.count("unit schedule ok") == 3   # direct, the same tables as blend weights, direct with a car sprite
 
 
-def _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh):
+def _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh, blend=False):
     """luts: [(int16 [bh,bw,2], uint16 [bh,bw])], masks: [uint8 [bh,bw]], frames: uint8 [n, ncams, fh, fw, 3]"""
     inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(inp, "wb") as f:
-        f.write(struct.pack("<7i", fw, fh, bw, bh, len(luts), frames.shape[0], int(car is not None)))
+        f.write(struct.pack("<8i", fw, fh, bw, bh, len(luts), frames.shape[0], int(car is not None), int(blend)))
         for (m1, m2), mk in zip(luts, masks):
             f.write(np.ascontiguousarray(m1, np.int16).tobytes())
             f.write(np.ascontiguousarray(m2, np.uint16).tobytes())
@@ -67,8 +67,8 @@ def _mask2d(m):
 
 
 @pytest.mark.parametrize("name,cfg,rig,blend,max_requests", [
-    # requests per frame = distinct source lines + write sectors of the partition; round 2's schedule paid ~136 k on config 3
-    ("config3_direct", W.CONFIG_S, W.rig_s, False, 108_000),
+    # requests per frame = distinct source lines + write sectors of the partition; every base tile of config 3 is a unit tile; round 2 paid ~136 k
+    ("config3_direct", W.CONFIG_S, W.rig_s, False, 112_000),
     ("config3_blend", W.CONFIG_S, W.rig_s, True, None),
     ("rig_4k_blend", W.CONFIG_4K, W.rig_4k, True, None),
 ])
@@ -84,10 +84,10 @@ def test_units_on_bench_rigs_match_the_oracle(exe, tmp_path, name, cfg, rig, ble
     car[y0:y0 + ch + 40, x0:x0 + cw + 40] = rng.integers(0, 256, (ch + 40, cw + 40, 3), dtype=np.uint8)
     luts = [cam.bev_maps for cam in gen.cameras]
     masks = [_mask2d(m) for m in gen.masks]
-    got = _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh)
+    got = _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh, blend)
     ref = gen(*[frames[0, i] for i in range(4)], car)
     w = got["written"] == 1
-    assert w.sum() > 0.5 * bw * bh, got["log"]          # the units take the bulk of the image
+    assert w.sum() > 0.95 * bw * bh, got["log"]         # the units take all of the image but the base tiles with border footprints
     assert np.array_equal(got["img"][0][w], ref[w]), name
     assert not got["img"][0][~w].any()
     if max_requests is not None:
