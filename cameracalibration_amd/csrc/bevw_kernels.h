@@ -466,22 +466,46 @@ __device__ __forceinline__ bool analytic_project(const AnalyticRig &R, int c, in
     return true;
 }
 
-// bilinear interpolation of the footprint in F, BORDER_CONSTANT 0 per tap, round half to even
+// bilinear interpolation of the footprint in F, BORDER_CONSTANT 0 per tap, round half to even.
+// Interior footprints of 4-byte aligned frames (every footprint but the ones on the frame border) are fetched as two aligned 12-byte
+// windows, one per footprint row, and realigned with v_alignbyte (two vector loads per contributor instead of twelve byte loads).
 template <bool BAL, typename F>
 __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src, int fw, int fh, const AnalyticTap<F> &tp, int out[3], int delta,
-                                                const int *sdiv, const int *hdiv)
+                                                const int *sdiv, const int *hdiv, bool aligned)
 {
     F t[4][3];
+    const size_t toff = ((size_t)tp.sy * fw + tp.sx) * 3;
+    if (aligned && (unsigned)tp.sx < (unsigned)(fw - 1) && (unsigned)tp.sy < (unsigned)(fh - 1) &&
+        (toff & ~(size_t)3) + (size_t)fw * 3 + 12 <= (size_t)fw * fh * 3) {
+        const uint32_t mis = (uint32_t)toff & 3u;
+        const uint32_t *p0 = reinterpret_cast<const uint32_t *>(src + (toff & ~(size_t)3));
+        const uint32_t *p1 = reinterpret_cast<const uint32_t *>(src + ((toff + (size_t)fw * 3) & ~(size_t)3));
+        const uint32_t mis1 = (uint32_t)(toff + (size_t)fw * 3) & 3u;
+        const uint32_t a0 = p0[0], a1 = p0[1], a2 = p0[2], b0 = p1[0], b1 = p1[1], b2 = p1[2];
+        // 8 footprint bytes of a row (B0 G0 R0 B1 G1 R1 x x) from the 12-byte window around them
+        const uint32_t r0x = __builtin_amdgcn_alignbyte(a1, a0, mis), r0y = __builtin_amdgcn_alignbyte(a2, a1, mis);
+        const uint32_t r1x = __builtin_amdgcn_alignbyte(b1, b0, mis1), r1y = __builtin_amdgcn_alignbyte(b2, b1, mis1);
+        int px[4][3] = {{(int)(r0x & 255u), (int)((r0x >> 8) & 255u), (int)((r0x >> 16) & 255u)},
+                        {(int)(r0x >> 24), (int)(r0y & 255u), (int)((r0y >> 8) & 255u)},
+                        {(int)(r1x & 255u), (int)((r1x >> 8) & 255u), (int)((r1x >> 16) & 255u)},
+                        {(int)(r1x >> 24), (int)(r1y & 255u), (int)((r1y >> 8) & 255u)}};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tx = tp.sx + (q & 1), ty = tp.sy + (q >> 1);
-        if ((unsigned)tx < (unsigned)fw && (unsigned)ty < (unsigned)fh) {
-            const uint8_t *p = src + ((size_t)ty * fw + tx) * 3;
-            int b = p[0], g = p[1], rr = p[2];
-            if (BAL) luminance_shift_px(b, g, rr, delta, sdiv, hdiv);
-            t[q][0] = (F)b; t[q][1] = (F)g; t[q][2] = (F)rr;
-        } else {
-            t[q][0] = t[q][1] = t[q][2] = (F)0;
+        for (int q = 0; q < 4; ++q) {
+            if (BAL) luminance_shift_px(px[q][0], px[q][1], px[q][2], delta, sdiv, hdiv);
+            t[q][0] = (F)px[q][0]; t[q][1] = (F)px[q][1]; t[q][2] = (F)px[q][2];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int tx = tp.sx + (q & 1), ty = tp.sy + (q >> 1);
+            if ((unsigned)tx < (unsigned)fw && (unsigned)ty < (unsigned)fh) {
+                const uint8_t *p = src + ((size_t)ty * fw + tx) * 3;
+                int b = p[0], g = p[1], rr = p[2];
+                if (BAL) luminance_shift_px(b, g, rr, delta, sdiv, hdiv);
+                t[q][0] = (F)b; t[q][1] = (F)g; t[q][2] = (F)rr;
+            } else {
+                t[q][0] = t[q][1] = t[q][2] = (F)0;
+            }
         }
     }
 #pragma unroll
@@ -493,7 +517,7 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
 
 // grid = (ceil(bw / 256), bh, ceil(batch / kAnalyticFrames)): a thread evaluates the projection of its pixel once per call and samples
 // kAnalyticFrames frames with it (the calibration of a handle is the same for every frame of a call; no table ever reaches memory)
-constexpr int kAnalyticFrames = 8;
+constexpr int kAnalyticFrames = 32;   // (8: the projection was a third of a 64-frame call; profiles/r03/sweeps.log)
 template <bool BLEND, bool BAL, typename F>
 __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh, int batch,
                                   const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
@@ -511,6 +535,9 @@ __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, in
     const int b_begin = blockIdx.z * kAnalyticFrames, b_end = min(batch, b_begin + kAnalyticFrames);
     const size_t frame_bytes = (size_t)fw * fh * 3;
     const size_t o = (size_t)y * bw + (x < bw ? x : 0);
+    // dword accesses: frames on 4-byte boundaries (window loads) / rows of whole pixel quads on 4-byte boundaries (12-byte stores)
+    const bool aligned = (frame_bytes & 3) == 0 && (((uintptr_t)frames) & 3) == 0;
+    const bool quad_store = (bw & 3) == 0 && (((uintptr_t)out) & 3) == 0;
     AnalyticTap<F> tap[4];
     int cam[4], msk[4], n = 0;
     if (x < bw) {
@@ -528,8 +555,8 @@ __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, in
             ++n;
         }
     }
-#pragma unroll 1
-    for (int b = b_begin; b < b_end; ++b) {
+#pragma unroll 4
+    for (int b = b_begin; b < b_end; ++b) {   // (unrolled: the footprint loads of four frames are in flight together)
         int acc[3] = {0, 0, 0};
         if (x < bw) {
 #pragma unroll
@@ -537,18 +564,30 @@ __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, in
                 if (k >= n) break;
                 const uint8_t *src = frames + ((size_t)b * 4 + cam[k]) * frame_bytes;
                 int v[3];
-                analytic_sample<BAL, F>(src, fw, fh, tap[k], v, BAL ? deltas[b * 4 + cam[k]] : 0, sdiv, hdiv);
+                analytic_sample<BAL, F>(src, fw, fh, tap[k], v, BAL ? deltas[b * 4 + cam[k]] : 0, sdiv, hdiv, aligned);
                 if (BLEND) {
                     const float wgt = blend_weight_f32(msk[k]);
                     v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
                 }
                 acc[0] = min(255, acc[0] + v[0]); acc[1] = min(255, acc[1] + v[1]); acc[2] = min(255, acc[2] + v[2]);
             }
-            uint8_t *d = out + ((size_t)b * bw * bh + o) * 3;
             if (!BAL && car != nullptr) {
                 acc[0] = min(255, acc[0] + car[o * 3]); acc[1] = min(255, acc[1] + car[o * 3 + 1]);
                 acc[2] = min(255, acc[2] + car[o * 3 + 2]);
             }
+        }
+        if (quad_store) {
+            // the 4 lanes of a pixel quad hand their pixels to the first one, which stores 12 bytes (bw % 4 == 0: a quad is inside the
+            // image or outside as a whole; blockDim.x is a multiple of 4)
+            const uint32_t P = (uint32_t)acc[0] | ((uint32_t)acc[1] << 8) | ((uint32_t)acc[2] << 16);
+            const int l0 = (int)(threadIdx.x & 63u) & ~3;
+            const uint32_t P0 = __shfl(P, l0, 64), P1 = __shfl(P, l0 + 1, 64), P2 = __shfl(P, l0 + 2, 64), P3 = __shfl(P, l0 + 3, 64);
+            if ((threadIdx.x & 3u) == 0 && x < bw) {
+                uint32_t *d = reinterpret_cast<uint32_t *>(out + ((size_t)b * bw * bh + o) * 3);
+                d[0] = P0 | (P1 << 24); d[1] = (P1 >> 8) | (P2 << 16); d[2] = (P2 >> 16) | (P3 << 8);
+            }
+        } else if (x < bw) {
+            uint8_t *d = out + ((size_t)b * bw * bh + o) * 3;
             d[0] = (uint8_t)acc[0]; d[1] = (uint8_t)acc[1]; d[2] = (uint8_t)acc[2];
         }
         if (BAL) {
