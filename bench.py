@@ -76,6 +76,7 @@ def parse_args():
                     help="row pitch of the device-resident BEV images (bevw_set_output_pitch): aligned = rows of whole 64-byte sectors "
                          "(1080 -> 1088 pixels, cv::cuda::GpuMat style), dense = the reference's host layout; the other layout is measured "
                          "too and reported beside the headline")
+    ap.add_argument("--single-layout", action="store_true", help="skip the measurement of the other device-image layout (profiling runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -342,7 +343,7 @@ def main():
             return make_buffers, g.sync, g.timer_start, g.timer_stop, g.timer_mark, g.timer_between
         bev, t_build = engine(layouts[0])
         make_buffers, sync, tstart, tstop, tmark, tbetween = harness(bev)
-        if len(layouts) > 1:
+        if len(layouts) > 1 and not a.single_layout:
             other_layout = (layouts[1], lambda: harness(engine(layouts[1])[0]))
         info = bev.plan_info()
         extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"],
@@ -442,7 +443,9 @@ def main():
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
-        "metric": w["metric"], "value": value, "unit": w["unit"], "n_gpus": d.world, "steps": a.steps,
+        # n_gpus = distinct devices the ranks ran on (ranks sharing one GPU -- the gloo plumbing check on a 1-GPU box -- are not GPUs)
+        "metric": w["metric"], "value": value, "unit": w["unit"], "n_gpus": min(d.world, max(1, _ffi.device_count())), "ranks": d.world,
+        "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True,
         "scaling": "strong" if (w["kind"] == "camera" and d.world <= 4) else "weak",
         "vs_baseline": None, "dtype": "u8", "data": "synthetic",

@@ -8,28 +8,34 @@ mkdir -p $O
 cd $R
 timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
-for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k; do
-  timeout 300 python bench.py --workload $w 2>/dev/null | tail -1 > $O/bench_$w.json
-  python -c "import json;d=json.load(open('$O/bench_$w.json'));print('$w',round(d['value']),d['unit'],'frac',round(d['roofline']['frac'],3),'cpu',d['cpu_baseline'] and round(d['cpu_baseline']['value'],1))"
+for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k direct_stitch_analytic_f32_b64 direct_stitch_analytic_f64_b64; do
+  timeout 600 python bench.py --workload $w 2>/dev/null | tail -1 > $O/bench_$w.json
+  python -c "import json;d=json.load(open('$O/bench_$w.json'));o=d.get('other_output_layout');print('$w',round(d['value']),d['unit'],'ms',round(d['ms_per_step'],4),'frac',round(d['roofline']['frac'],3),'placements',d['placements']['ms_per_step'],'| other layout',o and (o['output_layout'],round(o['ms_per_step'],4)),'| cpu',d['cpu_baseline'] and round(d['cpu_baseline']['value'],1))"
 done
 BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
-  bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
+  bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 --placements 1 --single-layout 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
 python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
 cd /tmp && export TMPDIR=/tmp
 for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k; do
   rm -rf /tmp/kt_$w
-  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
+  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
   case $w in blend_b256|blend_4k) continue;; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c
-    timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1
+    timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --single-layout --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1
     cp $(find /tmp/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${w}_$c.csv 2>/dev/null
   done
 done
 # per-class times of config 3: the same step launched class by class (BEVW_PLAN_ONELAUNCH=0)
 rm -rf /tmp/kt_classes
-BEVW_PLAN_ONELAUNCH=0 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_classes -- python $R/bench.py --workload direct_stitch_b256 --steps 10 --warmup 2 --no-cpu-baseline > /tmp/kt_classes.log 2>&1
+BEVW_PLAN_ONELAUNCH=0 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_classes -- python $R/bench.py --workload direct_stitch_b256 --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline > /tmp/kt_classes.log 2>&1
 cp $(find /tmp/kt_classes -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_direct_stitch_b256_per_class.csv
 cd $R
 python tools/summarize_pmc.py $O
+# request / latency counters of the merged stitch kernel (config 3, both device-image layouts) and of config 4's kernels
+bash tools/r03/pmc_merged.sh final/pmc_direct_stitch_aligned direct_stitch_b256 "" --single-layout > /dev/null 2>&1
+bash tools/r03/pmc_merged.sh final/pmc_direct_stitch_dense direct_stitch_b256 "" --single-layout --output-pitch dense > /dev/null 2>&1
+bash tools/r03/pmc_merged.sh final/pmc_blend_balance blend_balance_b256 "" --single-layout > /dev/null 2>&1
+for t in pmc_direct_stitch_aligned pmc_direct_stitch_dense pmc_blend_balance; do cp $O/$t/summary.txt $O/$t.txt; rm -rf $O/$t; done
+tail -30 $O/pmc_direct_stitch_aligned.txt

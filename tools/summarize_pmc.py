@@ -26,8 +26,8 @@ try:
     CAL = json.load(open(os.path.join(ROOT, "profiles", "pmc_calibration.json")))["factors"]
 except (OSError, ValueError, KeyError):
     CAL = None
-GROUP_LOADERS = ("k_plan_all", "k_plan_pair", "k_plan_block")   # pair-staged stitch kernels
-PER_STEP = ("k_plan_all", "k_plan_block", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
+GROUP_LOADERS = ("k_plan_all", "k_plan_pair", "k_plan_block", "k_plan_unit")   # pair-staged stitch kernels
+PER_STEP = ("k_plan_all", "k_plan_unit", "k_plan_block", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
 
 
 def kernel_sums(path):
@@ -77,7 +77,7 @@ def main(d):
             tw += b
             md.append("| `%s` | %.0f | %.0f |" % (k[:90], a, b))
         md += ["| **sum** | %.0f (%.0f MB) | %.0f (%.0f MB) |" % (tf, tf * 1024 / 1e6, tw, tw * 1024 / 1e6), ""]
-        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 2,
+        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 3,
                       "corrected": bool(CAL)}
     open(os.path.join(d, "rocprofv3_pmc_hbm_traffic.md"), "w").write("\n".join(md) + "\n")
     json.dump(traffic, open(os.path.join(d, "hbm_traffic.json"), "w"), indent=1)
