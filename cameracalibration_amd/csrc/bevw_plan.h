@@ -1282,9 +1282,14 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     // per-tap luminance kernel
     const bool use_staged = !balance && tune.lean && tune.staged && p.paired_ok && (((uintptr_t)d_frames) & 3u) == 0;
     a.batch = batch;
-    // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk
-    int nb = tune.nb > 0 ? tune.nb : 8;
-    if (batch < 8 * nb) nb = batch >= 8 ? batch / 8 : 1;
+    // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk.  A block reads its plan
+    // slice (4 bytes per pixel + the group list) once per chunk: 16 frames per block instead of 8 halve that traffic -- 1.8 M of the
+    // 13.6 M read requests of a config-3 step -- for -5 % (direct), -7 % (blend) (profiles/r03/sweeps.log; 32 frames: the tail of 8 long
+    // chunks costs more than it saves; round 2's 8-byte plan and class-ordered lists measured 16 slower)
+    // Batches of 32 .. 127 frame sets: 8 frames per block even when that leaves fewer than 8 chunks (the 4K rig at batch 32: 4 chunks in
+    // plain chunk-major order, -9 % against 8 chunks of 4 frames).  An explicit BEVW_PLAN_NB is taken as it is.
+    int nb = tune.nb > 0 ? tune.nb : (batch >= 128 ? 16 : (batch >= 32 ? 8 : (batch >= 8 ? batch / 8 : 1)));
+    if (nb > batch) nb = batch;
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
     a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? 1 : 0;
