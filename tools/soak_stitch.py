@@ -1,5 +1,5 @@
 """Parity soak (GPU box): random rigs / sizes / scales / modes / batches through BevGenerator.batch against the oracle.
-Usage: python tools/soak_stitch.py FIRST_SEED LAST_SEED   (prints every mismatch; round 1: seeds 0..600, none)"""
+Usage: python tools/soak_stitch.py FIRST_SEED LAST_SEED   (prints every mismatch; round 1: seeds 0..600, none; round 3 adds the output pitch and batches of 33 / 40 / 130)"""
 import sys, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from cameracalibration_amd import workloads as W
@@ -16,7 +16,7 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
                FOCAL_SCALE=float(rng.choice([0.5, 0.8, 1.0, 1.25, 2.0])), SIZE_SCALE=float(rng.choice([1.0, 1.5, 2.0, 2.5])))
     A = np.diag([fw / 1280.0, fh / 1024.0, 1.0]); U = np.diag([fw * cfg["SIZE_SCALE"] / 2560.0, fh * cfg["SIZE_SCALE"] / 2048.0, 1.0]); Bm = np.diag([bw / 1000.0, bh / 1000.0, 1.0])
     rig = {n: (A @ K, D.copy() * float(rng.choice([0.0, 1.0, 1.5])), Bm @ H @ np.linalg.inv(U)) for n, (K, D, H) in W.repo_rig().items()}
-    blend, balance = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)); batch = int(rng.choice([1, 2, 3, 8, 9, 17]))
+    blend, balance = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)); batch = int(rng.choice([1, 2, 3, 8, 9, 17, 33, 40, 130]))   # 33 / 40: fewer than 8 chunks of 8 frames; 130: chunks of 16
     kind = int(rng.integers(0, 3))
     frames = rng.integers(0, 256, (batch, 4, fh, fw, 3), dtype=np.uint8) if kind == 0 else (np.full((batch, 4, fh, fw, 3), int(rng.integers(0, 256)), np.uint8) if kind == 1 else (rng.integers(0, 256, (batch, 4, fh, fw, 1), dtype=np.uint8).repeat(3, axis=4)))
     frames[:, int(rng.integers(0, 4))] //= 2
@@ -26,7 +26,12 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         car[t:t + ch, l:l + cw] = rng.integers(0, 256, (ch, cw, 3), dtype=np.uint8)
     ns = SB.BevGenerator.get_args()
     for k, v in cfg.items(): setattr(ns, k, v)
-    bev = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=int(rng.choice([0, 0, 1])))
+    sched = int(rng.choice([0, 0, 1]))
+    pitch = 'dense' if sched == 1 else str(rng.choice(['dense', 'aligned']))   # (an output pitch needs the tile plan)
+    try:
+        bev = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=sched, output_pitch=pitch)
+    except Exception:
+        bev = SB.BevGenerator(blend=blend, balance=balance, rig=rig, schedule=sched)   # a rig whose plan is unusable refuses the pitch
     ref = O.RefBevGenerator(rig, cfg, blend=blend, balance=balance)
     got = bev.batch(frames, car)
     for b in range(batch):

@@ -1,18 +1,18 @@
 """Regenerate the measured blocks of DESIGN.md / BASELINE.md / README.md (between `<!-- name:begin -->` / `<!-- name:end -->`
-markers) from profiles/r02_final/bench_*.json, the rocprofv3 kernel statistics and profiles/hbm_traffic.json.  Run after
-tools/collect_profiles.sh and copying its output into profiles/r02_final/."""
+markers) from profiles/r03_final/bench_*.json, the rocprofv3 kernel statistics and profiles/hbm_traffic.json.  Run after
+tools/collect_profiles.sh and copying its output (gpurun_out/final/) into profiles/r03_final/."""
 import csv
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-P = os.path.join(ROOT, "profiles", "r02_final")
-W = ["direct_stitch_b256", "blend_b256", "blend_balance_b256", "undistort_b64", "blend_4k"]
+P = os.path.join(ROOT, "profiles", "r03_final")
+W = ["direct_stitch_b256", "blend_b256", "blend_balance_b256", "undistort_b64", "blend_4k", "direct_stitch_analytic_f32_b64", "direct_stitch_analytic_f64_b64"]
 d = {w: json.load(open(os.path.join(P, "bench_%s.json" % w))) for w in W}
 t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
 ALG = {"direct_stitch_b256": 5532357 * 256, "blend_balance_b256": 22585476 * 256, "undistort_b64": 5421912 * 64}
-R01 = {"direct_stitch_b256": "0.65-0.67 ms, 0.26-0.27 (driver: 0.263)", "blend_b256": "0.739 ms", "blend_balance_b256": "2.311 ms",
-       "undistort_b64": "0.157 ms", "blend_4k": "0.242 ms"}
+R02 = {"direct_stitch_b256": "0.590 ms, 0.30 (driver); 0.51-0.62 by placement", "blend_b256": "0.604 ms", "blend_balance_b256": "2.04 ms",
+       "undistort_b64": "0.111 ms", "blend_4k": "0.239 ms", "direct_stitch_analytic_f32_b64": "0.83 ms", "direct_stitch_analytic_f64_b64": "0.83 ms"}
 
 
 def fmt(v):
@@ -43,25 +43,28 @@ def design():
 
     def row(name, w, unit):
         x, main = d[w], w == "direct_stitch_b256"
-        r, c = x["roofline"], x["cpu_baseline"]
+        r, c, o = x["roofline"], x["cpu_baseline"], x.get("other_output_layout")
         v = fmt(x["value"]) + " " + unit
         fr = "%.3f" % r["frac"]
-        return "| %s | %s | %.3f, %.3f | %s | %s / %s %s | %s |" % (
-            name, "**" + v + "**" if main else v, r["kernel_ms"], r["kernel_ms_median"],
-            ("**" + fr + "** (this run's buffer placement; see below)") if main else fr,
-            format(round(c["value"], 1), ","), format(round(c["value_1_thread"], 1), ","), unit, R01[w])
+        pl = x["placements"]["ms_per_step"]
+        dense = ("%.3f (%.3f)" % (o["ms_per_step"], o["frac"])) if o else "-- (rows are whole sectors already)" if w == "undistort_b64" else "= headline"
+        return "| %s | %s | %.3f (%.3f ... %.3f) | %s | %s | %s / %s %s | %s |" % (
+            name, "**" + v + "**" if main else v, x["ms_per_step"], min(pl), max(pl), ("**" + fr + "**") if main else fr, dense,
+            format(round(c["value"], 1), ","), format(round(c["value_1_thread"], 1), ","), unit, R02[w])
     rows = [row("config 3 direct stitch, batch 256", "direct_stitch_b256", "frames/s"), row("blend only, batch 256", "blend_b256", "frames/s"),
             row("config 4 blend + balance, batch 256", "blend_balance_b256", "frames/s"), row("config 2 undistort, batch 64", "undistort_b64", "images/s"),
-            row("config 5 geometry (4K blend, 1 GPU, batch 32)", "blend_4k", "frames/s")]
-    hdr = ("| Workload | units/s | ms / step (mean, median) | roofline frac | CPU oracle %d threads / 1 thread | round 1 |\n|---|---|---|---|---|---|\n"
+            row("config 5 geometry (4K blend, 1 GPU, batch 32)", "blend_4k", "frames/s"),
+            row("analytic projection fp32, batch 64", "direct_stitch_analytic_f32_b64", "frames/s"),
+            row("analytic projection fp64, batch 64", "direct_stitch_analytic_f64_b64", "frames/s")]
+    hdr = ("| Workload | units/s | ms / step: median placement (min ... max of 5) | roofline frac | dense output layout: ms (frac) | CPU oracle %d threads / 1 thread | round 2 |\n|---|---|---|---|---|---|---|\n"
            % d["direct_stitch_b256"]["cpu_baseline"]["cores"])
     s = between(s, "measured-table", "\n" + hdr + "\n".join(rows) + "\n")
     ks = step_kernels("direct_stitch_b256")
     if len(ks) == 1:
-        txt = "`profiles/r02_final/rocprofv3_kernel_stats_direct_stitch_b256.csv` agrees: `%s` averages %.1f us under the profiler against `kernel_ms` %.3f of the un-profiled run." % (
+        txt = "`profiles/r03_final/rocprofv3_kernel_stats_direct_stitch_b256.csv` agrees: `%s` averages %.1f us under the profiler against `kernel_ms` %.3f of the un-profiled run." % (
             ks[0][0].split("<")[0], ks[0][1], d["direct_stitch_b256"]["roofline"]["kernel_ms"])
     else:
-        txt = "`profiles/r02_final/rocprofv3_kernel_stats_direct_stitch_b256.csv` agrees: %s = %.0f us (%s) against `kernel_ms` %.3f." % (
+        txt = "`profiles/r03_final/rocprofv3_kernel_stats_direct_stitch_b256.csv` agrees: %s = %.0f us (%s) against `kernel_ms` %.3f." % (
             " + ".join("%.1f" % us for _, us in ks), sum(us for _, us in ks), ", ".join("`%s`" % n.split("<")[0] for n, _ in ks),
             d["direct_stitch_b256"]["roofline"]["kernel_ms"])
     s = between(s, "rocprof-sum", txt)
@@ -71,7 +74,7 @@ def design():
         return x["fetch_bytes"] / 1e6, x["write_bytes"] / 1e6, (x["fetch_bytes"] + x["write_bytes"]) / ALG[w]
     a3, a2, a4 = tr("direct_stitch_b256"), tr("undistort_b64"), tr("blend_balance_b256")
     s = between(s, "traffic", "config 3 %s + %s MB = %.2f x the 1.416 GB algorithmic bytes; config 2 %s + %s MB = %.2f x; config 4 %s + %s MB = %.2f x the "
-                              "gather-twice accounting." % (fmt(a3[0]), fmt(a3[1]), a3[2], fmt(a2[0]), fmt(a2[1]), a2[2], fmt(a4[0]), fmt(a4[1]), a4[2]))
+                              "gather-twice accounting (round 2: 1.49 x / 1.27 x / 1.56 x)." % (fmt(a3[0]), fmt(a3[1]), a3[2], fmt(a2[0]), fmt(a2[1]), a2[2], fmt(a4[0]), fmt(a4[1]), a4[2]))
     open(p, "w").write(s)
 
 
@@ -81,21 +84,24 @@ def baseline():
     x = d
     c = lambda w: x[w]["cpu_baseline"]
     tr = t["direct_stitch_b256"]
-    new = ("\n| Measured here (round 2, `profiles/r02_final/`) | units/s | cores / GPUs | notes |\n|---|---|---|---|\n"
+    oth = lambda w: x[w].get("other_output_layout") or {"ms_per_step": x[w]["ms_per_step"], "frac": x[w]["roofline"]["frac"]}
+    new = ("\n| Measured here (round 3, `profiles/r03_final/`; GPU lines: median of 5 buffer placements) | units/s | cores / GPUs | notes |\n|---|---|---|---|\n"
            "| CPU oracle (reference op order, -O3 -march=native, OpenMP), config 3 direct stitch | %.1f frames/s (%.1f on 1 thread) | %d threads of the GPU box's host | `bench.py` `cpu_baseline`, kind \"port\" (cv2 itself is not installable) |\n"
            "| CPU oracle, blend only / config 4 blend+balance / config 2 undistort | %.1f / %.1f frames/s / %s images/s | %d threads | same |\n"
-           "| MI355X, config 3 direct stitch, batch 256 | **%s frames/s** (%.3f ms per step) | 1 GPU | roofline frac %.3f of 8 TB/s on compulsory bytes; measured HBM traffic %.2fx compulsory (calibrated counters); 0.51-0.62 ms for the same build depending on buffer placement (DESIGN.md section 4) |\n"
+           "| MI355X, config 3 direct stitch, batch 256 | **%s frames/s** (%.3f ms per step; dense output layout %.3f ms) | 1 GPU | roofline frac %.3f of 8 TB/s on compulsory bytes (dense layout %.3f); measured HBM traffic %.2fx compulsory (calibrated counters); round 2: 0.590 ms (driver), frac 0.30 |\n"
            "| MI355X, blend only, batch 256 | %s frames/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 4 blend + balance, batch 256 | %s frames/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 2 undistort, batch 64 | %s images/s | 1 GPU | frac %.3f |\n"
            "| MI355X, config 5 geometry (4K blend) on one GPU, batch 32 | %s frames/s | 1 GPU | frac %.3f; the camera-per-GPU form (`bench.py --workload blend_4k_camera_shard`) is built and bit-exact, its RCCL layer exercised world-1 only (1-GPU boxes) |\n"
-           "| Achievable HBM rates (`tools/hbm_stream.hip`, `profiles/r02/hbm_stream.log`) | stream read 6.4, write 5.9, copy 5.35, 9 : 16 read : write mix 5.16 TB/s; random 64-byte gather 3.56, 128-byte 5.9 TB/s | 1 GPU | the stitch moves 2.1 GB per config-3 step at 3.4-4.0 TB/s |\n") % (
+           "| Achievable HBM rates (`tools/hbm_stream.hip`, `profiles/r02/hbm_stream.log`) | stream read 6.4, write 5.9, copy 5.35, 9 : 16 read : write mix 5.16 TB/s; random 64-byte gather 3.56, 128-byte 5.9 TB/s | 1 GPU | the stitch moves %.2f GB per config-3 step |\n") % (
         c("direct_stitch_b256")["value"], c("direct_stitch_b256")["value_1_thread"], c("direct_stitch_b256")["cores"],
         c("blend_b256")["value"], c("blend_balance_b256")["value"], fmt(c("undistort_b64")["value"]), c("blend_b256")["cores"],
-        fmt(x["direct_stitch_b256"]["value"]), x["direct_stitch_b256"]["roofline"]["kernel_ms"], x["direct_stitch_b256"]["roofline"]["frac"],
+        fmt(x["direct_stitch_b256"]["value"]), x["direct_stitch_b256"]["ms_per_step"], oth("direct_stitch_b256")["ms_per_step"],
+        x["direct_stitch_b256"]["roofline"]["frac"], oth("direct_stitch_b256")["frac"],
         (tr["fetch_bytes"] + tr["write_bytes"]) / ALG["direct_stitch_b256"],
         fmt(x["blend_b256"]["value"]), x["blend_b256"]["roofline"]["frac"], fmt(x["blend_balance_b256"]["value"]), x["blend_balance_b256"]["roofline"]["frac"],
-        fmt(x["undistort_b64"]["value"]), x["undistort_b64"]["roofline"]["frac"], fmt(x["blend_4k"]["value"]), x["blend_4k"]["roofline"]["frac"])
+        fmt(x["undistort_b64"]["value"]), x["undistort_b64"]["roofline"]["frac"], fmt(x["blend_4k"]["value"]), x["blend_4k"]["roofline"]["frac"],
+        (tr["fetch_bytes"] + tr["write_bytes"]) / 1e9)
     s = between(s, "measured-rows", new)
     open(p, "w").write(s)
 
@@ -104,12 +110,14 @@ def readme():
     p = os.path.join(ROOT, "README.md")
     s = open(p).read()
     x = d
-    new = ("\n* 1 MI355X, batch 256, 4 x 1280x960 -> 1080x1080, `profiles/r02_final/` (one run; the same build measures 0.51-0.62 ms per step\n"
-           "  depending on where the batch buffers land physically): **%.1f k stitched frames/s** direct (%.0f %% of the 8 TB/s roofline on compulsory\n"
-           "  bytes), %d k blend, %d k blend+balance, %d k undistort images/s, %d k frames/s on the 4K rig; CPU oracle on %d host threads:\n"
-           "  %.0f frames/s (%.0f on one).  The driver's own round-1 run measured 379,472 frames/s (frac 0.264).  Details, profiles and the bound\n"
+    o = x["direct_stitch_b256"].get("other_output_layout") or {}
+    new = ("\n* 1 MI355X, batch 256, 4 x 1280x960 -> 1080x1080, `profiles/r03_final/` (median of 5 buffer placements per line; boxes differ by up to ~10 %%):\n"
+           "  **%.1f k stitched frames/s** direct (%.3f ms per step, %.0f %% of the 8 TB/s roofline on compulsory bytes; %.3f ms with the dense device-output\n"
+           "  layout), %d k blend, %d k blend+balance, %d k undistort images/s, %d k frames/s on the 4K rig; CPU oracle on %d host threads:\n"
+           "  %.0f frames/s (%.0f on one).  The driver's round-2 run measured 433,756 frames/s (0.590 ms, frac 0.30).  Details, profiles and the bound\n"
            "  analysis: `DESIGN.md`, `profiles/`.\n") % (
-        x["direct_stitch_b256"]["value"] / 1e3, x["direct_stitch_b256"]["roofline"]["frac"] * 100, round(x["blend_b256"]["value"] / 1e3),
+        x["direct_stitch_b256"]["value"] / 1e3, x["direct_stitch_b256"]["ms_per_step"], x["direct_stitch_b256"]["roofline"]["frac"] * 100,
+        o.get("ms_per_step", float("nan")), round(x["blend_b256"]["value"] / 1e3),
         round(x["blend_balance_b256"]["value"] / 1e3), round(x["undistort_b64"]["value"] / 1e3), round(x["blend_4k"]["value"] / 1e3),
         x["direct_stitch_b256"]["cpu_baseline"]["cores"], x["direct_stitch_b256"]["cpu_baseline"]["value"],
         x["direct_stitch_b256"]["cpu_baseline"]["value_1_thread"])
