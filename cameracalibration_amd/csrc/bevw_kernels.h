@@ -466,6 +466,28 @@ __device__ __forceinline__ bool analytic_project(const AnalyticRig &R, int c, in
     return true;
 }
 
+// The projection of every BEV pixel of camera c as a table: top-left texel (sx, sy) and the fractions as 21-bit fixed point
+// (bevw_unit.h: kUnitFracBits).  Pixels that sample nothing get sx = sy = INT16_MIN.  Evaluated once per handle and projection mode:
+// the host compiles the unit schedule (bevw_unit.h, wide plan) from it, and the table is dropped again.
+template <typename F>
+__global__ void k_analytic_map(AnalyticRig R, int c, int fw, int fh, int bw, int bh, int16_t *__restrict__ sxy, uint32_t *__restrict__ frac)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= bw || y >= bh) return;
+    const size_t o = (size_t)y * bw + x;
+    AnalyticTap<F> t;
+    if (!analytic_project<F>(R, c, x, y, fw, fh, t)) {
+        sxy[o * 2] = sxy[o * 2 + 1] = (int16_t)-32768;
+        frac[o * 2] = frac[o * 2 + 1] = 0u;
+        return;
+    }
+    const F one = (F)(1u << 21);
+    const uint32_t top = (1u << 21) - 1u;
+    sxy[o * 2] = (int16_t)t.sx; sxy[o * 2 + 1] = (int16_t)t.sy;
+    frac[o * 2] = min(top, (uint32_t)rint(t.ax * one));
+    frac[o * 2 + 1] = min(top, (uint32_t)rint(t.ay * one));
+}
+
 // bilinear interpolation of the footprint in F, BORDER_CONSTANT 0 per tap, round half to even.
 // Interior footprints of 4-byte aligned frames (every footprint but the ones on the frame border) are fetched as two aligned 12-byte
 // windows, one per footprint row, and realigned with v_alignbyte (two vector loads per contributor instead of twelve byte loads).
@@ -516,13 +538,15 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
 }
 
 // grid = (ceil(bw / 256), bh, ceil(batch / kAnalyticFrames)): a thread evaluates the projection of its pixel once per call and samples
-// kAnalyticFrames frames with it (the calibration of a handle is the same for every frame of a call; no table ever reaches memory)
+// kAnalyticFrames frames with it (the calibration of a handle is the same for every frame of a call; no table ever reaches memory).
+// tiles != nullptr: grid = (number of listed tiles, 1, chunks) -- a block takes one 32 x 8 base tile of the list (the tiles the unit
+// schedule of the analytic mode leaves over: frame-border footprints)
 constexpr int kAnalyticFrames = 32;   // (8: the projection was a third of a 64-frame call; profiles/r03/sweeps.log)
 template <bool BLEND, bool BAL, typename F>
 __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh, int batch,
                                   const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                                   const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
-                                  uint8_t *__restrict__ out)
+                                  uint8_t *__restrict__ out, const uint32_t *__restrict__ tiles = nullptr, int tiles_x = 0)
 {
     __shared__ int sdiv[256], hdiv[256];
     __shared__ unsigned long long part[3][4];
@@ -530,8 +554,14 @@ __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, in
         for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
         __syncthreads();
     }
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
+    int x = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (tiles != nullptr) {
+        const int t = (int)tiles[blockIdx.x];
+        x = (t % tiles_x) * 32 + (int)(threadIdx.x & 31u);
+        y = (t / tiles_x) * 8 + (int)(threadIdx.x >> 5);
+        if (y >= bh) { x = bw; y = 0; }     // below the image: an idle lane
+    }
     const int b_begin = blockIdx.z * kAnalyticFrames, b_end = min(batch, b_begin + kAnalyticFrames);
     const size_t frame_bytes = (size_t)fw * fh * 3;
     const size_t o = (size_t)y * bw + (x < bw ? x : 0);

@@ -1327,6 +1327,33 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     return hipSuccess;
 }
 
+// a plan that holds only a WIDE unit schedule (analytic projection mode: bevwarp.hip analytic_units_build) -> one launch of k_plan_unit_wide
+static inline hipError_t plan_unit_wide_launch(const Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, const uint8_t *d_car,
+                                               uint8_t *d_out, const PlanTuning &tune)
+{
+    if (p.n_un_all == 0) return hipSuccess;
+    PlanArgs a = {};
+    a.frames = d_frames; a.car = d_car; a.out = d_out;
+    a.fw = p.fw; a.fh = p.fh; a.bw = p.bw; a.bh = p.bh; a.pitch = p.pitch;
+    a.tiles_x = p.tiles_x; a.ntiles = p.ntiles; a.ncams = p.ncams;
+    a.un_desc = static_cast<const UnitDesc *>(p.un_desc);
+    a.un_entries = static_cast<const uint4 *>(p.un_entries);
+    a.un_gsrc = static_cast<const uint32_t *>(p.un_gsrc);
+    a.un_skew = p.un_skew;
+    a.batch = batch;
+    int nb = tune.nb > 0 ? tune.nb : (batch >= 128 ? 16 : (batch >= 32 ? 8 : (batch >= 8 ? batch / 8 : 1)));   // as plan_stitch_impl
+    if (nb > batch) nb = batch;
+    a.nb = nb;
+    a.nchunks = (batch + nb - 1) / nb;
+    a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? 1 : 0;
+    a.group_major = 0;
+    a.tile_list = static_cast<const uint32_t *>(p.list_un_all); a.nlist = p.n_un_all; a.ngroups = p.n_un_all;
+    const unsigned grid = a.xcd_affine ? (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8)) : (unsigned)(a.ngroups * a.nchunks);
+    if (blend) hipLaunchKernelGGL((k_plan_unit_wide<true>), dim3(grid), dim3(kUnitThreads), 0, st, a);
+    else hipLaunchKernelGGL((k_plan_unit_wide<false>), dim3(grid), dim3(kUnitThreads), 0, st, a);
+    return hipGetLastError();
+}
+
 // luminance-shift the sampled texel groups of every raw frame of the batch into `scratch` (same layout as `frames`)
 static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch,
                                        const int *d_deltas, const HsvTables *d_tab)

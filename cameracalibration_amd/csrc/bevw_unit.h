@@ -33,6 +33,12 @@
 // line never straddle two 64-lane load instructions (each line is requested once: round 3's first version, with plain
 // ascending slots, requested every sixth line twice).
 //
+// WIDE plans (the analytic projection mode, bevw_set_projection: positions from the camera model instead of the reference's
+// tables, row n1 of DESIGN.md section 0) carry 21-bit fractions: a second dword per pixel holds the low 16 bits of fx and fy,
+// the 5-bit fields of the entry the high bits.  The interpolation then runs in fp32 (bilinear_pairs_f32) on the same patch.
+// A pixel without a contributor points both rows at a group slot no group was dealt to (the masked lane's load returns zeros,
+// which the conversion keeps): it interpolates to 0 whatever its fractions.
+//
 // The plan is compiled on the HOST (unit_compile); tests/native/unit_emulate.cpp runs the same compiler and the per-lane
 // arithmetic below (unit_emulate) on a CPU, so the indexing of this file is checked without a GPU.
 #pragma once
@@ -96,6 +102,35 @@ __host__ __device__ __forceinline__ void unit_decode(uint32_t e, uint32_t &i0, u
     wy = ((32u - fy) << 6) | (fy << 22);
 }
 
+constexpr uint32_t kUnitFracBits = 21;        // wide plans: fraction = value / 2^21
+// wide plans: i0, i1 as unit_decode; the fractions as floats
+__host__ __device__ __forceinline__ void unit_decode_wide(uint32_t e, uint32_t f, uint32_t &i0, uint32_t &i1, float &fx, float &fy)
+{
+    i0 = e & 0xfffu;
+    i1 = ((e >> 10) & 0xffcu) | (e & 3u);
+    fx = (float)((((e >> 22) & 31u) << 16) | (f & 0xffffu)) * (1.0f / (float)(1u << kUnitFracBits));
+    fy = (float)(((e >> 27) << 16) | (f >> 16)) * (1.0f / (float)(1u << kUnitFracBits));
+}
+__host__ __device__ __forceinline__ bool unit_no_contributor(uint32_t e) { return ((e >> 2) & 1023u) == ((e >> 12) & 1023u); }
+// one pixel from its two pair entries in fp32: b0 b1 g0 g1 | r0 r1 of both footprint rows -> B | G << 8 | R << 16, round half to even.
+// (fmaf on both sides: the CPU emulation computes the same bits as the kernel.)
+__host__ __device__ __forceinline__ uint32_t bilinear_pairs_f32(uint2 q0, uint2 q1, float fx, float fy)
+{
+    auto lerp = [](float a, float b, float t) { return fmaf(t, b - a, a); };
+    auto ch = [&](uint32_t w0, uint32_t w1, int s) {
+        const float t = lerp((float)((w0 >> s) & 255u), (float)((w0 >> (s + 8)) & 255u), fx);
+        const float b = lerp((float)((w1 >> s) & 255u), (float)((w1 >> (s + 8)) & 255u), fx);
+        return (uint32_t)rintf(lerp(t, b, fy));     // a convex combination of bytes: 0 .. 255
+    };
+    return ch(q0.x, q1.x, 0) | (ch(q0.x, q1.x, 16) << 8) | (ch(q0.y, q1.y, 0) << 16);
+}
+
+// base-tile headers of a set of tables as k_plan_build leaves them (bevw_plan.h): second contributor / border footprint / empty.
+// (Host twin of that kernel's flags, for plans that are compiled from tables the GPU plan builder never saw: the analytic mode, and
+// tests/native/unit_emulate.cpp.)  A footprint with sx + 1 < 0 (e.g. the analytic map's "no sample" mark, INT16_MIN) contributes nothing.
+static inline std::vector<uint32_t> unit_host_headers(const std::vector<int16_t> lut1[4], const std::vector<uint8_t> mask[4], int ncams, int fw, int fh,
+                                                      int bw, int bh, int tiles_x, int tiles_y);
+
 struct UnitPlanHost {
     std::vector<UnitDesc> desc;
     std::vector<uint32_t> entries;             // per unit: [4 NQ slots][64 lanes][4 pixels]
@@ -104,6 +139,7 @@ struct UnitPlanHost {
     std::vector<uint32_t> all;                 // every unit in partition order: id | class << 28
     size_t claimed_tiles = 0;
     uint32_t skew = 0;                         // unit_skew constant of this plan
+    bool wide = false;                         // 21-bit fractions: one more uint4 per lane, quad slot and contributor
     // request arithmetic of the compiled partition (per frame): distinct 128-byte source lines, 64-byte write sectors
     size_t lines = 0, sectors = 0;
     size_t cls_lines[kUnitClasses] = {}, cls_sectors[kUnitClasses] = {}, cls_pixels[kUnitClasses] = {}, cls_groups[kUnitClasses] = {};
@@ -129,8 +165,11 @@ struct UnitTuning {
 // output row (bw rounded up to 4).  The contributor rule is k_plan_build's.
 static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::vector<uint16_t> lut2[4], const std::vector<uint8_t> mask[4],
                                 int ncams, int fw, int fh, int bw, int bh, int pitch, int tiles_x, int tiles_y, std::vector<uint32_t> &hdr,
-                                UnitPlanHost &out, const UnitTuning &tune = UnitTuning())
+                                UnitPlanHost &out, const UnitTuning &tune = UnitTuning(), const std::vector<uint32_t> *frac = nullptr)
 {
+    // frac != nullptr: a WIDE plan -- frac[c][2 o], frac[c][2 o + 1] = the 21-bit fractions of pixel o (lut2 is not read)
+    const bool wide = frac != nullptr;
+    out.wide = wide;
     const uint32_t frame_bytes = (uint32_t)fw * fh * 3, gpr = (uint32_t)fw / 4;
     const size_t set_bytes = (size_t)frame_bytes * ncams;
     constexpr uint32_t kNone = 0xffffffffu;
@@ -142,9 +181,12 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         own[t] = (hdr[t] & (kHdrSlow | kHdrBlock)) ? 0 : ((hdr[t] & kHdrSecond) ? (tune.own_double ? 2 : 0) : 1);
         if ((hdr[t] & kHdrEmpty) && !tune.own_empty) own[t] = 0;
     }
-    std::vector<uint32_t> poff[2], pcode[2];
+    std::vector<uint32_t> poff[2], pcode[2], pfrac[2];
     std::vector<uint8_t> pmask[2];
-    for (int k = 0; k < 2; ++k) { poff[k].assign((size_t)pitch * bh, kNone); pcode[k].assign((size_t)pitch * bh, 0u); pmask[k].assign((size_t)pitch * bh, 0); }
+    for (int k = 0; k < 2; ++k) {
+        poff[k].assign((size_t)pitch * bh, kNone); pcode[k].assign((size_t)pitch * bh, 0u); pmask[k].assign((size_t)pitch * bh, 0);
+        if (wide) pfrac[k].assign((size_t)pitch * bh, 0u);
+    }
     for (int y = 0; y < bh; ++y)
         for (int x = 0; x < bw; ++x) {
             const size_t t = (size_t)(y / 8) * tiles_x + x / 32;
@@ -160,7 +202,13 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
                 if ((size_t)(off / 12u + gpr) * 12u + 16u > set_bytes || count >= 2) { own[t] = 0; break; }   // the last group's window would overrun
                 if (m != 255u && own[t] == 1) own[t] = tune.own_double ? 2 : 0;                            // a blend weight
                 poff[count][(size_t)y * pitch + x] = off;
-                pcode[count][(size_t)y * pitch + x] = lut2[c][o] & (kQTab2 - 1);
+                if (wide) {
+                    const uint32_t fx = frac[c][o * 2] & ((1u << kUnitFracBits) - 1u), fy = frac[c][o * 2 + 1] & ((1u << kUnitFracBits) - 1u);
+                    pcode[count][(size_t)y * pitch + x] = (fx >> 16) | ((fy >> 16) << 5);
+                    pfrac[count][(size_t)y * pitch + x] = (fx & 0xffffu) | (fy << 16);
+                } else {
+                    pcode[count][(size_t)y * pitch + x] = lut2[c][o] & (kQTab2 - 1);
+                }
                 pmask[count][(size_t)y * pitch + x] = (uint8_t)m;
                 ++count;
             }
@@ -283,13 +331,15 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         // class: the cheapest (NQ, GR) that holds the unit (cost ~ 4 pixels x 14 VALU per quad slot, 8 v_perm + 2 ds_write per round)
         int cls = -1, best = 1 << 30;
         for (int c = 0; c < kUnitClasses; ++c) {
-            if (kUnitClassCON[c] != pass || kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < (int)used) continue;
+            if (kUnitClassCON[c] != pass || kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < (int)used + (wide ? 1 : 0)) continue;
             if (c == 4 && !tune.wide_double) continue;
             const int cost = kUnitClassNQ[c] * 64 + kUnitClassGR[c] * 14;
             if (cost < best) { best = cost; cls = c; }
         }
         if (cls < 0) return false;
-        const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], parts = pass == 2 ? 3 : 1;
+        const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], fpart = pass == 2 ? 3 : 1, parts = fpart + (wide ? pass : 0);
+        // wide: a pixel without a contributor reads the zero slot (the first one no group was dealt to)
+        const uint32_t zent = wide ? unit_entry(used, used, 0u, 0u) : 0u;
         UnitDesc d;
         d.pos = (uint32_t)(uint16_t)(int16_t)x0 | ((uint32_t)y0 << 16);
         d.shape = (uint32_t)w | ((uint32_t)h << 16);
@@ -309,8 +359,11 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
                 unit_quad((uint32_t)lq, sidx, lane, qx, row);
                 const int y = y0 + row, x = px_x(x0 + 4 * qx, y);
                 uint32_t *e = out.entries.data() + e0 + (((size_t)sidx * parts) * 64 + lane) * 4;   // the lane's 4 pixels; part k at e + k * 256
+                if (wide)
+                    for (int p = 0; p < 4; ++p)
+                        for (int con = 0; con < pass; ++con) e[con * 256 + p] = zent;
                 if (4 * qx >= w || row >= h || x < 0 || x >= pitch) continue;   // lane without a quad: zero entries, masked in the kernel
-                if (!owned(x, y)) { e[0] = kUnitSkip; continue; }
+                if (!owned(x, y)) { e[0] = zent | kUnitSkip; continue; }
                 if (!have_sum_tile) { d.sum_tile = (uint32_t)((y / 8) * tiles_x + x / 32); have_sum_tile = true; }
                 for (int p = 0; p < 4; ++p)
                     for (int con = 0; con < pass; ++con) {
@@ -319,6 +372,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
                         const uint32_t key = off / 12u, pk = (off - key * 12u) / 3u;
                         e[con * 256 + p] = unit_entry(slot_of(key), slot_of(key + gpr), pk, pcode[con][(size_t)y * pitch + x + p]);
                         if (pass == 2) e[2 * 256 + p] |= (uint32_t)pmask[con][(size_t)y * pitch + x + p] << (8 * con);
+                        if (wide) e[(fpart + con) * 256 + p] = pfrac[con][(size_t)y * pitch + x + p];
                     }
             }
         const size_t g0 = out.gsrc.size();
@@ -350,7 +404,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         if (st.quads == 0) continue;              // nothing a unit owns in here
         bool fits = false;   // some class holds the rectangle (emit decides finally: line-aligned slots may need a few more)
         for (int k = 0; k < kUnitClasses; ++k)
-            fits = fits || (kUnitClassCON[k] == pass && !(k == 4 && !tune.wide_double) && st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
+            fits = fits || (kUnitClassCON[k] == pass && !(k == 4 && !tune.wide_double) && st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads - (wide ? 1 : 0)) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
         // a rectangle that is mostly other classes' quads (a seam crossing it diagonally) idles most of its lanes: cut it further
         if (fits && (long)st.quads * 8 < (long)(c.w / 4) * c.h * 3 && (long)c.w * c.h > 1024) fits = false;
         if (fits && emit(c.x0, c.y0, c.w, c.h, st)) continue;
@@ -394,6 +448,33 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         if (own[t] != 0) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
 }
 
+static inline std::vector<uint32_t> unit_host_headers(const std::vector<int16_t> lut1[4], const std::vector<uint8_t> mask[4], int ncams, int fw, int fh,
+                                                      int bw, int bh, int tiles_x, int tiles_y)
+{
+    std::vector<uint32_t> hdr((size_t)tiles_x * tiles_y, 0u);
+    std::vector<uint8_t> any(hdr.size(), 0);
+    const uint32_t frame_bytes = (uint32_t)fw * fh * 3;
+    for (int y = 0; y < bh; ++y)
+        for (int x = 0; x < bw; ++x) {
+            const size_t o = (size_t)y * bw + x, t = (size_t)(y / 8) * tiles_x + x / 32;
+            int count = 0;
+            for (int c = 0; c < ncams; ++c) {
+                if (mask[c][o] == 0) continue;
+                const int sx = lut1[c][o * 2], sy = lut1[c][o * 2 + 1];
+                if (sx >= fw || sx + 1 < 0 || sy >= fh || sy + 1 < 0) continue;
+                const bool interior = (unsigned)sx < (unsigned)(fw - 1) && (unsigned)sy < (unsigned)(fh - 1);
+                const uint32_t toff = ((uint32_t)sy * fw + sx) * 3;
+                if (!(interior && (toff & ~3u) + (uint32_t)fw * 3 + 12 <= frame_bytes)) hdr[t] |= kHdrSlow;
+                ++count;
+            }
+            if (count > 1) hdr[t] |= kHdrSecond;
+            if (count > 0) any[t] = 1;
+        }
+    for (size_t t = 0; t < hdr.size(); ++t)
+        if (!any[t]) hdr[t] |= kHdrEmpty;
+    return hdr;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------------
 // CPU emulation of one unit and one frame: the per-lane steps of plan_unit_body in program order (group loads -> pair conversion
 // -> patch -> pixel interpolation -> 12-byte stores), with the same helpers.  Test infrastructure (tests/native/unit_emulate.cpp).
@@ -402,7 +483,7 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                                 const uint8_t *car, int pitch, uint8_t *out_img, uint32_t sums[3] = nullptr, std::vector<uint8_t> *written = nullptr)
 {
     const UnitDesc &d = up.desc[unit];
-    const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], NCON = kUnitClassCON[cls], parts = NCON == 2 ? 3 : 1;
+    const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], NCON = kUnitClassCON[cls], fpart = NCON == 2 ? 3 : 1, parts = fpart + (up.wide ? NCON : 0);
     std::vector<uint8_t> patch((size_t)kUnitMaxGroups * 32, 0xcd);
     if (d.groups != 0)
         for (int r = 0; r < GR; ++r)
@@ -430,11 +511,20 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                         int px[3] = {0, 0, 0};
                         for (int con = 0; con < NCON; ++con) {
                             uint32_t i0, i1, wxa, wy, acc[3];
-                            unit_decode(e[con * 256 + p], i0, i1, wxa, wy);
                             uint2 q0, q1;
-                            memcpy(&q0, patch.data() + (size_t)i0 * 8, 8);
-                            memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
-                            bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc);
+                            if (up.wide) {
+                                float fx, fy;
+                                unit_decode_wide(e[con * 256 + p], e[(fpart + con) * 256 + p], i0, i1, fx, fy);
+                                memcpy(&q0, patch.data() + (size_t)i0 * 8, 8);
+                                memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
+                                const uint32_t P3 = bilinear_pairs_f32(q0, q1, fx, fy);
+                                for (int k = 0; k < 3; ++k) acc[k] = ((P3 >> (8 * k)) & 255u) << 16;
+                            } else {
+                                unit_decode(e[con * 256 + p], i0, i1, wxa, wy);
+                                memcpy(&q0, patch.data() + (size_t)i0 * 8, 8);
+                                memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
+                                bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc);
+                            }
                             const float wf = NCON == 2 ? blend_weight_f32((int)((e[2 * 256 + p] >> (8 * con)) & 255u)) : 1.f;
                             for (int k = 0; k < 3; ++k) {
                                 const int v = (int)((acc[k] >> 16) & 255u), c = (blend && NCON == 2) ? (int)((float)v * wf) : v;
@@ -445,10 +535,8 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                         if (sums)
                             for (int k = 0; k < 3; ++k) sums[k] += (uint32_t)px[k];
                     }
-                uint32_t i0, i1, wxa, wy;
-                unit_decode(e[0], i0, i1, wxa, wy);
                 const int x = ux + 4 * qx + unit_skew(up.skew, uy + row);
-                if (4 * qx >= uw || row >= uh || x < 0 || x >= pitch || (wxa == 0 && (e[0] & kUnitSkip))) continue;   // the lane's store is masked
+                if (4 * qx >= uw || row >= uh || x < 0 || x >= pitch || (unit_no_contributor(e[0]) && (e[0] & kUnitSkip))) continue;   // the lane's store is masked
                 uint32_t o[3];
                 const size_t ooff = ((size_t)(uy + row) * pitch + x) * 3;
                 if (car) {
@@ -473,11 +561,15 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 // sprite is re-read per frame by the few units that lie under it.
 // NCON == 2: two plan entries and two blend weights per pixel (seams, blend overlaps): second contribution added with saturation
 // (cv2.add, surroundBEV.py:318-320), weights applied as trunc(f32(v) * w) when BLEND (surroundBEV.py:279-280).
-template <bool BLEND, bool SUMS, int NQ, int GR, int NCON>
+// WIDE: the plan carries 21-bit fractions and the pixels are interpolated in fp32 (the analytic projection mode); wxa / wy then hold the
+// bit patterns of fx / fy.
+template <bool BLEND, bool SUMS, int NQ, int GR, int NCON, bool WIDE = false>
 __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
 {
     static_assert(NQ >= 1 && NQ <= kUnitMaxNQ && GR >= 1 && GR <= kUnitMaxGR && (NCON == 1 || NCON == 2), "unit class");
-    constexpr int kParts = NCON == 2 ? 3 : 1;          // uint4 per lane and quad slot in the plan
+    static_assert(!(WIDE && SUMS), "wide plans carry no channel sums");
+    constexpr int kFPart = NCON == 2 ? 3 : 1;          // narrow part: the entries of each contributor (+ the blend weights)
+    constexpr int kParts = kFPart + (WIDE ? NCON : 0); // uint4 per lane and quad slot in the plan
     constexpr bool kWeights = BLEND && NCON == 2;
     const uint32_t *dp = reinterpret_cast<const uint32_t *>(a.un_desc + unit);
     const uint32_t pos = __builtin_amdgcn_readfirstlane(dp[0]), shape = __builtin_amdgcn_readfirstlane(dp[1]);
@@ -510,8 +602,19 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             const uint4 e4 = a.un_entries[((size_t)ent_off + sidx * kParts + con) * 64 + lane];   // the lane's 4 pixels of this slot
             const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
             if (con == 0) e0 = e[0];
+            if (WIDE) {
+                const uint4 f4 = a.un_entries[((size_t)ent_off + sidx * kParts + kFPart + con) * 64 + lane];
+                const uint32_t f[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][con][p], i1[j][con][p], wxa[j][con][p], wy[j][con][p]);
+                for (int p = 0; p < 4; ++p) {
+                    float fx, fy;
+                    unit_decode_wide(e[p], f[p], i0[j][con][p], i1[j][con][p], fx, fy);
+                    wxa[j][con][p] = __float_as_uint(fx); wy[j][con][p] = __float_as_uint(fy);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][con][p], i1[j][con][p], wxa[j][con][p], wy[j][con][p]);
+            }
         }
         if (kWeights) {
             const uint4 w4 = a.un_entries[((size_t)ent_off + sidx * kParts + 2) * 64 + lane];
@@ -519,7 +622,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #pragma unroll
             for (int p = 0; p < 4; ++p) { wf[j][0][p] = blend_weight_f32((int)(w[p] & 255u)); wf[j][NCON - 1][p] = blend_weight_f32((int)((w[p] >> 8) & 255u)); }
         }
-        const bool store = 4 * qx < uw && row < uh && x >= 0 && x < a.pitch && !(wxa[j][0][0] == 0 && (e0 & kUnitSkip));
+        const bool store = 4 * qx < uw && row < uh && x >= 0 && x < a.pitch && !(unit_no_contributor(e0) && (e0 & kUnitSkip));
         ooff_masked[j] = store ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: neither read (car) nor written
         const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
         car_or |= c.x | c.y | c.z;
@@ -578,6 +681,32 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         uint32_t tb = 0, tg = 0, tr = 0;
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
+            if (WIDE) {
+                uint32_t P[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    uint32_t v = bilinear_pairs_f32(pw[i0[j][0][p]], pw[i1[j][0][p]], __uint_as_float(wxa[j][0][p]), __uint_as_float(wy[j][0][p]));
+                    if (NCON == 2) {
+                        const uint32_t v1 = bilinear_pairs_f32(pw[i0[j][NCON - 1][p]], pw[i1[j][NCON - 1][p]], __uint_as_float(wxa[j][NCON - 1][p]),
+                                                               __uint_as_float(wy[j][NCON - 1][p]));
+                        uint32_t px = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            const uint32_t a0 = (v >> (8 * k)) & 255u, a1 = (v1 >> (8 * k)) & 255u;
+                            const int c0 = kWeights ? (int)((float)a0 * wf[j][0][p]) : (int)a0, c1 = kWeights ? (int)((float)a1 * wf[j][NCON - 1][p]) : (int)a1;
+                            px |= (uint32_t)min(255, c0 + c1) << (8 * k);
+                        }
+                        v = px;
+                    }
+                    P[p] = v;
+                }
+                if (car_any) {
+                    const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
+                    add_car(P, c.x, c.y, c.z);
+                }
+                pack_pixels(P, d[j][0], d[j][1], d[j][2]);
+                continue;
+            }
             uint32_t acc[4][3];
 #pragma unroll
             for (int p = 0; p < 4; ++p) bilinear_pairs(pw[i0[j][0][p]], pw[i1[j][0][p]], wxa[j][0][p], wxa[j][0][p] << 16, wy[j][0][p], acc[p]);
@@ -679,6 +808,25 @@ __device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_
         case 4: if (!BLEND) plan_unit_run<false, SUMS, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4]>(a, chunk, unit, lds); break;
         BEVW_UNIT_CASE(5)
         default: plan_unit_run<BLEND, SUMS, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6]>(a, chunk, unit, lds); break;
+    }
+#undef BEVW_UNIT_CASE
+}
+
+// wide plans (analytic projection): every unit class in one launch, partition order, as plan_unit_any
+template <bool BLEND>
+__global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) k_plan_unit_wide(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
+    uint32_t chunk, group;
+    if (!plan_block_map(a, blockIdx.x, chunk, group)) return;
+    if ((int)group >= a.nlist) return;
+    const uint32_t e = __builtin_amdgcn_readfirstlane(a.tile_list[group]), unit = e & 0x0fffffffu;
+#define BEVW_UNIT_CASE(C) case C: plan_unit_run<BLEND, false, kUnitClassNQ[C], kUnitClassGR[C], kUnitClassCON[C], true>(a, chunk, unit, patch); break;
+    switch (e >> 28) {
+        BEVW_UNIT_CASE(0) BEVW_UNIT_CASE(1) BEVW_UNIT_CASE(2) BEVW_UNIT_CASE(3)
+        case 4: if (!BLEND) plan_unit_run<false, false, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4], true>(a, chunk, unit, patch); break;
+        BEVW_UNIT_CASE(5)
+        default: plan_unit_run<BLEND, false, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6], true>(a, chunk, unit, patch); break;
     }
 #undef BEVW_UNIT_CASE
 }

@@ -63,6 +63,22 @@ static int use_device(int device)
     return BEVW_OK;
 }
 
+static UnitTuning unit_tuning_env()
+{
+    UnitTuning t;
+    if (const char *s = getenv("BEVW_UNIT_GROUPS")) t.max_groups = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_ROOT_W")) t.root_w = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_ROOT_H")) t.root_h = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_MIN_W")) t.min_w = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_LINE_COST")) t.line_cost = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_SECTOR_COST")) t.sector_cost = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_ALIGN_LINES")) t.align_lines = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_OWN_EMPTY")) t.own_empty = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_OWN_DOUBLE")) t.own_double = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_SKEW")) t.skew = atoi(s);
+    return t;
+}
+
 static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int ncams = 4, bool seam_tiles = true,
                       int out_pitch = 0, bool blend = false)
 {
@@ -74,20 +90,7 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     static const int block_env = [] { const char *s = getenv("BEVW_PLAN_BLOCK"); return s ? atoi(s) : 1; }();   // block tiles (bevw_block.h)
     static const int seam_env = [] { const char *s = getenv("BEVW_PLAN_SEAM"); return s ? atoi(s) : 1; }();      // seam block tiles
     static const int unit_env = [] { const char *s = getenv("BEVW_PLAN_UNITS"); return s ? atoi(s) : 1; }();     // unit schedule (bevw_unit.h)
-    static const UnitTuning unit_tune = [] {
-        UnitTuning t;
-        if (const char *s = getenv("BEVW_UNIT_GROUPS")) t.max_groups = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_ROOT_W")) t.root_w = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_ROOT_H")) t.root_h = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_MIN_W")) t.min_w = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_LINE_COST")) t.line_cost = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_SECTOR_COST")) t.sector_cost = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_ALIGN_LINES")) t.align_lines = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_OWN_EMPTY")) t.own_empty = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_OWN_DOUBLE")) t.own_double = atoi(s);
-        if (const char *s = getenv("BEVW_UNIT_SKEW")) t.skew = atoi(s);
-        return t;
-    }();
+    static const UnitTuning unit_tune = unit_tuning_env();
     UnitTuning tune = unit_tune;
     if (blend) tune.wide_double = 0;   // the blend kernels carry no two-quad two-contributor class (bevw_unit.h: plan_unit_any)
     // balance handles (seam_tiles == false): two-contributor units measured 4 % slower under the per-unit channel sums than the per-wave
@@ -808,6 +811,8 @@ struct bevw_handle {
     int pitch_px = 0;                 // pixels per row of the device-side BEV images (== bev_width unless a pitch was requested)
     DevBuf car_pitched;               // the car sprite with rows of pitch_px pixels (gain pass of a pitched handle)
     AnalyticRig arig;                 // filled by bevw_build
+    Plan aplan;                       // analytic modes: the WIDE unit schedule compiled from the projection (analytic_units_build)
+    int aplan_mode = -1;              // the projection mode aplan was compiled for (-1: none yet)
     // camera-per-GPU mode: the cameras this handle owns (shard_n == 0: all four, the ordinary BevGenerator)
     int shard_n = 0;
     int shard_cams[4] = {0, 1, 2, 3};
@@ -871,10 +876,84 @@ static int stitch_per_pixel(bevw_handle *h, const uint8_t *d_frames, int batch, 
     return launch_check("k_stitch_pp");
 }
 
-// BEVW_PROJ_ANALYTIC(_F32): the per-pixel stitch with the projection evaluated in the kernel (k_stitch_analytic)
+// Analytic modes on the unit schedule: the projection of every BEV pixel is evaluated ONCE per handle and mode on
+// the GPU (k_analytic_map, fp64 or fp32), the host compiles a WIDE unit plan from it (bevw_unit.h: 21-bit fractions, fp32 interpolation
+// from the LDS patch), and the map is dropped.  Base tiles the units do not take (frame-border footprints) stay on k_stitch_analytic.
+// Leaves h->aplan without units when the geometry does not allow them (the caller then runs the per-pixel kernel on everything).
+static int analytic_units_build(bevw_handle *h)
+{
+    const bevw_config &c = h->cfg;
+    Plan &p = h->aplan;
+    plan_release(p);
+    h->aplan_mode = h->projection;
+    static const int units_env = [] { const char *s = getenv("BEVW_ANALYTIC_UNITS"); return s ? atoi(s) : 1; }();
+    const int fw = c.frame_width, fh = c.frame_height, bw = c.bev_width, bh = c.bev_height;
+    if (!units_env || bw % 4 != 0 || fw % 4 != 0 || (size_t)fw * fh * 12 >= (1ull << 31) || fw > 32767 || fh > 32767) return BEVW_OK;
+    const size_t bpx = (size_t)bw * bh;
+    DevBuf d_sxy, d_frac;
+    BEVW_TRY(d_sxy.reserve(bpx * 4));
+    BEVW_TRY(d_frac.reserve(bpx * 8));
+    std::vector<int16_t> h1[4];
+    std::vector<uint16_t> h2[4];
+    std::vector<uint8_t> hm[4];
+    std::vector<uint32_t> hf[4];
+    for (int cam = 0; cam < 4; ++cam) {
+        const dim3 grid((bw + 255) / 256, bh), block(256);
+        if (h->projection == BEVW_PROJ_ANALYTIC_F32)
+            hipLaunchKernelGGL((k_analytic_map<float>), grid, block, 0, h->stream, h->arig, cam, fw, fh, bw, bh, d_sxy.as<int16_t>(), d_frac.as<uint32_t>());
+        else
+            hipLaunchKernelGGL((k_analytic_map<double>), grid, block, 0, h->stream, h->arig, cam, fw, fh, bw, bh, d_sxy.as<int16_t>(), d_frac.as<uint32_t>());
+        BEVW_TRY(launch_check("k_analytic_map"));
+        h1[cam].resize(bpx * 2); hf[cam].resize(bpx * 2); hm[cam].resize(bpx);
+        HIP_TRY(hipMemcpyAsync(h1[cam].data(), d_sxy.p, bpx * 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(hf[cam].data(), d_frac.p, bpx * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipMemcpyAsync(hm[cam].data(), h->mask[cam].p, bpx, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    p.lx = 8; p.ncams = 4;
+    p.fw = fw; p.fh = fh; p.bw = bw; p.bh = bh; p.pitch = bw;
+    p.tiles_x = (bw + 31) / 32; p.tiles_y = (bh + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y;
+    std::vector<uint32_t> hdr = unit_host_headers(h1, hm, 4, fw, fh, bw, bh, p.tiles_x, p.tiles_y);
+    UnitTuning tune = unit_tuning_env();
+    if (tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // one group slot stays free: the zeros of pixels without a contributor
+    tune.skew = 0;
+    if (c.blend) tune.wide_double = 0;
+    UnitPlanHost up;
+    unit_compile(h1, h2, hm, 4, fw, fh, bw, bh, bw, p.tiles_x, p.tiles_y, hdr, up, tune, hf);
+    if (up.desc.empty()) return BEVW_OK;
+    HIP_TRY(hipMalloc(&p.un_desc, up.desc.size() * sizeof(UnitDesc)));
+    HIP_TRY(hipMemcpy(p.un_desc, up.desc.data(), up.desc.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc(&p.un_entries, up.entries.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(p.un_entries, up.entries.data(), up.entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(plan_upload_list(up.gsrc, &p.un_gsrc));
+    HIP_TRY(plan_upload_list(up.all, &p.list_un_all));
+    p.n_un_all = (int)up.all.size();
+    p.un_lines = up.lines; p.un_sectors = up.sectors; p.un_skew = 0;
+    std::vector<uint32_t> left;
+    for (size_t t = 0; t < hdr.size(); ++t)
+        if (!(hdr[t] & kHdrBlock)) left.push_back((uint32_t)t);
+    HIP_TRY(plan_upload_list(left, &p.list_slow));
+    p.n_slow = (int)left.size();
+    return BEVW_OK;
+}
+
+// BEVW_PROJ_ANALYTIC(_F32): the unit schedule compiled from the projection (analytic_units_build), or -- balance handles, odd geometry,
+// unaligned buffers -- the per-pixel stitch with the projection evaluated in the kernel (k_stitch_analytic)
 static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
 {
     const bevw_config &c = h->cfg;
+    const uint32_t *left_tiles = nullptr;
+    int n_left = 0;
+    if (!c.balance && ((((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) == 0)) {
+        if (h->aplan_mode != h->projection) BEVW_TRY(analytic_units_build(h));
+        if (h->aplan.n_un_all) {
+            hipError_t e = plan_unit_wide_launch(h->aplan, h->stream, d_frames, batch, c.blend != 0, d_car, d_out, plan_tuning());
+            if (e != hipSuccess) return fail(BEVW_E_HIP, "k_plan_unit_wide launch failed: %s", hipGetErrorString(e));
+            if (h->aplan.n_slow == 0) return BEVW_OK;
+            left_tiles = static_cast<const uint32_t *>(h->aplan.list_slow);
+            n_left = h->aplan.n_slow;
+        }
+    }
     StitchTables T;
     for (int i = 0; i < 4; ++i) {
         T.lut1[i] = h->lut1[i].as<int16_t>();
@@ -888,16 +967,18 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
     for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const int nb = batch - b0 < per_launch ? batch - b0 : per_launch;
         dim3 grid((c.bev_width + 255) / 256, c.bev_height, (nb + kAnalyticFrames - 1) / kAnalyticFrames), block(256);
+        if (left_tiles) grid = dim3((unsigned)n_left, 1, (nb + kAnalyticFrames - 1) / kAnalyticFrames);
+        const int tiles_x = h->aplan.tiles_x;
         const uint8_t *fr = d_frames + (size_t)b0 * 4 * c.frame_width * c.frame_height * 3;
         uint8_t *o = d_out + (size_t)b0 * c.bev_width * c.bev_height * 3;
 #define LAUNCH_AN(BL, BA)                                                                                                   \
         do {                                                                                                                 \
             if (h->projection == BEVW_PROJ_ANALYTIC_F32)                                                                     \
                 hipLaunchKernelGGL((k_stitch_analytic<BL, BA, float>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
+                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o, left_tiles, tiles_x); \
             else                                                                                                             \
                 hipLaunchKernelGGL((k_stitch_analytic<BL, BA, double>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o); \
+                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o, left_tiles, tiles_x); \
         } while (0)
         if (c.blend && c.balance) LAUNCH_AN(true, true);
         else if (c.blend) LAUNCH_AN(true, false);
@@ -1042,6 +1123,8 @@ int bevw_set_camera(bevw_handle *h, int cam, const double K[9], const double D[4
 
 int bevw_build(bevw_handle *h)
 {
+    if (h) h->aplan_mode = -1;   // the analytic unit plan follows the masks and calibrations built here
+
     if (!h) return fail(BEVW_E_INVALID, "null handle");
     for (int c = 0; c < 4; ++c)
         if (h->owns(c) && !h->cam_set[c]) return fail(BEVW_E_INVALID, "camera %d has no K/D/H (bevw_set_camera)", c);
@@ -1180,6 +1263,7 @@ void bevw_destroy(bevw_handle *h)
         h->hsv.release(); h->vsums.release(); h->deltas.release(); h->chsums.release(); h->sdeltas.release();
         h->in.release(); h->out.release(); h->car.release(); h->tmp.release(); h->pre.release(); h->car_pitched.release();
         plan_release(h->plan);
+        plan_release(h->aplan);
         h->laps.release();
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);

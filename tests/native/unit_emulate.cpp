@@ -23,39 +23,13 @@ using namespace bevw;
 #define CHECK(c, ...) do { if (!(c)) { fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); return 1; } } while (0)
 
 struct Rig {
-    int fw, fh, bw, bh, ncams, nframes, blend = 0;
+    int fw, fh, bw, bh, ncams, nframes, blend = 0, wide = 0;
+    std::vector<uint32_t> fr[4];   // wide: 21-bit fractions, [bh][bw][2]
     std::vector<int16_t> l1[4];
     std::vector<uint16_t> l2[4];
     std::vector<uint8_t> mk[4];
     std::vector<uint8_t> frames, car;
 };
-
-// base-tile headers as k_plan_build leaves them (bevw_plan.h): second contributor / border footprint / empty
-static std::vector<uint32_t> host_headers(const Rig &r, int tiles_x, int tiles_y)
-{
-    std::vector<uint32_t> hdr((size_t)tiles_x * tiles_y, 0u);
-    std::vector<int> any(hdr.size(), 0);
-    const uint32_t frame_bytes = (uint32_t)r.fw * r.fh * 3;
-    for (int y = 0; y < r.bh; ++y)
-        for (int x = 0; x < r.bw; ++x) {
-            const size_t o = (size_t)y * r.bw + x, t = (size_t)(y / 8) * tiles_x + x / 32;
-            int count = 0;
-            for (int c = 0; c < r.ncams; ++c) {
-                if (r.mk[c][o] == 0) continue;
-                const int sx = r.l1[c][o * 2], sy = r.l1[c][o * 2 + 1];
-                if (sx >= r.fw || sx + 1 < 0 || sy >= r.fh || sy + 1 < 0) continue;
-                const bool interior = (unsigned)sx < (unsigned)(r.fw - 1) && (unsigned)sy < (unsigned)(r.fh - 1);
-                const uint32_t toff = ((uint32_t)sy * r.fw + sx) * 3;
-                if (!(interior && (toff & ~3u) + (uint32_t)r.fw * 3 + 12 <= frame_bytes)) hdr[t] |= kHdrSlow;
-                ++count;
-            }
-            if (count > 1) hdr[t] |= kHdrSecond;
-            if (count > 0) any[t] = 1;
-        }
-    for (size_t t = 0; t < hdr.size(); ++t)
-        if (!any[t]) hdr[t] |= kHdrEmpty;
-    return hdr;
-}
 
 // the reference's arithmetic for one BEV pixel: per camera remap (fixed-point bilinear), mask (direct: select, blend: trunc(f32(v) * f32(m / 255.0)),
 // surroundBEV.py:161-162 / 279-280), saturating adds in camera order (surroundBEV.py:318-320)
@@ -75,6 +49,11 @@ static int expected_px(const Rig &r, int b, int x, int y, int out[3])
             const int p00 = f[((size_t)sy * r.fw + sx) * 3 + k], p01 = f[((size_t)sy * r.fw + sx + 1) * 3 + k];
             const int p10 = f[((size_t)(sy + 1) * r.fw + sx) * 3 + k], p11 = f[((size_t)(sy + 1) * r.fw + sx + 1) * 3 + k];
             int v = ((p00 * (32 - fx) + p01 * fx) * (32 - fy) + (p10 * (32 - fx) + p11 * fx) * fy + 512) >> 10;
+            if (r.wide) {   // the analytic mode's specification (oracle/np_analytic.py: sample): fp64 bilinear, round half to even
+                const double ax = (double)r.fr[c][o * 2] / 2097152.0, ay = (double)r.fr[c][o * 2 + 1] / 2097152.0;
+                const double top = (1.0 - ax) * p00 + ax * p01, bot = (1.0 - ax) * p10 + ax * p11;
+                v = (int)nearbyint((1.0 - ay) * top + ay * bot);
+            }
             if (r.blend) v = (int)((float)v * (float)((double)m / 255.0));
             out[k] = std::min(255, out[k] + v);
         }
@@ -87,7 +66,7 @@ static int run(const Rig &r, const char *out_path)
 {
     CHECK(r.bw % 4 == 0, "this check handles BEV widths that are a multiple of 4");
     const int tiles_x = (r.bw + 31) / 32, tiles_y = (r.bh + 7) / 8, pitch = r.bw;
-    std::vector<uint32_t> hdr0 = host_headers(r, tiles_x, tiles_y), hdr = hdr0;
+    std::vector<uint32_t> hdr0 = unit_host_headers(r.l1, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, tiles_x, tiles_y), hdr = hdr0;
     UnitPlanHost up;
     UnitTuning tune;   // the library's knobs (csrc/bevwarp.hip: plan_build), so that partitions can be explored without a GPU
     if (const char *e = getenv("BEVW_UNIT_GROUPS")) tune.max_groups = atoi(e);
@@ -102,7 +81,8 @@ static int run(const Rig &r, const char *out_path)
     tune.wide_double = r.blend ? 0 : 1;   // as plan_build does for blend handles
     if (const char *e = getenv("BEVW_UNIT_WIDE_DOUBLE")) tune.wide_double = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_SKEW")) tune.skew = atoi(e);
-    unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune);
+    if (r.wide && tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // as analytic_units_build (csrc/bevwarp.hip)
+    unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune, r.wide ? r.fr : nullptr);
     CHECK(!up.desc.empty(), "no unit compiled");
     const size_t set_bytes = (size_t)r.fw * r.fh * 3 * r.ncams;
     size_t claimed = 0;
@@ -122,7 +102,7 @@ static int run(const Rig &r, const char *out_path)
         const UnitDesc &d = up.desc[u];
         const int GR = kUnitClassGR[cls_of[u]], NQ = kUnitClassNQ[cls_of[u]];
         const uint32_t *gs = up.gsrc.data() + (size_t)d.gs_off * kUnitThreads;
-        CHECK((int)d.groups <= GR * kUnitThreads, "unit %zu: %u groups in a class of %d", u, d.groups, GR * kUnitThreads);
+        CHECK((int)d.groups + (r.wide ? 1 : 0) <= GR * kUnitThreads, "unit %zu: %u groups in a class of %d", u, d.groups, GR * kUnitThreads);
         uint32_t last = 0, seen = 0;
         for (int s = 0; s < GR * kUnitThreads; ++s) {
             if (gs[s] == kPairNoGroup) continue;   // padding: the groups of one source line stay inside one 64-lane instruction
@@ -147,7 +127,7 @@ static int run(const Rig &r, const char *out_path)
             unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.blend != 0, r.car.empty() ? nullptr : r.car.data(), pitch,
                          img.data() + (size_t)b * pitch * r.bh * 3, nullptr, &wr);
         if (b == 0) written = wr;
-        size_t bad = 0;
+        size_t bad = 0, off_by_one = 0, total = 0;
         for (int y = 0; y < r.bh; ++y)
             for (int x = 0; x < r.bw; ++x) {
                 const bool cl = (hdr[(size_t)(y / 8) * tiles_x + x / 32] & kHdrBlock) != 0;
@@ -159,13 +139,19 @@ static int run(const Rig &r, const char *out_path)
                     int v = e[k];
                     if (!r.car.empty()) v = std::min(255, v + r.car[((size_t)y * r.bw + x) * 3 + k]);
                     const int got = img[(((size_t)b * r.bh + y) * pitch + x) * 3 + k];
+                    ++total;
+                    // wide: fp32 interpolation with 21-bit fractions against the fp64 specification -- a rounding flip here and there
+                    if (r.wide && (got == v + 1 || got == v - 1) && !r.blend) { ++off_by_one; continue; }
+                    if (r.wide && r.blend && got != v && std::abs(got - v) <= 1) { ++off_by_one; continue; }
                     if (got != v && bad++ < 5) fprintf(stderr, "frame %d pixel (%d, %d) channel %d: %d, expected %d\n", b, x, y, k, got, v);
                 }
             }
         CHECK(bad == 0, "%zu wrong bytes in frame %d", bad, b);
+        CHECK(off_by_one * 1000 <= total, "%zu of %zu bytes one LSB off the fp64 specification in frame %d", off_by_one, total, b);
+        if (r.wide && b == 0) printf("wide plan: %zu of %zu bytes one LSB off the fp64 specification\n", off_by_one, total);
     }
     // sums of the balance variant against the image
-    {
+    if (!r.wide) {
         uint32_t sums[3] = {0, 0, 0};
         std::vector<uint8_t> tmp((size_t)pitch * r.bh * 3, 0);
         for (size_t u = 0; u < up.desc.size(); ++u) unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data(), set_bytes, r.blend != 0, nullptr, pitch, tmp.data(), sums);
@@ -204,11 +190,12 @@ int main(int argc, char **argv)
         CHECK(f, "cannot read %s", argv[1]);
         int32_t head[8];
         CHECK(fread(head, 4, 8, f) == 8, "short header");
-        r.fw = head[0]; r.fh = head[1]; r.bw = head[2]; r.bh = head[3]; r.ncams = head[4]; r.nframes = head[5]; r.blend = head[7];
+        r.fw = head[0]; r.fh = head[1]; r.bw = head[2]; r.bh = head[3]; r.ncams = head[4]; r.nframes = head[5]; r.blend = head[7] & 1; r.wide = (head[7] >> 1) & 1;
         const size_t npx = (size_t)r.bw * r.bh;
         for (int c = 0; c < r.ncams; ++c) {
             r.l1[c].resize(npx * 2); r.l2[c].resize(npx); r.mk[c].resize(npx);
             CHECK(fread(r.l1[c].data(), 2, npx * 2, f) == npx * 2 && fread(r.l2[c].data(), 2, npx, f) == npx && fread(r.mk[c].data(), 1, npx, f) == npx, "short tables");
+            if (r.wide) { r.fr[c].resize(npx * 2); CHECK(fread(r.fr[c].data(), 4, npx * 2, f) == npx * 2, "short fractions"); }
         }
         r.frames.resize((size_t)r.nframes * r.ncams * r.fw * r.fh * 3);
         CHECK(fread(r.frames.data(), 1, r.frames.size(), f) == r.frames.size(), "short frames");
@@ -245,5 +232,20 @@ int main(int argc, char **argv)
     // once more with a car sprite over part of the image
     r.car.assign(npx * 3, 0);
     for (int y = 30; y < 90; ++y) for (int x = 50; x < 210; ++x) for (int k = 0; k < 3; ++k) r.car[((size_t)y * r.bw + x) * 3 + k] = (uint8_t)(x + 2 * y + 40 * k);
+    if (run(r, nullptr)) return 1;
+    // wide plans (analytic mode): the same geometry with 21-bit fractions, direct and blend; some pixels sample nothing (INT16_MIN mark)
+    r.wide = 1;
+    for (int c = 0; c < 2; ++c) {
+        r.fr[c].resize(npx * 2);
+        for (size_t o = 0; o < npx; ++o) {
+            seed = seed * 1664525u + 1013904223u;
+            r.fr[c][o * 2] = ((uint32_t)(r.l2[c][o] & 31) << 16) | (seed >> 16);
+            seed = seed * 1664525u + 1013904223u;
+            r.fr[c][o * 2 + 1] = ((uint32_t)((r.l2[c][o] >> 5) & 31) << 16) | (seed >> 16);
+        }
+    }
+    for (int y = 60; y < 75; ++y) for (int x = 10; x < 75; ++x) r.l1[0][((size_t)y * r.bw + x) * 2] = r.l1[0][((size_t)y * r.bw + x) * 2 + 1] = (int16_t)-32768;
+    if (run(r, nullptr)) return 1;
+    r.blend = 1;
     return run(r, nullptr);
 }

@@ -38,18 +38,22 @@ def exe(tmp_path_factory):
 def test_units_on_synthetic_tables(exe):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("unit schedule ok") == 3   # direct, the same tables as blend weights, direct with a car sprite
+    # direct, the same tables as blend weights, direct with a car sprite; then wide plans (21-bit fractions, fp32 interpolation): direct, blend
+    assert r.stdout.count("unit schedule ok") == 5
 
 
-def _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh, blend=False):
-    """luts: [(int16 [bh,bw,2], uint16 [bh,bw])], masks: [uint8 [bh,bw]], frames: uint8 [n, ncams, fh, fw, 3]"""
+def _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh, blend=False, fracs=None):
+    """luts: [(int16 [bh,bw,2], uint16 [bh,bw])], masks: [uint8 [bh,bw]], frames: uint8 [n, ncams, fh, fw, 3];
+    fracs: [uint32 [bh,bw,2]] 21-bit fractions -> a wide plan (the analytic projection mode)"""
     inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(inp, "wb") as f:
-        f.write(struct.pack("<8i", fw, fh, bw, bh, len(luts), frames.shape[0], int(car is not None), int(blend)))
-        for (m1, m2), mk in zip(luts, masks):
+        f.write(struct.pack("<8i", fw, fh, bw, bh, len(luts), frames.shape[0], int(car is not None), int(blend) | (2 if fracs is not None else 0)))
+        for i, ((m1, m2), mk) in enumerate(zip(luts, masks)):
             f.write(np.ascontiguousarray(m1, np.int16).tobytes())
             f.write(np.ascontiguousarray(m2, np.uint16).tobytes())
             f.write(np.ascontiguousarray(mk, np.uint8).tobytes())
+            if fracs is not None:
+                f.write(np.ascontiguousarray(fracs[i], np.uint32).tobytes())
         f.write(np.ascontiguousarray(frames, np.uint8).tobytes())
         if car is not None:
             f.write(np.ascontiguousarray(car, np.uint8).tobytes())
@@ -110,3 +114,38 @@ def test_units_on_the_undistort_map_match_the_oracle(exe, tmp_path):
     assert w.sum() > 0.9 * w.size, got["log"]
     assert np.array_equal(got["img"][0][w], ref[w])
     print(got["log"].strip())
+
+
+@pytest.mark.parametrize("blend", [False, True])
+def test_wide_units_from_the_analytic_projection_match_its_specification(exe, tmp_path, blend):
+    """The analytic projection mode on the unit schedule (csrc/bevwarp.hip: analytic_units_build): positions from oracle/np_analytic.project
+    (fp64), fractions rounded to 21 bits, fp32 interpolation from the LDS patch -- against the fp64 specification of the mode
+    (np_analytic.AnalyticBevGenerator): never more than 1 LSB apart, >= 99.9 % of the bytes identical (the GPU test's bar, tests/test_analytic.py)."""
+    from oracle import np_analytic
+
+    O.build()
+    cfg, rig = W.CONFIG_S, W.rig_s()
+    fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+    spec = np_analytic.AnalyticBevGenerator(rig, cfg, blend=blend)
+    luts, fracs = [], []
+    for px, py, valid in spec.proj:
+        sx, sy = np.floor(px), np.floor(py)
+        m1 = np.stack([sx, sy], -1).astype(np.int16)
+        m1[~valid] = -32768
+        fr = np.stack([np.minimum(np.rint((px - sx) * 2.0 ** 21), 2 ** 21 - 1), np.minimum(np.rint((py - sy) * 2.0 ** 21), 2 ** 21 - 1)], -1).astype(np.uint32)
+        fr[~valid] = 0
+        luts.append((m1, np.zeros((bh, bw), np.uint16)))
+        fracs.append(fr)
+    masks = [_mask2d(m) for m in spec.ref.masks]
+    frames = W.synthetic_frames(1, fw, fh, kind="random")
+    rng = np.random.default_rng(11)
+    car = np.zeros((bh, bw, 3), np.uint8)
+    car[400:700, 420:660] = rng.integers(0, 256, (300, 240, 3), dtype=np.uint8)
+    got = _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh, blend, fracs)
+    want = spec(*[frames[0, i] for i in range(4)], car)
+    w = got["written"] == 1
+    assert w.sum() > 0.95 * bw * bh, got["log"]
+    d = np.abs(got["img"][0].astype(np.int32) - want.astype(np.int32))[w]
+    assert d.max() <= 1, int(d.max())
+    assert (d == 0).mean() >= 0.999, float((d == 0).mean())
+    print(got["log"].strip(), "| identical: %.5f" % (d == 0).mean())
