@@ -158,6 +158,7 @@ struct UnitTuning {
     int own_double = 1;              // base tiles with a second contributor or a blend weight are unit tiles (classes with two entries per pixel)
     int wide_double = 1;             // the two-quad class of those units (its blend variant needs 177+ VGPRs: off for blend handles)
     int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
+    int row_order = 0;               // launch order of the rows of root cells (see the end of unit_compile)
 };
 
 // Host-side plan compiler of the units.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers (32 x 8 tiles,
@@ -299,7 +300,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
 
     // ---- emit one unit ---------------------------------------------------------------------------------------------------------
     const int root_w = std::min(tune.root_w, kUnitMaxWidth);
-    struct Order { uint64_t key; uint32_t entry; };
+    struct Order { uint64_t key; uint32_t entry; uint32_t row; uint64_t cost; };
     std::vector<Order> order;       // every unit with its place in the launch order: root cell by root cell, both passes interleaved
     std::vector<uint32_t> keys, slot;
     auto emit = [&](int x0, int y0, int w, int h, const Stats &st) {
@@ -379,10 +380,11 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         out.gsrc.resize(g0 + (size_t)GR * kUnitThreads, kPairNoGroup);
         for (int i = 0; i < count; ++i) out.gsrc[g0 + slot[(size_t)i]] = keys[(size_t)i] * 12u;
         out.list[cls].push_back((uint32_t)out.desc.size());
-        order.push_back({((uint64_t)(y0 / tune.root_h) << 48) | ((uint64_t)((x0 + 64) / root_w) << 32) | (uint64_t)order.size(),
-                         (uint32_t)out.desc.size() | ((uint32_t)cls << 28)});
-        out.desc.push_back(d);
         const size_t ws = (size_t)write_sectors(x0, y0, w, h);
+        order.push_back({((uint64_t)(y0 / tune.root_h) << 48) | ((uint64_t)((x0 + 64) / root_w) << 32) | (uint64_t)order.size(),
+                         (uint32_t)out.desc.size() | ((uint32_t)cls << 28), (uint32_t)(y0 / tune.root_h),
+                         (uint64_t)tune.line_cost * (uint64_t)st.lines + (uint64_t)ws});   // ~ the block's running time per frame
+        out.desc.push_back(d);
         out.lines += (size_t)st.lines;
         out.sectors += ws;
         out.cls_lines[cls] += (size_t)st.lines; out.cls_sectors[cls] += ws; out.cls_pixels[cls] += (size_t)st.pixels; out.cls_groups[cls] += (size_t)count;
@@ -441,6 +443,21 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         stack.push_back(b);
         stack.push_back(a);
     }
+    }
+    // Rows of root cells share no sector with each other (only x-neighbours do), so their order is free: tune.row_order
+    //   0 top to bottom; 1 the rows with the longest-running unit first; 2 the rows with the most work first; 3 bottom to top
+    if (tune.row_order != 0 && !order.empty()) {
+        uint32_t nrows = 0;
+        for (const Order &o : order) nrows = std::max(nrows, o.row + 1);
+        std::vector<uint64_t> rmax(nrows, 0), rsum(nrows, 0);
+        for (const Order &o : order) { rmax[o.row] = std::max(rmax[o.row], o.cost); rsum[o.row] += o.cost; }
+        std::vector<uint32_t> rows(nrows), rank(nrows);
+        for (uint32_t r = 0; r < nrows; ++r) rows[r] = r;
+        if (tune.row_order == 1) std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return rmax[a] > rmax[b]; });
+        else if (tune.row_order == 2) std::stable_sort(rows.begin(), rows.end(), [&](uint32_t a, uint32_t b) { return rsum[a] > rsum[b]; });
+        else std::reverse(rows.begin(), rows.end());
+        for (uint32_t i = 0; i < nrows; ++i) rank[rows[i]] = i;
+        for (Order &o : order) o.key = (o.key & 0x0000ffffffffffffull) | ((uint64_t)rank[o.row] << 48);
     }
     std::sort(order.begin(), order.end(), [](const Order &l, const Order &r) { return l.key < r.key; });
     for (const Order &o : order) out.all.push_back(o.entry);
@@ -563,6 +580,12 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 // (cv2.add, surroundBEV.py:318-320), weights applied as trunc(f32(v) * w) when BLEND (surroundBEV.py:279-280).
 // WIDE: the plan carries 21-bit fractions and the pixels are interpolated in fp32 (the analytic projection mode); wxa / wy then hold the
 // bit patterns of fx / fy.
+// (experiment: -DBEVW_UNIT_PRIO_ON raises the wave priority around the memory instructions of a frame; profiles/r03/sweeps.log)
+#ifdef BEVW_UNIT_PRIO_ON
+#define BEVW_UNIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define BEVW_UNIT_PRIO(x) ((void)0)
+#endif
 template <bool BLEND, bool SUMS, int NQ, int GR, int NCON, bool WIDE = false>
 __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
 {
@@ -676,7 +699,9 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             block_lds_barrier();
         }
         const uint2 *const pw = reinterpret_cast<const uint2 *>(lds + (DB ? ring * kPatch : 0));
+        BEVW_UNIT_PRIO(3);
         issue(b + D, ring);        // the ring slot of frame b has been converted
+        BEVW_UNIT_PRIO(0);
         uint32_t d[NQ][3];
         uint32_t tb = 0, tg = 0, tr = 0;
 #pragma unroll
@@ -762,9 +787,11 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         {
             uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
+            BEVW_UNIT_PRIO(3);
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
                 __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+            BEVW_UNIT_PRIO(0);
         }
         block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
     };
