@@ -159,6 +159,7 @@ struct UnitTuning {
     int wide_double = 1;             // the two-quad class of those units (its blend variant needs 177+ VGPRs: off for blend handles)
     int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
     int row_order = 0;               // launch order of the rows of root cells (see the end of unit_compile)
+    int own_padding = 1;             // the padding columns of a pitched output are written (zeros) by the units at the right edge
 };
 
 // Host-side plan compiler of the units.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers (32 x 8 tiles,
@@ -218,7 +219,12 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         for (int x = 0; x < bw; ++x)
             if (own[(size_t)(y / 8) * tiles_x + x / 32] == 0) poff[0][(size_t)y * pitch + x] = poff[1][(size_t)y * pitch + x] = kNone;
     int pass = 1;                     // the kind of base tile the partition pass at hand owns (1: single, 2: double)
-    auto owned = [&](int x, int y) { return x < bw && y < bh && own[(size_t)(y / 8) * tiles_x + x / 32] == pass; };
+    // Rows wider than the image (an output pitch of whole sectors, bevw_set_output_pitch): the quads of the padding columns belong to the
+    // unit of the base tile they lie in -- they have no contributor and are written as zeros, so that the LAST sector of every row reaches
+    // the memory whole too (a partially written sector costs about as much as ten whole ones: tools/store_pattern.hip,
+    // profiles/r03/store_pattern_units.log: 0.239 -> 0.200 ms for the store stream of a 256-frame batch)
+    const int bw_own = tune.own_padding ? std::min(pitch, tiles_x * 32) : bw;
+    auto owned = [&](int x, int y) { return x < bw_own && y < bh && own[(size_t)(y / 8) * tiles_x + x / 32] == pass; };
     // rows of P = 3 pitch bytes: byte P y + 12 q is a multiple of 64 <=> q = -(P / 4) * 11 * y (mod 16)   (3 * 11 = 1 mod 16).  Only when
     // every image of a batch starts on a sector boundary (P * bh a multiple of 64; the batch base is assumed 64-byte aligned -- with any
     // other base the plan is still correct, just not sector-aligned).
@@ -693,6 +699,23 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     auto acc_to_px = [](const uint32_t acc[3]) {
         return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
     };
+#ifdef BEVW_UNIT_ABLATE_MEMORY_ONLY
+    // timing experiment (wrong pixels): the same loads and stores per frame, no conversion, no LDS, no interpolation, no barrier
+    auto frame = [&](int b, int ring) {
+        uint32_t keep = 0;
+#pragma unroll
+        for (int r = 0; r < GR; ++r) keep ^= pf[ring][r].x ^ pf[ring][r].y ^ pf[ring][r].z ^ pf[ring][r].w;
+        // BEVW_UNIT_ABLATE_MEMORY_ONLY: 1 = loads and stores, 2 = loads only (a store that never fires keeps them alive), 3 = stores only
+        if (BEVW_UNIT_ABLATE_MEMORY_ONLY != 3) issue(b + D, ring);
+        uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            if (BEVW_UNIT_ABLATE_MEMORY_ONLY == 2 && keep != 0x12345679u) continue;
+            __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{keep, keep + i0[j][0][0], keep}, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+        }
+    };
+#else
     auto frame = [&](int b, int ring) {
         if (!DB) {
             land(ring);            // every wave finished reading the previous frame: barrier at the end of its step
@@ -795,12 +818,15 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         }
         block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
     };
+#endif
 #pragma unroll
     for (int u = 0; u < D; ++u) issue(b_begin + u, u);
+#ifndef BEVW_UNIT_ABLATE_MEMORY_ONLY
     if (DB) {
         land(0);
         block_lds_barrier();
     }
+#endif
 #pragma unroll 1
     for (int b = b_begin; b < b_end; b += D) {
 #pragma unroll

@@ -65,7 +65,16 @@ static int expected_px(const Rig &r, int b, int x, int y, int out[3])
 static int run(const Rig &r, const char *out_path)
 {
     CHECK(r.bw % 4 == 0, "this check handles BEV widths that are a multiple of 4");
-    const int tiles_x = (r.bw + 31) / 32, tiles_y = (r.bh + 7) / 8, pitch = r.bw;
+    const int tiles_x = (r.bw + 31) / 32, tiles_y = (r.bh + 7) / 8;
+    // BEVW_EMU_PITCH: pixels per output row (bevw_set_output_pitch); the padding columns inside the last base tile are written as zeros
+    const int pitch = getenv("BEVW_EMU_PITCH") ? atoi(getenv("BEVW_EMU_PITCH")) : r.bw;
+    CHECK(pitch >= r.bw && pitch % 4 == 0, "pitch %d", pitch);
+    const int bw_own = std::min(pitch, tiles_x * 32);
+    std::vector<uint8_t> car_p;   // the sprite with rows of `pitch` pixels
+    if (!r.car.empty()) {
+        car_p.assign((size_t)pitch * r.bh * 3, 0);
+        for (int y = 0; y < r.bh; ++y) memcpy(car_p.data() + (size_t)y * pitch * 3, r.car.data() + (size_t)y * r.bw * 3, (size_t)r.bw * 3);
+    }
     std::vector<uint32_t> hdr0 = unit_host_headers(r.l1, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, tiles_x, tiles_y), hdr = hdr0;
     UnitPlanHost up;
     UnitTuning tune;   // the library's knobs (csrc/bevwarp.hip: plan_build), so that partitions can be explored without a GPU
@@ -84,6 +93,16 @@ static int run(const Rig &r, const char *out_path)
     if (r.wide && tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // as analytic_units_build (csrc/bevwarp.hip)
     unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune, r.wide ? r.fr : nullptr);
     CHECK(!up.desc.empty(), "no unit compiled");
+    if (getenv("BEVW_EMU_HIST")) {   // owned pixels by unit width (diagnostics: narrow units write short row runs)
+        size_t hist[9] = {}, tot = 0;
+        for (const UnitDesc &d : up.desc) {
+            const int w = (int)(d.shape & 0xffffu), h = (int)(d.shape >> 16);
+            int b = 0;
+            while ((16 << b) < w) ++b;
+            hist[b] += (size_t)w * h; tot += (size_t)w * h;
+        }
+        for (int b = 0; b < 6; ++b) printf("width <= %3d: %5.1f %% of the unit area\n", 16 << b, 100.0 * hist[b] / tot);
+    }
     const size_t set_bytes = (size_t)r.fw * r.fh * 3 * r.ncams;
     size_t claimed = 0;
     for (size_t t = 0; t < hdr.size(); ++t) {
@@ -124,14 +143,18 @@ static int run(const Rig &r, const char *out_path)
     for (int b = 0; b < r.nframes; ++b) {
         std::vector<uint8_t> wr((size_t)pitch * r.bh, 0);
         for (size_t u = 0; u < up.desc.size(); ++u)
-            unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.blend != 0, r.car.empty() ? nullptr : r.car.data(), pitch,
+            unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.blend != 0, r.car.empty() ? nullptr : car_p.data(), pitch,
                          img.data() + (size_t)b * pitch * r.bh * 3, nullptr, &wr);
         if (b == 0) written = wr;
         size_t bad = 0, off_by_one = 0, total = 0;
         for (int y = 0; y < r.bh; ++y)
-            for (int x = 0; x < r.bw; ++x) {
-                const bool cl = (hdr[(size_t)(y / 8) * tiles_x + x / 32] & kHdrBlock) != 0;
+            for (int x = 0; x < pitch; ++x) {
+                const bool cl = x < bw_own && (hdr[(size_t)(y / 8) * tiles_x + x / 32] & kHdrBlock) != 0;
                 CHECK(wr[(size_t)y * pitch + x] == (cl ? 1 : 0), "pixel (%d, %d) stored %d times (claimed %d)", x, y, wr[(size_t)y * pitch + x], (int)cl);
+                if (x >= r.bw) {   // padding: zeros
+                    for (int k = 0; k < 3; ++k) CHECK(img[(((size_t)b * r.bh + y) * pitch + x) * 3 + k] == 0, "padding pixel (%d, %d) not zero", x, y);
+                    continue;
+                }
                 if (!cl) continue;
                 int e[3];
                 expected_px(r, b, x, y, e);
@@ -175,8 +198,8 @@ static int run(const Rig &r, const char *out_path)
         CHECK(f, "cannot write %s", out_path);
         const int32_t head[4] = {(int32_t)up.desc.size(), (int32_t)claimed, (int32_t)up.lines, (int32_t)up.sectors};
         fwrite(head, 4, 4, f);
-        fwrite(written.data(), 1, written.size(), f);
-        fwrite(img.data(), 1, img.size(), f);
+        for (int y = 0; y < r.bh; ++y) fwrite(written.data() + (size_t)y * pitch, 1, (size_t)r.bw, f);     // (dense rows, whatever the pitch)
+        for (size_t row = 0; row < (size_t)r.nframes * r.bh; ++row) fwrite(img.data() + row * pitch * 3, 1, (size_t)r.bw * 3, f);
         fclose(f);
     }
     return 0;

@@ -46,6 +46,85 @@ __global__ void __launch_bounds__(256) k_tiles(uint8_t *__restrict__ out, int ti
     }
 }
 
+// round 3: the UNIT store pattern -- a block of 4 waves owns a rectangle of (4 << LQ) x (NQ * 4 * (64 >> LQ)) pixels; a wave-store covers
+// 64 >> LQ rows of (1 << LQ) quads (LQ = 6: ONE row run of 768 bytes); rows are dealt to the waves round-robin (rr = 1) or in bands (rr = 0);
+// pitch = pixels per image row (1080 dense, 1088 whole sectors)
+// LW: log2 of the lanes per row inside ONE wave-store (LW == LQ: a wave-store is a band of whole unit rows; LW < LQ: the unit's width is cut into
+// 1 << (LQ - LW) column strips, a wave-store covers 64 >> LW rows of one strip)
+template <int LQ, int NQ, int LW = LQ>
+__global__ void __launch_bounds__(256) k_units(uint8_t *__restrict__ out, int pitch, int units_x, int nunits, int nb, int nchunks, int rr, int bw_eff)
+{
+    const uint32_t ng = (uint32_t)nunits, id = blockIdx.x;
+    const uint32_t x8 = id & 7u, k = id >> 3, chunk = x8 + 8u * (k / ng), unit = k % ng;
+    if ((int)chunk >= nchunks) return;
+    constexpr int W = 4 << LQ, RPS = 64 >> LW, COLS = 1 << (LQ - LW), H = NQ * 4 * RPS / COLS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ux = (int)(unit % units_x) * W, uy = (int)(unit / units_x) * H;
+    const size_t img = (size_t)pitch * BH * 3;
+    uint32_t off[NQ];
+    bool ok[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int sidx = rr ? j * 4 + wave : wave * NQ + j;
+        const int x = ux + 4 * ((sidx % COLS) * (1 << LW) + (lane & ((1 << LW) - 1))), y = uy + (sidx / COLS) * RPS + (lane >> LW);
+        ok[j] = x < bw_eff && y < BH;
+        off[j] = ((uint32_t)y * pitch + x) * 3;
+    }
+    uint8_t *ob = out + (size_t)chunk * nb * img;
+    uint32_t v0 = lane, v1 = unit, v2 = chunk;
+    for (int b = 0; b < nb; ++b, ob += img) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+            if (ok[j]) { uint32_t *op = reinterpret_cast<uint32_t *>(ob + off[j]); op[0] = v0 + b; op[1] = v1; op[2] = v2; }
+    }
+}
+// the 64 x 4 tile pattern written with k_units' code: strips of 64 x 4 pixels in raster order, 4 consecutive strips per block
+// (mode 0: 17 strips per row as k_tiles; mode 1: 4 strips per block but blocks never wrap to the next row: 5 blocks per row, the last one thin)
+__global__ void __launch_bounds__(256) k_strips(uint8_t *__restrict__ out, int pitch, int nb, int nchunks, int mode, int ng)
+{
+    const uint32_t id = blockIdx.x;
+    const uint32_t x8 = id & 7u, k = id >> 3, chunk = x8 + 8u * (k / ng), grp = k % ng;
+    if ((int)chunk >= nchunks) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int sx, sy;
+    if (mode == 0) { const int strip = (int)grp * 4 + wave; sx = strip % 17; sy = strip / 17; }
+    else { sx = (int)(grp % 5) * 4 + wave; sy = (int)(grp / 5); }
+    const int x = sx * 64 + 4 * (lane & 15), y = sy * 4 + (lane >> 4);
+    const bool ok = x < BW && y < BH;
+    const size_t img = (size_t)pitch * BH * 3;
+    const uint32_t off = ((uint32_t)y * pitch + x) * 3;
+    uint8_t *ob = out + (size_t)chunk * nb * img;
+    uint32_t v0 = lane, v1 = grp, v2 = chunk;
+    for (int b = 0; b < nb; ++b, ob += img)
+        if (ok) { uint32_t *op = reinterpret_cast<uint32_t *>(ob + off); op[0] = v0 + b; op[1] = v1; op[2] = v2; }
+}
+static void run_strips(uint8_t *out, int pitch, int nb, int mode, const char *name)
+{
+    const int ng = mode == 0 ? (17 * 270 + 3) / 4 : 5 * 270, nchunks = BATCH / nb;
+    const unsigned grid = ng * ((nchunks + 7) / 8 * 8);
+    const double bytes = (double)BATCH * BW * BH * 3;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto launch = [&] { hipLaunchKernelGGL(k_strips, dim3(grid), dim3(256), 0, 0, out, pitch, nb, nchunks, mode, ng); };
+    launch(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); for (int i = 0; i < 5; ++i) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    printf("%-60s %7.3f ms  %7.1f GB/s\n", name, ms, bytes / ms * 1e-6);
+}
+
+template <int LQ, int NQ, int LW = LQ> static void run_units(uint8_t *out, int pitch, int nb, int rr, const char *name, int bw_eff = BW)
+{
+    constexpr int W = 4 << LQ, H = NQ * 4 * (64 >> LW) / (1 << (LQ - LW));
+    const int units_x = (BW + W - 1) / W, units_y = (BH + H - 1) / H, nunits = units_x * units_y, nchunks = BATCH / nb;
+    const unsigned grid = nunits * ((nchunks + 7) / 8 * 8);
+    const double bytes = (double)BATCH * BW * BH * 3;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto launch = [&] { hipLaunchKernelGGL((k_units<LQ, NQ, LW>), dim3(grid), dim3(256), 0, 0, out, pitch, units_x, nunits, nb, nchunks, rr, bw_eff); };
+    launch(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); for (int i = 0; i < 5; ++i) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    printf("%-60s %7.3f ms  %7.1f GB/s\n", name, ms, bytes / ms * 1e-6);
+}
+
 template <typename F> static float timeit(F launch)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -66,10 +145,10 @@ template <int LX> static void run_tiles(uint8_t *out, int nb, int xcd, const cha
 
 int main()
 {
-    const size_t bytes = (size_t)BATCH * BW * BH * 3;
+    const size_t bytes = (size_t)BATCH * BW * BH * 3, alloc = (size_t)BATCH * 1088 * BH * 3;
     uint8_t *out;
-    CK(hipMalloc(&out, bytes));
-    CK(hipMemset(out, 0, bytes));
+    CK(hipMalloc(&out, alloc));
+    CK(hipMemset(out, 0, alloc));
     float ms = timeit([&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, (uint4 *)out, bytes / 16); });
     printf("%-44s %7.3f ms  %7.1f GB/s\n", "linear stream, 16 B per lane", ms, bytes / ms * 1e-6);
     run_tiles<8>(out, 8, 1, "32x8 tiles, 8 frames/block, XCD chunks [product]");
@@ -82,5 +161,48 @@ int main()
     run_tiles<8>(out, 8, 1, "  + 504 VALU per frame", 168);
     run_tiles<16>(out, 8, 1, "64x4 tiles, 8 frames/block, XCD chunks");
     run_tiles<4>(out, 8, 1, "16x16 tiles, 8 frames/block, XCD chunks");
+    // round 3: unit-shaped stores (profiles/r03/store_pattern_units.log)
+    run_units<6, 4>(out, 1080, 16, 1, "units 256x16, 16 frames/block, rows round-robin, dense");
+    run_units<6, 4>(out, 1088, 16, 1, "units 256x16, 16 frames/block, rows round-robin, pitch 1088");
+    run_units<6, 4>(out, 1088, 16, 0, "units 256x16, 16 frames/block, row bands, pitch 1088");
+    run_units<6, 4>(out, 1088, 8, 1, "units 256x16, 8 frames/block, pitch 1088");
+    run_units<6, 2>(out, 1088, 16, 1, "units 256x8, 16 frames/block, pitch 1088");
+    run_units<6, 1>(out, 1088, 16, 1, "units 256x4, 16 frames/block, pitch 1088");
+    run_units<5, 4>(out, 1088, 16, 1, "units 128x32, 16 frames/block, pitch 1088");
+    run_units<4, 4>(out, 1088, 16, 1, "units 64x64, 16 frames/block, pitch 1088");
+    run_units<4, 1>(out, 1088, 16, 1, "units 64x16, 16 frames/block, pitch 1088");
+    run_units<3, 4>(out, 1088, 16, 1, "units 32x128, 16 frames/block, pitch 1088");
+    run_units<6, 4, 5>(out, 1088, 16, 1, "units 256x16, wave-store = 2 rows x 384 B, pitch 1088");
+    run_units<6, 4, 4>(out, 1088, 16, 1, "units 256x16, wave-store = 4 rows x 192 B, pitch 1088");
+    run_units<6, 4, 3>(out, 1088, 16, 1, "units 256x16, wave-store = 8 rows x 96 B, pitch 1088");
+    run_units<6, 4, 4>(out, 1080, 16, 1, "units 256x16, wave-store = 4 rows x 192 B, dense");
+    run_units<6, 4, 3>(out, 1080, 16, 1, "units 256x16, wave-store = 8 rows x 96 B, dense");
+    run_units<6, 4, 4>(out, 1088, 16, 0, "units 256x16, 4 rows x 192 B, a wave owns a strip (rr 0), pitch 1088");
+    run_units<6, 4, 4>(out, 1088, 8, 1, "units 256x16, 4 rows x 192 B, 8 frames/block, pitch 1088");
+    run_units<5, 4, 4>(out, 1088, 16, 1, "units 128x32, 4 rows x 192 B, pitch 1088");
+    run_units<6, 2, 4>(out, 1088, 16, 1, "units 256x8, 4 rows x 192 B, pitch 1088");
+    run_units<6, 1, 4>(out, 1088, 16, 1, "units 256x4, 4 rows x 192 B, pitch 1088");
+    run_units<6, 1, 4>(out, 1080, 8, 1, "units 256x4, 4 rows x 192 B, 8 frames/block, dense");
+    run_tiles<16>(out, 8, 1, "64x4 tiles, 8 frames/block, XCD chunks (again)");
+    run_tiles<16>(out, 16, 1, "64x4 tiles, 16 frames/block, XCD chunks");
+    run_tiles<8>(out, 8, 1, "32x8 tiles, 8 frames/block, XCD chunks (again)");
+    run_units<6, 4>(out, 1088, 16, 1, "units 256x16, 16 frames/block, pitch 1088 (again)");
+    run_units<6, 4>(out, 1088, 16, 1, "units 256x16, 16 frames/block, pitch 1088, padding columns written too", 1088);
+    run_units<6, 4, 4>(out, 1088, 16, 1, "units 256x16, 4 rows x 192 B, pitch 1088, padding written too", 1088);
+    run_units<6, 1, 4>(out, 1088, 8, 1, "units 256x4, 4 rows x 192 B, 8 frames/block, pitch 1088, padding written", 1088);
+    run_units<6, 4>(out, 1088, 8, 1, "units 256x16, 8 frames/block, pitch 1088, padding written", 1088);
+    run_units<6, 1, 4>(out, 1080, 8, 1, "units 256x4, 4 rows x 192 B, 8 frames/block, dense, columns 0..1023 only", 1024);
+    run_units<6, 1, 4>(out, 1080, 8, 1, "units 256x4, 4 rows x 192 B, 8 frames/block, dense (again)");
+    run_units<4, 1>(out, 1080, 8, 1, "units 64x16 (4 waves stacked), 8 frames/block, dense");
+    run_units<4, 1>(out, 1088, 8, 1, "units 64x16 (4 waves stacked), 8 frames/block, pitch 1088, padding written", 1088);
+    run_units<4, 4>(out, 1088, 8, 1, "units 64x64, 8 frames/block, pitch 1088, padding written", 1088);
+    run_units<4, 4>(out, 1088, 16, 1, "units 64x64, 16 frames/block, pitch 1088, padding written", 1088);
+    run_units<5, 4>(out, 1088, 16, 1, "units 128x32, 16 frames/block, pitch 1088, padding written", 1088);
+    run_tiles<16>(out, 8, 1, "64x4 tiles, 8 frames/block, XCD chunks (third time)");
+    run_strips(out, 1080, 8, 0, "strips 64x4, 4 per block in raster order (= k_tiles), dense");
+    run_strips(out, 1080, 8, 1, "strips 64x4, 4 per block, 5 blocks per row (= k_units 256x4), dense");
+    run_strips(out, 1088, 8, 0, "strips 64x4, raster order, pitch 1088");
+    run_strips(out, 1088, 8, 1, "strips 64x4, 5 blocks per row, pitch 1088");
+    run_strips(out, 1088, 16, 0, "strips 64x4, raster order, pitch 1088, 16 frames/block");
     return 0;
 }
