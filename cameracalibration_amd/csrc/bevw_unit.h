@@ -160,6 +160,7 @@ struct UnitTuning {
     int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
     int row_order = 0;               // launch order of the rows of root cells (see the end of unit_compile)
     int own_padding = 1;             // the padding columns of a pitched output are written (zeros) by the units at the right edge
+    int stagger = 0;                 // pixels the column grid of the root cells shifts per row of cells (0: the same columns in every row)
 };
 
 // Host-side plan compiler of the units.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers (32 x 8 tiles,
@@ -307,6 +308,13 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     // ---- emit one unit ---------------------------------------------------------------------------------------------------------
     const int root_w = std::min(tune.root_w, kUnitMaxWidth);
     struct Order { uint64_t key; uint32_t entry; uint32_t row; uint64_t cost; };
+    // left edge of the root cells of the row of cells that holds y0.  tune.stagger: the column grid shifts from one row of cells to the next
+    // (experiment: blocks that cover the same columns in every row write slower than blocks whose phase cycles, tools/store_pattern.hip)
+    auto row_start = [&](int y0) {
+        int xs = skew ? -col_step : 0;
+        if (tune.stagger > 0) xs -= (((y0 / tune.root_h) * tune.stagger) % root_w) / col_step * col_step;
+        return xs;
+    };
     std::vector<Order> order;       // every unit with its place in the launch order: root cell by root cell, both passes interleaved
     std::vector<uint32_t> keys, slot;
     auto emit = [&](int x0, int y0, int w, int h, const Stats &st) {
@@ -387,7 +395,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         for (int i = 0; i < count; ++i) out.gsrc[g0 + slot[(size_t)i]] = keys[(size_t)i] * 12u;
         out.list[cls].push_back((uint32_t)out.desc.size());
         const size_t ws = (size_t)write_sectors(x0, y0, w, h);
-        order.push_back({((uint64_t)(y0 / tune.root_h) << 48) | ((uint64_t)((x0 + 64) / root_w) << 32) | (uint64_t)order.size(),
+        order.push_back({((uint64_t)(y0 / tune.root_h) << 48) | ((uint64_t)((x0 - row_start(y0)) / root_w) << 32) | (uint64_t)order.size(),
                          (uint32_t)out.desc.size() | ((uint32_t)cls << 28), (uint32_t)(y0 / tune.root_h),
                          (uint64_t)tune.line_cost * (uint64_t)st.lines + (uint64_t)ws});   // ~ the block's running time per frame
         out.desc.push_back(d);
@@ -402,7 +410,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     std::vector<Cell> stack;
     for (pass = 1; pass <= 2; ++pass) {
     for (int y0 = 0; y0 < bh; y0 += tune.root_h)
-        for (int x0 = skew ? -col_step : 0; x0 < pitch; x0 += root_w) stack.push_back({x0, y0, std::min(root_w, pitch - x0), std::min(tune.root_h, bh - y0)});
+        for (int x0 = row_start(y0); x0 < pitch; x0 += root_w) stack.push_back({x0, y0, std::min(root_w, pitch - x0), std::min(tune.root_h, bh - y0)});
     std::reverse(stack.begin(), stack.end());   // pop in row-major order: neighbouring units are neighbours in the class lists
     while (!stack.empty()) {
         Cell c = stack.back();

@@ -78,6 +78,7 @@ static UnitTuning unit_tuning_env()
     if (const char *s = getenv("BEVW_UNIT_SKEW")) t.skew = atoi(s);
     if (const char *s = getenv("BEVW_UNIT_ROW_ORDER")) t.row_order = atoi(s);
     if (const char *s = getenv("BEVW_UNIT_OWN_PADDING")) t.own_padding = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_STAGGER")) t.stagger = atoi(s);
     return t;
 }
 

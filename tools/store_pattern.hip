@@ -88,7 +88,10 @@ __global__ void __launch_bounds__(256) k_strips(uint8_t *__restrict__ out, int p
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int sx, sy;
     if (mode == 0) { const int strip = (int)grp * 4 + wave; sx = strip % 17; sy = strip / 17; }
-    else { sx = (int)(grp % 5) * 4 + wave; sy = (int)(grp / 5); }
+    else if (mode == 1) { sx = (int)(grp % 5) * 4 + wave; sy = (int)(grp / 5); }
+    else if (mode == 2) { const int c = (int)(grp % 5), first = c < 2 ? 4 * c : 8 + 3 * (c - 2), n = c < 2 ? 4 : 3; sx = wave < n ? first + wave : 99; sy = (int)(grp / 5); }   // 4,4,3,3,3 strips
+    else if (mode == 3) { sx = (int)(grp % 4) * 4 + wave; sy = (int)(grp / 4); }          // columns 0..1023 only, 4 blocks per row
+    else { const int strip = (int)grp * 4 + wave; sx = strip % 16; sy = strip / 16; if (sy >= 270) sx = 99; }   // mode 4: = mode 3 (16 strips per row in raster order)
     const int x = sx * 64 + 4 * (lane & 15), y = sy * 4 + (lane >> 4);
     const bool ok = x < BW && y < BH;
     const size_t img = (size_t)pitch * BH * 3;
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) k_strips(uint8_t *__restrict__ out, int p
 }
 static void run_strips(uint8_t *out, int pitch, int nb, int mode, const char *name)
 {
-    const int ng = mode == 0 ? (17 * 270 + 3) / 4 : 5 * 270, nchunks = BATCH / nb;
+    const int ng = mode == 0 ? (17 * 270 + 3) / 4 : mode >= 3 ? 4 * 270 : 5 * 270, nchunks = BATCH / nb;
     const unsigned grid = ng * ((nchunks + 7) / 8 * 8);
     const double bytes = (double)BATCH * BW * BH * 3;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -204,5 +207,9 @@ int main()
     run_strips(out, 1088, 8, 0, "strips 64x4, raster order, pitch 1088");
     run_strips(out, 1088, 8, 1, "strips 64x4, 5 blocks per row, pitch 1088");
     run_strips(out, 1088, 16, 0, "strips 64x4, raster order, pitch 1088, 16 frames/block");
+    run_strips(out, 1080, 8, 2, "strips 64x4, 5 blocks per row of 4,4,3,3,3 strips, dense");
+    run_strips(out, 1080, 8, 3, "strips 64x4, columns 0..1023 only (4 blocks per row), dense  [5 % fewer bytes]");
+    run_strips(out, 1080, 8, 0, "strips 64x4, raster order, dense (again)");
+    run_strips(out, 1080, 8, 1, "strips 64x4, 5 blocks per row, dense (again)");
     return 0;
 }
