@@ -105,15 +105,19 @@ void bevw_destroy(bevw_handle *h);
 int bevw_get_undistort_map(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2); /* Camera.undistort_maps */
 int bevw_get_lut(bevw_handle *h, int cam, int16_t *map1, uint16_t *map2);           /* Camera.bev_maps       */
 int bevw_get_mask(bevw_handle *h, int cam, uint8_t *mask);  /* Mask.mask / BlendMask.mask (u8, before /255.0)   */
-/* Projection mode of bevw_run* (SURVEY.md 8 row g1; BASELINE.json north_star: "inverts H and applies the K/D fisheye model per output
- * pixel").  BEVW_PROJ_LUT (default) is the reference's path: the tables Camera.__init__ builds (surroundBEV.py:82-102) compiled into
- * the contributor plan -- bit-exact against the oracle.  BEVW_PROJ_ANALYTIC evaluates inverse homography + fisheye model per frame and
- * pixel in fp64 and interpolates the four texels in fp64: no tables, not the reference's fixed-point arithmetic; judged against the
- * table path by PSNR (tests/test_analytic.py).  Masks, blend weights, balance and the car are unchanged.  Call before or after
- * bevw_build; not available on camera-shard handles. */
+/* Projection mode of bevw_run* (DESIGN.md row n1; BASELINE.json north_star: "inverts H and applies the K/D fisheye model per output
+ * pixel ... with LDS-staged input tiles").  BEVW_PROJ_LUT (default) is the reference's path: the tables Camera.__init__ builds
+ * (surroundBEV.py:82-102) compiled into the contributor plan -- bit-exact against the oracle.  BEVW_PROJ_ANALYTIC samples every BEV pixel at
+ * the position the camera model gives (inverse homography + fisheye model in fp64, fractions kept to 2^-21 pixel) with float-weight bilinear
+ * interpolation: no fixed-point tables, not the reference's arithmetic; equal to its NumPy specification to <= 1 LSB and judged against the
+ * table path by PSNR (tests/test_analytic.py).  The calibration of a handle is fixed, so the projection is evaluated once per handle and
+ * mode (on the GPU) and compiled into a unit schedule with wide fractions (csrc/bevw_unit.h); the per-frame kernel stages source texels
+ * through LDS exactly as the table mode does and interpolates in fp32.  Balance handles, BEV widths that are not a multiple of 4 and
+ * unaligned buffers run the per-pixel kernel that evaluates the model itself (fp64 throughout).  Masks, blend weights, balance and the car
+ * are unchanged.  Call before or after bevw_build; not available on camera-shard handles or with an output pitch. */
 #define BEVW_PROJ_LUT 0
-#define BEVW_PROJ_ANALYTIC 1       /* fp64 projection and interpolation: equals its NumPy specification (oracle/np_analytic.py) */
-#define BEVW_PROJ_ANALYTIC_F32 2   /* the same formulas in fp32: ~3x faster, held against the fp64 mode by PSNR */
+#define BEVW_PROJ_ANALYTIC 1       /* fp64 projection: equals its NumPy specification (oracle/np_analytic.py) to <= 1 LSB, >= 99.9 % of the bytes */
+#define BEVW_PROJ_ANALYTIC_F32 2   /* the same formulas in fp32 (positions good to ~1e-4 pixel): held against the fp64 mode by PSNR */
 int bevw_set_projection(bevw_handle *h, int mode);
 int bevw_plan_info(bevw_handle *h, int32_t info[8]);        /* [0] max contributors/pixel, [1] plan usable, [2] schedule in use */
 

@@ -120,3 +120,47 @@ def test_hip_analytic_f32_against_fp64(ffi, SB, oracle, repo_rig, blend):
     print("analytic fp32 vs fp64, blend=%s: PSNR %.1f dB, %.2f %% identical, max %d LSB" % (blend, psnr(f64, f32), 100 * (d == 0).mean(), int(d.max())))
     assert psnr(f64, f32) > 55.0
     assert (d == 0).mean() > 0.97
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blend", [False, True])
+def test_hip_analytic_units_on_the_bench_rig_batch_of_64(ffi, SB, oracle, blend):
+    """The analytic mode on the unit schedule (wide plan: csrc/bevwarp.hip analytic_units_build, csrc/bevw_unit.h k_plan_unit_wide) on the bench
+    rig with the bench's batch size, device-resident, all-random frames and a car sprite: every BEV of the batch is independent of its position
+    (chunk / XCD mapping, the ragged tail of a 19-frame batch) and within 1 LSB of the fp64 specification, >= 99.9 % of the bytes identical."""
+    from oracle import np_analytic
+
+    cfg, rig = W.CONFIG_S, W.rig_s()
+    a = SB.BevGenerator.get_args()
+    for k, v in cfg.items():
+        setattr(a, k, v)
+    bw, bh = cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+    uniq, batch = 2, 64
+    frames = W.synthetic_frames(uniq, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=11, kind="random")
+    rng = np.random.default_rng(5)
+    car = np.zeros((bh, bw, 3), np.uint8)
+    car[380:720, 400:680] = rng.integers(0, 256, (340, 280, 3), dtype=np.uint8)
+    bev = SB.BevGenerator(blend=blend, balance=False, rig=rig, projection='analytic')
+    spec = np_analytic.AnalyticBevGenerator(rig, cfg, blend=blend)
+    d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
+    d_car = ffi.DeviceBuffer(car.nbytes)
+    d_out = ffi.DeviceBuffer(batch * bw * bh * 3)
+    d_out.fill(0x5A)
+    d_car.upload(car)
+    for b in range(batch):
+        d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
+    bev.run_device(d_in.ptr, batch, d_car.ptr, d_out.ptr)
+    bev.sync()
+    out = d_out.download((batch, bh, bw, 3))
+    for b in range(uniq, batch):
+        assert np.array_equal(out[b], out[b % uniq]), b
+    for b in range(uniq):
+        d = np.abs(out[b].astype(np.int32) - spec(*frames[b], car).astype(np.int32))
+        assert d.max() <= 1, int(d.max())
+        assert (d == 0).mean() >= 0.999, float((d == 0).mean())
+    # a ragged batch through the host-buffer entry point, no sprite
+    rag = bev.batch(np.concatenate([frames] * 9 + [frames[:1]]))
+    want0 = spec(*frames[0])
+    d = np.abs(rag[18].astype(np.int32) - want0.astype(np.int32))
+    assert d.max() <= 1 and (d == 0).mean() >= 0.999
+    assert np.array_equal(rag[18], rag[0]) and np.array_equal(rag[17], rag[1])

@@ -20,7 +20,6 @@ for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k
   rm -rf /tmp/kt_$w
   timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
-  case $w in blend_b256|blend_4k) continue;; esac
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c
     timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --single-layout --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1

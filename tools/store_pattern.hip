@@ -146,8 +146,19 @@ template <int LX> static void run_tiles(uint8_t *out, int nb, int xcd, const cha
     printf("%-44s %7.3f ms  %7.1f GB/s\n", name, ms, bytes / ms * 1e-6);
 }
 
-int main()
+int main(int argc, char **argv)
 {
+    if (argc > 1) {   // "strips": only the strip assignments, dense, 8 frames per block (counter runs: 6 dispatches per mode, modes 0 1 3 4 in this order)
+        const size_t alloc = (size_t)BATCH * 1088 * BH * 3;
+        uint8_t *out;
+        CK(hipMalloc(&out, alloc));
+        CK(hipMemset(out, 0, alloc));
+        run_strips(out, 1080, 8, 0, "strips 64x4, raster order (17 per row), dense");
+        run_strips(out, 1080, 8, 1, "strips 64x4, 5 blocks per row, dense");
+        run_strips(out, 1080, 8, 3, "strips 64x4, columns 0..1023, 4 blocks per row, dense");
+        run_strips(out, 1080, 8, 4, "strips 64x4, columns 0..1023, 16 strips per row in raster order, dense");
+        return 0;
+    }
     const size_t bytes = (size_t)BATCH * BW * BH * 3, alloc = (size_t)BATCH * 1088 * BH * 3;
     uint8_t *out;
     CK(hipMalloc(&out, alloc));

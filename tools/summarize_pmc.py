@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 STEPS, WARMUP = 3, 1
-UNITS = {"direct_stitch_b256": 256, "blend_balance_b256": 256, "undistort_b64": 64}
+UNITS = {"direct_stitch_b256": 256, "blend_balance_b256": 256, "undistort_b64": 64, "blend_4k": 32, "blend_b256": 256}
 # kernels whose reads are wide coalesced streams (16 B per lane): FETCH_SIZE tallies their 128-byte requests at 64 bytes on
 # gfx950 (MI355X_MICROARCH.md, HBM section) -> doubled.  Calibration in this very run: k_vsum reads exactly
 # 256 x 4 x 1280 x 960 x 3 B = 3775 MB per launch and FETCH_SIZE reports half of that.
@@ -51,7 +51,7 @@ def main(d):
           "WRITE_SIZE is exact (x%.2f for the 8 x 96-byte tile stores), so write traffic above the output bytes is real (partial-sector evictions)." %
           (CAL or {}).get("tile_stores", 1.0), ""]
     traffic = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes "
-                           "(profiles/r02_final/rocprofv3_pmc_hbm_traffic.md, tools/collect_profiles.sh), corrected with the factors of "
+                           "(profiles/r03_final/rocprofv3_pmc_hbm_traffic.md, tools/collect_profiles.sh), corrected with the factors of "
                            "profiles/pmc_calibration.json (measured on known byte counts); bench.py copies the "
                            "figure of the workload it runs into roofline.traffic."}
     for w, units in UNITS.items():
