@@ -160,6 +160,7 @@ struct UnitTuning {
     int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
     int row_order = 0;               // launch order of the rows of root cells (see the end of unit_compile)
     int own_padding = 1;             // the padding columns of a pitched output are written (zeros) by the units at the right edge
+    int run_cost = 0;                // cost of one more row run (experiment: wider units write longer runs; profiles/r03/sweeps.log)
     int stagger = 0;                 // pixels the column grid of the root cells shifts per row of cells (0: the same columns in every row)
 };
 
@@ -441,7 +442,8 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
             const Stats s0 = cell_stats(c.x0, c.y0, w2, c.h), s1 = cell_stats(c.x0 + w2, c.y0, c.w - w2, c.h);
             const long cost = (long)tune.line_cost * (s0.lines + s1.lines) +
                               (long)tune.sector_cost * (write_sectors(c.x0, c.y0, w2, c.h) + write_sectors(c.x0 + w2, c.y0, c.w - w2, c.h) -
-                                                        write_sectors(c.x0, c.y0, c.w, c.h));
+                                                        write_sectors(c.x0, c.y0, c.w, c.h)) +
+                              (long)tune.run_cost * c.h;      // a column cut doubles the row runs the two units write
             if (best < 0 || cost < best) {
                 best = cost;
                 a = {c.x0, c.y0, w2, c.h};
