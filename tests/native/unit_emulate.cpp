@@ -12,6 +12,7 @@
 //   in : int32 fw fh bw bh ncams nframes has_car blend | per camera: int16 lut1[bh][bw][2], uint16 lut2[bh][bw], uint8 mask[bh][bw]
 //        | uint8 frames[nframes][ncams][fh][fw][3] | uint8 car[bh][bw][3] if has_car
 //   out: int32 nunits claimed_tiles lines sectors | uint8 written[bh][bw] | uint8 image[nframes][bh][bw][3] (unwritten pixels 0)
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
@@ -62,12 +63,16 @@ static int expected_px(const Rig &r, int b, int x, int y, int out[3])
     return n;
 }
 
+static bool g_allow_no_units = false;   // fuzz mode: a rig whose every base tile has a border footprint compiles nothing -- fine
+
 static int run(const Rig &r, const char *out_path)
 {
     CHECK(r.bw % 4 == 0, "this check handles BEV widths that are a multiple of 4");
     const int tiles_x = (r.bw + 31) / 32, tiles_y = (r.bh + 7) / 8;
     // BEVW_EMU_PITCH: pixels per output row (bevw_set_output_pitch); the padding columns inside the last base tile are written as zeros
-    const int pitch = getenv("BEVW_EMU_PITCH") ? atoi(getenv("BEVW_EMU_PITCH")) : r.bw;
+    // ("aligned": rows of whole 64-byte sectors, as BEVW_PITCH_ALIGNED)
+    const char *pe = getenv("BEVW_EMU_PITCH");
+    const int pitch = !pe ? r.bw : (strcmp(pe, "aligned") == 0 ? (r.bw + 63) / 64 * 64 : atoi(pe));
     CHECK(pitch >= r.bw && pitch % 4 == 0, "pitch %d", pitch);
     const int bw_own = std::min(pitch, tiles_x * 32);
     std::vector<uint8_t> car_p;   // the sprite with rows of `pitch` pixels
@@ -95,6 +100,7 @@ static int run(const Rig &r, const char *out_path)
     if (const char *e = getenv("BEVW_UNIT_ROW_ORDER")) tune.row_order = atoi(e);
     if (r.wide && tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // as analytic_units_build (csrc/bevwarp.hip)
     unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune, r.wide ? r.fr : nullptr);
+    if (up.desc.empty() && g_allow_no_units) { printf("unit schedule ok: no unit (every base tile left to the other classes)\n"); return 0; }
     CHECK(!up.desc.empty(), "no unit compiled");
     if (getenv("BEVW_EMU_HIST")) {   // owned pixels by unit width (diagnostics: narrow units write short row runs)
         size_t hist[9] = {}, tot = 0;
@@ -228,6 +234,62 @@ int main(int argc, char **argv)
         if (head[6]) { r.car.resize(npx * 3); CHECK(fread(r.car.data(), 1, r.car.size(), f) == r.car.size(), "short car"); }
         fclose(f);
         return run(r, argc >= 3 ? argv[2] : nullptr);
+    }
+    if (argc >= 1 && getenv("BEVW_EMU_FUZZ")) {
+        // BEVW_EMU_FUZZ="seed count": random small rigs -- sizes, 1..4 cameras with smooth maps of random scale / orientation that leave the frame
+        // in places, band masks with overlaps (blend weights when blend), holes, random fractions, wide plans with "no sample" patches, car
+        // sprites -- each checked pixel by pixel against the formula as above
+        unsigned seed = 1, count = 8;
+        sscanf(getenv("BEVW_EMU_FUZZ"), "%u %u", &seed, &count);
+        g_allow_no_units = true;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return seed >> 8; };
+        auto uni = [&](int lo, int hi) { return lo + (int)(rnd() % (unsigned)(hi - lo + 1)); };
+        for (unsigned it = 0; it < count; ++it) {
+            Rig q;
+            q.fw = 4 * uni(16, 110); q.fh = uni(40, 260); q.bw = 4 * uni(9, 80); q.bh = uni(9, 150); q.ncams = uni(1, 4); q.nframes = 2;
+            q.blend = uni(0, 1); q.wide = uni(0, 2) == 0;
+            const size_t n = (size_t)q.bw * q.bh;
+            for (int c = 0; c < q.ncams; ++c) {
+                q.l1[c].resize(n * 2); q.l2[c].resize(n); q.mk[c].assign(n, 0);
+                if (q.wide) q.fr[c].resize(n * 2);
+                const double sc = 0.3 + (rnd() % 1000) / 1000.0 * 2.7, th = (rnd() % 4) * 1.5707963267948966 + ((int)(rnd() % 200) - 100) / 400.0;
+                const double a = sc * cos(th), b = -sc * sin(th), d = sc * sin(th), e = sc * cos(th);
+                const double cx = q.fw / 2.0 + uni(-30, 30), cy = q.fh / 2.0 + uni(-20, 20);
+                const int band0 = uni(0, q.bw / 2), band1 = uni(q.bw / 2, q.bw), vertical = uni(0, 1);
+                const int hx0 = uni(0, q.bw - 1), hy0 = uni(0, q.bh - 1), hw = uni(0, 70), hh = uni(0, 40);
+                for (int y = 0; y < q.bh; ++y)
+                    for (int x = 0; x < q.bw; ++x) {
+                        const size_t o = (size_t)y * q.bw + x;
+                        const double u = x - q.bw / 2.0, v = y - q.bh / 2.0;
+                        const double px = a * u + b * v + cx + 0.002 * u * v, py = d * u + e * v + cy + 0.001 * u * u;
+                        const double fx = floor(px), fy = floor(py);
+                        q.l1[c][o * 2] = (int16_t)std::max(-3000.0, std::min(3000.0, fx));
+                        q.l1[c][o * 2 + 1] = (int16_t)std::max(-3000.0, std::min(3000.0, fy));
+                        q.l2[c][o] = (uint16_t)(rnd() & 1023u);
+                        if (q.wide) {
+                            q.fr[c][o * 2] = ((uint32_t)(q.l2[c][o] & 31) << 16) | (rnd() & 0xffffu);
+                            q.fr[c][o * 2 + 1] = ((uint32_t)((q.l2[c][o] >> 5) & 31) << 16) | (rnd() & 0xffffu);
+                            if (x >= hx0 / 2 && x < hx0 / 2 + hw / 2 && y >= hy0 / 2 && y < hy0 / 2 + hh) q.l1[c][o * 2] = q.l1[c][o * 2 + 1] = (int16_t)-32768;
+                        }
+                        const int t = vertical ? y * q.bw / std::max(1, q.bh) : x;
+                        int m = (t >= band0 && t < band1) ? 255 : 0;
+                        if (m && q.blend && (t - band0 < 12 || band1 - t <= 12)) m = 20 * (1 + (t - band0 < 12 ? t - band0 : band1 - 1 - t));   // a weight ramp at the band edges
+                        if (x >= hx0 && x < hx0 + hw && y >= hy0 && y < hy0 + hh) m = 0;      // a hole
+                        q.mk[c][o] = (uint8_t)m;
+                    }
+            }
+            q.frames.resize((size_t)q.nframes * q.ncams * q.fw * q.fh * 3);
+            for (uint8_t &v : q.frames) v = (uint8_t)(rnd() >> 4);
+            if (uni(0, 1)) {
+                q.car.assign(n * 3, 0);
+                const int x0 = uni(0, q.bw - 1), y0 = uni(0, q.bh - 1);
+                for (int y = y0; y < std::min(q.bh, y0 + 40); ++y) for (int x = x0; x < std::min(q.bw, x0 + 60); ++x) for (int k = 0; k < 3; ++k) q.car[((size_t)y * q.bw + x) * 3 + k] = (uint8_t)(rnd() >> 3);
+            }
+            printf("fuzz %u: %d x %d frames, %d x %d BEV, %d cameras, blend %d, wide %d, car %d: ", it, q.fw, q.fh, q.bw, q.bh, q.ncams, q.blend, q.wide, (int)!q.car.empty());
+            fflush(stdout);
+            if (run(q, nullptr)) return 1;
+        }
+        return 0;
     }
     // synthetic rig: two cameras, 520 x 300 frames, 328 x 150 BEV (partial tiles at the right / bottom edge)
     r.fw = 520; r.fh = 300; r.bw = 328; r.bh = 150; r.ncams = 2; r.nframes = 2;

@@ -149,3 +149,16 @@ def test_wide_units_from_the_analytic_projection_match_its_specification(exe, tm
     assert d.max() <= 1, int(d.max())
     assert (d == 0).mean() >= 0.999, float((d == 0).mean())
     print(got["log"].strip(), "| identical: %.5f" % (d == 0).mean())
+
+
+@pytest.mark.parametrize("seed,pitch", [(2, None), (5, None), (8, "aligned")])
+def test_units_on_random_rigs(exe, seed, pitch):
+    """Fuzz of the plan compiler + the emulated kernel body: random sizes, 1..4 cameras with smooth maps of random scale and orientation that leave
+    the frame in places, band masks with overlaps and weight ramps, holes, wide plans with "no sample" patches, car sprites, dense rows or rows of
+    whole sectors -- every stored pixel against the formula, every claimed quad stored exactly once (tests/native/unit_emulate.cpp, BEVW_EMU_FUZZ)."""
+    env = dict(os.environ, BEVW_EMU_FUZZ="%d 25" % seed)
+    if pitch:
+        env["BEVW_EMU_PITCH"] = pitch
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert r.stdout.count("unit schedule ok") == 25
