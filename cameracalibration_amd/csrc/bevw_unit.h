@@ -462,7 +462,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
     }
     // Rows of root cells share no sector with each other (only x-neighbours do), so their order is free: tune.row_order
     //   0 top to bottom; 1 the rows with the longest-running unit first; 2 the rows with the most work first; 3 bottom to top
-    if (tune.row_order != 0 && !order.empty()) {
+    if (tune.row_order >= 1 && tune.row_order <= 3 && !order.empty()) {
         uint32_t nrows = 0;
         for (const Order &o : order) nrows = std::max(nrows, o.row + 1);
         std::vector<uint64_t> rmax(nrows, 0), rsum(nrows, 0);
@@ -476,6 +476,16 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         for (Order &o : order) o.key = (o.key & 0x0000ffffffffffffull) | ((uint64_t)rank[o.row] << 48);
     }
     std::sort(order.begin(), order.end(), [](const Order &l, const Order &r) { return l.key < r.key; });
+    // tune.row_order 4: longest unit first whatever its place (pure LPT); 5 / 6: the spatial order twice -- first the units above the
+    // median / upper-quartile cost, then the rest -- so that the blocks that start last are short ones (experiments: profiles/r03/sweeps.log)
+    if (tune.row_order == 4) std::stable_sort(order.begin(), order.end(), [](const Order &l, const Order &r) { return l.cost > r.cost; });
+    if ((tune.row_order == 5 || tune.row_order == 6) && !order.empty()) {
+        std::vector<uint64_t> cs;
+        for (const Order &o : order) cs.push_back(o.cost);
+        std::sort(cs.begin(), cs.end());
+        const uint64_t cut = cs[tune.row_order == 5 ? cs.size() / 2 : cs.size() / 4];
+        std::stable_partition(order.begin(), order.end(), [cut](const Order &o) { return o.cost >= cut; });
+    }
     for (const Order &o : order) out.all.push_back(o.entry);
     for (size_t t = 0; t < own.size(); ++t)
         if (own[t] != 0) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
