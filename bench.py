@@ -384,7 +384,8 @@ def main():
             ms = C.c_float()
             _ffi.check(L.bevw_remapper_timer_between(r, a_, b_, C.byref(ms)))
             return float(ms.value)
-        extra = {"frame": [fw, fh], "schedule": "per_pixel"}
+        # (the remapper compiles its maps into a 1-camera unit plan; k_remap_lut, one thread per pixel, only when that plan is unusable)
+        extra = {"frame": [fw, fh], "schedule": "tile_plan (1-camera plan of the undistort maps)"}
         if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline_undistort(w, K, D, ucfg, unique, a.cpu_seconds)
 
