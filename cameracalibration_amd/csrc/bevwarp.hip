@@ -100,6 +100,10 @@ static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, in
     // balance handles (seam_tiles == false): two-contributor units measured 4 % slower under the per-unit channel sums than the per-wave
     // pair classes (profiles/r03/sweeps.log), as the seam block tiles of round 2 did
     if (!seam_tiles && !getenv("BEVW_UNIT_OWN_DOUBLE")) tune.own_double = 0;
+    // rows of whole sectors (an output pitch): column cuts on sector boundaries are free, all others split a sector for good -> a higher
+    // price per write sector (3 -> 8: -0.4 ... -2 % on config 3, -2 % on the 4K rig, nothing slower; profiles/r03/sweeps.log).  The dense
+    // layout keeps 3: there every cut shares sectors and the price only drives the source lines up (40 k -> 50 k per frame)
+    if (out_pitch > 0 && !getenv("BEVW_UNIT_SECTOR_COST")) tune.sector_cost = 8;
     hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
                                    block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, tune, out_pitch);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
