@@ -376,6 +376,54 @@ class BevGenerator:
         check(lib().bevw_run(self._engine.h, ptr(frames), frames.shape[0], car_p, ptr(out)))
         return out
 
+    # ---- additive: compressed in, compressed out (row f4) ----------------------------------------------------
+    def jpeg(self, files, car=None, quality=95):
+        """main.py:74-89 with the pixels resident in HBM: ``files`` is a sequence of frame sets, each the four camera FILES' bytes
+        (front, back, left, right: what main.py hands to cv2.imread); the result is one complete ``.jpg`` file per set -- the bytes
+        cv2.imwrite(path, bev(front, back, left, right, car)) would write (libjpeg at quality 95, 4:2:0).  Decode, stitch and
+        encode all run on the GPU (imgcodecs.JpegCodec); only compressed bytes cross PCIe."""
+        try:
+            from .. import imgcodecs
+        except ImportError:   # top-level import of this package (main.py's drop-in layout)
+            import importlib
+            imgcodecs = importlib.import_module("cameracalibration_amd.imgcodecs")
+
+        c = self._engine.cfg
+        sets = [tuple(bytes(f) for f in s) for s in files]
+        if not sets or any(len(s) != 4 for s in sets):
+            raise Exception("files must be a non-empty sequence of (front, back, left, right) JPEG files")
+        B = len(sets)
+        if getattr(self, "_codec", None) is None:
+            self._codec = imgcodecs.JpegCodec(self.device)
+        info = self._codec.decode_stage([f for s in sets for f in s])
+        if (info["width"], info["height"]) != (c.frame_width, c.frame_height):
+            raise Exception("camera files are {}x{}, FRAME is {}x{}".format(info["width"], info["height"], c.frame_width,
+                                                                             c.frame_height))
+        frame = c.frame_height * c.frame_width * 3
+        image = c.bev_height * self.out_pitch * 3
+        need = (B * 4 * frame, B * image)
+        bufs = getattr(self, "_jpeg_bufs", None)
+        if bufs is None or bufs[0].nbytes < need[0] or bufs[1].nbytes < need[1]:
+            if bufs is not None:
+                bufs[0].free()
+                bufs[1].free()
+            bufs = self._jpeg_bufs = (_ffi.DeviceBuffer(need[0], self.device), _ffi.DeviceBuffer(need[1], self.device))
+        d_car = None
+        if car is not None:
+            car = _ffi.as_u8_image(car, "car")
+            if car.shape[:2] != (c.bev_height, c.bev_width):
+                raise Exception("car must be padded to the BEV size (padding())")
+            if getattr(self, "_jpeg_car", None) is None:
+                self._jpeg_car = _ffi.DeviceBuffer(car.nbytes, self.device)
+            self._jpeg_car.upload(car)
+            d_car = self._jpeg_car.ptr
+        self._codec.decode_run_device(bufs[0].ptr, frame, c.frame_width * 3)
+        self._codec.sync()
+        self.run_device(bufs[0].ptr, B, d_car, bufs[1].ptr)
+        self.sync()
+        self._codec.encode_run_device(bufs[1].ptr, B, c.bev_width, c.bev_height, image, self.out_pitch * 3, quality)
+        return self._codec.files()
+
     def run_device(self, d_frames: int, batch: int, d_car, d_out: int) -> None:
         """Asynchronous launch on device-resident buffers (raw pointers from DeviceBuffer)."""
         check(lib().bevw_run_device(self._engine.h, d_frames, batch, d_car, d_out))

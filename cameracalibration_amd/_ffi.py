@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
 PROJ_LUT, PROJ_ANALYTIC, PROJ_ANALYTIC_F32 = 0, 1, 2   # bevw_set_projection
@@ -101,6 +101,22 @@ SIGNATURES = {
     "bevw_translate_u8c3": (_i, [_i, _vp, _i, _i, _i, _i, _i, _vp]),
     "bevw_resize_dsize": (_i, [_i, _i, _d, _d, _vp]),
     "bevw_resize_linear_u8c3": (_i, [_i, _vp, _i, _i, _d, _d, _i, _vp]),
+    "bevw_jpeg_probe": (_i, [_vp, _sz, _vp]),
+    "bevw_jpeg_create": (_i, [_i, _pvp]),
+    "bevw_jpeg_destroy": (None, [_vp]),
+    "bevw_jpeg_decode_stage": (_i, [_vp, _vp, _vp, _i]),
+    "bevw_jpeg_decode_run_device": (_i, [_vp, _vp, _sz, _sz]),
+    "bevw_jpeg_decode": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "bevw_jpeg_decode_info": (_i, [_vp, _vp]),
+    "bevw_jpeg_get_planes": (_i, [_vp, _i, _vp]),
+    "bevw_jpeg_encode_bound": (_i, [_i, _i, _i, _vp]),
+    "bevw_jpeg_encode_run_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i]),
+    "bevw_jpeg_encoded_sizes": (_i, [_vp, _vp]),
+    "bevw_jpeg_encoded_copy": (_i, [_vp, _i, _vp, _sz]),
+    "bevw_jpeg_encode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "bevw_jpeg_sync": (_i, [_vp]),
+    "bevw_jpeg_timer_mark": (_i, [_vp, _i]),
+    "bevw_jpeg_timer_between": (_i, [_vp, _i, _i, _vp]),
 }
 
 _lib = None

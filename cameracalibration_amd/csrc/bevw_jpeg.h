@@ -1,0 +1,799 @@
+// bevw_jpeg.h -- the JPEG wire format either side of the path, gfx950 only.
+//
+// The reference reads its camera frames with cv2.imread (main.py:74-77, Tools/undistort.py:63) and writes the stitched
+// image with cv2.imwrite (SurroundBirdEyeView/surroundBEV.py:340, main.py:88); for ".jpg" both are libjpeg(-turbo) with the
+// library's defaults (baseline Huffman, ISLOW DCT, fancy upsampling; quality 95, 4:2:0, Annex-K tables).  This header holds
+// the device side of both directions, bit-exact against that library (oracle/jpegoracle.c, pinned against Pillow's
+// libjpeg-turbo), so that frames can enter and leave HBM compressed:
+//
+//   decode   host: marker parsing + byte un-stuffing inside the staging copy (the bytes have to be gathered for the H2D
+//                  transfer anyway; no entropy decoding on the host);
+//            k_jpeg_sync0 / k_jpeg_sync : Huffman decoding is sequential by nature.  The entropy-coded segment is cut into
+//                  subsequences of kSubBits bits; every lane decodes one from a GUESSED state (first bit of the
+//                  subsequence, DC of the first block of an MCU), then again from the exit state of its predecessor,
+//                  until no exit state changes -- JPEG's Huffman codes self-synchronise within a few dozen symbols, so
+//                  this takes 2 - 3 rounds (correctness does not rest on it: the fixed point is reached by induction
+//                  from the first subsequence of every restart segment, whose state is known).  A prefix sum of the blocks
+//                  completed and of the DC differences per component turns the states into output positions;
+//            k_jpeg_coef  : decodes every subsequence once more from its TRUE entry state and writes the coefficients;
+//            k_jpeg_idct  : jpeg_idct_islow, 8 blocks per wave (lane = block x column, transpose through LDS);
+//            k_jpeg_color : fancy (triangle) chroma upsampling + YCbCr -> BGR, written straight into the caller's frame layout.
+//   encode   k_jenc_ycc   : BGR -> YCbCr + chroma downsampling with libjpeg's edge replication;
+//            k_jenc_fdct  : jpeg_fdct_islow + quantisation, dummy blocks of partial MCUs;
+//            k_jenc_len / k_jenc_scan / k_jenc_bits / k_jenc_stuff : Huffman code lengths per block, a prefix sum to bit
+//                  offsets, every block written at its offset (atomic OR on shared words), 0xFF byte stuffing by a
+//                  second prefix sum; the file header is assembled once per batch.
+//
+// Everything a lane does is a __host__ __device__ function, so tests/native/jpeg_emulate.cpp runs the same arithmetic and the
+// same synchronisation fixed point on a CPU against the oracle (no product path calls them on the host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+namespace bevw {
+namespace jpg {
+
+constexpr int kSubBits = 1024;   // bits per subsequence of the entropy-coded data (a multiple of 32)
+constexpr uint32_t kNoRestart = 0xffffffffu;
+
+// jutils.c jpeg_natural_order: zigzag position -> row-major position
+__host__ __device__ __forceinline__ int natural_of(int k)
+{
+    const uint8_t t[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                           41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                           30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+    return t[k & 63];
+}
+// the inverse: row-major position -> zigzag position
+__host__ __device__ __forceinline__ int zigzag_of(int n)
+{
+    const uint8_t t[64] = {0,  1,  5,  6,  14, 15, 27, 28, 2,  4,  7,  13, 16, 26, 29, 42, 3,  8,  12, 17, 25, 30,
+                           41, 43, 9,  11, 18, 24, 31, 40, 44, 53, 10, 19, 23, 32, 39, 45, 52, 54, 20, 22, 33, 38,
+                           46, 51, 55, 60, 21, 34, 37, 47, 50, 56, 59, 61, 35, 36, 48, 49, 57, 58, 62, 63};
+    return t[n & 63];
+}
+
+// ---- geometry shared by all images of one batch -----------------------------------------------------------------------
+struct Geom {
+    int32_t w, h, nc, hs, vs;    // image size, components (1 or 3), luma sampling factors (chroma is 1 x 1)
+    int32_t mcux, mcuy, bpm, nY; // MCUs per row / column, blocks per MCU, luma blocks per MCU
+    int32_t wb[3], hb[3];        // sample planes in blocks (whole MCUs)
+    int32_t blk_off[3];          // first block of each component inside one image's coefficient buffer
+    int32_t nblk;                // blocks per image
+    int32_t plane_off[3];        // byte offset of each sample plane inside one image's plane buffer
+    int32_t plane_bytes;
+    int32_t dw, dh;              // the chroma components' real size (jdmaster.c downsampled_width / _height)
+};
+
+inline Geom make_geom(int w, int h, int nc, int hs, int vs)
+{
+    Geom G;
+    memset(&G, 0, sizeof G);
+    G.w = w; G.h = h; G.nc = nc;
+    if (nc == 1) hs = vs = 1;
+    G.hs = hs; G.vs = vs;
+    G.mcux = (w + 8 * hs - 1) / (8 * hs);
+    G.mcuy = (h + 8 * vs - 1) / (8 * vs);
+    G.nY = hs * vs;
+    G.bpm = nc == 1 ? 1 : G.nY + 2;
+    int boff = 0, poff = 0;
+    for (int c = 0; c < nc; ++c) {
+        G.wb[c] = G.mcux * (c == 0 ? hs : 1);
+        G.hb[c] = G.mcuy * (c == 0 ? vs : 1);
+        G.blk_off[c] = boff;
+        boff += G.wb[c] * G.hb[c];
+        G.plane_off[c] = poff;
+        poff += G.wb[c] * G.hb[c] * 64;
+    }
+    G.nblk = boff;
+    G.plane_bytes = poff;
+    G.dw = (w + hs - 1) / hs;
+    G.dh = (h + vs - 1) / vs;
+    return G;
+}
+
+// ---- decoding tables ----------------------------------------------------------------------------------------------------
+struct HuffTab {          // jdhuff.c jpeg_make_d_derived_tbl, 9-bit look-ahead
+    uint16_t fast[512];   // len << 8 | symbol for codes of <= 9 bits, 0 otherwise
+    int32_t maxcode[18];  // largest code of each length, -1 if none; [17] = sentinel
+    int32_t valoff[18];
+    uint8_t vals[256];
+};
+static_assert(sizeof(HuffTab) % 16 == 0, "HuffTab is copied to LDS in 16-byte pieces");
+struct TableSet { HuffTab t[6]; };   // [2 c] = DC table of component c, [2 c + 1] = its AC table
+
+struct ImageDesc {
+    uint32_t stream_word;   // first 32-bit word of this image's un-stuffed entropy-coded bytes in the batch stream buffer
+    uint32_t stream_bytes;
+    uint32_t seg_first;     // this image's first entry in the segment tables (nseg + 1 entries each)
+    uint32_t nseg;          // restart segments (1 without DRI)
+    uint32_t sub_first;     // first subsequence slot of this image
+    uint32_t nsub;
+    uint32_t tables;        // TableSet index
+    uint32_t quant;         // quantiser triple index (3 x 64 uint16, row-major)
+    uint32_t seg_blocks;    // blocks per restart segment (kNoRestart without DRI)
+    uint32_t pad[3];
+};
+
+// a state of the sequential decoder between two symbols: bit position | block inside the MCU << 32 | zigzag position << 40
+__host__ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t z, uint32_t k) { return (uint64_t)p | ((uint64_t)z << 32) | ((uint64_t)k << 40); }
+
+struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
+
+// jdhuff.c decode_mcu_slow over the bits [entry position, end_bit) of one image's entropy-coded data, starting between two symbols
+// in state `entry`.  Returns the state in which the first symbol at or after end_bit is met, the number of blocks completed and
+// the sum of the DC differences per component.  WRITE: the entry state is the true one; `blk` is the index (scan order) of the
+// block in progress, pred the DC predictions; coefficients are written (row-major int16, DC already predicted) until blk_cap.
+template <bool WRITE>
+__host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words, const HuffTab *tabs, const Geom &G, uint64_t entry,
+                                             uint32_t end_bit, int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0,
+                                             int32_t pred1, int32_t pred2)
+{
+    uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
+    SubOut R;
+    R.cnt = 0; R.dc0 = R.dc1 = R.dc2 = 0;
+    // bit buffer: `have` valid bits at the top of acc, next word to load = widx
+    uint32_t widx = p >> 5;
+    uint64_t acc = (uint64_t)__builtin_bswap32(words[widx++]) << 32;
+    acc <<= (p & 31u);
+    int have = 32 - (int)(p & 31u);
+    // position of the block in progress (WRITE)
+    int mx = 0, my = 0;
+    size_t baddr = 0;
+    if (WRITE) {
+        const uint32_t mcu = blk / (uint32_t)G.bpm;
+        mx = (int)(mcu % (uint32_t)G.mcux);
+        my = (int)(mcu / (uint32_t)G.mcux);
+    }
+    bool fresh = true;   // baddr must be recomputed
+    while (p < end_bit && (!WRITE || blk < blk_cap)) {
+        if (have <= 32) {
+            acc |= (uint64_t)__builtin_bswap32(words[widx++]) << (32 - have);
+            have += 32;
+        }
+        const int c = (int)z < G.nY ? 0 : 1 + (int)z - G.nY;
+        if (WRITE && fresh) {
+            int bx, by;
+            if (c == 0) { bx = mx * G.hs + (int)z % G.hs; by = my * G.vs + (int)z / G.hs; }
+            else { bx = mx; by = my; }
+            baddr = ((size_t)G.blk_off[c] + (size_t)by * G.wb[c] + bx) * 64;
+            fresh = false;
+        }
+        const HuffTab &T = tabs[2 * c + (k ? 1 : 0)];
+        const uint32_t peek = (uint32_t)(acc >> 48);
+        uint32_t len, sym;
+        const uint32_t e = T.fast[peek >> 7];
+        if (e) {
+            len = e >> 8;
+            sym = e & 255u;
+        } else {
+            len = 16; sym = 0;   // corrupt data: libjpeg warns and yields 0
+            for (int l = 10; l <= 16; ++l) {
+                const int32_t code = (int32_t)(peek >> (16 - l));
+                if (code <= T.maxcode[l]) { len = (uint32_t)l; sym = T.vals[(code + T.valoff[l]) & 255]; break; }
+            }
+        }
+        acc <<= len;
+        have -= (int)len;
+        uint32_t used = len;
+        if (k == 0) {
+            const uint32_t s = sym > 16u ? 16u : sym;
+            int32_t diff = 0;
+            if (s) {
+                const int32_t r = (int32_t)(acc >> (64 - s));
+                acc <<= s;
+                have -= (int)s;
+                used += s;
+                diff = r < (1 << (s - 1)) ? r - (1 << s) + 1 : r;   // HUFF_EXTEND
+            }
+            if (c == 0) { R.dc0 += diff; pred0 += diff; }
+            else if (c == 1) { R.dc1 += diff; pred1 += diff; }
+            else { R.dc2 += diff; pred2 += diff; }
+            if (WRITE) coef[baddr] = (int16_t)(c == 0 ? pred0 : (c == 1 ? pred1 : pred2));
+            k = 1;
+        } else {
+            const uint32_t r = sym >> 4, s = sym & 15u;
+            if (s) {
+                k += r;
+                const int32_t v = (int32_t)(acc >> (64 - s));
+                acc <<= s;
+                have -= (int)s;
+                used += s;
+                if (WRITE && k <= 63u) coef[baddr + natural_of((int)k)] = (int16_t)(v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
+                ++k;
+            } else if (r == 15u) {
+                k += 16;
+            } else {
+                k = 64;   // EOB
+            }
+        }
+        if (k >= 64u) {   // block complete
+            k = 0;
+            ++R.cnt;
+            ++blk;
+            fresh = true;
+            if (++z == (uint32_t)G.bpm) {
+                z = 0;
+                if (WRITE && ++mx == G.mcux) { mx = 0; ++my; }
+            }
+        }
+        p += used;
+    }
+    R.exit = pack_state(p, z, k);
+    return R;
+}
+
+// ---- jidctint.c / jfdctint.c ------------------------------------------------------------------------------------------------
+#define BEVW_JFIX_0_298631336 2446
+#define BEVW_JFIX_0_390180644 3196
+#define BEVW_JFIX_0_541196100 4433
+#define BEVW_JFIX_0_765366865 6270
+#define BEVW_JFIX_0_899976223 7373
+#define BEVW_JFIX_1_175875602 9633
+#define BEVW_JFIX_1_501321110 12299
+#define BEVW_JFIX_1_847759065 15137
+#define BEVW_JFIX_1_961570560 16069
+#define BEVW_JFIX_2_053119869 16819
+#define BEVW_JFIX_2_562915447 20995
+#define BEVW_JFIX_3_072711026 25172
+
+__host__ __device__ __forceinline__ int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// one 8-point pass of jpeg_idct_islow (CONST_BITS 13): in[0..7] -> out[0..7] descaled by `shift`
+__host__ __device__ __forceinline__ void idct_1d(const int32_t in[8], int32_t out[8], int shift)
+{
+    int32_t z2 = in[2], z3 = in[6];
+    int32_t z1 = (z2 + z3) * BEVW_JFIX_0_541196100;
+    int32_t tmp2 = z1 + z3 * (-BEVW_JFIX_1_847759065);
+    int32_t tmp3 = z1 + z2 * BEVW_JFIX_0_765366865;
+    int32_t tmp0 = (int32_t)((uint32_t)(in[0] + in[4]) << 13);
+    int32_t tmp1 = (int32_t)((uint32_t)(in[0] - in[4]) << 13);
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    int32_t z4 = tmp1 + tmp3;
+    const int32_t z5 = (z3 + z4) * BEVW_JFIX_1_175875602;
+    tmp0 *= BEVW_JFIX_0_298631336; tmp1 *= BEVW_JFIX_2_053119869; tmp2 *= BEVW_JFIX_3_072711026; tmp3 *= BEVW_JFIX_1_501321110;
+    z1 *= -BEVW_JFIX_0_899976223; z2 *= -BEVW_JFIX_2_562915447; z3 *= -BEVW_JFIX_1_961570560; z4 *= -BEVW_JFIX_0_390180644;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    out[0] = descale(tmp10 + tmp3, shift); out[7] = descale(tmp10 - tmp3, shift);
+    out[1] = descale(tmp11 + tmp2, shift); out[6] = descale(tmp11 - tmp2, shift);
+    out[2] = descale(tmp12 + tmp1, shift); out[5] = descale(tmp12 - tmp1, shift);
+    out[3] = descale(tmp13 + tmp0, shift); out[4] = descale(tmp13 - tmp0, shift);
+}
+// sample_range_limit + CENTERJSAMPLE indexed with x & RANGE_MASK (jdmaster.c prepare_range_limit_table)
+__host__ __device__ __forceinline__ uint32_t range_limit(int32_t x)
+{
+    const int32_t i = x & 1023;
+    return (uint32_t)(i < 128 ? i + 128 : (i < 512 ? 255 : (i < 896 ? 0 : i - 896)));
+}
+// one 8-point pass of jpeg_fdct_islow: pass 0 = rows (results scaled up by 4), pass 1 = columns (descaled)
+__host__ __device__ __forceinline__ void fdct_1d(const int32_t in[8], int32_t out[8], int pass)
+{
+    const int32_t tmp0 = in[0] + in[7], tmp7 = in[0] - in[7], tmp1 = in[1] + in[6], tmp6 = in[1] - in[6];
+    const int32_t tmp2 = in[2] + in[5], tmp5 = in[2] - in[5], tmp3 = in[3] + in[4], tmp4 = in[3] - in[4];
+    const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    const int sh = pass == 0 ? 11 : 15;   // CONST_BITS -/+ PASS1_BITS
+    if (pass == 0) { out[0] = (tmp10 + tmp11) * 4; out[4] = (tmp10 - tmp11) * 4; }
+    else { out[0] = descale(tmp10 + tmp11, 2); out[4] = descale(tmp10 - tmp11, 2); }
+    int32_t z1 = (tmp12 + tmp13) * BEVW_JFIX_0_541196100;
+    out[2] = descale(z1 + tmp13 * BEVW_JFIX_0_765366865, sh);
+    out[6] = descale(z1 + tmp12 * (-BEVW_JFIX_1_847759065), sh);
+    z1 = tmp4 + tmp7;
+    int32_t z2 = tmp5 + tmp6, z3 = tmp4 + tmp6, z4 = tmp5 + tmp7;
+    const int32_t z5 = (z3 + z4) * BEVW_JFIX_1_175875602;
+    const int32_t t4 = tmp4 * BEVW_JFIX_0_298631336, t5 = tmp5 * BEVW_JFIX_2_053119869, t6 = tmp6 * BEVW_JFIX_3_072711026,
+                  t7 = tmp7 * BEVW_JFIX_1_501321110;
+    z1 *= -BEVW_JFIX_0_899976223; z2 *= -BEVW_JFIX_2_562915447; z3 *= -BEVW_JFIX_1_961570560; z4 *= -BEVW_JFIX_0_390180644;
+    z3 += z5; z4 += z5;
+    out[7] = descale(t4 + z1 + z3, sh); out[5] = descale(t5 + z2 + z4, sh);
+    out[3] = descale(t6 + z2 + z3, sh); out[1] = descale(t7 + z1 + z4, sh);
+}
+// jcdctmgr.c quantize: coef / (8 q), rounded half away from zero
+__host__ __device__ __forceinline__ int32_t quantize(int32_t v, int32_t q)
+{
+    const int32_t qv = q << 3;
+    int32_t t = v < 0 ? -v : v;
+    t += qv >> 1;
+    t = t >= qv ? t / qv : 0;
+    return v < 0 ? -t : t;
+}
+
+// ---- colour -------------------------------------------------------------------------------------------------------------------
+// jdcolor.c ycc_rgb_convert (SCALEBITS 16) for one pixel, packed B | G << 8 | R << 16
+__host__ __device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
+{
+    const int32_t cr_r = (91881 * (cr - 128) + 32768) >> 16;
+    const int32_t cb_b = (116130 * (cb - 128) + 32768) >> 16;
+    const int32_t g_off = (-22554 * (cb - 128) + 32768 - 46802 * (cr - 128)) >> 16;
+    int r = y + cr_r, g = y + g_off, b = y + cb_b;
+    r = r < 0 ? 0 : (r > 255 ? 255 : r);
+    g = g < 0 ? 0 : (g > 255 ? 255 : g);
+    b = b < 0 ? 0 : (b > 255 ? 255 : b);
+    return (uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16);
+}
+// jccolor.c rgb_ycc_convert
+__host__ __device__ __forceinline__ void bgr_to_ycc(int b, int g, int r, int &y, int &cb, int &cr)
+{
+    y = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
+    cb = (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
+    cr = (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
+}
+
+// jdsample.c: the chroma sample of component plane C (pitch cp, real size dw x dh) seen by luma position (x, y)
+__host__ __device__ __forceinline__ int upsample_at(const uint8_t *__restrict__ C, int cp, int dw, int dh, int hs, int vs, int x, int y)
+{
+    if (hs == 1) return C[(size_t)y * cp + x];
+    const int cx = x >> 1;
+    if (vs == 1) {   // h2v1_fancy_upsample (box filter when the component is <= 2 samples wide)
+        if (dw <= 2) return C[(size_t)y * cp + cx];
+        int nx = (x & 1) ? cx + 1 : cx - 1;
+        nx = nx < 0 ? 0 : (nx > dw - 1 ? dw - 1 : nx);
+        const int t = C[(size_t)y * cp + cx], o = C[(size_t)y * cp + nx];
+        return (3 * t + o + 1 + (x & 1)) >> 2;
+    }
+    const int cy = y >> 1;   // h2v2_fancy_upsample
+    if (dw <= 2) return C[(size_t)cy * cp + cx];
+    int ny = (y & 1) ? cy + 1 : cy - 1, nx = (x & 1) ? cx + 1 : cx - 1;
+    ny = ny < 0 ? 0 : (ny > dh - 1 ? dh - 1 : ny);
+    nx = nx < 0 ? 0 : (nx > dw - 1 ? dw - 1 : nx);
+    const int tcs = 3 * C[(size_t)cy * cp + cx] + C[(size_t)ny * cp + cx];
+    const int ocs = 3 * C[(size_t)cy * cp + nx] + C[(size_t)ny * cp + nx];
+    return (3 * tcs + ocs + 8 - (x & 1)) >> 4;
+}
+
+// ---- encoding tables ------------------------------------------------------------------------------------------------------
+struct EncHuff { uint16_t code[256]; uint8_t len[256]; };   // jchuff.c jpeg_make_c_derived_tbl
+struct EncTables {
+    EncHuff dc[2], ac[2];     // luma, chroma
+    uint16_t q[2][64];        // quantisers, row-major
+};
+
+__host__ __device__ __forceinline__ int bit_length(int v) { return v ? 32 - __builtin_clz((unsigned)v) : 0; }
+
+// jchuff.c encode_one_block on a block stored in zigzag order.  EMIT = false: the number of bits only.
+// EMIT: bits are ORed into `out` (32-bit words, most significant bit first) starting at bit `pos`; the first and the last word a
+// block touches may be shared with its neighbours (atomic), the words in between are its own.
+template <bool EMIT>
+__host__ __device__ inline uint32_t encode_block(const int16_t *__restrict__ zz, int last_dc, const EncHuff &D, const EncHuff &A, uint32_t *out,
+                                                 uint32_t pos)
+{
+    uint32_t bits = 0;
+    uint64_t acc = 0;   // EMIT: pending bits, right-aligned
+    int nacc = 0;
+    uint32_t widx = pos >> 5;
+    int lead = (int)(pos & 31u);   // bits of out[widx] that belong to earlier blocks
+    bool first = true;
+    auto put = [&](uint32_t code, int len) {
+        bits += (uint32_t)len;
+        if (!EMIT || !len) return;
+        acc = (acc << len) | (code & ((1u << len) - 1u));
+        nacc += len;
+        while (lead + nacc >= 32) {
+            const int take = 32 - lead;
+            const uint32_t w = (uint32_t)(acc >> (nacc - take)) & (take == 32 ? 0xffffffffu : ((1u << take) - 1u));
+            nacc -= take;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (first) atomicOr(&out[widx], w); else out[widx] = w;
+#else
+            if (first) out[widx] |= w; else out[widx] = w;
+#endif
+            first = false;
+            lead = 0;
+            ++widx;
+        }
+    };
+    int temp = zz[0] - last_dc, temp2 = temp;
+    if (temp < 0) { temp = -temp; --temp2; }
+    int nb = bit_length(temp);
+    put(D.code[nb], D.len[nb]);
+    if (nb) put((uint32_t)temp2, nb);
+    int r = 0;
+    for (int k = 1; k < 64; ++k) {
+        temp = zz[k];
+        if (temp == 0) { ++r; continue; }
+        while (r > 15) { put(A.code[0xF0], A.len[0xF0]); r -= 16; }
+        temp2 = temp;
+        if (temp < 0) { temp = -temp; --temp2; }
+        nb = bit_length(temp);
+        put(A.code[(r << 4) + nb], A.len[(r << 4) + nb]);
+        put((uint32_t)temp2, nb);
+        r = 0;
+    }
+    if (r > 0) put(A.code[0], A.len[0]);
+    if (EMIT && nacc > 0) {   // the tail shares its word with the next block
+        const uint32_t w = (uint32_t)(acc & ((1ull << nacc) - 1ull)) << (32 - lead - nacc);
+#if defined(__HIP_DEVICE_COMPILE__)
+        atomicOr(&out[widx], w);
+#else
+        out[widx] |= w;
+#endif
+    }
+    return bits;
+}
+
+// index (scan order) of the block whose DC is the prediction of block `blk`, or -1 for the first block of a component
+__host__ __device__ __forceinline__ int dc_predecessor(int blk, const Geom &G)
+{
+    const int mcu = blk / G.bpm, z = blk % G.bpm;
+    if (z < G.nY) return z > 0 ? blk - 1 : (mcu > 0 ? blk - G.bpm + G.nY - 1 : -1);
+    return mcu > 0 ? blk - G.bpm : -1;
+}
+
+
+// ---- per-lane bodies of the encoder's first two kernels ----------------------------------------------------------------------
+// k_jenc_ycc: the lane of chroma position (xc, yo) of the padded chroma plane converts its hs x vs pixels (jccolor.c), writes their
+// luma samples and the downsampled chroma pair (jcsample.c h2v2_downsample: bias 1, 2, 1, 2 ...; h2v1_downsample: 0, 1, 0, 1 ...).
+// Reads are clamped to the image: libjpeg replicates the last column / row BEFORE averaging (expand_right_edge), but pads the
+// chroma planes below the last real chroma row with COPIES of that row (jcprepct.c pre_process_data).
+__host__ __device__ inline void enc_ycc_at(const uint8_t *__restrict__ bgr, size_t pitch, const Geom &G, int xc, int yo, uint8_t *__restrict__ Y,
+                                           uint8_t *__restrict__ Cb, uint8_t *__restrict__ Cr)
+{
+    const int yw = G.wb[0] * 8, cw = G.wb[1] * 8;
+    int scb = 0, scr = 0;
+    const int ysrc = yo < G.dh ? yo : G.dh - 1;
+    for (int j = 0; j < G.vs; ++j)
+        for (int i = 0; i < G.hs; ++i) {
+            const int X = xc * G.hs + i;
+            const int sx = X < G.w ? X : G.w - 1;
+            {   // luma of the position itself
+                const int Yp = yo * G.vs + j;
+                const int sy = Yp < G.h ? Yp : G.h - 1;
+                const uint8_t *px = bgr + (size_t)sy * pitch + (size_t)sx * 3;
+                int y, cb, cr;
+                bgr_to_ycc(px[0], px[1], px[2], y, cb, cr);
+                Y[(size_t)Yp * yw + X] = (uint8_t)y;
+                if (yo == ysrc) { scb += cb; scr += cr; continue; }
+            }
+            const int Ys = ysrc * G.vs + j;
+            const int sy = Ys < G.h ? Ys : G.h - 1;
+            const uint8_t *px = bgr + (size_t)sy * pitch + (size_t)sx * 3;
+            int y, cb, cr;
+            bgr_to_ycc(px[0], px[1], px[2], y, cb, cr);
+            scb += cb;
+            scr += cr;
+        }
+    if (G.hs == 2 && G.vs == 2) {
+        const int bias = 1 + (xc & 1);
+        scb = (scb + bias) >> 2;
+        scr = (scr + bias) >> 2;
+    } else if (G.hs == 2) {
+        const int bias = xc & 1;
+        scb = (scb + bias) >> 1;
+        scr = (scr + bias) >> 1;
+    }
+    Cb[(size_t)yo * cw + xc] = (uint8_t)scb;
+    Cr[(size_t)yo * cw + xc] = (uint8_t)scr;
+}
+
+// k_jenc_fdct: which samples block g (scan order) transforms.  jccoefct.c compress_data: blocks of the last MCU column / row that
+// lie beyond the component's own width_in_blocks / height_in_blocks are dummies -- AC = 0, DC = the quantised DC of the previous
+// block of the MCU (the block to the left; for a dummy ROW the last block of the row above).  The chain always ends at a real
+// block (rx, ry), and a block's DC depends on its samples only, so a dummy is "the root's DC, nothing else".
+__host__ __device__ __forceinline__ void enc_block_root(const Geom &G, int g, int &comp, int &rx, int &ry, bool &dc_only)
+{
+    const int mcu = g / G.bpm, z = g % G.bpm;
+    const int mx = mcu % G.mcux, my = mcu / G.mcux;
+    int bx, by, rwb, rhb;
+    if (z < G.nY) {
+        comp = 0;
+        bx = mx * G.hs + z % G.hs;
+        by = my * G.vs + z / G.hs;
+        rwb = (G.w + 7) >> 3;
+        rhb = (G.h + 7) >> 3;
+    } else {
+        comp = 1 + z - G.nY;
+        bx = mx;
+        by = my;
+        rwb = (G.dw + 7) >> 3;
+        rhb = (G.dh + 7) >> 3;
+    }
+    dc_only = false;
+    rx = bx;
+    ry = by;
+    if (by >= rhb) {
+        dc_only = true;
+        ry = by - 1;
+        rx = mx * (comp == 0 ? G.hs : 1) + (comp == 0 ? G.hs : 1) - 1;
+    }
+    if (rx >= rwb) {
+        dc_only = true;
+        rx = rwb - 1;
+    }
+}
+
+// ---- host side: marker parsing (jdmarker.c) and the staging copy -----------------------------------------------------------
+struct RawHuff { uint8_t bits[17]; uint8_t vals[256]; bool ok; };
+struct Parsed {
+    int w, h, nc, hs, vs, ri, orientation;
+    int tq[3], td[3], ta[3];
+    uint16_t q[4][64];   // row-major
+    bool qok[4];
+    RawHuff dc[4], ac[4];
+    size_t scan_off;     // first entropy-coded byte
+};
+enum { kParseOk = 0, kParseFormat = -1, kParseUnsupported = -2 };
+
+inline int exif_orientation(const uint8_t *p, size_t n)
+{
+    if (n < 14 || memcmp(p, "Exif\0\0", 6) != 0) return 0;
+    const uint8_t *t = p + 6;
+    const size_t tn = n - 6;
+    const bool le = t[0] == 'I' && t[1] == 'I';
+    if (!le && !(t[0] == 'M' && t[1] == 'M')) return 0;
+    auto rd16 = [&](size_t o) -> uint32_t { return le ? (uint32_t)t[o] | ((uint32_t)t[o + 1] << 8) : ((uint32_t)t[o] << 8) | t[o + 1]; };
+    auto rd32 = [&](size_t o) -> uint32_t { return le ? rd16(o) | (rd16(o + 2) << 16) : (rd16(o) << 16) | rd16(o + 2); };
+    const size_t off = rd32(4);
+    if (off + 2 > tn) return 0;
+    const uint32_t cnt = rd16(off);
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const size_t e = off + 2 + 12 * (size_t)i;
+        if (e + 12 > tn) return 0;
+        if (rd16(e) == 0x0112) return (int)rd16(e + 8);
+    }
+    return 0;
+}
+
+// What cv2.imread accepts and this engine decodes: baseline / extended-sequential Huffman, 8 bit, one interleaved scan, grey or
+// YCbCr with luma 1x1 / 2x1 / 2x2.  Everything else is refused by name (why): the caller falls back to its own decoder knowingly.
+inline int parse_header(const uint8_t *d, size_t n, Parsed &P, std::string &why)
+{
+    memset(&P, 0, sizeof P);
+    if (!d || n < 4 || d[0] != 0xFF || d[1] != 0xD8) { why = "not a JPEG file (no SOI)"; return kParseFormat; }
+    size_t i = 2;
+    bool sof = false;
+    int id[3] = {0, 0, 0};
+    for (;;) {
+        if (i + 4 > n || d[i] != 0xFF) { why = "truncated or corrupt marker stream"; return kParseFormat; }
+        while (i < n && d[i] == 0xFF) ++i;
+        if (i >= n) { why = "truncated marker stream"; return kParseFormat; }
+        const int m = d[i++];
+        if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
+        if (m == 0xD9) { why = "EOI before any scan"; return kParseFormat; }
+        if (i + 2 > n) { why = "truncated marker segment"; return kParseFormat; }
+        const size_t L = ((size_t)d[i] << 8) | d[i + 1];
+        if (L < 2 || i + L > n) { why = "truncated marker segment"; return kParseFormat; }
+        const uint8_t *s = d + i + 2;
+        const size_t sl = L - 2;
+        if (m == 0xC0 || m == 0xC1) {
+            if (sl < 6 || s[0] != 8) { why = "sample precision other than 8 bits"; return kParseUnsupported; }
+            P.h = (s[1] << 8) | s[2];
+            P.w = (s[3] << 8) | s[4];
+            P.nc = s[5];
+            if (P.w <= 0 || P.h <= 0) { why = "empty image / DNL height"; return kParseUnsupported; }
+            if ((P.nc != 1 && P.nc != 3) || sl < 6 + 3 * (size_t)P.nc) { why = "component count other than 1 or 3"; return kParseUnsupported; }
+            int hsv[3] = {1, 1, 1}, vsv[3] = {1, 1, 1};
+            for (int c = 0; c < P.nc; ++c) {
+                id[c] = s[6 + 3 * c];
+                hsv[c] = s[7 + 3 * c] >> 4;
+                vsv[c] = s[7 + 3 * c] & 15;
+                P.tq[c] = s[8 + 3 * c];
+                if (P.tq[c] > 3) { why = "quantisation table index > 3"; return kParseFormat; }
+            }
+            if (P.nc == 1) {
+                P.hs = P.vs = 1;   // a single-component scan is never interleaved (jdinput.c per_scan_setup)
+            } else {
+                if (hsv[1] != 1 || vsv[1] != 1 || hsv[2] != 1 || vsv[2] != 1) { why = "chroma sampling other than 1x1"; return kParseUnsupported; }
+                if (!((hsv[0] == 1 && vsv[0] == 1) || (hsv[0] == 2 && vsv[0] == 1) || (hsv[0] == 2 && vsv[0] == 2))) {
+                    why = "luma sampling other than 1x1, 2x1, 2x2";
+                    return kParseUnsupported;
+                }
+                P.hs = hsv[0];
+                P.vs = vsv[0];
+            }
+            sof = true;
+        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            why = "progressive / lossless / arithmetic-coded JPEG";
+            return kParseUnsupported;
+        } else if (m == 0xC4) {
+            size_t o = 0;
+            while (o < sl) {
+                if (o + 17 > sl) { why = "truncated DHT"; return kParseFormat; }
+                const int tc = s[o] >> 4, th = s[o] & 15;
+                if (tc > 1 || th > 3) { why = "bad DHT class / index"; return kParseFormat; }
+                RawHuff &t = tc ? P.ac[th] : P.dc[th];
+                memset(&t, 0, sizeof t);
+                int cnt = 0;
+                for (int l = 1; l <= 16; ++l) { t.bits[l] = s[o + l]; cnt += s[o + l]; }
+                if (cnt > 256 || o + 17 + (size_t)cnt > sl) { why = "truncated DHT"; return kParseFormat; }
+                memcpy(t.vals, s + o + 17, (size_t)cnt);
+                t.ok = true;
+                o += 17 + (size_t)cnt;
+            }
+        } else if (m == 0xDB) {
+            size_t o = 0;
+            while (o < sl) {
+                const int pq = s[o] >> 4, tq = s[o] & 15;
+                if (tq > 3 || pq > 1 || o + 1 + (pq ? 128u : 64u) > sl) { why = "bad DQT"; return kParseFormat; }
+                for (int k = 0; k < 64; ++k)
+                    P.q[tq][natural_of(k)] = pq ? (uint16_t)((s[o + 1 + 2 * k] << 8) | s[o + 2 + 2 * k]) : s[o + 1 + k];
+                P.qok[tq] = true;
+                o += 1 + (pq ? 128u : 64u);
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) { why = "bad DRI"; return kParseFormat; }
+            P.ri = (s[0] << 8) | s[1];
+        } else if (m == 0xE1) {
+            const int o = exif_orientation(s, sl);
+            if (o) P.orientation = o;
+        } else if (m == 0xDA) {
+            if (!sof) { why = "SOS before SOF"; return kParseFormat; }
+            if (sl < 1 || s[0] != P.nc || sl < 1 + 2 * (size_t)P.nc + 3) { why = "non-interleaved (multi-scan) JPEG"; return kParseUnsupported; }
+            for (int c = 0; c < P.nc; ++c) {
+                if (s[1 + 2 * c] != id[c]) { why = "scan components out of frame order"; return kParseUnsupported; }
+                P.td[c] = s[2 + 2 * c] >> 4;
+                P.ta[c] = s[2 + 2 * c] & 15;
+                if (P.td[c] > 3 || P.ta[c] > 3) { why = "bad table selector in SOS"; return kParseFormat; }
+            }
+            if (s[1 + 2 * P.nc] != 0 || s[2 + 2 * P.nc] != 63 || s[3 + 2 * P.nc] != 0) { why = "spectral selection / successive approximation"; return kParseUnsupported; }
+            P.scan_off = i + L;
+            break;
+        }
+        i += L;
+    }
+    for (int c = 0; c < P.nc; ++c)
+        if (!P.qok[P.tq[c]] || !P.dc[P.td[c]].ok || !P.ac[P.ta[c]].ok) { why = "a table the scan refers to is missing"; return kParseFormat; }
+    if (P.orientation > 1) { why = "EXIF orientation other than 1 (cv2.imread would rotate the image)"; return kParseUnsupported; }
+    return kParseOk;
+}
+
+inline bool make_hufftab(const RawHuff &r, HuffTab &T)
+{
+    memset(&T, 0, sizeof T);
+    int p = 0, code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        T.valoff[l] = p - code;
+        if (r.bits[l]) {
+            for (int i = 0; i < r.bits[l]; ++i) {
+                if (l <= 9) {
+                    const int c0 = (code + i) << (9 - l);
+                    for (int f = 0; f < (1 << (9 - l)); ++f) T.fast[c0 + f] = (uint16_t)((l << 8) | r.vals[p + i]);
+                }
+            }
+            p += r.bits[l];
+            code += r.bits[l];
+            if (code > (1 << l)) return false;
+            T.maxcode[l] = code - 1;
+        } else {
+            T.maxcode[l] = -1;
+        }
+        code <<= 1;
+    }
+    T.maxcode[17] = 0xFFFFF;
+    memcpy(T.vals, r.vals, 256);
+    return true;
+}
+
+// The staging copy: entropy-coded bytes of d[off ...) with 0xFF 0x00 -> 0xFF, RSTn markers dropped (their positions recorded) and
+// everything from the next marker on left out.  dst needs n - off + 16 bytes; seg_byte receives nseg + 1 byte offsets.
+inline size_t unstuff_scan(const uint8_t *d, size_t n, size_t off, uint8_t *dst, std::vector<uint32_t> &seg_byte)
+{
+    seg_byte.clear();
+    seg_byte.push_back(0);
+    size_t i = off, o = 0;
+    while (i < n) {
+        const uint8_t *f = (const uint8_t *)memchr(d + i, 0xFF, n - i);
+        const size_t run = f ? (size_t)(f - (d + i)) : n - i;
+        memcpy(dst + o, d + i, run);
+        o += run;
+        i += run;
+        if (!f) break;
+        size_t j = i + 1;
+        while (j < n && d[j] == 0xFF) ++j;
+        if (j >= n) break;
+        const uint8_t m = d[j];
+        if (m == 0) { dst[o++] = 0xFF; i = j + 1; }
+        else if (m >= 0xD0 && m <= 0xD7) { seg_byte.push_back((uint32_t)o); i = j + 1; }
+        else break;
+    }
+    seg_byte.push_back((uint32_t)o);
+    memset(dst + o, 0, 16);
+    return o;
+}
+
+// ---- the file header cv2.imwrite's libjpeg writes (jcmarker.c): SOI, JFIF APP0, DQT x 2, SOF0, DHT x 4, SOS --------------
+// jcparam.c std_luminance_quant_tbl / std_chrominance_quant_tbl (ITU T.81 Annex K.1, K.2), row-major
+inline const uint8_t *std_quant(int t)
+{
+    static const uint8_t q[2][64] = {
+        {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,  69,  56,
+         14, 17, 22, 29, 51,  87,  80,  62,  18, 22, 37, 56, 68,  109, 103, 77,  24, 35, 55, 64, 81,  104, 113, 92,
+         49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99},
+        {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+         99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99}};
+    return q[t];
+}
+// Annex K.3 - K.6 (jcparam.c std_huff_tables): bits[1..16] then the symbols
+inline const uint8_t *std_huff(int cls, int t, int &nvals)
+{
+    static const uint8_t dc0[] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    static const uint8_t dc1[] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+    static const uint8_t ac0[] = {
+        0,    2,    1,    3,    3,    2,    4,    3,    5,    5,    4,    4,    0,    0,    1,    0x7d, 0x01, 0x02, 0x03, 0x00, 0x04, 0x11,
+        0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1, 0xc1,
+        0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a,
+        0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+        0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87,
+        0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2,
+        0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+        0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+        0xf9, 0xfa};
+    static const uint8_t ac1[] = {
+        0,    2,    1,    2,    4,    4,    3,    4,    7,    5,    4,    4,    0,    1,    2,    0x77, 0x00, 0x01, 0x02, 0x03, 0x11, 0x04,
+        0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1, 0x09,
+        0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28,
+        0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+        0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85,
+        0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9,
+        0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+        0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8,
+        0xf9, 0xfa};
+    nvals = cls == 0 ? 12 : 162;
+    return cls == 0 ? (t == 0 ? dc0 : dc1) : (t == 0 ? ac0 : ac1);
+}
+
+inline void make_enchuff(const uint8_t *bits_vals, EncHuff &E)
+{
+    memset(&E, 0, sizeof E);
+    const uint8_t *bits = bits_vals - 1, *vals = bits_vals + 16;   // bits[1..16]
+    int p = 0;
+    uint32_t code = 0;
+    for (int l = 1; l <= 16; ++l) {
+        for (int i = 0; i < bits[l]; ++i, ++p) {
+            E.code[vals[p]] = (uint16_t)code++;
+            E.len[vals[p]] = (uint8_t)l;
+        }
+        code <<= 1;
+    }
+}
+
+// jcparam.c jpeg_set_quality(quality, force_baseline = TRUE) + the derived Huffman tables
+inline void make_enc_tables(int quality, EncTables &T)
+{
+    quality = quality <= 0 ? 1 : (quality > 100 ? 100 : quality);
+    const int scale = quality < 50 ? 5000 / quality : 200 - quality * 2;
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 64; ++i) {
+            long v = ((long)std_quant(t)[i] * scale + 50L) / 100L;
+            T.q[t][i] = (uint16_t)(v <= 0 ? 1 : (v > 255 ? 255 : v));
+        }
+    int nv;
+    for (int t = 0; t < 2; ++t) {
+        make_enchuff(std_huff(0, t, nv), T.dc[t]);
+        make_enchuff(std_huff(1, t, nv), T.ac[t]);
+    }
+}
+
+// jcmarker.c write_file_header / write_frame_header / write_scan_header for a 3-component baseline image
+inline std::vector<uint8_t> make_file_header(int w, int h, int hs, int vs, const EncTables &T)
+{
+    std::vector<uint8_t> H;
+    auto b = [&](int v) { H.push_back((uint8_t)v); };
+    auto w16 = [&](int v) { b(v >> 8); b(v & 255); };
+    w16(0xFFD8);
+    w16(0xFFE0); w16(16); b('J'); b('F'); b('I'); b('F'); b(0); b(1); b(1); b(0); w16(1); w16(1); b(0); b(0);
+    for (int t = 0; t < 2; ++t) {
+        w16(0xFFDB); w16(67); b(t);
+        for (int k = 0; k < 64; ++k) b(T.q[t][natural_of(k)]);
+    }
+    w16(0xFFC0); w16(17); b(8); w16(h); w16(w); b(3);
+    b(1); b((hs << 4) | vs); b(0);
+    b(2); b(0x11); b(1);
+    b(3); b(0x11); b(1);
+    for (int t = 0; t < 2; ++t)
+        for (int cls = 0; cls < 2; ++cls) {
+            int nv;
+            const uint8_t *bv = std_huff(cls, t, nv);
+            w16(0xFFC4); w16(2 + 1 + 16 + nv); b((cls << 4) | t);
+            for (int i = 0; i < 16 + nv; ++i) b(bv[i]);
+        }
+    w16(0xFFDA); w16(12); b(3); b(1); b(0x00); b(2); b(0x11); b(3); b(0x11); b(0); b(63); b(0);
+    return H;
+}
+}  // namespace jpg
+}  // namespace bevw

@@ -21,6 +21,7 @@
 #include "bevw_kernels.h"
 #include "bevw_plan.h"
 #include "bevw_comm.h"
+#include "bevw_jpeg_codec.h"
 
 using namespace bevw;
 
@@ -1864,3 +1865,407 @@ int bevw_timer_stop(bevw_handle *h, float *elapsed_ms)
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// JPEG either side of the path: cv2.imread (main.py:74-77) / cv2.imwrite (surroundBEV.py:340)
+// ---------------------------------------------------------------------------------------------------------------
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { release(); }
+    int reserve(size_t n)
+    {
+        if (n <= cap) return BEVW_OK;
+        release();
+        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; return fail(BEVW_E_NOMEM, "hipHostMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
+        cap = n;
+        return BEVW_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct bevw_jpeg {
+    int device = 0;
+    hipStream_t st = nullptr;
+    LapTimer timer;
+    // decode: what bevw_jpeg_decode_stage left on the device
+    jpg::Geom G{};
+    int n = 0;
+    bool staged = false, decoded = false;
+    size_t total_sub = 0;
+    uint32_t max_sub = 0;
+    PinnedBuf h_stream;
+    std::vector<jpg::ImageDesc> h_desc;
+    std::vector<uint32_t> h_seg_byte, h_seg_sub;
+    std::vector<jpg::TableSet> h_tabs;
+    std::vector<uint16_t> h_quant;
+    DevBuf d_stream, d_desc, d_seg_byte, d_seg_sub, d_tabs, d_quant;
+    DevBuf d_entry, d_exit, d_sums, d_base, d_endbit, d_meta, d_rounds, d_coef, d_planes, d_img;
+    // encode
+    jpg::Geom EG{};
+    int en = 0, e_quality = -1, e_sampling = -1;
+    jpg::EncTables etabs;
+    std::vector<uint8_t> header;
+    DevBuf d_etabs, d_header, d_eplanes, d_zz, d_bitlen, d_bitbuf, d_totals, d_files, d_sizes, d_src;
+    size_t buf_words = 0, file_cap = 0;
+    std::vector<uint32_t> sizes;
+    bool encoded = false, sizes_valid = false;
+};
+
+static int jpeg_parse_fail(int st, int index, const std::string &why)
+{
+    return fail(BEVW_E_INVALID, "JPEG %d: %s%s", index, st == jpg::kParseUnsupported ? "outside the supported subset: " : "", why.c_str());
+}
+
+int bevw_jpeg_probe(const uint8_t *data, size_t len, int32_t info[8])
+{
+    if (!data || !info) return fail(BEVW_E_INVALID, "bevw_jpeg_probe: null argument");
+    jpg::Parsed P;
+    std::string why;
+    const int st = jpg::parse_header(data, len, P, why);
+    if (st) return jpeg_parse_fail(st, 0, why);
+    info[0] = P.w; info[1] = P.h; info[2] = P.nc; info[3] = P.hs; info[4] = P.vs; info[5] = P.ri; info[6] = P.orientation; info[7] = 0;
+    return BEVW_OK;
+}
+
+int bevw_jpeg_create(int device, bevw_jpeg **out)
+{
+    if (!out) return fail(BEVW_E_INVALID, "bevw_jpeg_create: null out");
+    *out = nullptr;
+    BEVW_TRY(use_device(device));
+    bevw_jpeg *j = new (std::nothrow) bevw_jpeg();
+    if (!j) return fail(BEVW_E_NOMEM, "out of host memory");
+    j->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&j->st, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete j; return fail(BEVW_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    *out = j;
+    return BEVW_OK;
+}
+
+void bevw_jpeg_destroy(bevw_jpeg *j)
+{
+    if (!j) return;
+    (void)hipSetDevice(j->device);
+    if (j->st) { (void)hipStreamSynchronize(j->st); (void)hipStreamDestroy(j->st); }
+    j->timer.release();
+    delete j;
+}
+
+int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_t *len, int n)
+{
+    if (!j || !data || !len || n <= 0 || n > 65535) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_stage: bad argument (1 <= n <= 65535)");
+    BEVW_TRY(use_device(j->device));
+    HIP_TRY(hipStreamSynchronize(j->st));   // the staging buffers of the previous batch may still be in flight
+    j->staged = j->decoded = false;
+    std::vector<jpg::Parsed> P((size_t)n);
+    size_t bound = 0;
+    for (int i = 0; i < n; ++i) {
+        std::string why;
+        if (!data[i]) return fail(BEVW_E_INVALID, "JPEG %d: null pointer", i);
+        const int st = jpg::parse_header(data[i], len[i], P[i], why);
+        if (st) return jpeg_parse_fail(st, i, why);
+        if (i && (P[i].w != P[0].w || P[i].h != P[0].h || P[i].nc != P[0].nc || P[i].hs != P[0].hs || P[i].vs != P[0].vs))
+            return fail(BEVW_E_INVALID, "JPEG %d is %dx%d (%d components, luma %dx%d) but the batch is %dx%d (%d, %dx%d): one geometry per batch", i,
+                        P[i].w, P[i].h, P[i].nc, P[i].hs, P[i].vs, P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
+        bound += ((len[i] - P[i].scan_off + 16 + 15) & ~(size_t)15) + 16;
+    }
+    if (bound >= ((size_t)1 << 32)) return fail(BEVW_E_INVALID, "batch of %zu entropy-coded bytes: split it (4 GiB per batch)", bound);
+    j->G = jpg::make_geom(P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
+    const jpg::Geom &G = j->G;
+    BEVW_TRY(j->h_stream.reserve(bound));
+    j->h_desc.assign((size_t)n, jpg::ImageDesc());
+    j->h_seg_byte.clear();
+    j->h_seg_sub.clear();
+    j->h_tabs.clear();
+    j->h_quant.assign((size_t)n * 192, 0);
+    std::vector<std::string> keys;
+    std::vector<uint32_t> seg;
+    size_t off = 0, sub_total = 0;
+    uint32_t max_sub = 0;
+    for (int i = 0; i < n; ++i) {
+        jpg::ImageDesc &D = j->h_desc[i];
+        // tables: identical table sets are shared (cameras of one rig write the same ones)
+        std::string key;
+        for (int c = 0; c < P[i].nc; ++c) {
+            key.append((const char *)&P[i].dc[P[i].td[c]], sizeof(jpg::RawHuff));
+            key.append((const char *)&P[i].ac[P[i].ta[c]], sizeof(jpg::RawHuff));
+        }
+        size_t t = 0;
+        while (t < keys.size() && keys[t] != key) ++t;
+        if (t == keys.size()) {
+            jpg::TableSet T;
+            memset(&T, 0, sizeof T);
+            for (int c = 0; c < P[i].nc; ++c)
+                if (!jpg::make_hufftab(P[i].dc[P[i].td[c]], T.t[2 * c]) || !jpg::make_hufftab(P[i].ac[P[i].ta[c]], T.t[2 * c + 1]))
+                    return fail(BEVW_E_INVALID, "JPEG %d: over-subscribed Huffman table", i);
+            keys.push_back(key);
+            j->h_tabs.push_back(T);
+        }
+        D.tables = (uint32_t)t;
+        D.quant = (uint32_t)i;
+        for (int c = 0; c < P[i].nc; ++c) memcpy(&j->h_quant[(size_t)i * 192 + c * 64], P[i].q[P[i].tq[c]], 128);
+        // the staging copy
+        uint8_t *dst = (uint8_t *)j->h_stream.p + off;
+        const size_t nb = jpg::unstuff_scan(data[i], len[i], P[i].scan_off, dst, seg);
+        const uint32_t nseg = (uint32_t)seg.size() - 1;
+        const uint32_t nmcu = (uint32_t)G.mcux * (uint32_t)G.mcuy;
+        const uint32_t want = P[i].ri ? (nmcu + (uint32_t)P[i].ri - 1) / (uint32_t)P[i].ri : 1u;
+        if (nseg != want) return fail(BEVW_E_INVALID, "JPEG %d: %u restart segments in the data, %u expected from DRI", i, nseg, want);
+        D.stream_word = (uint32_t)(off >> 2);
+        D.stream_bytes = (uint32_t)nb;
+        D.seg_first = (uint32_t)j->h_seg_byte.size();
+        D.nseg = nseg;
+        D.seg_blocks = P[i].ri ? (uint32_t)P[i].ri * (uint32_t)G.bpm : jpg::kNoRestart;
+        D.sub_first = (uint32_t)sub_total;
+        uint32_t subs = 0;
+        for (uint32_t s = 0; s <= nseg; ++s) {
+            j->h_seg_byte.push_back(seg[s]);
+            j->h_seg_sub.push_back(subs);
+            if (s < nseg) subs += ((seg[s + 1] - seg[s]) * 8u + (uint32_t)jpg::kSubBits - 1u) / (uint32_t)jpg::kSubBits;
+        }
+        D.nsub = subs;
+        sub_total += subs;
+        if (subs > max_sub) max_sub = subs;
+        off += (nb + 16 + 15) & ~(size_t)15;
+    }
+    if (sub_total >= ((size_t)1 << 31)) return fail(BEVW_E_INVALID, "batch too large");
+    j->n = n;
+    j->total_sub = sub_total;
+    j->max_sub = max_sub;
+    BEVW_TRY(j->d_stream.reserve(off + 64));
+    BEVW_TRY(j->d_desc.reserve(j->h_desc.size() * sizeof(jpg::ImageDesc)));
+    BEVW_TRY(j->d_seg_byte.reserve(j->h_seg_byte.size() * 4));
+    BEVW_TRY(j->d_seg_sub.reserve(j->h_seg_sub.size() * 4));
+    BEVW_TRY(j->d_tabs.reserve(j->h_tabs.size() * sizeof(jpg::TableSet)));
+    BEVW_TRY(j->d_quant.reserve(j->h_quant.size() * 2));
+    HIP_TRY(hipMemcpyAsync(j->d_stream.p, j->h_stream.p, off, hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size() * sizeof(jpg::ImageDesc), hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_seg_byte.p, j->h_seg_byte.data(), j->h_seg_byte.size() * 4, hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_seg_sub.p, j->h_seg_sub.data(), j->h_seg_sub.size() * 4, hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_tabs.p, j->h_tabs.data(), j->h_tabs.size() * sizeof(jpg::TableSet), hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_quant.p, j->h_quant.data(), j->h_quant.size() * 2, hipMemcpyHostToDevice, j->st));
+    j->staged = true;
+    return BEVW_OK;
+}
+
+int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_bytes, size_t row_pitch_bytes)
+{
+    if (!j || !d_out) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_run_device: null argument");
+    if (!j->staged) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_run_device before bevw_jpeg_decode_stage");
+    const jpg::Geom &G = j->G;
+    if (row_pitch_bytes < (size_t)G.w * 3 || image_stride_bytes < row_pitch_bytes * (size_t)G.h)
+        return fail(BEVW_E_INVALID, "output layout (pitch %zu, stride %zu) too small for %dx%d BGR", row_pitch_bytes, image_stride_bytes, G.w, G.h);
+    BEVW_TRY(use_device(j->device));
+    const size_t ns = j->total_sub ? j->total_sub : 1, n = (size_t)j->n;
+    BEVW_TRY(j->d_entry.reserve(ns * 8));
+    BEVW_TRY(j->d_exit.reserve(ns * 8));
+    BEVW_TRY(j->d_sums.reserve(ns * 16));
+    BEVW_TRY(j->d_base.reserve(ns * 16));
+    BEVW_TRY(j->d_endbit.reserve(ns * 4));
+    BEVW_TRY(j->d_meta.reserve(ns * 4));
+    BEVW_TRY(j->d_rounds.reserve(n * 4));
+    BEVW_TRY(j->d_coef.reserve(n * (size_t)G.nblk * 128));
+    BEVW_TRY(j->d_planes.reserve(n * (size_t)G.plane_bytes));
+    jpg::SubArrays A{j->d_entry.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_sums.as<int4>(), j->d_base.as<int4>(), j->d_endbit.as<uint32_t>(),
+                     j->d_meta.as<uint32_t>()};
+    const jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
+    const uint32_t *stream = j->d_stream.as<uint32_t>();
+    const jpg::TableSet *tabs = j->d_tabs.as<jpg::TableSet>();
+    HIP_TRY(hipMemsetAsync(j->d_coef.p, 0, n * (size_t)G.nblk * 128, j->st));
+    if (j->max_sub) {
+        const dim3 gs((j->max_sub + 255) / 256, (unsigned)n);
+        jpg::k_jpeg_sync0<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
+        BEVW_TRY(launch_check("k_jpeg_sync0"));
+        jpg::k_jpeg_sync<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(img, stream, tabs, G, A, j->d_rounds.as<uint32_t>());
+        BEVW_TRY(launch_check("k_jpeg_sync"));
+        jpg::k_jpeg_coef<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_coef.as<int16_t>());
+        BEVW_TRY(launch_check("k_jpeg_coef"));
+    }
+    jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(img, G, j->d_coef.as<int16_t>(), j->d_quant.as<uint16_t>(),
+                                                                                 j->d_planes.as<uint8_t>());
+    BEVW_TRY(launch_check("k_jpeg_idct"));
+    const int aligned = ((uintptr_t)d_out % 4 == 0 && image_stride_bytes % 4 == 0 && row_pitch_bytes % 4 == 0) ? 1 : 0;
+    jpg::k_jpeg_color<<<dim3(((G.w + 3) / 4 + 63) / 64, (G.h + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
+        G, j->d_planes.as<uint8_t>(), (uint8_t *)d_out, image_stride_bytes, row_pitch_bytes, aligned);
+    BEVW_TRY(launch_check("k_jpeg_color"));
+    j->decoded = true;
+    return BEVW_OK;
+}
+
+int bevw_jpeg_decode(bevw_jpeg *j, const uint8_t *const *data, const size_t *len, int n, uint8_t *out)
+{
+    if (!out) return fail(BEVW_E_INVALID, "bevw_jpeg_decode: null out");
+    BEVW_TRY(bevw_jpeg_decode_stage(j, data, len, n));
+    const size_t image = (size_t)j->G.w * j->G.h * 3;
+    BEVW_TRY(j->d_img.reserve(image * (size_t)n));
+    BEVW_TRY(bevw_jpeg_decode_run_device(j, j->d_img.p, image, (size_t)j->G.w * 3));
+    HIP_TRY(hipMemcpyAsync(out, j->d_img.p, image * (size_t)n, hipMemcpyDeviceToHost, j->st));
+    HIP_TRY(hipStreamSynchronize(j->st));
+    return BEVW_OK;
+}
+
+int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8])
+{
+    if (!j || !info) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_info: null argument");
+    if (!j->staged) return fail(BEVW_E_INVALID, "nothing staged");
+    BEVW_TRY(use_device(j->device));
+    int64_t rounds = 0;
+    if (j->decoded && j->max_sub) {
+        std::vector<uint32_t> r((size_t)j->n);
+        HIP_TRY(hipMemcpyAsync(r.data(), j->d_rounds.p, r.size() * 4, hipMemcpyDeviceToHost, j->st));
+        HIP_TRY(hipStreamSynchronize(j->st));
+        for (uint32_t v : r) rounds = v > rounds ? v : rounds;
+    }
+    size_t stream_bytes = 0;
+    for (const jpg::ImageDesc &D : j->h_desc) stream_bytes += D.stream_bytes;
+    info[0] = j->n; info[1] = j->G.w; info[2] = j->G.h; info[3] = (int64_t)j->total_sub; info[4] = rounds; info[5] = (int64_t)stream_bytes;
+    info[6] = j->G.nblk; info[7] = (int64_t)j->h_tabs.size();
+    return BEVW_OK;
+}
+
+int bevw_jpeg_get_planes(bevw_jpeg *j, int index, uint8_t *planes)
+{
+    if (!j || !planes || !j->decoded || index < 0 || index >= j->n) return fail(BEVW_E_INVALID, "bevw_jpeg_get_planes: nothing decoded / bad index");
+    BEVW_TRY(use_device(j->device));
+    HIP_TRY(hipMemcpyAsync(planes, j->d_planes.as<uint8_t>() + (size_t)index * j->G.plane_bytes, (size_t)j->G.plane_bytes, hipMemcpyDeviceToHost, j->st));
+    HIP_TRY(hipStreamSynchronize(j->st));
+    return BEVW_OK;
+}
+
+int bevw_jpeg_encode_bound(int width, int height, int sampling, size_t *bound)
+{
+    const int hs = sampling >> 4, vs = sampling & 15;
+    if (!bound || width <= 0 || height <= 0 || width > 65500 || height > 65500 || !((hs == 1 && vs == 1) || (hs == 2 && vs == 1) || (hs == 2 && vs == 2)))
+        return fail(BEVW_E_INVALID, "bevw_jpeg_encode_bound: bad size / sampling (0x11, 0x21, 0x22)");
+    const jpg::Geom G = jpg::make_geom(width, height, 3, hs, vs);
+    *bound = 1024 + (size_t)G.nblk * 209 * 2;   // header + every block at its longest, every byte stuffed
+    return BEVW_OK;
+}
+
+int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int width, int height, size_t image_stride_bytes, size_t row_pitch_bytes,
+                                int quality, int sampling)
+{
+    if (!j || !d_bgr || n <= 0 || n > 65535) return fail(BEVW_E_INVALID, "bevw_jpeg_encode_run_device: bad argument (1 <= n <= 65535)");
+    size_t bound = 0;
+    BEVW_TRY(bevw_jpeg_encode_bound(width, height, sampling, &bound));
+    if (quality < 1 || quality > 100) return fail(BEVW_E_INVALID, "JPEG quality %d outside 1..100", quality);
+    if (row_pitch_bytes < (size_t)width * 3 || image_stride_bytes < row_pitch_bytes * (size_t)height)
+        return fail(BEVW_E_INVALID, "input layout (pitch %zu, stride %zu) too small for %dx%d BGR", row_pitch_bytes, image_stride_bytes, width, height);
+    BEVW_TRY(use_device(j->device));
+    j->encoded = j->sizes_valid = false;
+    const jpg::Geom G = jpg::make_geom(width, height, 3, sampling >> 4, sampling & 15);
+    if (quality != j->e_quality || sampling != j->e_sampling || width != j->EG.w || height != j->EG.h) {
+        HIP_TRY(hipStreamSynchronize(j->st));
+        jpg::make_enc_tables(quality, j->etabs);
+        j->header = jpg::make_file_header(width, height, G.hs, G.vs, j->etabs);
+        BEVW_TRY(j->d_etabs.reserve(sizeof(jpg::EncTables)));
+        BEVW_TRY(j->d_header.reserve(j->header.size()));
+        HIP_TRY(hipMemcpyAsync(j->d_etabs.p, &j->etabs, sizeof(jpg::EncTables), hipMemcpyHostToDevice, j->st));
+        HIP_TRY(hipMemcpyAsync(j->d_header.p, j->header.data(), j->header.size(), hipMemcpyHostToDevice, j->st));
+        j->e_quality = quality;
+        j->e_sampling = sampling;
+    }
+    j->EG = G;
+    j->en = n;
+    const size_t N = (size_t)n;
+    j->buf_words = ((size_t)G.nblk * 209 + 3) / 4 + 4;
+    j->file_cap = (j->header.size() + j->buf_words * 8 + 16 + 15) & ~(size_t)15;
+    BEVW_TRY(j->d_eplanes.reserve(N * (size_t)G.plane_bytes));
+    BEVW_TRY(j->d_zz.reserve(N * (size_t)G.nblk * 128));
+    BEVW_TRY(j->d_bitlen.reserve(N * (size_t)G.nblk * 4));
+    BEVW_TRY(j->d_bitbuf.reserve(N * j->buf_words * 4));
+    BEVW_TRY(j->d_totals.reserve(N * 8));
+    BEVW_TRY(j->d_files.reserve(N * j->file_cap));
+    BEVW_TRY(j->d_sizes.reserve(N * 4));
+    const jpg::EncTables *tabs = j->d_etabs.as<jpg::EncTables>();
+    jpg::k_jenc_ycc<<<dim3((G.wb[1] * 8 + 63) / 64, (G.hb[1] * 8 + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
+        G, (const uint8_t *)d_bgr, image_stride_bytes, row_pitch_bytes, j->d_eplanes.as<uint8_t>());
+    BEVW_TRY(launch_check("k_jenc_ycc"));
+    jpg::k_jenc_fdct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(G, j->d_eplanes.as<uint8_t>(), tabs, j->d_zz.as<int16_t>());
+    BEVW_TRY(launch_check("k_jenc_fdct"));
+    const dim3 gb((G.nblk + 255) / 256, (unsigned)n);
+    jpg::k_jenc_len<<<gb, 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jenc_len"));
+    jpg::k_jenc_scan<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(G, j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words,
+                                                                    j->d_totals.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jenc_scan"));
+    jpg::k_jenc_bits<<<gb, 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words);
+    BEVW_TRY(launch_check("k_jenc_bits"));
+    jpg::k_jenc_stuff<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
+                                                                     j->d_header.as<uint8_t>(), (uint32_t)j->header.size(), j->d_files.as<uint8_t>(),
+                                                                     j->file_cap, j->d_sizes.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jenc_stuff"));
+    j->encoded = true;
+    return BEVW_OK;
+}
+
+int bevw_jpeg_encoded_sizes(bevw_jpeg *j, size_t *sizes)
+{
+    if (!j || !sizes || !j->encoded) return fail(BEVW_E_INVALID, "bevw_jpeg_encoded_sizes: nothing encoded");
+    BEVW_TRY(use_device(j->device));
+    if (!j->sizes_valid) {
+        j->sizes.assign((size_t)j->en, 0);
+        HIP_TRY(hipMemcpyAsync(j->sizes.data(), j->d_sizes.p, (size_t)j->en * 4, hipMemcpyDeviceToHost, j->st));
+        HIP_TRY(hipStreamSynchronize(j->st));
+        j->sizes_valid = true;
+    }
+    for (int i = 0; i < j->en; ++i) {
+        if (!j->sizes[i]) return fail(BEVW_E_HIP, "image %d overflowed its file buffer (internal error)", i);
+        sizes[i] = j->sizes[i];
+    }
+    return BEVW_OK;
+}
+
+int bevw_jpeg_encoded_copy(bevw_jpeg *j, int index, uint8_t *dst, size_t cap)
+{
+    if (!j || !dst || !j->encoded || index < 0 || index >= j->en) return fail(BEVW_E_INVALID, "bevw_jpeg_encoded_copy: nothing encoded / bad index");
+    if (!j->sizes_valid) {
+        std::vector<size_t> tmp((size_t)j->en);
+        BEVW_TRY(bevw_jpeg_encoded_sizes(j, tmp.data()));
+    }
+    if (cap < j->sizes[index]) return fail(BEVW_E_INVALID, "file %d needs %u bytes, %zu given", index, j->sizes[index], cap);
+    BEVW_TRY(use_device(j->device));
+    HIP_TRY(hipMemcpyAsync(dst, j->d_files.as<uint8_t>() + (size_t)index * j->file_cap, j->sizes[index], hipMemcpyDeviceToHost, j->st));
+    HIP_TRY(hipStreamSynchronize(j->st));
+    return BEVW_OK;
+}
+
+int bevw_jpeg_encode(bevw_jpeg *j, const uint8_t *bgr, int n, int width, int height, int quality, int sampling, uint8_t *out, size_t cap_each,
+                     size_t *sizes)
+{
+    if (!j || !bgr || !out || !sizes || n <= 0) return fail(BEVW_E_INVALID, "bevw_jpeg_encode: bad argument");
+    BEVW_TRY(use_device(j->device));
+    const size_t image = (size_t)width * height * 3;
+    BEVW_TRY(j->d_src.reserve(image * (size_t)n));
+    HIP_TRY(hipMemcpyAsync(j->d_src.p, bgr, image * (size_t)n, hipMemcpyHostToDevice, j->st));
+    BEVW_TRY(bevw_jpeg_encode_run_device(j, j->d_src.p, n, width, height, image, (size_t)width * 3, quality, sampling));
+    BEVW_TRY(bevw_jpeg_encoded_sizes(j, sizes));
+    for (int i = 0; i < n; ++i) BEVW_TRY(bevw_jpeg_encoded_copy(j, i, out + (size_t)i * cap_each, cap_each));
+    return BEVW_OK;
+}
+
+int bevw_jpeg_sync(bevw_jpeg *j)
+{
+    if (!j) return fail(BEVW_E_INVALID, "null jpeg context");
+    BEVW_TRY(use_device(j->device));
+    HIP_TRY(hipStreamSynchronize(j->st));
+    return BEVW_OK;
+}
+
+int bevw_jpeg_timer_mark(bevw_jpeg *j, int slot)
+{
+    if (!j) return fail(BEVW_E_INVALID, "null jpeg context");
+    BEVW_TRY(use_device(j->device));
+    return j->timer.mark(slot, j->st);
+}
+
+int bevw_jpeg_timer_between(bevw_jpeg *j, int slot_a, int slot_b, float *elapsed_ms)
+{
+    if (!j) return fail(BEVW_E_INVALID, "null jpeg context");
+    BEVW_TRY(use_device(j->device));
+    return j->timer.between(slot_a, slot_b, elapsed_ms);
+}

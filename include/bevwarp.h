@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BEVW_ABI_VERSION 2
+#define BEVW_ABI_VERSION 3
 
 typedef enum bevw_status {
     BEVW_OK = 0,
@@ -63,6 +63,7 @@ typedef struct bevw_config {
 typedef struct bevw_handle bevw_handle;   /* a BevGenerator: 4 cameras + masks        (surroundBEV.py:282-325) */
 typedef struct bevw_remapper bevw_remapper; /* one fixed-point remap table on the device (cv2.remap call sites)   */
 typedef struct bevw_comm bevw_comm;       /* an RCCL communicator of one camera group (camera-per-GPU mode)        */
+typedef struct bevw_jpeg bevw_jpeg;       /* a JPEG decode / encode context: one HIP stream + scratch (cv2.imread / cv2.imwrite) */
 
 /* ---- library / device ------------------------------------------------------------------------------------ */
 int bevw_abi_version(void);
@@ -262,6 +263,52 @@ int bevw_translate_u8c3(int device, const uint8_t *src, int width, int height, i
 int bevw_resize_dsize(int src_w, int src_h, double fx, double fy, int32_t dsize[2]);
 int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h, double fx, double fy, int batch,
                             uint8_t *dst);
+
+/* ---- JPEG either side of the path: cv2.imread (main.py:74-77, Tools/undistort.py:63) and ------- */
+/* ---- cv2.imwrite (surroundBEV.py:340, main.py:88, Tools/undistort.py:71) -------------------------------------------------------- */
+/* For ".jpg" both cv2 calls are libjpeg(-turbo) with its defaults; the kernels reproduce that library bit for bit (baseline Huffman,
+ * jpeg_idct_islow, fancy upsampling, ycc_rgb_convert; encode: rgb_ycc_convert, h2v2_downsample, jpeg_fdct_islow, Annex-K tables at
+ * cv2's quality 95, 4:2:0) -- oracle/jpegoracle.c, pinned against Pillow's libjpeg-turbo.  Entropy decoding runs ON THE GPU
+ * (self-synchronising parallel Huffman decoding, csrc/bevw_jpeg.h); the host parses markers and removes the 0xFF 0x00 stuffing inside the
+ * staging copy of the H2D transfer.  Supported: baseline / extended-sequential Huffman, 8 bit, one interleaved scan, grey (expanded to BGR,
+ * as IMREAD_COLOR does) or YCbCr with luma 1x1 / 2x1 / 2x2, restart intervals.  Progressive, arithmetic, CMYK, 12-bit, multi-scan files and
+ * EXIF orientations other than 1 are REFUSED (BEVW_E_INVALID, reason in bevw_last_error()): there is no CPU decoder behind this.
+ *
+ *   bevw_jpeg_probe            header only: info = width, height, components, luma h, luma v, restart interval, EXIF orientation, 0
+ *   bevw_jpeg_decode_stage     n files of ONE geometry: parse, un-stuff into pinned memory, enqueue the H2D copies
+ *   bevw_jpeg_decode_run_device  enqueue the decode of the staged batch; image i is written as BGR rows of row_pitch_bytes at
+ *                              d_out + i * image_stride_bytes -- with image_stride = FH*FW*3 the n = 4*batch images ARE the
+ *                              [batch][4][FH][FW][3] frame sets bevw_run_device reads (files ordered front, back, left, right per set)
+ *   bevw_jpeg_decode           both + copy to a dense host array [n][h][w][3]  (= [cv2.imread(f) for f in files])
+ *   bevw_jpeg_decode_info      info = images, width, height, subsequences, fixed-point rounds (max over images), entropy-coded bytes,
+ *                              blocks per image, distinct Huffman table sets
+ *   bevw_jpeg_get_planes       test hook: the sample planes of image `index` after the inverse DCT (Y, Cb, Cr; whole MCUs)
+ *   bevw_jpeg_encode_run_device  enqueue cv2.imwrite x n of device images (BGR rows of row_pitch_bytes, e.g. the padded rows of
+ *                              BEVW_PITCH_ALIGNED); sampling 0x22 = 4:2:0 (cv2's default), 0x21 = 4:2:2, 0x11 = 4:4:4
+ *   bevw_jpeg_encoded_sizes / _copy   synchronise; byte count of every file; one complete file (SOI ... EOI) to host memory
+ *   bevw_jpeg_encode           host images in, files out (out + i * cap_each, sizes[i]); cap_each >= bevw_jpeg_encode_bound
+ * All "run" calls are asynchronous on the context's own stream; bevw_jpeg_sync waits; timer marks as for handles. */
+#define BEVW_JPEG_420 0x22
+#define BEVW_JPEG_422 0x21
+#define BEVW_JPEG_444 0x11
+int bevw_jpeg_probe(const uint8_t *data, size_t len, int32_t info[8]);
+int bevw_jpeg_create(int device, bevw_jpeg **out);
+void bevw_jpeg_destroy(bevw_jpeg *j);
+int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_t *len, int n);
+int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_bytes, size_t row_pitch_bytes);
+int bevw_jpeg_decode(bevw_jpeg *j, const uint8_t *const *data, const size_t *len, int n, uint8_t *out);
+int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8]);
+int bevw_jpeg_get_planes(bevw_jpeg *j, int index, uint8_t *planes);
+int bevw_jpeg_encode_bound(int width, int height, int sampling, size_t *bound);
+int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int width, int height, size_t image_stride_bytes,
+                                size_t row_pitch_bytes, int quality, int sampling);
+int bevw_jpeg_encoded_sizes(bevw_jpeg *j, size_t *sizes);
+int bevw_jpeg_encoded_copy(bevw_jpeg *j, int index, uint8_t *dst, size_t cap);
+int bevw_jpeg_encode(bevw_jpeg *j, const uint8_t *bgr, int n, int width, int height, int quality, int sampling, uint8_t *out,
+                     size_t cap_each, size_t *sizes);
+int bevw_jpeg_sync(bevw_jpeg *j);
+int bevw_jpeg_timer_mark(bevw_jpeg *j, int slot);
+int bevw_jpeg_timer_between(bevw_jpeg *j, int slot_a, int slot_b, float *elapsed_ms);
 
 #ifdef __cplusplus
 }

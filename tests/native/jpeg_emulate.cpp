@@ -1,0 +1,239 @@
+// Host-only run of the JPEG kernels' per-lane code (cameracalibration_amd/csrc/bevw_jpeg.h) -- needs no GPU.
+//
+// Every lane function of the JPEG kernels is __host__ __device__; this program drives them in plain loops in the order the kernels
+// do (one loop iteration = one lane), including the synchronisation fixed point of the parallel Huffman decoder, and writes what
+// the device would write.  tests/test_jpeg_emulate.py compares the results with the oracle (oracle/jpegoracle.c) and with Pillow's
+// libjpeg-turbo.  Compiled with hipcc (only the host part runs).
+//
+//   jpeg_emulate decode <in.jpg> <out.bin>       out: int32 w h rounds nsub | uint8 bgr[h][w][3]
+//   jpeg_emulate encode <in.bin> <out.jpg>       in : int32 w h quality sampling | uint8 bgr[h][w][3]
+#include <cstdio>
+#include <cstdlib>
+#include <hip/hip_runtime.h>
+
+#include "../../cameracalibration_amd/csrc/bevw_jpeg.h"
+
+using namespace bevw::jpg;
+
+static std::vector<uint8_t> read_file(const char *p)
+{
+    std::vector<uint8_t> v;
+    FILE *f = fopen(p, "rb");
+    if (!f) return v;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n);
+    if (n && fread(v.data(), 1, (size_t)n, f) != (size_t)n) v.clear();
+    fclose(f);
+    return v;
+}
+
+static int do_decode(const char *in, const char *out)
+{
+    const std::vector<uint8_t> raw = read_file(in);
+    Parsed P;
+    std::string why;
+    const int st = parse_header(raw.data(), raw.size(), P, why);
+    if (st) { fprintf(stderr, "parse: %d %s\n", st, why.c_str()); return 2; }
+    const Geom G = make_geom(P.w, P.h, P.nc, P.hs, P.vs);
+    TableSet T;
+    for (int c = 0; c < P.nc; ++c)
+        if (!make_hufftab(P.dc[P.td[c]], T.t[2 * c]) || !make_hufftab(P.ac[P.ta[c]], T.t[2 * c + 1])) { fprintf(stderr, "bad huffman table\n"); return 2; }
+    std::vector<uint8_t> stream(raw.size() + 64);
+    std::vector<uint32_t> seg_byte;
+    const size_t nbytes = unstuff_scan(raw.data(), raw.size(), P.scan_off, stream.data(), seg_byte);
+    (void)nbytes;
+    const uint32_t *words = (const uint32_t *)stream.data();
+    const int nseg = (int)seg_byte.size() - 1;
+    const uint32_t seg_blocks = P.ri ? (uint32_t)P.ri * (uint32_t)G.bpm : kNoRestart;
+    // subsequences per segment
+    std::vector<uint32_t> seg_sub(nseg + 1, 0);
+    for (int s = 0; s < nseg; ++s) seg_sub[s + 1] = seg_sub[s] + ((seg_byte[s + 1] - seg_byte[s]) * 8 + kSubBits - 1) / kSubBits;
+    const int nsub = (int)seg_sub[nseg];
+    std::vector<uint64_t> entry(nsub), exitst(nsub);
+    std::vector<SubOut> sums(nsub);
+    std::vector<uint32_t> endbit(nsub), segof(nsub);
+    std::vector<uint8_t> first(nsub);
+    // k_jpeg_sync0: every subsequence from the guessed state
+    for (int s = 0; s < nseg; ++s)
+        for (uint32_t j = seg_sub[s]; j < seg_sub[s + 1]; ++j) {
+            const uint32_t start = seg_byte[s] * 8 + (j - seg_sub[s]) * kSubBits;
+            uint32_t end = start + kSubBits;
+            if (end > seg_byte[s + 1] * 8) end = seg_byte[s + 1] * 8;
+            entry[j] = pack_state(start, 0, 0);
+            endbit[j] = end;
+            segof[j] = (uint32_t)s;
+            first[j] = j == seg_sub[s];
+            sums[j] = decode_sub<false>(words, T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0);
+            exitst[j] = sums[j].exit;
+        }
+    // k_jpeg_sync: rounds until no exit state changes (lanes of a round read the exit states of the previous round or newer)
+    int rounds = 0;
+    for (;;) {
+        bool changed = false;
+        ++rounds;
+        for (int j = nsub - 1; j >= 1; --j) {   // descending: every lane sees the PREVIOUS round's states (the slowest legal schedule)
+            if (first[j]) continue;
+            const uint64_t in = exitst[j - 1];
+            if (in == entry[j]) continue;
+            entry[j] = in;
+            sums[j] = decode_sub<false>(words, T.t, G, in, endbit[j], nullptr, 0, 0, 0, 0, 0);
+            if (sums[j].exit != exitst[j]) { exitst[j] = sums[j].exit; changed = true; }
+        }
+        if (!changed) break;
+        if (rounds > nsub + 2) { fprintf(stderr, "no fixed point\n"); return 3; }
+    }
+    // prefix sums with a reset at every restart segment
+    std::vector<uint32_t> base_blk(nsub);
+    std::vector<int32_t> base_dc(3 * (size_t)nsub);
+    {
+        uint32_t cb = 0;
+        int32_t d0 = 0, d1 = 0, d2 = 0;
+        for (int j = 0; j < nsub; ++j) {
+            if (first[j]) { cb = 0; d0 = d1 = d2 = 0; }
+            base_blk[j] = (seg_blocks == kNoRestart ? 0u : segof[j] * seg_blocks) + cb;
+            base_dc[3 * j] = d0; base_dc[3 * j + 1] = d1; base_dc[3 * j + 2] = d2;
+            cb += (uint32_t)sums[j].cnt; d0 += sums[j].dc0; d1 += sums[j].dc1; d2 += sums[j].dc2;
+        }
+    }
+    // k_jpeg_coef
+    std::vector<int16_t> coef((size_t)G.nblk * 64, 0);
+    for (int j = 0; j < nsub; ++j) {
+        uint32_t cap = (uint32_t)G.nblk;
+        if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
+        decode_sub<true>(words, T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2]);
+    }
+    // k_jpeg_idct: lane = (block, column), then (block, row)
+    std::vector<uint8_t> planes((size_t)G.plane_bytes);
+    for (int c = 0; c < G.nc; ++c) {
+        const uint16_t *q = P.q[P.tq[c]];
+        const int pw = G.wb[c] * 8;
+        for (int b = 0; b < G.wb[c] * G.hb[c]; ++b) {
+            const int16_t *cf = coef.data() + ((size_t)G.blk_off[c] + b) * 64;
+            int32_t ws[64];
+            for (int col = 0; col < 8; ++col) {
+                int32_t in[8], o[8];
+                for (int r = 0; r < 8; ++r) in[r] = (int32_t)cf[r * 8 + col] * (int32_t)q[r * 8 + col];
+                idct_1d(in, o, 11);
+                for (int r = 0; r < 8; ++r) ws[r * 8 + col] = o[r];
+            }
+            const int bx = b % G.wb[c], by = b / G.wb[c];
+            for (int r = 0; r < 8; ++r) {
+                int32_t o[8];
+                idct_1d(ws + r * 8, o, 18);
+                for (int x = 0; x < 8; ++x) planes[(size_t)G.plane_off[c] + (size_t)(by * 8 + r) * pw + bx * 8 + x] = (uint8_t)range_limit(o[x]);
+            }
+        }
+    }
+    // k_jpeg_color
+    std::vector<uint8_t> bgr((size_t)G.w * G.h * 3);
+    for (int y = 0; y < G.h; ++y)
+        for (int x = 0; x < G.w; ++x) {
+            const int Yv = planes[(size_t)G.plane_off[0] + (size_t)y * G.wb[0] * 8 + x];
+            uint32_t px;
+            if (G.nc == 1) px = (uint32_t)Yv * 0x010101u;
+            else {
+                const int cb = upsample_at(planes.data() + G.plane_off[1], G.wb[1] * 8, G.dw, G.dh, G.hs, G.vs, x, y);
+                const int cr = upsample_at(planes.data() + G.plane_off[2], G.wb[2] * 8, G.dw, G.dh, G.hs, G.vs, x, y);
+                px = ycc_to_bgr(Yv, cb, cr);
+            }
+            uint8_t *o = bgr.data() + ((size_t)y * G.w + x) * 3;
+            o[0] = (uint8_t)px; o[1] = (uint8_t)(px >> 8); o[2] = (uint8_t)(px >> 16);
+        }
+    FILE *f = fopen(out, "wb");
+    if (!f) return 2;
+    const int32_t hdr[4] = {G.w, G.h, rounds, nsub};
+    fwrite(hdr, 4, 4, f);
+    fwrite(bgr.data(), 1, bgr.size(), f);
+    fclose(f);
+    printf("decoded %dx%d nc=%d %dx%d: %d segments, %d subsequences, %d rounds\n", G.w, G.h, G.nc, G.hs, G.vs, nseg, nsub, rounds);
+    return 0;
+}
+
+static int do_encode(const char *in, const char *out)
+{
+    const std::vector<uint8_t> raw = read_file(in);
+    if (raw.size() < 16) return 2;
+    const int32_t *hd = (const int32_t *)raw.data();
+    const int w = hd[0], h = hd[1], quality = hd[2], sampling = hd[3];
+    const uint8_t *bgr = raw.data() + 16;
+    const Geom G = make_geom(w, h, 3, sampling >> 4, sampling & 15);
+    EncTables T;
+    make_enc_tables(quality, T);
+    // k_jenc_ycc
+    std::vector<uint8_t> planes((size_t)G.plane_bytes);
+    for (int yo = 0; yo < G.hb[1] * 8; ++yo)
+        for (int xc = 0; xc < G.wb[1] * 8; ++xc)
+            enc_ycc_at(bgr, (size_t)w * 3, G, xc, yo, planes.data() + G.plane_off[0], planes.data() + G.plane_off[1], planes.data() + G.plane_off[2]);
+    // k_jenc_fdct: lane = (block, row), then (block, column)
+    std::vector<int16_t> zz((size_t)G.nblk * 64);
+    for (int g = 0; g < G.nblk; ++g) {
+        int comp, rx, ry;
+        bool dc_only;
+        enc_block_root(G, g, comp, rx, ry, dc_only);
+        const int pw = G.wb[comp] * 8;
+        const uint8_t *Pl = planes.data() + G.plane_off[comp];
+        int32_t ws[64];
+        for (int r = 0; r < 8; ++r) {
+            int32_t in8[8], o[8];
+            for (int x = 0; x < 8; ++x) in8[x] = (int32_t)Pl[(size_t)(ry * 8 + r) * pw + rx * 8 + x] - 128;
+            fdct_1d(in8, o, 0);
+            for (int x = 0; x < 8; ++x) ws[r * 8 + x] = o[x];
+        }
+        for (int c = 0; c < 8; ++c) {
+            int32_t in8[8], o[8];
+            for (int r = 0; r < 8; ++r) in8[r] = ws[r * 8 + c];
+            fdct_1d(in8, o, 1);
+            for (int r = 0; r < 8; ++r) {
+                int32_t v = quantize(o[r], T.q[comp ? 1 : 0][r * 8 + c]);
+                if (dc_only && (r | c)) v = 0;
+                zz[(size_t)g * 64 + zigzag_of(r * 8 + c)] = (int16_t)v;
+            }
+        }
+    }
+    // k_jenc_len + k_jenc_scan
+    std::vector<uint32_t> pos(G.nblk + 1, 0);
+    for (int g = 0; g < G.nblk; ++g) {
+        const int z = g % G.bpm, pr = dc_predecessor(g, G);
+        const int last = pr < 0 ? 0 : zz[(size_t)pr * 64];
+        const int t = z < G.nY ? 0 : 1;
+        pos[g + 1] = pos[g] + encode_block<false>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], nullptr, 0);
+    }
+    const uint32_t total_bits = pos[G.nblk];
+    const uint32_t nbytes = (total_bits + 7) / 8;
+    std::vector<uint32_t> words(nbytes / 4 + 2, 0);
+    // k_jenc_bits
+    for (int g = 0; g < G.nblk; ++g) {
+        const int z = g % G.bpm, pr = dc_predecessor(g, G);
+        const int last = pr < 0 ? 0 : zz[(size_t)pr * 64];
+        const int t = z < G.nY ? 0 : 1;
+        const uint32_t n = encode_block<true>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], words.data(), pos[g]);
+        if (n != pos[g + 1] - pos[g]) { fprintf(stderr, "length mismatch at block %d\n", g); return 3; }
+    }
+    // k_jenc_stuff
+    std::vector<uint8_t> file = make_file_header(w, h, G.hs, G.vs, T);
+    const int pad = (int)(nbytes * 8 - total_bits);
+    for (uint32_t i = 0; i < nbytes; ++i) {
+        uint8_t b = (uint8_t)(words[i >> 2] >> (24 - 8 * (i & 3)));
+        if (i == nbytes - 1) b |= (uint8_t)((1u << pad) - 1u);
+        file.push_back(b);
+        if (b == 0xFF) file.push_back(0);
+    }
+    file.push_back(0xFF);
+    file.push_back(0xD9);
+    FILE *f = fopen(out, "wb");
+    if (!f) return 2;
+    fwrite(file.data(), 1, file.size(), f);
+    fclose(f);
+    printf("encoded %dx%d q%d %dx%d: %u bits, %zu bytes\n", w, h, quality, G.hs, G.vs, total_bits, file.size());
+    return 0;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc == 4 && !strcmp(argv[1], "decode")) return do_decode(argv[2], argv[3]);
+    if (argc == 4 && !strcmp(argv[1], "encode")) return do_encode(argv[2], argv[3]);
+    fprintf(stderr, "usage: jpeg_emulate decode in.jpg out.bin | encode in.bin out.jpg\n");
+    return 1;
+}

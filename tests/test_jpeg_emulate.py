@@ -1,0 +1,78 @@
+"""CPU run of the JPEG kernels' per-lane code (tests/native/jpeg_emulate.cpp): the functions in cameracalibration_amd/csrc/bevw_jpeg.h
+are __host__ __device__, so the parallel Huffman decoder's fixed point, the inverse / forward DCT, the colour code and the bit writer
+the GPU runs are checked here, without a GPU, against Pillow's libjpeg-turbo (row f4)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from tests import _jpeg_common as JC
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
+pytest.importorskip("PIL")
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    d = tmp_path_factory.mktemp("jpeg_emulate")
+    exe = str(d / "jpeg_emulate")
+    hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
+    r = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-pass-failed", "-o", exe,
+                        os.path.join(ROOT, "tests", "native", "jpeg_emulate.cpp")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+
+    class Emu:
+        def decode(self, raw):
+            a, b = str(d / "in.jpg"), str(d / "out.bin")
+            open(a, "wb").write(raw)
+            r = subprocess.run([exe, "decode", a, b], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            buf = open(b, "rb").read()
+            w, h, rounds, nsub = np.frombuffer(buf[:16], np.int32)
+            return np.frombuffer(buf[16:], np.uint8).reshape(h, w, 3), int(rounds), int(nsub)
+
+        def encode(self, im, q=95, samp=0x22):
+            a, b = str(d / "in.bin"), str(d / "out.jpg")
+            h, w = im.shape[:2]
+            open(a, "wb").write(np.array([w, h, q, samp], np.int32).tobytes() + np.ascontiguousarray(im).tobytes())
+            r = subprocess.run([exe, "encode", a, b], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stdout + r.stderr
+            return open(b, "rb").read()
+
+    return Emu()
+
+
+def test_parallel_huffman_decoder_reaches_the_sequential_decoders_states(emu):
+    for name, raw in JC.repo_camera_jpegs().items():
+        got, rounds, nsub = emu.decode(raw)
+        assert np.array_equal(got, JC.pil_decode(raw)), name
+        assert nsub > 500 and 1 <= rounds <= nsub   # ~1 KB of entropy-coded data per lane; a handful of rounds, not nsub of them
+
+
+@pytest.mark.parametrize("sub,samp", JC.SUBSAMPLINGS)
+def test_emulated_kernels_equal_libjpeg_turbo(emu, sub, samp):
+    for h, w in ((8, 8), (1, 1), (3, 5), (17, 33), (40, 56), (100, 75), (64, 2), (4, 5), (120, 200)):
+        for kind in (0, 1, 2):
+            q = (95, 30, 100)[kind]
+            im = JC.image(h, w, kind)
+            f = JC.pil_encode(im, q, sub)
+            assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f)), (h, w, kind)
+            assert emu.encode(im, q, samp) == f, (h, w, kind)
+
+
+def test_emulated_restart_segments_and_grey(emu):
+    im = JC.image(200, 300, 2)
+    f = JC.pil_encode_gray(im[:, :, 0])
+    assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f))
+    for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=3), dict(restart_marker_rows=1)):
+        f = JC.pil_encode(im, 90, 2, **kw)
+        assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f)), kw
+
+
+def test_emulated_bev_sized_file(emu):
+    im = JC.image(1080, 1080, 2)
+    assert emu.encode(im) == JC.pil_encode(im)

@@ -1,0 +1,166 @@
+"""Row f4 on the GPU: the HIP JPEG decoder / encoder (through the C-ABI, cameracalibration_amd.imgcodecs) against the oracle
+(oracle/jpegoracle.c) AND against Pillow's libjpeg-turbo, the library behind cv2.imread / cv2.imwrite (main.py:74-77,
+surroundBEV.py:340).  Byte work: tolerance 0.  Run with `-m gpu` on an MI355X."""
+import io
+
+import numpy as np
+import pytest
+
+from cameracalibration_amd import workloads as W
+from tests import _jpeg_common as JC
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("PIL")
+
+
+@pytest.fixture(scope="module")
+def IC():
+    from cameracalibration_amd import _ffi, imgcodecs
+
+    _ffi.require_device()
+    return imgcodecs
+
+
+@pytest.fixture(scope="module")
+def codec(IC):
+    c = IC.JpegCodec(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def JO():
+    from oracle import jpeg
+
+    jpeg.build()
+    return jpeg
+
+
+def test_decode_reference_camera_files(IC, codec, JO):
+    files = list(JC.repo_camera_jpegs().values())
+    got = codec.decode(files)
+    info = codec.decode_info()
+    assert info["images"] == 4 and (info["width"], info["height"]) == (1280, 1024) and info["rounds"] >= 1
+    for i, raw in enumerate(files):
+        want, planes = JO.imdecode(raw, planes=True)
+        assert np.array_equal(got[i], want), f"file {i}: {np.count_nonzero(got[i] != want)} bytes differ from the oracle"
+        assert np.array_equal(got[i], JC.pil_decode(raw)), f"file {i} differs from libjpeg-turbo"
+        mine = codec.planes(i, sum(p.size for p in planes))   # the intermediate after the inverse DCT as well
+        assert np.array_equal(mine, np.concatenate([p.reshape(-1) for p in planes]))
+
+
+@pytest.mark.parametrize("sub,samp", JC.SUBSAMPLINGS)
+def test_decode_matrix(codec, JO, sub, samp):
+    for h, w in JC.SIZES + ((300, 420),):
+        files = [JC.pil_encode(JC.image(h, w, kind), q, sub) for kind in (0, 1, 2) for q in (95, 30)]   # one geometry, six quantisers
+        got = codec.decode(files)
+        for i, f in enumerate(files):
+            assert np.array_equal(got[i], JO.imdecode(f)), (h, w, i)
+            assert np.array_equal(got[i], JC.pil_decode(f)), (h, w, i)
+
+
+def test_decode_grey_restart_and_private_tables(codec, JO):
+    im = JC.image(200, 300, 2)
+    f = JC.pil_encode_gray(im[:, :, 0])
+    assert np.array_equal(codec.decode([f])[0], JC.pil_decode(f))
+    for kw in (dict(restart_marker_blocks=1), dict(restart_marker_blocks=3), dict(restart_marker_rows=1), dict(restart_marker_rows=4)):
+        files = [JC.pil_encode(JC.image(200, 300, k), 90, 2, **kw) for k in (0, 1, 2)]
+        got = codec.decode(files)
+        for i, f in enumerate(files):
+            assert np.array_equal(got[i], JC.pil_decode(f)), (kw, i)
+    # optimize=True: every file carries its own Huffman tables -> several table sets inside one batch
+    files = [JC.pil_encode(JC.image(120, 168, k, seed=s), 85, 2, optimize=True) for k in (0, 1, 2) for s in (0, 1)]
+    got = codec.decode(files)
+    assert codec.decode_info()["table_sets"] > 1
+    for i, f in enumerate(files):
+        assert np.array_equal(got[i], JO.imdecode(f)) and np.array_equal(got[i], JC.pil_decode(f)), i
+
+
+def test_decode_larger_batch_many_rounds(codec):
+    # 64 camera-sized files (the reference's four, re-encoded at several qualities): thousands of subsequences per image
+    base = [JC.pil_decode(r) for r in JC.repo_camera_jpegs().values()]
+    files = [JC.pil_encode(base[i % 4], 60 + (i % 8) * 5, 2) for i in range(32)]
+    got = codec.decode(files)
+    for i in (0, 5, 13, 31):
+        assert np.array_equal(got[i], JC.pil_decode(files[i])), i
+    assert codec.decode_info()["subsequences"] > 10000
+
+
+@pytest.mark.parametrize("sub,samp", JC.SUBSAMPLINGS)
+def test_encode_matrix(codec, JO, sub, samp):
+    for h, w in JC.SIZES:
+        for q in (95, 50, 100, 10):
+            ims = np.stack([JC.image(h, w, kind) for kind in (0, 1, 2)])
+            files = codec.encode(ims, q, samp)
+            for k in range(3):
+                assert files[k] == JO.imencode(ims[k], q, samp), (h, w, q, k)
+                assert files[k] == JC.pil_encode(ims[k], q, sub), (h, w, q, k)
+
+
+def test_encode_bev_sized_batch_and_pitched_rows(IC, codec):
+    from cameracalibration_amd import _ffi
+
+    ims = np.stack([JC.image(1080, 1080, k) for k in (2, 0, 1, 2)])
+    files = codec.encode(ims)
+    for k in range(4):
+        assert files[k] == JC.pil_encode(ims[k]), k
+    # rows of 1088 pixels (BEVW_PITCH_ALIGNED): the encoder reads the pitched device image directly
+    pitched = np.zeros((2, 1080, 1088, 3), np.uint8)
+    pitched[:, :, :1080] = ims[:2]
+    pitched[:, :, 1080:] = 77   # padding columns must not leak into the file
+    d = _ffi.DeviceBuffer(pitched.nbytes).upload(pitched)
+    codec.encode_run_device(d.ptr, 2, 1080, 1080, pitched[0].nbytes, 1088 * 3)
+    got = codec.files()
+    d.free()
+    assert got[0] == files[0] and got[1] == files[1]
+
+
+def test_cv2_names_round_trip(IC, tmp_path):
+    im = JC.image(97, 131, 2)
+    p = str(tmp_path / "bev.jpg")
+    assert IC.imwrite(p, im)
+    raw = open(p, "rb").read()
+    assert raw == JC.pil_encode(im)                      # cv2.imwrite defaults: quality 95, 4:2:0
+    assert np.array_equal(IC.imread(p), JC.pil_decode(raw))
+    ok, buf = IC.imencode(".jpg", im, [IC.IMWRITE_JPEG_QUALITY, 70])
+    assert ok and buf.tobytes() == JC.pil_encode(im, 70)
+    assert np.array_equal(IC.imdecode(buf), JC.pil_decode(buf.tobytes()))
+
+
+def test_refusals_are_loud(IC, codec):
+    from PIL import Image
+    from cameracalibration_amd._ffi import BevwError
+
+    im = JC.image(32, 32, 2)
+    b = io.BytesIO()
+    Image.fromarray(im).save(b, "JPEG", progressive=True)
+    with pytest.raises(BevwError, match="progressive"):
+        codec.decode([b.getvalue()])
+    with pytest.raises(BevwError, match="not a JPEG"):
+        codec.decode([b"\x89PNG\r\n\x1a\n" + bytes(64)])
+    with pytest.raises(BevwError, match="one geometry"):
+        codec.decode([JC.pil_encode(im), JC.pil_encode(JC.image(32, 40, 2))])
+    with pytest.raises(BevwError):
+        codec.decode([JC.pil_encode(im)[:300]])
+
+
+def test_main_py_with_files_in_and_a_file_out(IC, JO, repo_rig, oracle):
+    """main.py:72-89 end to end on compressed data: four camera FILES in, the stitched .jpg out, against
+    cv2.imwrite(bev(*[cv2.imread(f) ...])) restated by the two oracles."""
+    from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+
+    cams = JC.repo_camera_jpegs()
+    files = [cams[n] for n in W.CAMERA_NAMES]
+    cfg = dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350)
+    ns = SB.BevGenerator.get_args()
+    for k, v in cfg.items():
+        setattr(ns, k, v)
+    car = SB.padding(repo_rig.image("car"), cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"])
+    frames = [JO.imdecode(f) for f in files]
+    for blend, balance, pitch in ((False, False, "dense"), (True, True, "dense"), (False, False, "aligned")):
+        bev = SB.BevGenerator(blend=blend, balance=balance, rig=repo_rig.rig, output_pitch=pitch)
+        ref = oracle.RefBevGenerator(repo_rig.rig, cfg, blend=blend, balance=balance)
+        want = JO.imencode(ref(*frames, car))
+        got = bev.jpeg([files, files[::-1]], car)
+        assert len(got) == 2 and got[0] == want, (blend, balance, pitch)
+        assert got[1] == JO.imencode(ref(*frames[::-1], car))
