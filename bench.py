@@ -14,6 +14,7 @@ prints ONE JSON line.  Workloads = BASELINE.json configs:
     blend_balance_b256   same sizes, BevGenerator(blend=True, balance=True)
     undistort_b64        single fisheye undistort remap 1280x960, batch 64
     blend_4k             4-cam 3840x2160 -> 1080x1080 blend, batch 32
+    jpeg_decode_b64 / jpeg_encode_b64 / jpeg_bev_jpeg_b64   the JPEG wire format either side of the path on the GPU (row f4)
 
 `roofline.achieved` = algorithmic bytes of the workload (cameracalibration_amd/workloads.py) x units
 per launch / the launch's average duration measured with HIP events on the engine's own stream.
@@ -55,6 +56,14 @@ WORKLOADS = {
                                            metric="stitched BEV frames/sec (4-cam 1280x960->1080x1080, analytic fp64 projection per frame)"),
     # BASELINE config 5 in its camera-per-GPU form: ranks own cameras, parts travel over RCCL
     # send/recv, the stitch rank rotates.  1, 2 or a multiple of 4 ranks; every group of 4 ranks is a replica.
+    # the JPEG wire format either side of the path, on the GPU (cameracalibration_amd/imgcodecs.py).  Inputs resident =
+    # the staged (parsed + un-stuffed) compressed streams / the device images; the timed region is the kernels only.
+    "jpeg_decode_b64": dict(kind="jpeg", mode="decode", cfg="S", batch=64, unit="images/s",
+                            metric="camera JPEG files decoded into frame sets per second (1280x960 baseline 4:2:0 -> BGR)"),
+    "jpeg_encode_b64": dict(kind="jpeg", mode="encode", cfg="S", batch=64, unit="images/s",
+                            metric="BEV images encoded to .jpg files per second (1080x1080 BGR -> baseline 4:2:0, quality 95)"),
+    "jpeg_bev_jpeg_b64": dict(kind="jpeg", mode="pipeline", cfg="S", batch=64, unit="frames/s", blend=False, balance=False,
+                              metric="stitched BEV frames/sec, compressed in and out (4 x 1280x960 .jpg -> 1080x1080 .jpg)"),
     "blend_4k_camera_shard": dict(kind="camera", cfg="4K", blend=True, balance=False, batch=32, unit="frames/s",
                                   metric="stitched BEV frames/sec (4-cam 3840x2160->1080x1080, blend, camera per GPU)"),
 }
@@ -257,6 +266,144 @@ def cpu_baseline_undistort(w, K, D, ucfg, unique, seconds):
             "sample": f"{n} images in {dt:.1f} s (oracle orc_remap_u8, OpenMP {cores} threads); 1 thread: {one:.1f} {w['unit']}"}
 
 
+def camera_like_jpegs(n_files: int, width: int, height: int, seed: int, quality: int = 90):
+    """Synthetic camera FILES: the smooth synthetic frames, 2 x 2 box-filtered (sensor-like noise level), written by libjpeg-turbo (Pillow)
+    at `quality`, 4:2:0 -- input generation only, outside every timed region."""
+    import io
+    from PIL import Image
+    from cameracalibration_amd import workloads as W
+
+    frames = W.synthetic_frames((n_files + 3) // 4, width, height, seed=seed).reshape(-1, height, width, 3)[:n_files]
+    files = []
+    for f in frames:
+        g = f.astype(np.int32)
+        g = ((g + np.roll(g, 1, 0) + np.roll(g, 1, 1) + np.roll(np.roll(g, 1, 0), 1, 1) + 2) // 4).astype(np.uint8)
+        b = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(g[:, :, ::-1])).save(b, "JPEG", quality=quality, subsampling=2)
+        files.append(b.getvalue())
+    return files
+
+
+def jpeg_cpu_baseline(mode, files, images, seconds):
+    """libjpeg-turbo itself (Pillow's build, SIMD) on the host cores -- the library cv2.imread / cv2.imwrite wrap, so kind = reference.
+    Pillow releases the GIL inside the codec: one thread per usable core."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from oracle import oracle as O
+
+    cores = O.usable_cores(64)
+    pil_images = [Image.fromarray(np.ascontiguousarray(im[:, :, ::-1])) for im in images] if images is not None else None
+
+    def dec(i):
+        return np.asarray(Image.open(io.BytesIO(files[i % len(files)])).convert("RGB")).shape
+
+    def enc(i):
+        b = io.BytesIO()
+        pil_images[i % len(pil_images)].save(b, "JPEG", quality=95, subsampling=2)
+        return b.tell()
+    fn = dec if mode == "decode" else enc
+    t0 = time.perf_counter()
+    fn(0)
+    one = 1.0 / (time.perf_counter() - t0)
+    n, t0 = 0, time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        while time.perf_counter() - t0 < seconds:
+            list(ex.map(fn, range(n, n + 4 * cores)))
+            n += 4 * cores
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "images/s", "cores": cores, "kind": "reference", "value_1_thread": one,
+            "sample": f"{n} images {mode}d in {dt:.1f} s by Pillow's libjpeg-turbo (SIMD), {cores} threads"}
+
+
+def main_jpeg(a, d, w, dev):
+    """Row f4 workloads.  One step = one batch through the JPEG kernels (decode: staged streams -> frame sets; encode: device images ->
+    files in HBM; pipeline: decode + stitch + encode with the host synchronisations the three streams need)."""
+    import ctypes as C
+    from cameracalibration_amd import _ffi, imgcodecs, workloads as W
+    from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+
+    cfg = W.CONFIG_S
+    batch = a.batch or w["batch"]
+    fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+    mode = w["mode"]
+    codec = imgcodecs.JpegCodec(dev)
+    uniq_files = camera_like_jpegs(8, fw, fh, seed=W.SEED + d.rank)
+    files = [uniq_files[i % len(uniq_files)] for i in range(batch * 4)]
+    uniq_bev = W.synthetic_frames(1, bw, bh, seed=W.SEED + 17 + d.rank)[0]          # four BEV-sized camera-like images
+    bev_images = np.stack([uniq_bev[i % 4] for i in range(batch)])
+    d_frames = _ffi.DeviceBuffer(batch * 4 * fh * fw * 3, dev)
+    d_bev = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
+    extra = {"frame": [fw, fh], "bev": [bw, bh], "jpeg_in": "baseline 4:2:0 quality 90, %d bytes per file (synthetic camera-like frames)" % (
+        sum(len(f) for f in uniq_files) // len(uniq_files)), "jpeg_out": "baseline 4:2:0 quality 95 (cv2.imwrite's defaults)"}
+    if mode in ("decode", "pipeline"):
+        codec.decode_stage(files)
+        codec.sync()
+    if mode == "decode":
+        units = batch * 4
+        step = lambda: codec.decode_run_device(d_frames.ptr, fh * fw * 3, fw * 3)
+        alg = sum(len(f) for f in files) // len(files) + fh * fw * 3
+    elif mode == "encode":
+        units = batch
+        d_bev.upload(bev_images)
+        step = lambda: codec.encode_run_device(d_bev.ptr, batch, bw, bh, bh * bw * 3, bw * 3)
+        step()
+        alg = sum(len(f) for f in codec.files()) // batch + bh * bw * 3
+    else:
+        units = batch
+        ns = SB.BevGenerator.get_args()
+        for k, v in cfg.items():
+            setattr(ns, k, v)
+        bev = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=W.rig_s(), device=dev)
+
+        def step():
+            codec.decode_run_device(d_frames.ptr, fh * fw * 3, fw * 3)
+            codec.sync()
+            bev.run_device(d_frames.ptr, batch, None, d_bev.ptr)
+            bev.sync()
+            codec.encode_run_device(d_bev.ptr, batch, bw, bh, bh * bw * 3, bw * 3)
+        step()
+        alg = 4 * (sum(len(f) for f in files) // len(files)) + sum(len(f) for f in codec.files()) // batch
+    for _ in range(a.warmup):
+        step()
+    codec.sync()
+    d.barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        codec.timer_mark(i)
+        step()
+    codec.timer_mark(a.steps)
+    codec.sync()
+    d.barrier()
+    wall = d.max(time.perf_counter() - t0)
+    ev_ms = d.max(codec.timer_between(0, a.steps))
+    info = codec.decode_info() if mode != "encode" else {}
+    sizes = codec.files() if mode != "decode" else []
+    if mode != "encode":
+        extra.update(subsequences_per_image=info["subsequences"] // info["images"], fixed_point_rounds_max=info["rounds"],
+                     huffman_table_sets=info["table_sets"])
+    if sizes:
+        extra["bytes_per_output_file"] = sum(len(f) for f in sizes) // len(sizes)
+    cpu = None
+    if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline and mode != "pipeline":
+        cpu = jpeg_cpu_baseline(mode, uniq_files, list(uniq_bev), min(a.cpu_seconds, 8.0))
+    launch_ms = ev_ms / a.steps
+    achieved = alg * units / (launch_ms * 1e-3) / 1e9
+    out = {"metric": w["metric"], "value": units * d.world * a.steps / wall, "unit": w["unit"], "n_gpus": min(d.world, max(1, _ffi.device_count())),
+           "ranks": d.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+           "config": dict({"workload": a.workload, "batch_per_gpu": batch, "units_per_step": units, "device": _ffi.device_name(dev),
+                           "sharding": "files across ranks, no data-path collective"}, **extra),
+           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel_ms": launch_ms, "algorithmic_bytes_per_unit": alg, "units_per_launch": units,
+                        "note": "compressed bytes + pixels per unit; the entropy stages are latency / ALU bound, not HBM bound (DESIGN.md section 9)"},
+           "cpu_baseline": cpu}
+    if d.rank == 0:
+        print(json.dumps(out), flush=True)
+    codec.close()
+    d.close()
+
+
 def main():
     a = parse_args()
     d = Dist()
@@ -267,6 +414,8 @@ def main():
     _ffi.require_device()  # loud: this bench has no CPU path
     dev = d.local_rank if _ffi.device_count() > d.local_rank else 0
     w = WORKLOADS[a.workload]
+    if w["kind"] == "jpeg":
+        return main_jpeg(a, d, w, dev)
     batch = a.batch or w["batch"]
     sched = {"auto": _ffi.SCHED_AUTO, "pixel": _ffi.SCHED_PER_PIXEL, "plan": _ffi.SCHED_TILE_PLAN}[a.schedule]
     alg_bytes = W.ALGORITHMIC_BYTES[a.workload]
