@@ -131,13 +131,15 @@ struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
 template <bool WRITE>
 __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words, const HuffTab *tabs, const Geom &G, uint64_t entry,
                                              uint32_t end_bit, int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0,
-                                             int32_t pred1, int32_t pred2)
+                                             int32_t pred1, int32_t pred2, uint32_t word_base = 0, const uint8_t *nat = nullptr)
 {
+    // word_base: `words` starts at that word of the image's stream (k_jpeg_coef keeps its work-group's slice in LDS); nat: the
+    // natural-order table in memory of the caller's choice (LDS there: a global-memory look-up would queue behind the stores)
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
     SubOut R;
     R.cnt = 0; R.dc0 = R.dc1 = R.dc2 = 0;
     // bit buffer: `have` valid bits at the top of acc, next word to load = widx
-    uint32_t widx = p >> 5;
+    uint32_t widx = (p >> 5) - word_base;
     uint64_t acc = (uint64_t)__builtin_bswap32(words[widx++]) << 32;
     acc <<= (p & 31u);
     int have = 32 - (int)(p & 31u);
@@ -203,7 +205,7 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
                 acc <<= s;
                 have -= (int)s;
                 used += s;
-                if (WRITE && k <= 63u) coef[baddr + natural_of((int)k)] = (int16_t)(v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
+                if (WRITE && k <= 63u) coef[baddr + (nat ? (int)nat[k] : natural_of((int)k))] = (int16_t)(v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
                 ++k;
             } else if (r == 15u) {
                 k += 16;
@@ -415,6 +417,31 @@ __host__ __device__ inline uint32_t encode_block(const int16_t *__restrict__ zz,
 #endif
     }
     return bits;
+}
+
+// The two halves of encode_block<false>: the bits of the AC coefficients (known as soon as the block is quantised: k_jenc_fdct) and of
+// the DC difference (needs the previous block of the component: k_jenc_scan).  aclen / dclen = EncHuff::len of the component's tables.
+__host__ __device__ inline uint32_t ac_code_bits(const int16_t *zz, const uint8_t *aclen)
+{
+    uint32_t bits = 0;
+    int r = 0;
+    for (int k = 1; k < 64; ++k) {
+        int t = zz[k];
+        if (t == 0) { ++r; continue; }
+        bits += (uint32_t)(r >> 4) * aclen[0xF0];
+        r &= 15;
+        if (t < 0) t = -t;
+        const int nb = bit_length(t);
+        bits += (uint32_t)aclen[(r << 4) + nb] + (uint32_t)nb;
+        r = 0;
+    }
+    if (r > 0) bits += aclen[0];
+    return bits;
+}
+__host__ __device__ __forceinline__ uint32_t dc_code_bits(int diff, const uint8_t *dclen)
+{
+    const int nb = bit_length(diff < 0 ? -diff : diff);
+    return (uint32_t)dclen[nb] + (uint32_t)nb;
 }
 
 // index (scan order) of the block whose DC is the prediction of block `blk`, or -1 for the first block of a component

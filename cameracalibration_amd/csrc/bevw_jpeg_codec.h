@@ -34,6 +34,31 @@ template <typename V> __device__ __forceinline__ V block_exscan_serial(V v, V *l
     return r;
 }
 
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+// sum over a 256-thread block (every thread gets it); lds: 4 words
+__device__ __forceinline__ uint32_t block256_sum(uint32_t v, uint32_t *lds)
+{
+    const uint32_t w = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = w;
+    __syncthreads();
+    const uint32_t t = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return t;
+}
+
 // ---- decode ----------------------------------------------------------------------------------------------------------------------
 struct SubArrays {
     uint64_t *entry;    // state at the first symbol of the subsequence
@@ -71,6 +96,33 @@ __global__ __launch_bounds__(256) void k_jpeg_sync0(const ImageDesc *__restrict_
     A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
     A.endbit[slot] = end;
     A.meta[slot] = lo | (j == ss[lo] ? 0x80000000u : 0u);
+}
+
+// One synchronisation round over the whole batch at full occupancy: exit states are read from `xin` (the previous round) and written to
+// `xout`, so no lane sees a state of its own round.  The host runs an even number of these before the per-image kernel below, which
+// then only has the stragglers left (the first re-decode touches nearly every subsequence: the guessed state is almost never the true one).
+__global__ __launch_bounds__(256) void k_jpeg_sync_round(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
+                                                         const TableSet *__restrict__ tabs, Geom G, SubArrays A, const uint64_t *__restrict__ xin,
+                                                         uint64_t *__restrict__ xout)
+{
+    __shared__ TableSet T;
+    const ImageDesc D = img[blockIdx.y];
+    lds_copy(&T, tabs + D.tables);
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= D.nsub) return;
+    const size_t slot = (size_t)D.sub_first + j;
+    uint64_t out = xin[slot];
+    if (!(A.meta[slot] & 0x80000000u)) {
+        const uint64_t in = xin[slot - 1];
+        if (in != A.entry[slot]) {
+            A.entry[slot] = in;
+            const SubOut R = decode_sub<false>(stream + D.stream_word, T.t, G, in, A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+            A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
+            out = R.exit;
+        }
+    }
+    xout[slot] = out;
 }
 
 __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -142,14 +194,28 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     }
 }
 
+// The final pass: every subsequence decoded from its true entry state, coefficients written.  The work-group's slice of the entropy-coded
+// data and the natural-order table sit in LDS: on gfx9 loads and stores share one in-order counter, so a refill of the bit buffer from
+// global memory would wait for every scattered coefficient store issued before it.
 __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
                                                    const TableSet *__restrict__ tabs, Geom G, SubArrays A, int16_t *__restrict__ coef)
 {
     __shared__ TableSet T;
+    __shared__ uint32_t sw[256 * (kSubBits / 32) + 8];
+    __shared__ uint8_t nat[64];
     const ImageDesc D = img[blockIdx.y];
+    const uint32_t jb = blockIdx.x * 256u;
+    if (jb >= D.nsub) return;
     lds_copy(&T, tabs + D.tables);
+    if (threadIdx.x < 64) nat[threadIdx.x] = (uint8_t)natural_of((int)threadIdx.x);
+    const uint32_t jl = min(jb + 256u, D.nsub) - 1u;
+    // entry positions grow with the subsequence index: the slice starts at the first lane's entry and ends behind the last lane's last refill
+    const uint32_t w0 = (uint32_t)A.entry[(size_t)D.sub_first + jb] >> 5;
+    const uint32_t w1 = (A.endbit[(size_t)D.sub_first + jl] >> 5) + 3u;
+    const uint32_t nw = min(w1 - w0, (uint32_t)(256 * (kSubBits / 32) + 8));
+    for (uint32_t i = threadIdx.x; i < nw; i += 256u) sw[i] = stream[D.stream_word + w0 + i];
     __syncthreads();
-    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t j = jb + threadIdx.x;
     if (j >= D.nsub) return;
     const size_t slot = (size_t)D.sub_first + j;
     const int4 b = A.base[slot];
@@ -158,8 +224,7 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
         const unsigned long long c2 = (unsigned long long)((A.meta[slot] & 0x7fffffffu) + 1u) * D.seg_blocks;
         if (c2 < cap) cap = (uint32_t)c2;
     }
-    decode_sub<true>(stream + D.stream_word, T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
-                     b.z, b.w);
+    decode_sub<true>(sw, T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y, b.z, b.w, w0, nat);
 }
 
 // jpeg_idct_islow: a wave transforms 8 blocks; lane = (block, column) for the column pass, (block, row) for the row pass, the 8 x 8
@@ -196,39 +261,79 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const ImageDesc *__restrict__
     *reinterpret_cast<uint2 *>(P + (size_t)(by * 8 + c) * pw + bx * 8) = v;
 }
 
-// jdsample.c + jdcolor.c: a lane makes 4 neighbouring BGR pixels.  dst image i starts at out + i * image_stride, rows are row_pitch bytes.
+// jdsample.c + jdcolor.c, any sampling: `count` neighbouring BGR pixels of row y from position x0 on, byte stores.
+__device__ __forceinline__ void color_pixels_generic(const Geom &G, const uint8_t *__restrict__ P, uint8_t *__restrict__ o, int x0, int count, int y)
+{
+    const uint8_t *Yp = P + G.plane_off[0] + (size_t)y * (G.wb[0] * 8) + x0;
+    for (int i = 0; i < count; ++i) {
+        uint32_t px;
+        if (G.nc == 1) {
+            px = (uint32_t)Yp[i] * 0x010101u;
+        } else {
+            const int cb = upsample_at(P + G.plane_off[1], G.wb[1] * 8, G.dw, G.dh, G.hs, G.vs, x0 + i, y);
+            const int cr = upsample_at(P + G.plane_off[2], G.wb[2] * 8, G.dw, G.dh, G.hs, G.vs, x0 + i, y);
+            px = ycc_to_bgr(Yp[i], cb, cr);
+        }
+        o[3 * i] = (uint8_t)px;
+        o[3 * i + 1] = (uint8_t)(px >> 8);
+        o[3 * i + 2] = (uint8_t)(px >> 16);
+    }
+}
+
+// A lane makes 4 neighbouring BGR pixels.  dst image i starts at out + i * image_stride, rows are row_pitch bytes.
 __global__ __launch_bounds__(256) void k_jpeg_color(Geom G, const uint8_t *__restrict__ planes, uint8_t *__restrict__ out, size_t image_stride,
-                                                    size_t row_pitch, int aligned)
+                                                    size_t row_pitch)
 {
     const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
     if (x0 >= G.w || y >= G.h) return;
+    color_pixels_generic(G, planes + (size_t)blockIdx.z * G.plane_bytes, out + (size_t)blockIdx.z * image_stride + (size_t)y * row_pitch + (size_t)x0 * 3,
+                         x0, min(4, G.w - x0), y);
+}
+
+// The camera case -- 4:2:0, dword-aligned destination: a lane makes 8 neighbouring pixels of one row from one 8-byte luma load and, per
+// chroma component and source row, one aligned 4-sample load plus the two neighbours (h2v2_fancy_upsample: column sums 3 near + far, then
+// (3 this + neighbour + 8 | 7) >> 4), and stores 24 bytes as 6 dwords.  Lanes that straddle the right edge take the generic path.
+__global__ __launch_bounds__(256) void k_jpeg_color_h2v2(Geom G, const uint8_t *__restrict__ planes, uint8_t *__restrict__ out, size_t image_stride,
+                                                         size_t row_pitch)
+{
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 8, y = blockIdx.y * 4 + threadIdx.y;
+    if (x0 >= G.w || y >= G.h) return;
     const uint8_t *P = planes + (size_t)blockIdx.z * G.plane_bytes;
-    const uint8_t *Yp = P + G.plane_off[0] + (size_t)y * (G.wb[0] * 8) + x0;   // the luma plane is at least 4 samples wider than x0
-    uint32_t px[4];
+    uint8_t *o = out + (size_t)blockIdx.z * image_stride + (size_t)y * row_pitch + (size_t)x0 * 3;
+    if (x0 + 8 > G.w) {
+        color_pixels_generic(G, P, o, x0, G.w - x0, y);
+        return;
+    }
+    const int cy = y >> 1, cx = x0 >> 1, cp = G.wb[1] * 8;
+    int ny = (y & 1) ? cy + 1 : cy - 1;
+    ny = ny < 0 ? 0 : (ny > G.dh - 1 ? G.dh - 1 : ny);
+    const int li = cx > 0 ? cx - 1 : 0, ri = cx + 4 > G.dw - 1 ? G.dw - 1 : cx + 4;
+    int up[2][8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = x0 + i;
-        if (G.nc == 1) {
-            px[i] = (uint32_t)Yp[i] * 0x010101u;
-        } else {
-            const int xs = x < G.w ? x : G.w - 1;   // lanes past the right edge compute a pixel that is never stored
-            const int cb = upsample_at(P + G.plane_off[1], G.wb[1] * 8, G.dw, G.dh, G.hs, G.vs, xs, y);
-            const int cr = upsample_at(P + G.plane_off[2], G.wb[2] * 8, G.dw, G.dh, G.hs, G.vs, xs, y);
-            px[i] = ycc_to_bgr(Yp[i], cb, cr);
+    for (int c = 0; c < 2; ++c) {
+        const uint8_t *r0 = P + G.plane_off[1 + c] + (size_t)cy * cp, *r1 = P + G.plane_off[1 + c] + (size_t)ny * cp;
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(r0 + cx), b = *reinterpret_cast<const uint32_t *>(r1 + cx);
+        int cs[6];
+        cs[0] = 3 * r0[li] + r1[li];
+        cs[5] = 3 * r0[ri] + r1[ri];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[1 + i] = 3 * (int)((a >> (8 * i)) & 255u) + (int)((b >> (8 * i)) & 255u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            up[c][2 * i] = (3 * cs[1 + i] + cs[i] + 8) >> 4;
+            up[c][2 * i + 1] = (3 * cs[1 + i] + cs[2 + i] + 7) >> 4;
         }
     }
-    uint8_t *o = out + (size_t)blockIdx.z * image_stride + (size_t)y * row_pitch + (size_t)x0 * 3;
-    if (aligned && x0 + 4 <= G.w) {
-        uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
-        o32[0] = px[0] | (px[1] << 24);
-        o32[1] = (px[1] >> 8) | (px[2] << 16);
-        o32[2] = (px[2] >> 16) | (px[3] << 8);
-    } else {
-        for (int i = 0; i < 4 && x0 + i < G.w; ++i) {
-            o[3 * i] = (uint8_t)px[i];
-            o[3 * i + 1] = (uint8_t)(px[i] >> 8);
-            o[3 * i + 2] = (uint8_t)(px[i] >> 16);
-        }
+    const uint2 yv = *reinterpret_cast<const uint2 *>(P + G.plane_off[0] + (size_t)y * (G.wb[0] * 8) + x0);
+    uint32_t px[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) px[i] = ycc_to_bgr((int)(((i < 4 ? yv.x : yv.y) >> (8 * (i & 3))) & 255u), up[0][i], up[1][i]);
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        o32[3 * h + 0] = px[4 * h] | (px[4 * h + 1] << 24);
+        o32[3 * h + 1] = (px[4 * h + 1] >> 8) | (px[4 * h + 2] << 16);
+        o32[3 * h + 2] = (px[4 * h + 2] >> 16) | (px[4 * h + 3] << 8);
     }
 }
 
@@ -243,11 +348,15 @@ __global__ __launch_bounds__(256) void k_jenc_ycc(Geom G, const uint8_t *__restr
 }
 
 // jpeg_fdct_islow + quantisation: lane = (block, row) for the row pass, (block, column) for the column pass; blocks are numbered and
-// stored in scan order (MCU by MCU), coefficients in zigzag order -- what the entropy coder walks.
+// stored in scan order (MCU by MCU), coefficients in zigzag order -- what the entropy coder walks.  The quantised block also goes to LDS,
+// where one lane per block counts the bits of its AC codes (jchuff.c encode_one_block without the DC part, which needs the neighbour).
 __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__restrict__ planes, const EncTables *__restrict__ tabs,
-                                                   int16_t *__restrict__ zz)
+                                                   int16_t *__restrict__ zz, uint16_t *__restrict__ acbits, int16_t *__restrict__ dcq)
 {
     __shared__ int32_t ws[4][8 * 72];
+    __shared__ int16_t zl[4][8][64];
+    __shared__ uint8_t alen[2][256];
+    for (int i = threadIdx.x; i < 512; i += 256) alen[i >> 8][i & 255] = tabs->ac[i >> 8].len[i & 255];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane >> 3, r = lane & 7;
     const int g = (blockIdx.x * 4 + wave) * 8 + b;
     const bool valid = g < G.nblk;
@@ -269,46 +378,52 @@ __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__rest
         for (int x = 0; x < 8; ++x) ws[wave][b * 72 + r * 8 + x] = out[x];
     }
     __syncthreads();
-    if (!valid) return;
-    const int c = r;   // the lane now owns column c of its block
+    if (valid) {
+        const int c = r;   // the lane now owns column c of its block
 #pragma unroll
-    for (int y = 0; y < 8; ++y) in[y] = ws[wave][b * 72 + y * 8 + c];
-    fdct_1d(in, out, 1);
-    const uint16_t *q = tabs->q[comp ? 1 : 0];
-    int16_t *o = zz + ((size_t)blockIdx.y * G.nblk + g) * 64;
+        for (int y = 0; y < 8; ++y) in[y] = ws[wave][b * 72 + y * 8 + c];
+        fdct_1d(in, out, 1);
+        const uint16_t *q = tabs->q[comp ? 1 : 0];
+        int16_t *o = zz + ((size_t)blockIdx.y * G.nblk + g) * 64;
 #pragma unroll
-    for (int y = 0; y < 8; ++y) {
-        int32_t v = quantize(out[y], (int32_t)q[y * 8 + c]);
-        if (dc_only && (y | c)) v = 0;
-        o[zigzag_of(y * 8 + c)] = (int16_t)v;
+        for (int y = 0; y < 8; ++y) {
+            int32_t v = quantize(out[y], (int32_t)q[y * 8 + c]);
+            if (dc_only && (y | c)) v = 0;
+            const int k = zigzag_of(y * 8 + c);
+            o[k] = (int16_t)v;
+            zl[wave][b][k] = (int16_t)v;
+        }
+    }
+    __syncthreads();
+    if (valid && r == 0) {
+        const size_t blk = (size_t)blockIdx.y * G.nblk + g;
+        acbits[blk] = (uint16_t)ac_code_bits(zl[wave][b], alen[comp ? 1 : 0]);
+        dcq[blk] = zl[wave][b][0];
     }
 }
 
-__global__ __launch_bounds__(256) void k_jenc_len(Geom G, const int16_t *__restrict__ zz, const EncTables *__restrict__ tabs, uint32_t *__restrict__ bitlen)
-{
-    __shared__ EncTables T;
-    lds_copy(&T, tabs);
-    __syncthreads();
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= G.nblk) return;
-    const int16_t *Z = zz + (size_t)blockIdx.y * G.nblk * 64;
-    const int pr = dc_predecessor(g, G);
-    const int last = pr < 0 ? 0 : Z[(size_t)pr * 64];
-    const int t = (g % G.bpm) < G.nY ? 0 : 1;
-    bitlen[(size_t)blockIdx.y * G.nblk + g] = encode_block<false>(Z + (size_t)g * 64, last, T.dc[t], T.ac[t], nullptr, 0);
-}
-
-// One block per image: bit offsets of the blocks (exclusive prefix of their lengths, in place), the byte count, and the bit buffer zeroed
-// up to the last word any block will touch.
-__global__ __launch_bounds__(kSyncThreads) void k_jenc_scan(Geom G, uint32_t *__restrict__ bitlen, uint32_t *__restrict__ bitbuf, size_t buf_words,
-                                                             uint32_t *__restrict__ totals)
+// One block per image: the length of every block's code (AC bits from k_jenc_fdct + the DC difference's code), bit offsets (exclusive
+// prefix), the byte count, and the bit buffer zeroed up to the last word any block will touch.
+__global__ __launch_bounds__(kSyncThreads) void k_jenc_scan(Geom G, const uint16_t *__restrict__ acbits, const int16_t *__restrict__ dcq,
+                                                             const EncTables *__restrict__ tabs, uint32_t *__restrict__ bitpos,
+                                                             uint32_t *__restrict__ bitbuf, size_t buf_words, uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t lds[kSyncThreads + 1];
-    uint32_t *B = bitlen + (size_t)blockIdx.x * G.nblk;
+    __shared__ uint8_t dlen[2][16];
+    if (threadIdx.x < 32) dlen[threadIdx.x >> 4][threadIdx.x & 15] = tabs->dc[threadIdx.x >> 4].len[threadIdx.x & 15];
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * G.nblk;
+    uint32_t *B = bitpos + base;
     const uint32_t n = (uint32_t)G.nblk, L = (n + kSyncThreads - 1) / kSyncThreads;
     const uint32_t g0 = threadIdx.x * L, g1 = min(g0 + L, n);
     uint32_t run = 0;
-    for (uint32_t g = g0; g < g1; ++g) run += B[g];
+    for (uint32_t g = g0; g < g1; ++g) {
+        const int pr = dc_predecessor((int)g, G);
+        const int diff = (int)dcq[base + g] - (pr < 0 ? 0 : (int)dcq[base + pr]);
+        const uint32_t len = (uint32_t)acbits[base + g] + dc_code_bits(diff, dlen[((int)g % G.bpm) < G.nY ? 0 : 1]);
+        B[g] = len;
+        run += len;
+    }
     uint32_t total;
     uint32_t carry = block_exscan_serial<uint32_t>(run, lds, total);
     for (uint32_t g = g0; g < g1; ++g) { const uint32_t t = B[g]; B[g] = carry; carry += t; }
@@ -319,60 +434,108 @@ __global__ __launch_bounds__(kSyncThreads) void k_jenc_scan(Geom G, uint32_t *__
     for (uint32_t i = threadIdx.x; i < nw; i += kSyncThreads) W[i] = 0u;
 }
 
-__global__ __launch_bounds__(256) void k_jenc_bits(Geom G, const int16_t *__restrict__ zz, const EncTables *__restrict__ tabs,
-                                                   const uint32_t *__restrict__ bitpos, uint32_t *__restrict__ bitbuf, size_t buf_words)
+// Every block written at its bit offset.  The 256 blocks of a work-group are staged in LDS (row pitch 33 words: a lane walking its own
+// block meets no bank conflict), because 64 lanes reading 64 different 128-byte lines of global memory per instruction is what made the
+// first version slow.
+__global__ __launch_bounds__(256) void k_jenc_bits(Geom G, const int16_t *__restrict__ zz, const int16_t *__restrict__ dcq,
+                                                   const EncTables *__restrict__ tabs, const uint32_t *__restrict__ bitpos, uint32_t *__restrict__ bitbuf,
+                                                   size_t buf_words)
 {
     __shared__ EncTables T;
+    __shared__ uint32_t zl[256 * 33];
     lds_copy(&T, tabs);
+    const int g0 = blockIdx.x * 256;
+    const int count = min(256, G.nblk - g0);
+    const size_t base = (size_t)blockIdx.y * G.nblk;
+    const uint32_t *Z = reinterpret_cast<const uint32_t *>(zz + (base + g0) * 64);
+    for (int i = threadIdx.x; i < count * 32; i += 256) zl[(i >> 5) * 33 + (i & 31)] = Z[i];
     __syncthreads();
-    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int g = g0 + threadIdx.x;
     if (g >= G.nblk) return;
-    const int16_t *Z = zz + (size_t)blockIdx.y * G.nblk * 64;
     const int pr = dc_predecessor(g, G);
-    const int last = pr < 0 ? 0 : Z[(size_t)pr * 64];
+    const int last = pr < 0 ? 0 : dcq[base + pr];
     const int t = (g % G.bpm) < G.nY ? 0 : 1;
-    encode_block<true>(Z + (size_t)g * 64, last, T.dc[t], T.ac[t], bitbuf + (size_t)blockIdx.y * buf_words, bitpos[(size_t)blockIdx.y * G.nblk + g]);
+    encode_block<true>(reinterpret_cast<const int16_t *>(zl + threadIdx.x * 33), last, T.dc[t], T.ac[t], bitbuf + (size_t)blockIdx.y * buf_words,
+                       bitpos[base + g]);
 }
 
-// One block per image: the file = header | entropy-coded bytes with a 0x00 after every 0xFF (jchuff.c emit_bits; the last byte is filled
-// with 1-bits first, flush_bits) | EOI.  Thread t owns the bytes [t L, (t + 1) L): count its 0xFF bytes, prefix, write.
-__global__ __launch_bounds__(kSyncThreads) void k_jenc_stuff(const uint32_t *__restrict__ bitbuf, size_t buf_words, const uint32_t *__restrict__ totals,
-                                                              const uint8_t *__restrict__ header, uint32_t header_len, uint8_t *__restrict__ files,
-                                                              size_t file_cap, uint32_t *__restrict__ sizes)
+// The file = header | entropy-coded bytes with a 0x00 after every 0xFF (jchuff.c emit_bits; the last byte is filled with 1-bits first,
+// flush_bits) | EOI.  The bytes are cut into chunks of kStuffChunk; k_jenc_ffcount counts the 0xFF bytes of every chunk, k_jenc_stuff
+// adds up the counts of the chunks in front of its own, scans its 256 lanes (16 bytes each) and writes.
+constexpr uint32_t kStuffChunk = 4096;
+
+// the 16 bytes [byte0, byte0 + 16) of an image's bit buffer as 4 big-endian words, the last byte of the stream padded with 1-bits;
+// returns how many of the bytes that exist are 0xFF
+__device__ __forceinline__ uint32_t stuff_load16(const uint32_t *__restrict__ W, uint32_t byte0, uint32_t nbytes, uint32_t pad, uint32_t v[4])
 {
-    __shared__ uint32_t lds[kSyncThreads + 1];
-    const uint32_t *W = bitbuf + (size_t)blockIdx.x * buf_words;
-    const uint32_t total_bits = totals[2 * blockIdx.x], nbytes = totals[2 * blockIdx.x + 1];
-    const uint32_t pad = nbytes * 8u - total_bits;
-    uint8_t *F = files + (size_t)blockIdx.x * file_cap;
-    for (uint32_t i = threadIdx.x; i < header_len; i += kSyncThreads) F[i] = header[i];
-    const uint32_t L = (((nbytes + kSyncThreads - 1) / kSyncThreads) + 3u) & ~3u;   // whole words per thread
-    const uint32_t b0 = min(threadIdx.x * L, nbytes), b1 = min(b0 + L, nbytes);
-    auto byte_at = [&](uint32_t i) -> uint32_t {
-        uint32_t v = (W[i >> 2] >> (24u - 8u * (i & 3u))) & 255u;
-        if (i == nbytes - 1u) v |= (1u << pad) - 1u;
-        return v;
-    };
     uint32_t nff = 0;
-    for (uint32_t i = b0; i < b1; ++i) nff += byte_at(i) == 255u;
-    uint32_t total_ff;
-    uint32_t o = block_exscan_serial<uint32_t>(nff, lds, total_ff);
-    const size_t need = (size_t)header_len + nbytes + total_ff + 2;
-    if (need > file_cap) {   // cannot happen with the capacity the host reserves; never write out of bounds
-        if (threadIdx.x == 0) sizes[blockIdx.x] = 0;
-        return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = byte0 + 4u * i;
+        uint32_t w = b < nbytes ? W[b >> 2] : 0u;
+        if (b < nbytes && nbytes - b <= 4u) w |= ((1u << pad) - 1u) << (8u * (3u - (nbytes - 1u - b)));   // the stream's last byte is in this word
+        v[i] = w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) nff += (b + k < nbytes) && ((w >> (24 - 8 * k)) & 255u) == 255u;
     }
+    return nff;
+}
+
+__global__ __launch_bounds__(256) void k_jenc_ffcount(const uint32_t *__restrict__ bitbuf, size_t buf_words, const uint32_t *__restrict__ totals,
+                                                      uint32_t *__restrict__ chunk_ff, uint32_t nchunk)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t total_bits = totals[2 * blockIdx.y], nbytes = totals[2 * blockIdx.y + 1];
+    if (blockIdx.x * kStuffChunk >= nbytes) return;
+    uint32_t v[4];
+    const uint32_t nff = stuff_load16(bitbuf + (size_t)blockIdx.y * buf_words, blockIdx.x * kStuffChunk + threadIdx.x * 16u, nbytes, nbytes * 8u - total_bits, v);
+    const uint32_t t = block256_sum(nff, lds);
+    if (threadIdx.x == 0) chunk_ff[(size_t)blockIdx.y * nchunk + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(256) void k_jenc_stuff(const uint32_t *__restrict__ bitbuf, size_t buf_words, const uint32_t *__restrict__ totals,
+                                                    const uint32_t *__restrict__ chunk_ff, uint32_t nchunk, const uint8_t *__restrict__ header,
+                                                    uint32_t header_len, uint8_t *__restrict__ files, size_t file_cap, uint32_t *__restrict__ sizes)
+{
+    __shared__ uint32_t lds[4];
+    const uint32_t total_bits = totals[2 * blockIdx.y], nbytes = totals[2 * blockIdx.y + 1];
+    const uint32_t c0 = blockIdx.x * kStuffChunk;
+    if (c0 >= nbytes) return;
+    uint8_t *F = files + (size_t)blockIdx.y * file_cap;
+    if (blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < header_len; i += 256u) F[i] = header[i];
+    // 0xFF bytes in the chunks before this one
+    uint32_t before = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) before += chunk_ff[(size_t)blockIdx.y * nchunk + i];
+    before = block256_sum(before, lds);
+    uint32_t v[4];
+    const uint32_t byte0 = c0 + threadIdx.x * 16u;
+    const uint32_t nff = stuff_load16(bitbuf + (size_t)blockIdx.y * buf_words, byte0, nbytes, nbytes * 8u - total_bits, v);
+    // exclusive prefix over the 256 lanes
+    const uint32_t incl = wave_incl_scan(nff);
+    if ((threadIdx.x & 63) == 63) lds[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t excl = incl - nff;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) excl += lds[w];
+    const uint32_t chunk_total = lds[0] + lds[1] + lds[2] + lds[3];
     uint8_t *E = F + header_len;
-    o += b0;
-    for (uint32_t i = b0; i < b1; ++i) {
-        const uint32_t v = byte_at(i);
-        E[o++] = (uint8_t)v;
-        if (v == 255u) E[o++] = 0;
-    }
-    if (threadIdx.x == 0) {
-        E[nbytes + total_ff] = 0xFF;
-        E[nbytes + total_ff + 1] = 0xD9;
-        sizes[blockIdx.x] = (uint32_t)need;
+    size_t o = (size_t)byte0 + before + excl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = byte0 + 4u * i + k;
+            if (b < nbytes) {
+                const uint32_t x = (v[i] >> (24 - 8 * k)) & 255u;
+                E[o++] = (uint8_t)x;
+                if (x == 255u) E[o++] = 0;
+            }
+        }
+    if (threadIdx.x == 0 && c0 + kStuffChunk >= nbytes) {   // the last chunk closes the file
+        const size_t end = (size_t)nbytes + before + chunk_total;
+        E[end] = 0xFF;
+        E[end + 1] = 0xD9;
+        sizes[blockIdx.y] = (uint32_t)(header_len + end + 2);
     }
 }
 

@@ -1904,13 +1904,13 @@ struct bevw_jpeg {
     std::vector<jpg::TableSet> h_tabs;
     std::vector<uint16_t> h_quant;
     DevBuf d_stream, d_desc, d_seg_byte, d_seg_sub, d_tabs, d_quant;
-    DevBuf d_entry, d_exit, d_sums, d_base, d_endbit, d_meta, d_rounds, d_coef, d_planes, d_img;
+    DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_rounds, d_coef, d_planes, d_img;
     // encode
     jpg::Geom EG{};
     int en = 0, e_quality = -1, e_sampling = -1;
     jpg::EncTables etabs;
     std::vector<uint8_t> header;
-    DevBuf d_etabs, d_header, d_eplanes, d_zz, d_bitlen, d_bitbuf, d_totals, d_files, d_sizes, d_src;
+    DevBuf d_etabs, d_header, d_eplanes, d_zz, d_acbits, d_dcq, d_bitlen, d_bitbuf, d_totals, d_chunk_ff, d_files, d_sizes, d_src;
     size_t buf_words = 0, file_cap = 0;
     std::vector<uint32_t> sizes;
     bool encoded = false, sizes_valid = false;
@@ -2063,6 +2063,7 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     const size_t ns = j->total_sub ? j->total_sub : 1, n = (size_t)j->n;
     BEVW_TRY(j->d_entry.reserve(ns * 8));
     BEVW_TRY(j->d_exit.reserve(ns * 8));
+    BEVW_TRY(j->d_exit2.reserve(ns * 8));
     BEVW_TRY(j->d_sums.reserve(ns * 16));
     BEVW_TRY(j->d_base.reserve(ns * 16));
     BEVW_TRY(j->d_endbit.reserve(ns * 4));
@@ -2080,6 +2081,11 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
         const dim3 gs((j->max_sub + 255) / 256, (unsigned)n);
         jpg::k_jpeg_sync0<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
         BEVW_TRY(launch_check("k_jpeg_sync0"));
+        // two full-occupancy rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
+        jpg::k_jpeg_sync_round<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_exit.as<uint64_t>(), j->d_exit2.as<uint64_t>());
+        BEVW_TRY(launch_check("k_jpeg_sync_round"));
+        jpg::k_jpeg_sync_round<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>());
+        BEVW_TRY(launch_check("k_jpeg_sync_round"));
         jpg::k_jpeg_sync<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(img, stream, tabs, G, A, j->d_rounds.as<uint32_t>());
         BEVW_TRY(launch_check("k_jpeg_sync"));
         jpg::k_jpeg_coef<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_coef.as<int16_t>());
@@ -2088,10 +2094,16 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(img, G, j->d_coef.as<int16_t>(), j->d_quant.as<uint16_t>(),
                                                                                  j->d_planes.as<uint8_t>());
     BEVW_TRY(launch_check("k_jpeg_idct"));
-    const int aligned = ((uintptr_t)d_out % 4 == 0 && image_stride_bytes % 4 == 0 && row_pitch_bytes % 4 == 0) ? 1 : 0;
-    jpg::k_jpeg_color<<<dim3(((G.w + 3) / 4 + 63) / 64, (G.h + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
-        G, j->d_planes.as<uint8_t>(), (uint8_t *)d_out, image_stride_bytes, row_pitch_bytes, aligned);
-    BEVW_TRY(launch_check("k_jpeg_color"));
+    const bool aligned = (uintptr_t)d_out % 4 == 0 && image_stride_bytes % 4 == 0 && row_pitch_bytes % 4 == 0;
+    if (aligned && G.nc == 3 && G.hs == 2 && G.vs == 2 && G.dw > 2) {
+        jpg::k_jpeg_color_h2v2<<<dim3(((G.w + 7) / 8 + 63) / 64, (G.h + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
+            G, j->d_planes.as<uint8_t>(), (uint8_t *)d_out, image_stride_bytes, row_pitch_bytes);
+        BEVW_TRY(launch_check("k_jpeg_color_h2v2"));
+    } else {
+        jpg::k_jpeg_color<<<dim3(((G.w + 3) / 4 + 63) / 64, (G.h + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
+            G, j->d_planes.as<uint8_t>(), (uint8_t *)d_out, image_stride_bytes, row_pitch_bytes);
+        BEVW_TRY(launch_check("k_jpeg_color"));
+    }
     j->decoded = true;
     return BEVW_OK;
 }
@@ -2173,7 +2185,7 @@ int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int widt
     j->en = n;
     const size_t N = (size_t)n;
     j->buf_words = ((size_t)G.nblk * 209 + 3) / 4 + 4;
-    j->file_cap = (j->header.size() + j->buf_words * 8 + 16 + 15) & ~(size_t)15;
+    j->file_cap = (j->header.size() + j->buf_words * 8 + 16 + 15) & ~(size_t)15;   // every byte stuffed + EOI: cannot overflow
     BEVW_TRY(j->d_eplanes.reserve(N * (size_t)G.plane_bytes));
     BEVW_TRY(j->d_zz.reserve(N * (size_t)G.nblk * 128));
     BEVW_TRY(j->d_bitlen.reserve(N * (size_t)G.nblk * 4));
@@ -2185,19 +2197,26 @@ int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int widt
     jpg::k_jenc_ycc<<<dim3((G.wb[1] * 8 + 63) / 64, (G.hb[1] * 8 + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
         G, (const uint8_t *)d_bgr, image_stride_bytes, row_pitch_bytes, j->d_eplanes.as<uint8_t>());
     BEVW_TRY(launch_check("k_jenc_ycc"));
-    jpg::k_jenc_fdct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(G, j->d_eplanes.as<uint8_t>(), tabs, j->d_zz.as<int16_t>());
+    BEVW_TRY(j->d_acbits.reserve(N * (size_t)G.nblk * 2));
+    BEVW_TRY(j->d_dcq.reserve(N * (size_t)G.nblk * 2));
+    const uint32_t nchunk = (uint32_t)((j->buf_words * 4 + jpg::kStuffChunk - 1) / jpg::kStuffChunk);
+    BEVW_TRY(j->d_chunk_ff.reserve(N * nchunk * 4));
+    jpg::k_jenc_fdct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(G, j->d_eplanes.as<uint8_t>(), tabs, j->d_zz.as<int16_t>(),
+                                                                                 j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>());
     BEVW_TRY(launch_check("k_jenc_fdct"));
-    const dim3 gb((G.nblk + 255) / 256, (unsigned)n);
-    jpg::k_jenc_len<<<gb, 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jenc_len"));
-    jpg::k_jenc_scan<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(G, j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words,
-                                                                    j->d_totals.as<uint32_t>());
+    jpg::k_jenc_scan<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(G, j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>(),
+                                                                    j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>());
     BEVW_TRY(launch_check("k_jenc_scan"));
-    jpg::k_jenc_bits<<<gb, 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words);
+    jpg::k_jenc_bits<<<dim3((G.nblk + 255) / 256, (unsigned)n), 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), j->d_dcq.as<int16_t>(), tabs,
+                                                                                   j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words);
     BEVW_TRY(launch_check("k_jenc_bits"));
-    jpg::k_jenc_stuff<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
-                                                                     j->d_header.as<uint8_t>(), (uint32_t)j->header.size(), j->d_files.as<uint8_t>(),
-                                                                     j->file_cap, j->d_sizes.as<uint32_t>());
+    jpg::k_jenc_ffcount<<<dim3(nchunk, (unsigned)n), 256, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
+                                                                        j->d_chunk_ff.as<uint32_t>(), nchunk);
+    BEVW_TRY(launch_check("k_jenc_ffcount"));
+    jpg::k_jenc_stuff<<<dim3(nchunk, (unsigned)n), 256, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
+                                                                      j->d_chunk_ff.as<uint32_t>(), nchunk, j->d_header.as<uint8_t>(),
+                                                                      (uint32_t)j->header.size(), j->d_files.as<uint8_t>(), j->file_cap,
+                                                                      j->d_sizes.as<uint32_t>());
     BEVW_TRY(launch_check("k_jenc_stuff"));
     j->encoded = true;
     return BEVW_OK;

@@ -7,6 +7,7 @@
 //
 //   jpeg_emulate decode <in.jpg> <out.bin>       out: int32 w h rounds nsub | uint8 bgr[h][w][3]
 //   jpeg_emulate encode <in.bin> <out.jpg>       in : int32 w h quality sampling | uint8 bgr[h][w][3]
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
@@ -97,12 +98,22 @@ static int do_decode(const char *in, const char *out)
             cb += (uint32_t)sums[j].cnt; d0 += sums[j].dc0; d1 += sums[j].dc1; d2 += sums[j].dc2;
         }
     }
-    // k_jpeg_coef
+    // k_jpeg_coef: work-groups of 256 subsequences, each with its slice of the stream (and the natural-order table) in "LDS"
     std::vector<int16_t> coef((size_t)G.nblk * 64, 0);
-    for (int j = 0; j < nsub; ++j) {
-        uint32_t cap = (uint32_t)G.nblk;
-        if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
-        decode_sub<true>(words, T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2]);
+    uint8_t nat[64];
+    for (int k = 0; k < 64; ++k) nat[k] = (uint8_t)natural_of(k);
+    for (int jb = 0; jb < nsub; jb += 256) {
+        const int jl = std::min(jb + 256, nsub) - 1;
+        const uint32_t w0 = (uint32_t)entry[jb] >> 5, w1 = (endbit[jl] >> 5) + 3u;
+        if (w1 - w0 > 256u * (kSubBits / 32) + 8u) { fprintf(stderr, "stream slice of %u words does not fit\n", w1 - w0); return 3; }
+        std::vector<uint32_t> sw(256 * (kSubBits / 32) + 8, 0xdeadbeefu);
+        for (uint32_t i = 0; i < w1 - w0; ++i) sw[i] = words[w0 + i];
+        for (int j = jb; j <= jl; ++j) {
+            uint32_t cap = (uint32_t)G.nblk;
+            if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
+            decode_sub<true>(sw.data(), T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2],
+                             w0, nat);
+        }
     }
     // k_jpeg_idct: lane = (block, column), then (block, row)
     std::vector<uint8_t> planes((size_t)G.plane_bytes);
@@ -192,13 +203,22 @@ static int do_encode(const char *in, const char *out)
             }
         }
     }
-    // k_jenc_len + k_jenc_scan
+    // k_jenc_fdct's last step (AC code bits per block, the quantised DC aside) + k_jenc_scan (DC code bits, prefix)
+    std::vector<uint16_t> acbits(G.nblk);
+    std::vector<int16_t> dcq(G.nblk);
+    for (int g = 0; g < G.nblk; ++g) {
+        const int t = (g % G.bpm) < G.nY ? 0 : 1;
+        acbits[g] = (uint16_t)ac_code_bits(zz.data() + (size_t)g * 64, T.ac[t].len);
+        dcq[g] = zz[(size_t)g * 64];
+    }
     std::vector<uint32_t> pos(G.nblk + 1, 0);
     for (int g = 0; g < G.nblk; ++g) {
         const int z = g % G.bpm, pr = dc_predecessor(g, G);
-        const int last = pr < 0 ? 0 : zz[(size_t)pr * 64];
+        const int last = pr < 0 ? 0 : dcq[pr];
         const int t = z < G.nY ? 0 : 1;
-        pos[g + 1] = pos[g] + encode_block<false>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], nullptr, 0);
+        const uint32_t len = (uint32_t)acbits[g] + dc_code_bits((int)dcq[g] - last, T.dc[t].len);
+        if (len != encode_block<false>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], nullptr, 0)) { fprintf(stderr, "split length differs at block %d\n", g); return 3; }
+        pos[g + 1] = pos[g] + len;
     }
     const uint32_t total_bits = pos[G.nblk];
     const uint32_t nbytes = (total_bits + 7) / 8;
