@@ -99,8 +99,9 @@ inline Geom make_geom(int w, int h, int nc, int hs, int vs)
 // ---- decoding tables ----------------------------------------------------------------------------------------------------
 struct HuffTab {          // jdhuff.c jpeg_make_d_derived_tbl, 9-bit look-ahead
     uint16_t fast[512];   // len << 8 | symbol for codes of <= 9 bits, 0 otherwise
-    int32_t maxcode[18];  // largest code of each length, -1 if none; [17] = sentinel
-    int32_t valoff[18];
+    uint32_t ub[8];       // ub[l - 9], l = 9 .. 16: the first 16-bit window (left-justified) that is NOT a code of length <= l
+    int32_t valoff[18];   // index of the first symbol of length l minus its first code
+    uint32_t pad[2];
     uint8_t vals[256];
 };
 static_assert(sizeof(HuffTab) % 16 == 0, "HuffTab is copied to LDS in 16-byte pieces");
@@ -131,18 +132,22 @@ struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
 template <bool WRITE>
 __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words, const HuffTab *tabs, const Geom &G, uint64_t entry,
                                              uint32_t end_bit, int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0,
-                                             int32_t pred1, int32_t pred2, uint32_t word_base = 0, const uint8_t *nat = nullptr)
+                                             int32_t pred1, int32_t pred2, uint32_t word_base = 0, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr)
 {
+    // WRITE: a block belongs to the lane in whose range it STARTS.  The owner assembles it in lbuf (64 int16 of its own, LDS on the device),
+    // keeps decoding past end_bit until the block is complete, and stores it whole -- eight 16-byte stores that cover two full 64-byte
+    // sectors, no read-modify-write of zeroed lines, no zero fill of the coefficient buffer.  The block in progress at a lane's entry
+    // (k != 0) is its predecessor's: it is decoded for the state only.
     // word_base: `words` starts at that word of the image's stream (k_jpeg_coef keeps its work-group's slice in LDS); nat: the
     // natural-order table in memory of the caller's choice (LDS there: a global-memory look-up would queue behind the stores)
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
     SubOut R;
     R.cnt = 0; R.dc0 = R.dc1 = R.dc2 = 0;
-    // bit buffer: `have` valid bits at the top of acc, next word to load = widx
-    uint32_t widx = (p >> 5) - word_base;
-    uint64_t acc = (uint64_t)__builtin_bswap32(words[widx++]) << 32;
-    acc <<= (p & 31u);
-    int have = 32 - (int)(p & 31u);
+    // bit window: w0 | w1 = the two (big-endian) words around the read position, `off` = bits of w0 already used; the word after them
+    // is always in flight (nraw): a wave meets a refill in nearly every iteration, and waiting for a load where it is issued would cost
+    // the whole wave a memory latency per symbol.  One 32-bit window holds a whole symbol (code <= 16 bits + <= 16 extra bits).
+    uint32_t widx = (p >> 5) - word_base, off = p & 31u;
+    uint32_t w0 = __builtin_bswap32(words[widx]), w1 = __builtin_bswap32(words[widx + 1]), nraw = words[widx + 2];
     // position of the block in progress (WRITE)
     int mx = 0, my = 0;
     size_t baddr = 0;
@@ -152,11 +157,8 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
         my = (int)(mcu / (uint32_t)G.mcux);
     }
     bool fresh = true;   // baddr must be recomputed
-    while (p < end_bit && (!WRITE || blk < blk_cap)) {
-        if (have <= 32) {
-            acc |= (uint64_t)__builtin_bswap32(words[widx++]) << (32 - have);
-            have += 32;
-        }
+    bool own = k == 0;   // WRITE: the block in progress started inside this lane's range
+    while (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit) {
         const int c = (int)z < G.nY ? 0 : 1 + (int)z - G.nY;
         if (WRITE && fresh) {
             int bx, by;
@@ -164,56 +166,60 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
             else { bx = mx; by = my; }
             baddr = ((size_t)G.blk_off[c] + (size_t)by * G.wb[c] + bx) * 64;
             fresh = false;
+            if (own) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) reinterpret_cast<uint4 *>(lbuf)[i] = make_uint4(0u, 0u, 0u, 0u);
+#else
+                memset(lbuf, 0, 128);
+#endif
+            }
         }
         const HuffTab &T = tabs[2 * c + (k ? 1 : 0)];
-        const uint32_t peek = (uint32_t)(acc >> 48);
+        const uint32_t window = off ? (w0 << off) | (w1 >> (32u - off)) : w0;
+        const uint32_t peek = window >> 16;
         uint32_t len, sym;
         const uint32_t e = T.fast[peek >> 7];
         if (e) {
             len = e >> 8;
             sym = e & 255u;
         } else {
-            len = 16; sym = 0;   // corrupt data: libjpeg warns and yields 0
-            for (int l = 10; l <= 16; ++l) {
-                const int32_t code = (int32_t)(peek >> (16 - l));
-                if (code <= T.maxcode[l]) { len = (uint32_t)l; sym = T.vals[(code + T.valoff[l]) & 255]; break; }
-            }
+            // a code of 10 .. 16 bits: its length is 10 + the number of limits the window has reached (no loop: with 64 lanes some lane
+            // is here in most iterations, and every lane of the wave pays for the longest path)
+            len = 10u + (peek >= T.ub[1]) + (peek >= T.ub[2]) + (peek >= T.ub[3]) + (peek >= T.ub[4]) + (peek >= T.ub[5]) + (peek >= T.ub[6]);
+            sym = T.vals[((peek >> (16u - len)) + (uint32_t)T.valoff[len]) & 255u];
+            if (peek >= T.ub[7]) { len = 16; sym = 0; }   // not a code at all (corrupt data): libjpeg warns and yields 0
         }
-        acc <<= len;
-        have -= (int)len;
-        uint32_t used = len;
+        // the extra bits: a DC symbol IS their count, an AC symbol is run << 4 | count
+        const uint32_t s = k == 0 ? (sym > 16u ? 16u : sym) : (sym & 15u);
+        int32_t v = 0;
+        if (s) {
+            v = (int32_t)((window << len) >> (32u - s));
+            v = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;   // HUFF_EXTEND
+        }
         if (k == 0) {
-            const uint32_t s = sym > 16u ? 16u : sym;
-            int32_t diff = 0;
-            if (s) {
-                const int32_t r = (int32_t)(acc >> (64 - s));
-                acc <<= s;
-                have -= (int)s;
-                used += s;
-                diff = r < (1 << (s - 1)) ? r - (1 << s) + 1 : r;   // HUFF_EXTEND
-            }
-            if (c == 0) { R.dc0 += diff; pred0 += diff; }
-            else if (c == 1) { R.dc1 += diff; pred1 += diff; }
-            else { R.dc2 += diff; pred2 += diff; }
-            if (WRITE) coef[baddr] = (int16_t)(c == 0 ? pred0 : (c == 1 ? pred1 : pred2));
+            if (c == 0) { R.dc0 += v; pred0 += v; }
+            else if (c == 1) { R.dc1 += v; pred1 += v; }
+            else { R.dc2 += v; pred2 += v; }
+            if (WRITE && own) lbuf[0] = (int16_t)(c == 0 ? pred0 : (c == 1 ? pred1 : pred2));
             k = 1;
+        } else if (s) {
+            k += sym >> 4;
+            if (WRITE && own && k <= 63u) lbuf[nat ? (int)nat[k] : natural_of((int)k)] = (int16_t)v;
+            ++k;
         } else {
-            const uint32_t r = sym >> 4, s = sym & 15u;
-            if (s) {
-                k += r;
-                const int32_t v = (int32_t)(acc >> (64 - s));
-                acc <<= s;
-                have -= (int)s;
-                used += s;
-                if (WRITE && k <= 63u) coef[baddr + (nat ? (int)nat[k] : natural_of((int)k))] = (int16_t)(v < (1 << (s - 1)) ? v - (1 << s) + 1 : v);
-                ++k;
-            } else if (r == 15u) {
-                k += 16;
-            } else {
-                k = 64;   // EOB
-            }
+            k = (sym >> 4) == 15u ? k + 16u : 64u;   // ZRL : EOB
         }
         if (k >= 64u) {   // block complete
+            if (WRITE && own) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) reinterpret_cast<uint4 *>(coef + baddr)[i] = reinterpret_cast<const uint4 *>(lbuf)[i];
+#else
+                memcpy(coef + baddr, lbuf, 128);
+#endif
+            }
+            own = true;
             k = 0;
             ++R.cnt;
             ++blk;
@@ -223,7 +229,16 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
                 if (WRITE && ++mx == G.mcux) { mx = 0; ++my; }
             }
         }
+        const uint32_t used = len + s;
         p += used;
+        off += used;
+        if (off >= 32u) {
+            off -= 32u;
+            w0 = w1;
+            w1 = __builtin_bswap32(nraw);
+            ++widx;
+            nraw = words[widx + 2];
+        }
     }
     R.exit = pack_state(p, z, k);
     return R;
@@ -675,23 +690,18 @@ inline bool make_hufftab(const RawHuff &r, HuffTab &T)
     int p = 0, code = 0;
     for (int l = 1; l <= 16; ++l) {
         T.valoff[l] = p - code;
-        if (r.bits[l]) {
-            for (int i = 0; i < r.bits[l]; ++i) {
-                if (l <= 9) {
-                    const int c0 = (code + i) << (9 - l);
-                    for (int f = 0; f < (1 << (9 - l)); ++f) T.fast[c0 + f] = (uint16_t)((l << 8) | r.vals[p + i]);
-                }
+        for (int i = 0; i < r.bits[l]; ++i) {
+            if (l <= 9) {
+                const int c0 = (code + i) << (9 - l);
+                for (int f = 0; f < (1 << (9 - l)); ++f) T.fast[c0 + f] = (uint16_t)((l << 8) | r.vals[p + i]);
             }
-            p += r.bits[l];
-            code += r.bits[l];
-            if (code > (1 << l)) return false;
-            T.maxcode[l] = code - 1;
-        } else {
-            T.maxcode[l] = -1;
         }
+        p += r.bits[l];
+        code += r.bits[l];
+        if (code > (1 << l)) return false;
+        if (l >= 9) T.ub[l - 9] = (uint32_t)code << (16 - l);   // canonical codes: windows below this are codes of length <= l
         code <<= 1;
     }
-    T.maxcode[17] = 0xFFFFF;
     memcpy(T.vals, r.vals, 256);
     return true;
 }

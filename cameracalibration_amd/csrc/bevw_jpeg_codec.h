@@ -194,28 +194,21 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     }
 }
 
-// The final pass: every subsequence decoded from its true entry state, coefficients written.  The work-group's slice of the entropy-coded
-// data and the natural-order table sit in LDS: on gfx9 loads and stores share one in-order counter, so a refill of the bit buffer from
-// global memory would wait for every scattered coefficient store issued before it.
+// The final pass: every subsequence decoded from its true entry state, coefficients written.  A block is assembled in the LDS slot of the
+// lane in whose range it starts (72 int16 per lane: 16-byte aligned, lanes spread over 8 banks) and stored whole; the natural-order table
+// sits in LDS too (a global-memory look-up would queue behind the stores: on gfx9 loads and stores share one in-order counter).
 __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
                                                    const TableSet *__restrict__ tabs, Geom G, SubArrays A, int16_t *__restrict__ coef)
 {
     __shared__ TableSet T;
-    __shared__ uint32_t sw[256 * (kSubBits / 32) + 8];
+    __shared__ __attribute__((aligned(16))) int16_t lbuf[256][72];
     __shared__ uint8_t nat[64];
     const ImageDesc D = img[blockIdx.y];
-    const uint32_t jb = blockIdx.x * 256u;
-    if (jb >= D.nsub) return;
+    if (blockIdx.x * 256u >= D.nsub) return;
     lds_copy(&T, tabs + D.tables);
     if (threadIdx.x < 64) nat[threadIdx.x] = (uint8_t)natural_of((int)threadIdx.x);
-    const uint32_t jl = min(jb + 256u, D.nsub) - 1u;
-    // entry positions grow with the subsequence index: the slice starts at the first lane's entry and ends behind the last lane's last refill
-    const uint32_t w0 = (uint32_t)A.entry[(size_t)D.sub_first + jb] >> 5;
-    const uint32_t w1 = (A.endbit[(size_t)D.sub_first + jl] >> 5) + 3u;
-    const uint32_t nw = min(w1 - w0, (uint32_t)(256 * (kSubBits / 32) + 8));
-    for (uint32_t i = threadIdx.x; i < nw; i += 256u) sw[i] = stream[D.stream_word + w0 + i];
     __syncthreads();
-    const uint32_t j = jb + threadIdx.x;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= D.nsub) return;
     const size_t slot = (size_t)D.sub_first + j;
     const int4 b = A.base[slot];
@@ -224,7 +217,8 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
         const unsigned long long c2 = (unsigned long long)((A.meta[slot] & 0x7fffffffu) + 1u) * D.seg_blocks;
         if (c2 < cap) cap = (uint32_t)c2;
     }
-    decode_sub<true>(sw, T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y, b.z, b.w, w0, nat);
+    decode_sub<true>(stream + D.stream_word, T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y, b.z,
+                     b.w, 0, nat, lbuf[threadIdx.x]);
 }
 
 // jpeg_idct_islow: a wave transforms 8 blocks; lane = (block, column) for the column pass, (block, row) for the row pass, the 8 x 8

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
@@ -1890,7 +1891,8 @@ struct PinnedBuf {
 
 struct bevw_jpeg {
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st2 = nullptr;   // st2: the odd slices of a decode batch
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
     LapTimer timer;
     // decode: what bevw_jpeg_decode_stage left on the device
     jpg::Geom G{};
@@ -1941,7 +1943,10 @@ int bevw_jpeg_create(int device, bevw_jpeg **out)
     if (!j) return fail(BEVW_E_NOMEM, "out of host memory");
     j->device = device;
     hipError_t e = hipStreamCreateWithFlags(&j->st, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete j; return fail(BEVW_E_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&j->st2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_a, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_b, hipEventDisableTiming);
+    if (e != hipSuccess) { bevw_jpeg_destroy(j); return fail(BEVW_E_HIP, "stream / event creation failed: %s", hipGetErrorString(e)); }
     *out = j;
     return BEVW_OK;
 }
@@ -1950,7 +1955,10 @@ void bevw_jpeg_destroy(bevw_jpeg *j)
 {
     if (!j) return;
     (void)hipSetDevice(j->device);
+    if (j->st2) { (void)hipStreamSynchronize(j->st2); (void)hipStreamDestroy(j->st2); }
     if (j->st) { (void)hipStreamSynchronize(j->st); (void)hipStreamDestroy(j->st); }
+    if (j->ev_a) (void)hipEventDestroy(j->ev_a);
+    if (j->ev_b) (void)hipEventDestroy(j->ev_b);
     j->timer.release();
     delete j;
 }
@@ -2076,33 +2084,53 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     const jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
     const uint32_t *stream = j->d_stream.as<uint32_t>();
     const jpg::TableSet *tabs = j->d_tabs.as<jpg::TableSet>();
-    HIP_TRY(hipMemsetAsync(j->d_coef.p, 0, n * (size_t)G.nblk * 128, j->st));
-    if (j->max_sub) {
-        const dim3 gs((j->max_sub + 255) / 256, (unsigned)n);
-        jpg::k_jpeg_sync0<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
-        BEVW_TRY(launch_check("k_jpeg_sync0"));
-        // two full-occupancy rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
-        jpg::k_jpeg_sync_round<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_exit.as<uint64_t>(), j->d_exit2.as<uint64_t>());
-        BEVW_TRY(launch_check("k_jpeg_sync_round"));
-        jpg::k_jpeg_sync_round<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>());
-        BEVW_TRY(launch_check("k_jpeg_sync_round"));
-        jpg::k_jpeg_sync<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(img, stream, tabs, G, A, j->d_rounds.as<uint32_t>());
-        BEVW_TRY(launch_check("k_jpeg_sync"));
-        jpg::k_jpeg_coef<<<gs, 256, 0, j->st>>>(img, stream, tabs, G, A, j->d_coef.as<int16_t>());
-        BEVW_TRY(launch_check("k_jpeg_coef"));
-    }
-    jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(img, G, j->d_coef.as<int16_t>(), j->d_quant.as<uint16_t>(),
-                                                                                 j->d_planes.as<uint8_t>());
-    BEVW_TRY(launch_check("k_jpeg_idct"));
+    // (no zero fill of the coefficient buffer: k_jpeg_coef stores every block whole)
+    // The batch runs as `parts` independent slices alternating over two streams: the tail of the synchronisation (a few lanes per image
+    // walking their subsequences again, the rest of the chip idle) of one slice overlaps the throughput-bound kernels of the other.
+    static const int parts_env = [] { const char *e = getenv("BEVW_JPEG_PARTS"); return e ? atoi(e) : 0; }();
+    const size_t parts = parts_env > 0 ? std::min<size_t>((size_t)parts_env, n) : (n >= 32 ? 2 : 1);   // measured: 2 slices -6 %, 4 and more lose (launches too small)
     const bool aligned = (uintptr_t)d_out % 4 == 0 && image_stride_bytes % 4 == 0 && row_pitch_bytes % 4 == 0;
-    if (aligned && G.nc == 3 && G.hs == 2 && G.vs == 2 && G.dw > 2) {
-        jpg::k_jpeg_color_h2v2<<<dim3(((G.w + 7) / 8 + 63) / 64, (G.h + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
-            G, j->d_planes.as<uint8_t>(), (uint8_t *)d_out, image_stride_bytes, row_pitch_bytes);
-        BEVW_TRY(launch_check("k_jpeg_color_h2v2"));
-    } else {
-        jpg::k_jpeg_color<<<dim3(((G.w + 3) / 4 + 63) / 64, (G.h + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
-            G, j->d_planes.as<uint8_t>(), (uint8_t *)d_out, image_stride_bytes, row_pitch_bytes);
-        BEVW_TRY(launch_check("k_jpeg_color"));
+    if (parts > 1) {
+        HIP_TRY(hipEventRecord(j->ev_a, j->st));          // the staging copies were enqueued on st
+        HIP_TRY(hipStreamWaitEvent(j->st2, j->ev_a, 0));
+    }
+    for (size_t part = 0; part < parts; ++part) {
+        const size_t first = n * part / parts, m = n * (part + 1) / parts - first;
+        if (!m) continue;
+        hipStream_t st = (part & 1) ? j->st2 : j->st;
+        const jpg::ImageDesc *im = img + first;
+        int16_t *coef = j->d_coef.as<int16_t>() + first * (size_t)G.nblk * 64;
+        uint8_t *planes = j->d_planes.as<uint8_t>() + first * (size_t)G.plane_bytes;
+        if (j->max_sub) {
+            const dim3 gs((j->max_sub + 255) / 256, (unsigned)m);
+            jpg::k_jpeg_sync0<<<gs, 256, 0, st>>>(im, stream, tabs, G, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
+            BEVW_TRY(launch_check("k_jpeg_sync0"));
+            // two full-occupancy rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
+            jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit.as<uint64_t>(), j->d_exit2.as<uint64_t>());
+            BEVW_TRY(launch_check("k_jpeg_sync_round"));
+            jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>());
+            BEVW_TRY(launch_check("k_jpeg_sync_round"));
+            jpg::k_jpeg_sync<<<(unsigned)m, jpg::kSyncThreads, 0, st>>>(im, stream, tabs, G, A, j->d_rounds.as<uint32_t>() + first);
+            BEVW_TRY(launch_check("k_jpeg_sync"));
+            jpg::k_jpeg_coef<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, coef);
+            BEVW_TRY(launch_check("k_jpeg_coef"));
+        }
+        jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)m), 256, 0, st>>>(im, G, coef, j->d_quant.as<uint16_t>(), planes);
+        BEVW_TRY(launch_check("k_jpeg_idct"));
+        uint8_t *dst = (uint8_t *)d_out + first * image_stride_bytes;
+        if (aligned && G.nc == 3 && G.hs == 2 && G.vs == 2 && G.dw > 2) {
+            jpg::k_jpeg_color_h2v2<<<dim3(((G.w + 7) / 8 + 63) / 64, (G.h + 3) / 4, (unsigned)m), dim3(64, 4), 0, st>>>(G, planes, dst, image_stride_bytes,
+                                                                                                                           row_pitch_bytes);
+            BEVW_TRY(launch_check("k_jpeg_color_h2v2"));
+        } else {
+            jpg::k_jpeg_color<<<dim3(((G.w + 3) / 4 + 63) / 64, (G.h + 3) / 4, (unsigned)m), dim3(64, 4), 0, st>>>(G, planes, dst, image_stride_bytes,
+                                                                                                                      row_pitch_bytes);
+            BEVW_TRY(launch_check("k_jpeg_color"));
+        }
+    }
+    if (parts > 1) {   // everything the caller enqueues on st afterwards (and bevw_jpeg_sync) sees the whole batch
+        HIP_TRY(hipEventRecord(j->ev_b, j->st2));
+        HIP_TRY(hipStreamWaitEvent(j->st, j->ev_b, 0));
     }
     j->decoded = true;
     return BEVW_OK;

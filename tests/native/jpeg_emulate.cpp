@@ -98,22 +98,16 @@ static int do_decode(const char *in, const char *out)
             cb += (uint32_t)sums[j].cnt; d0 += sums[j].dc0; d1 += sums[j].dc1; d2 += sums[j].dc2;
         }
     }
-    // k_jpeg_coef: work-groups of 256 subsequences, each with its slice of the stream (and the natural-order table) in "LDS"
-    std::vector<int16_t> coef((size_t)G.nblk * 64, 0);
+    // k_jpeg_coef: every block assembled and stored by the lane in whose range it starts
+    std::vector<int16_t> coef((size_t)G.nblk * 64, 0x7777);   // no zero fill: every block must be stored whole by its owner
     uint8_t nat[64];
     for (int k = 0; k < 64; ++k) nat[k] = (uint8_t)natural_of(k);
-    for (int jb = 0; jb < nsub; jb += 256) {
-        const int jl = std::min(jb + 256, nsub) - 1;
-        const uint32_t w0 = (uint32_t)entry[jb] >> 5, w1 = (endbit[jl] >> 5) + 3u;
-        if (w1 - w0 > 256u * (kSubBits / 32) + 8u) { fprintf(stderr, "stream slice of %u words does not fit\n", w1 - w0); return 3; }
-        std::vector<uint32_t> sw(256 * (kSubBits / 32) + 8, 0xdeadbeefu);
-        for (uint32_t i = 0; i < w1 - w0; ++i) sw[i] = words[w0 + i];
-        for (int j = jb; j <= jl; ++j) {
-            uint32_t cap = (uint32_t)G.nblk;
-            if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
-            decode_sub<true>(sw.data(), T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2],
-                             w0, nat);
-        }
+    for (int j = 0; j < nsub; ++j) {
+        uint32_t cap = (uint32_t)G.nblk;
+        if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
+        int16_t lbuf[64];
+        decode_sub<true>(words, T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2], 0, nat,
+                         lbuf);
     }
     // k_jpeg_idct: lane = (block, column), then (block, row)
     std::vector<uint8_t> planes((size_t)G.plane_bytes);

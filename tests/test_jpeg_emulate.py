@@ -73,6 +73,16 @@ def test_emulated_restart_segments_and_grey(emu):
         assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f)), kw
 
 
+def test_emulated_private_huffman_tables_and_long_codes(emu):
+    # optimize=True: file-specific tables (other code-length profiles than Annex K); quality 100 noise: 16-bit codes in every block
+    for k, q in ((0, 85), (1, 100), (2, 40), (1, 97)):
+        im = JC.image(136, 200, k)
+        f = JC.pil_encode(im, q, 2, optimize=True)
+        assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f)), (k, q)
+    f = JC.pil_encode(JC.image(96, 160, 1), 100, 0)
+    assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f))
+
+
 def test_emulated_bev_sized_file(emu):
     im = JC.image(1080, 1080, 2)
     assert emu.encode(im) == JC.pil_encode(im)
