@@ -346,9 +346,15 @@ def main_jpeg(a, d, w, dev):
     d_bev = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
     extra = {"frame": [fw, fh], "bev": [bw, bh], "jpeg_in": "baseline 4:2:0 quality 90, %d bytes per file (synthetic camera-like frames)" % (
         sum(len(f) for f in uniq_files) // len(uniq_files)), "jpeg_out": "baseline 4:2:0 quality 95 (cv2.imwrite's defaults)"}
+    stage_ms = None
     if mode in ("decode", "pipeline"):
         codec.decode_stage(files)
         codec.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):   # the host side of a batch: marker parsing + un-stuffing into pinned memory + the H2D copies (compressed bytes only)
+            codec.decode_stage(files)
+            codec.sync()
+        stage_ms = (time.perf_counter() - t0) / 3 * 1e3
     if mode == "decode":
         units = batch * 4
         step = lambda: codec.decode_run_device(d_frames.ptr, fh * fw * 3, fw * 3)
@@ -394,6 +400,11 @@ def main_jpeg(a, d, w, dev):
                      huffman_table_sets=info["table_sets"])
     if sizes:
         extra["bytes_per_output_file"] = sum(len(f) for f in sizes) // len(sizes)
+    if stage_ms is not None:
+        extra["host_stage_ms_per_batch"] = round(stage_ms, 3)
+        extra["host_stage_files_per_s"] = round(batch * 4 / (stage_ms * 1e-3))
+        extra["host_stage_note"] = ("marker parsing + un-stuffing into pinned memory (host threads) + H2D of the compressed bytes for one batch; "
+                                    "outside the timed region (inputs resident = staged streams); a pipelined caller overlaps it with the kernels")
     cpu = None
     if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline and mode != "pipeline":
         cpu = jpeg_cpu_baseline(mode, uniq_files, list(uniq_bev), min(a.cpu_seconds, 8.0))

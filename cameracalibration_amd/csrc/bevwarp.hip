@@ -17,6 +17,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "bevw_kernels.h"
@@ -1991,9 +1993,6 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     j->h_tabs.clear();
     j->h_quant.assign((size_t)n * 192, 0);
     std::vector<std::string> keys;
-    std::vector<uint32_t> seg;
-    size_t off = 0, sub_total = 0;
-    uint32_t max_sub = 0;
     for (int i = 0; i < n; ++i) {
         jpg::ImageDesc &D = j->h_desc[i];
         // tables: identical table sets are shared (cameras of one rig write the same ones)
@@ -2016,29 +2015,50 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
         D.tables = (uint32_t)t;
         D.quant = (uint32_t)i;
         for (int c = 0; c < P[i].nc; ++c) memcpy(&j->h_quant[(size_t)i * 192 + c * 64], P[i].q[P[i].tq[c]], 128);
-        // the staging copy
-        uint8_t *dst = (uint8_t *)j->h_stream.p + off;
-        const size_t nb = jpg::unstuff_scan(data[i], len[i], P[i].scan_off, dst, seg);
+    }
+    // The staging copy (un-stuffing, ~2.4 GB/s per core): every file has its own slot in the pinned buffer (sized from the file length, so
+    // the slots are known before any byte is looked at) and the files are dealt over the host threads.
+    std::vector<size_t> slot_off((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) slot_off[i + 1] = slot_off[i] + (((len[i] - P[i].scan_off + 16 + 15) & ~(size_t)15) + 16);
+    std::vector<std::vector<uint32_t>> segs((size_t)n);
+    std::vector<size_t> nbs((size_t)n, 0);
+    {
+        static const int threads_env = [] { const char *e = getenv("BEVW_JPEG_HOST_THREADS"); return e ? atoi(e) : 0; }();
+        int nt = threads_env > 0 ? threads_env : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        nt = std::max(1, std::min(nt, n / 8));   // a thread per >= 8 files, else not worth starting
+        auto work = [&](int t) {
+            for (int i = t; i < n; i += nt) nbs[i] = jpg::unstuff_scan(data[i], len[i], P[i].scan_off, (uint8_t *)j->h_stream.p + slot_off[i], segs[i]);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+        work(0);
+        for (std::thread &th : pool) th.join();
+    }
+    size_t sub_total = 0;
+    uint32_t max_sub = 0;
+    const size_t off = slot_off[n];
+    for (int i = 0; i < n; ++i) {
+        jpg::ImageDesc &D = j->h_desc[i];
+        const std::vector<uint32_t> &seg = segs[i];
         const uint32_t nseg = (uint32_t)seg.size() - 1;
         const uint32_t nmcu = (uint32_t)G.mcux * (uint32_t)G.mcuy;
         const uint32_t want = P[i].ri ? (nmcu + (uint32_t)P[i].ri - 1) / (uint32_t)P[i].ri : 1u;
         if (nseg != want) return fail(BEVW_E_INVALID, "JPEG %d: %u restart segments in the data, %u expected from DRI", i, nseg, want);
-        D.stream_word = (uint32_t)(off >> 2);
-        D.stream_bytes = (uint32_t)nb;
+        D.stream_word = (uint32_t)(slot_off[i] >> 2);
+        D.stream_bytes = (uint32_t)nbs[i];
         D.seg_first = (uint32_t)j->h_seg_byte.size();
         D.nseg = nseg;
         D.seg_blocks = P[i].ri ? (uint32_t)P[i].ri * (uint32_t)G.bpm : jpg::kNoRestart;
         D.sub_first = (uint32_t)sub_total;
         uint32_t subs = 0;
-        for (uint32_t s = 0; s <= nseg; ++s) {
-            j->h_seg_byte.push_back(seg[s]);
+        for (uint32_t s2 = 0; s2 <= nseg; ++s2) {
+            j->h_seg_byte.push_back(seg[s2]);
             j->h_seg_sub.push_back(subs);
-            if (s < nseg) subs += ((seg[s + 1] - seg[s]) * 8u + (uint32_t)jpg::kSubBits - 1u) / (uint32_t)jpg::kSubBits;
+            if (s2 < nseg) subs += ((seg[s2 + 1] - seg[s2]) * 8u + (uint32_t)jpg::kSubBits - 1u) / (uint32_t)jpg::kSubBits;
         }
         D.nsub = subs;
         sub_total += subs;
         if (subs > max_sub) max_sub = subs;
-        off += (nb + 16 + 15) & ~(size_t)15;
     }
     if (sub_total >= ((size_t)1 << 31)) return fail(BEVW_E_INVALID, "batch too large");
     j->n = n;
