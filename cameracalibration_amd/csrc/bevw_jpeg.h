@@ -125,29 +125,51 @@ __host__ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t z, 
 
 struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
 
+constexpr int kLaneBlock = 72;                  // int16 per lane of k_jpeg_coef's LDS block slots (64 + padding: 16-byte aligned, 8 banks)
+constexpr int kColWords = kSubBits / 32 + 4;   // words a lane can touch while it stays inside its own subsequence (+ look-ahead)
+
+// Where a lane reads the 32-bit words of the entropy-coded data from.  `words` is the image's un-stuffed stream.  With 64 lanes walking 64
+// different 128-byte stretches of it, every word load of a wave touches 64 cache lines, the lines of 32 waves do not fit the L1 and the
+// stream was fetched from memory 14 x (profiles/r03_jpeg/pmc_decode_v3.txt).  k_jpeg_columns therefore lays the kColWords words of every
+// subsequence out as a COLUMN (word w of subsequence j at col[w * stride + j]): lanes of a wave, which advance at about the same pace, then
+// read neighbouring addresses.  Words beyond the column (a lane finishing a long block past its range) come from the stream itself.
+struct WordSource {
+    const uint32_t *words;   // the image's stream (32-bit words)
+    const uint32_t *col;     // this lane's column, or nullptr
+    uint32_t stride;         // subsequences of the image
+    uint32_t word0;          // stream index of the column's first word
+    __host__ __device__ __forceinline__ uint32_t at(uint32_t w) const
+    {
+        const uint32_t d = w - word0;
+        return (col && d < (uint32_t)kColWords) ? col[(size_t)d * stride] : words[w];
+    }
+};
+
 // jdhuff.c decode_mcu_slow over the bits [entry position, end_bit) of one image's entropy-coded data, starting between two symbols
 // in state `entry`.  Returns the state in which the first symbol at or after end_bit is met, the number of blocks completed and
 // the sum of the DC differences per component.  WRITE: the entry state is the true one; `blk` is the index (scan order) of the
 // block in progress, pred the DC predictions; coefficients are written (row-major int16, DC already predicted) until blk_cap.
 template <bool WRITE>
-__host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words, const HuffTab *tabs, const Geom &G, uint64_t entry,
+__host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTab *tabs, const Geom &G, uint64_t entry,
                                              uint32_t end_bit, int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0,
-                                             int32_t pred1, int32_t pred2, uint32_t word_base = 0, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr)
+                                             int32_t pred1, int32_t pred2, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr, bool alive = true)
 {
-    // WRITE: a block belongs to the lane in whose range it STARTS.  The owner assembles it in lbuf (64 int16 of its own, LDS on the device),
-    // keeps decoding past end_bit until the block is complete, and stores it whole -- eight 16-byte stores that cover two full 64-byte
-    // sectors, no read-modify-write of zeroed lines, no zero fill of the coefficient buffer.  The block in progress at a lane's entry
-    // (k != 0) is its predecessor's: it is decoded for the state only.
-    // word_base: `words` starts at that word of the image's stream (k_jpeg_coef keeps its work-group's slice in LDS); nat: the
-    // natural-order table in memory of the caller's choice (LDS there: a global-memory look-up would queue behind the stores)
+    // WRITE: a block belongs to the lane in whose range it STARTS.  The owner assembles it in lbuf (64 int16 of its own, LDS on the device,
+    // zero at entry), keeps decoding past end_bit until the block is complete, and the block is stored whole -- no read-modify-write of
+    // zeroed lines, no zero fill of the coefficient buffer.  The block in progress at a lane's entry (k != 0) is its predecessor's: it is
+    // decoded for the state only.  On the device the STORE is the wave's job: all 64 lanes stay in the loop until the last one is done
+    // (`alive` = false for lanes without a subsequence), and after every symbol the blocks completed in that step are written one after the
+    // other, lane i storing coefficient i -- one 128-byte request per block instead of eight 16-byte ones (the pass was bound by its
+    // 59 M write requests, profiles/r03_jpeg/pmc_decode_v3.txt).  The host build (tests/native/jpeg_emulate.cpp) stores with memcpy.
+    // nat: the natural-order table in memory of the caller's choice (LDS on the device: a global-memory look-up would queue behind the stores)
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
     SubOut R;
     R.cnt = 0; R.dc0 = R.dc1 = R.dc2 = 0;
     // bit window: w0 | w1 = the two (big-endian) words around the read position, `off` = bits of w0 already used; the word after them
     // is always in flight (nraw): a wave meets a refill in nearly every iteration, and waiting for a load where it is issued would cost
     // the whole wave a memory latency per symbol.  One 32-bit window holds a whole symbol (code <= 16 bits + <= 16 extra bits).
-    uint32_t widx = (p >> 5) - word_base, off = p & 31u;
-    uint32_t w0 = __builtin_bswap32(words[widx]), w1 = __builtin_bswap32(words[widx + 1]), nraw = words[widx + 2];
+    uint32_t widx = p >> 5, off = p & 31u;
+    uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
     // position of the block in progress (WRITE)
     int mx = 0, my = 0;
     size_t baddr = 0;
@@ -158,7 +180,20 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
     }
     bool fresh = true;   // baddr must be recomputed
     bool own = k == 0;   // WRITE: the block in progress started inside this lane's range
-    while (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = (int)(threadIdx.x & 63u);
+    int16_t *const wave_lbuf = WRITE ? lbuf - (size_t)lane * kLaneBlock : nullptr;   // lbuf of lane 0 of this wave
+#endif
+    for (;;) {
+        const bool go = alive && (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit);
+        bool flush = false;      // WRITE: this lane completed a block of its own in this step (at flush_addr)
+        size_t flush_addr = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (WRITE ? !__any(go) : !go) break;
+#else
+        if (!go) break;
+#endif
+      if (go) {
         const int c = (int)z < G.nY ? 0 : 1 + (int)z - G.nY;
         if (WRITE && fresh) {
             int bx, by;
@@ -166,14 +201,6 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
             else { bx = mx; by = my; }
             baddr = ((size_t)G.blk_off[c] + (size_t)by * G.wb[c] + bx) * 64;
             fresh = false;
-            if (own) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) reinterpret_cast<uint4 *>(lbuf)[i] = make_uint4(0u, 0u, 0u, 0u);
-#else
-                memset(lbuf, 0, 128);
-#endif
-            }
         }
         const HuffTab &T = tabs[2 * c + (k ? 1 : 0)];
         const uint32_t window = off ? (w0 << off) | (w1 >> (32u - off)) : w0;
@@ -213,10 +240,11 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
         if (k >= 64u) {   // block complete
             if (WRITE && own) {
 #if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) reinterpret_cast<uint4 *>(coef + baddr)[i] = reinterpret_cast<const uint4 *>(lbuf)[i];
+                flush = true;
+                flush_addr = baddr;
 #else
                 memcpy(coef + baddr, lbuf, 128);
+                memset(lbuf, 0, 128);
 #endif
             }
             own = true;
@@ -237,8 +265,23 @@ __host__ __device__ inline SubOut decode_sub(const uint32_t *__restrict__ words,
             w0 = w1;
             w1 = __builtin_bswap32(nraw);
             ++widx;
-            nraw = words[widx + 2];
+            nraw = src.at(widx + 2);
         }
+      }   // if (go)
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (WRITE) {
+            unsigned long long done = __ballot(flush);
+            while (done) {
+                const int srcl = __ffsll((long long)done) - 1;
+                done &= done - 1ull;
+                const uint32_t alo = (uint32_t)__shfl((int)(uint32_t)flush_addr, srcl, 64), ahi = (uint32_t)__shfl((int)(uint32_t)((unsigned long long)flush_addr >> 32), srcl, 64);
+                const size_t a = (size_t)(((unsigned long long)ahi << 32) | alo);
+                int16_t *blk_l = wave_lbuf + (size_t)srcl * kLaneBlock;
+                coef[a + lane] = blk_l[lane];
+                blk_l[lane] = 0;
+            }
+        }
+#endif
     }
     R.exit = pack_state(p, z, k);
     return R;

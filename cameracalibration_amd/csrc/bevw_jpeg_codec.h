@@ -67,16 +67,21 @@ struct SubArrays {
     int4 *base;         // exclusive prefix of `sums` inside the restart segment (x = index of the block in progress, scan order)
     uint32_t *endbit;   // last bit (exclusive) the subsequence owns
     uint32_t *meta;     // restart segment | first-of-segment << 31
+    uint32_t *word0;    // stream index of the first word of the subsequence's column
+    uint32_t *cols;     // the columns: word w of subsequence j of an image at cols[kColWords * sub_first + w * nsub + j]
 };
 
-__global__ __launch_bounds__(256) void k_jpeg_sync0(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
-                                                    const TableSet *__restrict__ tabs, Geom G, const uint32_t *__restrict__ seg_byte,
-                                                    const uint32_t *__restrict__ seg_sub, SubArrays A)
+__device__ __forceinline__ WordSource word_source(const SubArrays &A, const ImageDesc &D, const uint32_t *__restrict__ stream, uint32_t j)
 {
-    __shared__ TableSet T;
+    return WordSource{stream + D.stream_word, A.cols + (size_t)kColWords * D.sub_first + j, D.nsub, A.word0[(size_t)D.sub_first + j]};
+}
+
+// Lays the words of every subsequence out as a column (see WordSource) and records where it starts; also the per-subsequence constants
+// the later kernels need (last bit owned, restart segment, first-of-segment flag, the guessed entry state).
+__global__ __launch_bounds__(256) void k_jpeg_columns(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
+                                                      const uint32_t *__restrict__ seg_byte, const uint32_t *__restrict__ seg_sub, SubArrays A)
+{
     const ImageDesc D = img[blockIdx.y];
-    lds_copy(&T, tabs + D.tables);
-    __syncthreads();
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= D.nsub) return;
     const uint32_t *sb = seg_byte + D.seg_first, *ss = seg_sub + D.seg_first;
@@ -88,14 +93,33 @@ __global__ __launch_bounds__(256) void k_jpeg_sync0(const ImageDesc *__restrict_
     const uint32_t start = sb[lo] * 8u + (j - ss[lo]) * (uint32_t)kSubBits;
     uint32_t end = start + (uint32_t)kSubBits;
     if (end > sb[lo + 1] * 8u) end = sb[lo + 1] * 8u;
-    const uint64_t e = pack_state(start, 0, 0);
-    const SubOut R = decode_sub<false>(stream + D.stream_word, T.t, G, e, end, nullptr, 0, 0, 0, 0, 0);
     const size_t slot = (size_t)D.sub_first + j;
-    A.entry[slot] = e;
-    A.exitst[slot] = R.exit;
-    A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
+    A.entry[slot] = pack_state(start, 0, 0);
     A.endbit[slot] = end;
     A.meta[slot] = lo | (j == ss[lo] ? 0x80000000u : 0u);
+    A.word0[slot] = start >> 5;
+    const uint32_t *src = stream + D.stream_word + (start >> 5);
+    uint32_t *dst = A.cols + (size_t)kColWords * D.sub_first + j;
+    uint32_t v[kColWords];
+#pragma unroll
+    for (int w = 0; w < kColWords; ++w) v[w] = src[w];   // (the stream buffer is padded: the last subsequence of a batch may read past its data)
+#pragma unroll
+    for (int w = 0; w < kColWords; ++w) dst[(size_t)w * D.nsub] = v[w];
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_sync0(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
+                                                    const TableSet *__restrict__ tabs, Geom G, SubArrays A)
+{
+    __shared__ TableSet T;
+    const ImageDesc D = img[blockIdx.y];
+    lds_copy(&T, tabs + D.tables);
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= D.nsub) return;
+    const size_t slot = (size_t)D.sub_first + j;
+    const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, A.entry[slot], A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+    A.exitst[slot] = R.exit;
+    A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
 }
 
 // One synchronisation round over the whole batch at full occupancy: exit states are read from `xin` (the previous round) and written to
@@ -117,7 +141,7 @@ __global__ __launch_bounds__(256) void k_jpeg_sync_round(const ImageDesc *__rest
         const uint64_t in = xin[slot - 1];
         if (in != A.entry[slot]) {
             A.entry[slot] = in;
-            const SubOut R = decode_sub<false>(stream + D.stream_word, T.t, G, in, A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+            const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
             A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
             out = R.exit;
         }
@@ -139,7 +163,6 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     const ImageDesc D = img[blockIdx.x];
     lds_copy(&T, tabs + D.tables);
     __syncthreads();
-    const uint32_t *words = stream + D.stream_word;
     volatile uint64_t *vexit = A.exitst + D.sub_first;
     uint64_t *entry = A.entry + D.sub_first;
     uint32_t rounds = 0;
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
             const uint64_t in = vexit[j - 1];
             if (in == entry[j]) continue;
             entry[j] = in;
-            const SubOut R = decode_sub<false>(words, T.t, G, in, A.endbit[D.sub_first + j], nullptr, 0, 0, 0, 0, 0);
+            const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[D.sub_first + j], nullptr, 0, 0, 0, 0, 0);
             A.sums[D.sub_first + j] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
             if (R.exit != vexit[j]) { vexit[j] = R.exit; changed = 1; }
         }
@@ -195,30 +218,33 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
 }
 
 // The final pass: every subsequence decoded from its true entry state, coefficients written.  A block is assembled in the LDS slot of the
-// lane in whose range it starts (72 int16 per lane: 16-byte aligned, lanes spread over 8 banks) and stored whole; the natural-order table
-// sits in LDS too (a global-memory look-up would queue behind the stores: on gfx9 loads and stores share one in-order counter).
+// lane in whose range it starts (kLaneBlock int16 per lane) and stored by the whole wave, one coefficient per lane (decode_sub); the
+// natural-order table sits in LDS too (a global-memory look-up would queue behind the stores: on gfx9 loads and stores share one
+// in-order counter).
 __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
                                                    const TableSet *__restrict__ tabs, Geom G, SubArrays A, int16_t *__restrict__ coef)
 {
     __shared__ TableSet T;
-    __shared__ __attribute__((aligned(16))) int16_t lbuf[256][72];
+    __shared__ __attribute__((aligned(16))) int16_t lbuf[256][kLaneBlock];
     __shared__ uint8_t nat[64];
     const ImageDesc D = img[blockIdx.y];
     if (blockIdx.x * 256u >= D.nsub) return;
     lds_copy(&T, tabs + D.tables);
     if (threadIdx.x < 64) nat[threadIdx.x] = (uint8_t)natural_of((int)threadIdx.x);
+    for (int i = threadIdx.x; i < 256 * kLaneBlock / 2; i += 256) reinterpret_cast<uint32_t *>(&lbuf[0][0])[i] = 0u;
     __syncthreads();
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
-    if (j >= D.nsub) return;
-    const size_t slot = (size_t)D.sub_first + j;
+    const bool alive = j < D.nsub;   // the other lanes of the last wave have no subsequence but take part in the stores
+    const uint32_t jj = alive ? j : D.nsub - 1u;
+    const size_t slot = (size_t)D.sub_first + jj;
     const int4 b = A.base[slot];
     uint32_t cap = (uint32_t)G.nblk;
     if (D.seg_blocks != kNoRestart) {
         const unsigned long long c2 = (unsigned long long)((A.meta[slot] & 0x7fffffffu) + 1u) * D.seg_blocks;
         if (c2 < cap) cap = (uint32_t)c2;
     }
-    decode_sub<true>(stream + D.stream_word, T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y, b.z,
-                     b.w, 0, nat, lbuf[threadIdx.x]);
+    decode_sub<true>(word_source(A, D, stream, jj), T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
+                     b.z, b.w, nat, lbuf[threadIdx.x], alive);
 }
 
 // jpeg_idct_islow: a wave transforms 8 blocks; lane = (block, column) for the column pass, (block, row) for the row pass, the 8 x 8

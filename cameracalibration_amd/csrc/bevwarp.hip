@@ -1908,7 +1908,7 @@ struct bevw_jpeg {
     std::vector<jpg::TableSet> h_tabs;
     std::vector<uint16_t> h_quant;
     DevBuf d_stream, d_desc, d_seg_byte, d_seg_sub, d_tabs, d_quant;
-    DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_rounds, d_coef, d_planes, d_img;
+    DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_word0, d_cols, d_rounds, d_coef, d_planes, d_img;
     // encode
     jpg::Geom EG{};
     int en = 0, e_quality = -1, e_sampling = -1;
@@ -2064,7 +2064,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     j->n = n;
     j->total_sub = sub_total;
     j->max_sub = max_sub;
-    BEVW_TRY(j->d_stream.reserve(off + 64));
+    BEVW_TRY(j->d_stream.reserve(off + 256));   // k_jpeg_columns copies a fixed kColWords words per subsequence, the last one past its data
     BEVW_TRY(j->d_desc.reserve(j->h_desc.size() * sizeof(jpg::ImageDesc)));
     BEVW_TRY(j->d_seg_byte.reserve(j->h_seg_byte.size() * 4));
     BEVW_TRY(j->d_seg_sub.reserve(j->h_seg_sub.size() * 4));
@@ -2096,11 +2096,13 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     BEVW_TRY(j->d_base.reserve(ns * 16));
     BEVW_TRY(j->d_endbit.reserve(ns * 4));
     BEVW_TRY(j->d_meta.reserve(ns * 4));
+    BEVW_TRY(j->d_word0.reserve(ns * 4));
+    BEVW_TRY(j->d_cols.reserve(ns * 4 * (size_t)jpg::kColWords));
     BEVW_TRY(j->d_rounds.reserve(n * 4));
     BEVW_TRY(j->d_coef.reserve(n * (size_t)G.nblk * 128));
     BEVW_TRY(j->d_planes.reserve(n * (size_t)G.plane_bytes));
     jpg::SubArrays A{j->d_entry.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_sums.as<int4>(), j->d_base.as<int4>(), j->d_endbit.as<uint32_t>(),
-                     j->d_meta.as<uint32_t>()};
+                     j->d_meta.as<uint32_t>(), j->d_word0.as<uint32_t>(), j->d_cols.as<uint32_t>()};
     const jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
     const uint32_t *stream = j->d_stream.as<uint32_t>();
     const jpg::TableSet *tabs = j->d_tabs.as<jpg::TableSet>();
@@ -2123,7 +2125,9 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
         uint8_t *planes = j->d_planes.as<uint8_t>() + first * (size_t)G.plane_bytes;
         if (j->max_sub) {
             const dim3 gs((j->max_sub + 255) / 256, (unsigned)m);
-            jpg::k_jpeg_sync0<<<gs, 256, 0, st>>>(im, stream, tabs, G, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
+            jpg::k_jpeg_columns<<<gs, 256, 0, st>>>(im, stream, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
+            BEVW_TRY(launch_check("k_jpeg_columns"));
+            jpg::k_jpeg_sync0<<<gs, 256, 0, st>>>(im, stream, tabs, G, A);
             BEVW_TRY(launch_check("k_jpeg_sync0"));
             // two full-occupancy rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
             jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit.as<uint64_t>(), j->d_exit2.as<uint64_t>());

@@ -52,6 +52,14 @@ static int do_decode(const char *in, const char *out)
     std::vector<uint32_t> seg_sub(nseg + 1, 0);
     for (int s = 0; s < nseg; ++s) seg_sub[s + 1] = seg_sub[s] + ((seg_byte[s + 1] - seg_byte[s]) * 8 + kSubBits - 1) / kSubBits;
     const int nsub = (int)seg_sub[nseg];
+    // k_jpeg_columns: word w of subsequence j at col[w * nsub + j]
+    std::vector<uint32_t> col((size_t)kColWords * std::max(nsub, 1)), word0(nsub);
+    for (int s = 0; s < nseg; ++s)
+        for (uint32_t j = seg_sub[s]; j < seg_sub[s + 1]; ++j) {
+            word0[j] = (seg_byte[s] * 8 + (j - seg_sub[s]) * kSubBits) >> 5;
+            for (int w = 0; w < kColWords; ++w) col[(size_t)w * nsub + j] = words[word0[j] + w];
+        }
+    auto source = [&](int j) { return WordSource{words, col.data() + j, (uint32_t)nsub, word0[j]}; };
     std::vector<uint64_t> entry(nsub), exitst(nsub);
     std::vector<SubOut> sums(nsub);
     std::vector<uint32_t> endbit(nsub), segof(nsub);
@@ -66,7 +74,7 @@ static int do_decode(const char *in, const char *out)
             endbit[j] = end;
             segof[j] = (uint32_t)s;
             first[j] = j == seg_sub[s];
-            sums[j] = decode_sub<false>(words, T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0);
+            sums[j] = decode_sub<false>(source((int)j), T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0);
             exitst[j] = sums[j].exit;
         }
     // k_jpeg_sync: rounds until no exit state changes (lanes of a round read the exit states of the previous round or newer)
@@ -79,7 +87,7 @@ static int do_decode(const char *in, const char *out)
             const uint64_t in = exitst[j - 1];
             if (in == entry[j]) continue;
             entry[j] = in;
-            sums[j] = decode_sub<false>(words, T.t, G, in, endbit[j], nullptr, 0, 0, 0, 0, 0);
+            sums[j] = decode_sub<false>(source(j), T.t, G, in, endbit[j], nullptr, 0, 0, 0, 0, 0);
             if (sums[j].exit != exitst[j]) { exitst[j] = sums[j].exit; changed = true; }
         }
         if (!changed) break;
@@ -105,9 +113,8 @@ static int do_decode(const char *in, const char *out)
     for (int j = 0; j < nsub; ++j) {
         uint32_t cap = (uint32_t)G.nblk;
         if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
-        int16_t lbuf[64];
-        decode_sub<true>(words, T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2], 0, nat,
-                         lbuf);
+        int16_t lbuf[64] = {0};
+        decode_sub<true>(source(j), T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2], nat, lbuf);
     }
     // k_jpeg_idct: lane = (block, column), then (block, row)
     std::vector<uint8_t> planes((size_t)G.plane_bytes);
