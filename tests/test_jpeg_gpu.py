@@ -86,6 +86,30 @@ def test_decode_larger_batch_many_rounds(codec):
     assert codec.decode_info()["subsequences"] > 10000
 
 
+def test_bench_sized_batch_decodes_into_frame_sets(IC, codec):
+    """BASELINE's batch: 256 frame sets = 1024 camera files of 1280 x 960 in one call, written as the [256][4][960][1280][3] buffer
+    bevw_run_device reads; sampled images against libjpeg-turbo, all of them through a checksum (identical files must give identical frames)."""
+    from cameracalibration_amd import _ffi
+
+    uniq = [JC.pil_encode(JC.image(960, 1280, 2, seed=s), 88, 2) for s in range(6)]
+    files = [uniq[(i * 5 + i // 7) % 6] for i in range(1024)]
+    frame = 960 * 1280 * 3
+    d = _ffi.DeviceBuffer(1024 * frame)
+    codec.decode_stage(files)
+    codec.decode_run_device(d.ptr, frame, 1280 * 3)
+    codec.sync()
+    want = [JC.pil_decode(u) for u in uniq]
+    sums = [int(w.astype(np.uint64).sum()) for w in want]
+    for i0 in range(0, 1024, 64):
+        got = d.download((64, 960, 1280, 3), offset=i0 * frame)
+        for k in range(64):
+            u = ((i0 + k) * 5 + (i0 + k) // 7) % 6
+            assert int(got[k].astype(np.uint64).sum()) == sums[u], i0 + k
+        assert np.array_equal(got[0], want[(i0 * 5 + i0 // 7) % 6]) and np.array_equal(got[63], want[((i0 + 63) * 5 + (i0 + 63) // 7) % 6])
+    d.free()
+    assert codec.decode_info()["images"] == 1024
+
+
 @pytest.mark.parametrize("sub,samp", JC.SUBSAMPLINGS)
 def test_encode_matrix(codec, JO, sub, samp):
     for h, w in JC.SIZES:

@@ -77,6 +77,41 @@ def test_undistort_tool_matches_oracle(oracle, repo_rig, tmp_path):
         U.DEFAULT_K, U.DEFAULT_D, oracle.camera_mat_dst(U.DEFAULT_K, 1280, 1024, 1, 1), (1280, 1024))[0])
 
 
+@pytest.mark.gpu
+def test_undistort_tool_with_jpeg_files_in_and_out(oracle, repo_rig, tmp_path):
+    """Tools/undistort.py:60-77 with its default formats: cv2.imread of .jpg files, cv2.imwrite(.jpg, quality).  The GPU codec reads and
+    writes them; the files must be the ones libjpeg-turbo (Pillow) writes for the oracle's pixels.  A progressive file in the directory is
+    outside the codec's subset and goes through Pillow; a file of another size is skipped."""
+    import io
+
+    from PIL import Image
+
+    from cameracalibration_amd.Tools import undistort as U
+    from tests import _jpeg_common as JC
+
+    K, D, _ = repo_rig.rig["front"]
+    np.save(tmp_path / "K.npy", K)
+    np.save(tmp_path / "D.npy", D)
+    src, dst = tmp_path / "in", tmp_path / "out"
+    src.mkdir(); dst.mkdir()
+    cams = JC.repo_camera_jpegs()
+    for n in ("front", "left"):
+        (src / f"{n}.jpg").write_bytes(cams[n])                       # the reference's own files
+    b = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(repo_rig.image("back")[:, :, ::-1])).save(b, "JPEG", quality=90, progressive=True)
+    (src / "prog.jpg").write_bytes(b.getvalue())
+    (src / "small.jpg").write_bytes(JC.pil_encode(JC.image(64, 80, 2)))
+    n = U.main(["-path_read", str(src) + "/", "-path_save", str(dst) + "/", "-path_k", str(tmp_path / "K.npy"),
+                "-path_d", str(tmp_path / "D.npy"), "-quality", "92"])
+    assert n == 3
+    Kd = oracle.camera_mat_dst(K, 1280, 1024, 1, 1)
+    m1, m2 = oracle.fisheye_init_undistort_rectify_map(K, D, Kd, (1280, 1024))
+    for name, raw in (("front", cams["front"]), ("left", cams["left"]), ("prog", b.getvalue())):
+        want = JC.pil_encode(oracle.remap(JC.pil_decode(raw), m1, m2), 92)
+        assert (dst / f"{name}.jpg").read_bytes() == want, name
+    assert not (dst / "small.jpg").exists()
+
+
 def test_align_time_matches_reference_goldens():
     """tests/golden/time_align.json was produced by the reference's own align_time (make_time_align_goldens.py)."""
     import json
