@@ -378,7 +378,7 @@ class BevGenerator:
 
     # ---- additive: compressed in, compressed out (row f4) ----------------------------------------------------
     def jpeg(self, files, car=None, quality=95):
-        """main.py:74-89 with the pixels resident in HBM: ``files`` is a sequence of frame sets, each the four camera FILES' bytes
+        """main.py:74-84 + surroundBEV.py:340 with the pixels resident in HBM: ``files`` is a sequence of frame sets, each the four camera FILES' bytes
         (front, back, left, right: what main.py hands to cv2.imread); the result is one complete ``.jpg`` file per set -- the bytes
         cv2.imwrite(path, bev(front, back, left, right, car)) would write (libjpeg at quality 95, 4:2:0).  Decode, stitch and
         encode all run on the GPU (imgcodecs.JpegCodec); only compressed bytes cross PCIe."""
@@ -456,18 +456,23 @@ class BevGenerator:
 
 
 def main():
-    """surroundBEV.py:327-345 without the GUI: reads ./data like the reference and writes ./surround.png."""
+    """surroundBEV.py:327-345 without the GUI: reads ./data like the reference and writes ./surround.jpg (:340).  The four camera .jpg files
+    are decoded and the result is encoded on the GPU (imgcodecs: the bytes cv2.imread gives, the file cv2.imwrite writes); car.jpg is a PNG
+    in the reference's data and goes through Pillow."""
     from PIL import Image
 
-    def imread(p):
-        return np.ascontiguousarray(np.asarray(Image.open(p).convert("RGB"))[:, :, ::-1])
+    try:
+        from .. import imgcodecs
+    except ImportError:
+        import importlib
+        imgcodecs = importlib.import_module("cameracalibration_amd.imgcodecs")
 
     base = _data_dir()
-    front, back, left, right = (imread(base + '/{0}/{0}.jpg'.format(n)) for n in CAMERA_NAMES)
-    car = padding(imread(base + '/car.jpg'), BEV_WIDTH, BEV_HEIGHT)
+    front, back, left, right = (imgcodecs.imread(base + '/{0}/{0}.jpg'.format(n)) for n in CAMERA_NAMES)
+    car = padding(np.ascontiguousarray(np.asarray(Image.open(base + '/car.jpg').convert("RGB"))[:, :, ::-1]), BEV_WIDTH, BEV_HEIGHT)
     bev = BevGenerator()
     surround = bev(front, back, left, right, car)
-    Image.fromarray(np.ascontiguousarray(surround[:, :, ::-1])).save('./surround.png')
+    imgcodecs.imwrite('./surround.jpg', surround)
 
 
 if __name__ == '__main__':

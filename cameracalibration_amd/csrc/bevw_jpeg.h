@@ -1,7 +1,7 @@
 // bevw_jpeg.h -- the JPEG wire format either side of the path, gfx950 only.
 //
-// The reference reads its camera frames with cv2.imread (main.py:74-77, Tools/undistort.py:63) and writes the stitched
-// image with cv2.imwrite (SurroundBirdEyeView/surroundBEV.py:340, main.py:88); for ".jpg" both are libjpeg(-turbo) with the
+// The reference reads its camera frames with cv2.imread (main.py:74-77, Tools/undistort.py:65) and writes the stitched
+// image with cv2.imwrite (SurroundBirdEyeView/surroundBEV.py:340, Tools/undistort.py:73); for ".jpg" both are libjpeg(-turbo) with the
 // library's defaults (baseline Huffman, ISLOW DCT, fancy upsampling; quality 95, 4:2:0, Annex-K tables).  This header holds
 // the device side of both directions, bit-exact against that library (oracle/jpegoracle.c, pinned against Pillow's
 // libjpeg-turbo), so that frames can enter and leave HBM compressed:

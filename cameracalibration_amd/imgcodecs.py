@@ -1,7 +1,7 @@
 """JPEG either side of the path on the GPU -- the cv2.imgcodecs calls of the reference.
 
-The reference reads camera frames with ``cv2.imread`` (main.py:74-77, Tools/undistort.py:63, extrinsicCalib.py:185-186) and writes
-its results with ``cv2.imwrite`` (SurroundBirdEyeView/surroundBEV.py:340, main.py:88, Tools/undistort.py:71).  This module keeps
+The reference reads camera frames with ``cv2.imread`` (main.py:74-77, Tools/undistort.py:65, extrinsicCalib.py:203-204) and writes
+its results with ``cv2.imwrite`` (SurroundBirdEyeView/surroundBEV.py:340, Tools/undistort.py:73, extrinsicCalib.py:211).  This module keeps
 those names -- ``imread / imwrite / imdecode / imencode`` -- for JPEG files and adds the batch form the engine is for
 (:class:`JpegCodec`): many files of one geometry decoded straight into the frame-set layout ``BevGenerator.run_device`` reads, and
 device images encoded into complete ``.jpg`` files, without the pixels ever visiting the host.
@@ -195,7 +195,7 @@ def imencode(ext: str, img, params=None, device: int = 0):
 
 
 def imwrite(path: str, img, params=None, device: int = 0) -> bool:
-    """cv2.imwrite(path.jpg, img) (surroundBEV.py:340, main.py:88): libjpeg's file at quality 95, 4:2:0."""
+    """cv2.imwrite(path.jpg, img) (surroundBEV.py:340, Tools/undistort.py:73): libjpeg's file at quality 95, 4:2:0."""
     ext = "." + path.rsplit(".", 1)[-1] if "." in path else ""
     ok, data = imencode(ext, img, params, device)
     with open(path, "wb") as f:

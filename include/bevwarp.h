@@ -264,8 +264,8 @@ int bevw_resize_dsize(int src_w, int src_h, double fx, double fy, int32_t dsize[
 int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h, double fx, double fy, int batch,
                             uint8_t *dst);
 
-/* ---- JPEG either side of the path: cv2.imread (main.py:74-77, Tools/undistort.py:63) and ------- */
-/* ---- cv2.imwrite (surroundBEV.py:340, main.py:88, Tools/undistort.py:71) -------------------------------------------------------- */
+/* ---- JPEG either side of the path: cv2.imread (main.py:74-77, Tools/undistort.py:65) and ------- */
+/* ---- cv2.imwrite (surroundBEV.py:340, Tools/undistort.py:73, extrinsicCalib.py:211) -------------------------------------------------------- */
 /* For ".jpg" both cv2 calls are libjpeg(-turbo) with its defaults; the kernels reproduce that library bit for bit (baseline Huffman,
  * jpeg_idct_islow, fancy upsampling, ycc_rgb_convert; encode: rgb_ycc_convert, h2v2_downsample, jpeg_fdct_islow, Annex-K tables at
  * cv2's quality 95, 4:2:0) -- oracle/jpegoracle.c, pinned against Pillow's libjpeg-turbo.  Entropy decoding runs ON THE GPU

@@ -4,9 +4,9 @@
  * TEST INFRASTRUCTURE ONLY: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's library;
  * the product (cameracalibration_amd/) never does.
  *
- * What it restates.  The reference reads its camera frames with cv2.imread (main.py:74-77; Tools/undistort.py:63;
- * ExtrinsicCalibration/extrinsicCalib.py:185-186) and writes results with cv2.imwrite (SurroundBirdEyeView/surroundBEV.py:340,
- * main.py:88, Tools/undistort.py:71).  For ".jpg" both are thin wrappers around libjpeg(-turbo) with the library's defaults
+ * What it restates.  The reference reads its camera frames with cv2.imread (main.py:74-77; Tools/undistort.py:65;
+ * ExtrinsicCalibration/extrinsicCalib.py:203-204) and writes results with cv2.imwrite (SurroundBirdEyeView/surroundBEV.py:340,
+ * Tools/undistort.py:73, ExtrinsicCalibration/extrinsicCalib.py:211).  For ".jpg" both are thin wrappers around libjpeg(-turbo) with the library's defaults
  * (opencv/modules/imgcodecs/src/grfmt_jpeg.cpp: jpeg_read_header + jpeg_start_decompress with out_color_space BGR;
  * jpeg_set_defaults + jpeg_set_quality(95, TRUE) + jpeg_start_compress).  libjpeg-turbo is a third-party dependency that is
  * absent from /root/reference (it is inside the opencv-python wheel); its published algorithm is restated here, function by
@@ -546,7 +546,7 @@ EXPORT int jo_decode_bgr(const uint8_t *data, size_t len, uint8_t *out, uint8_t 
 }
 
 /* ---------------------------------------------------------------------------------------------------------------------- */
-/* encoder: cv2.imwrite("x.jpg", bgr) = libjpeg defaults at quality 95 (surroundBEV.py:340, main.py:88)                      */
+/* encoder: cv2.imwrite("x.jpg", bgr) = libjpeg defaults at quality 95 (surroundBEV.py:340, Tools/undistort.py:73)                      */
 /* ---------------------------------------------------------------------------------------------------------------------- */
 /* jcparam.c std_luminance_quant_tbl / std_chrominance_quant_tbl (ITU T.81 Annex K.1 / K.2), natural order */
 static const uint8_t kStdQ[2][64] = {

@@ -169,7 +169,7 @@ def test_refusals_are_loud(IC, codec):
 
 
 def test_main_py_with_files_in_and_a_file_out(IC, JO, repo_rig, oracle):
-    """main.py:72-89 end to end on compressed data: four camera FILES in, the stitched .jpg out, against
+    """main.py:72-84 (runBEV) + surroundBEV.py:340 end to end on compressed data: four camera FILES in, the stitched .jpg out, against
     cv2.imwrite(bev(*[cv2.imread(f) ...])) restated by the two oracles."""
     from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
 
