@@ -214,6 +214,12 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
         const uint32_t blk0 = D.seg_blocks == kNoRestart ? 0u : seg * D.seg_blocks;
         A.base[D.sub_first + j] = make_int4((int)(blk0 + (uint32_t)run.x), run.y, run.z, run.w);
         run = add4(run, A.sums[D.sub_first + j]);
+        // a restart segment (or the whole scan) that ends before all of its blocks are there: a truncated or corrupt file.  The image is
+        // flagged (bit 31 of rounds_out); the blocks that are missing keep whatever the coefficient buffer held.
+        if (j + 1 == D.nsub || (A.meta[D.sub_first + j + 1] & 0x80000000u)) {
+            const uint32_t want = D.seg_blocks == kNoRestart ? (uint32_t)G.nblk : min(D.seg_blocks, (uint32_t)G.nblk - blk0);
+            if ((uint32_t)run.x < want) atomicOr(&rounds_out[blockIdx.x], 0x80000000u);
+        }
     }
 }
 

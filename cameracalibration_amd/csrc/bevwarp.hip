@@ -2064,7 +2064,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     j->n = n;
     j->total_sub = sub_total;
     j->max_sub = max_sub;
-    BEVW_TRY(j->d_stream.reserve(off + 256));   // k_jpeg_columns copies a fixed kColWords words per subsequence, the last one past its data
+    BEVW_TRY(j->d_stream.reserve(off + 1024));   // k_jpeg_columns copies a fixed kColWords words per subsequence, and a lane finishing a block of corrupt data can run ~250 bytes past the end
     BEVW_TRY(j->d_desc.reserve(j->h_desc.size() * sizeof(jpg::ImageDesc)));
     BEVW_TRY(j->d_seg_byte.reserve(j->h_seg_byte.size() * 4));
     BEVW_TRY(j->d_seg_sub.reserve(j->h_seg_sub.size() * 4));
@@ -2169,6 +2169,10 @@ int bevw_jpeg_decode(bevw_jpeg *j, const uint8_t *const *data, const size_t *len
     BEVW_TRY(bevw_jpeg_decode_run_device(j, j->d_img.p, image, (size_t)j->G.w * 3));
     HIP_TRY(hipMemcpyAsync(out, j->d_img.p, image * (size_t)n, hipMemcpyDeviceToHost, j->st));
     HIP_TRY(hipStreamSynchronize(j->st));
+    int64_t info[8];
+    BEVW_TRY(bevw_jpeg_decode_info(j, info));
+    if (info[6])
+        return fail(BEVW_E_INVALID, "%lld of the %d files end before their image is complete (truncated / corrupt entropy-coded data)", (long long)info[6], n);
     return BEVW_OK;
 }
 
@@ -2177,17 +2181,20 @@ int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8])
     if (!j || !info) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_info: null argument");
     if (!j->staged) return fail(BEVW_E_INVALID, "nothing staged");
     BEVW_TRY(use_device(j->device));
-    int64_t rounds = 0;
+    int64_t rounds = 0, short_images = 0;
     if (j->decoded && j->max_sub) {
         std::vector<uint32_t> r((size_t)j->n);
         HIP_TRY(hipMemcpyAsync(r.data(), j->d_rounds.p, r.size() * 4, hipMemcpyDeviceToHost, j->st));
         HIP_TRY(hipStreamSynchronize(j->st));
-        for (uint32_t v : r) rounds = v > rounds ? v : rounds;
+        for (uint32_t v : r) {
+            rounds = std::max<int64_t>(rounds, v & 0x7fffffffu);
+            short_images += v >> 31;
+        }
     }
     size_t stream_bytes = 0;
     for (const jpg::ImageDesc &D : j->h_desc) stream_bytes += D.stream_bytes;
     info[0] = j->n; info[1] = j->G.w; info[2] = j->G.h; info[3] = (int64_t)j->total_sub; info[4] = rounds; info[5] = (int64_t)stream_bytes;
-    info[6] = j->G.nblk; info[7] = (int64_t)j->h_tabs.size();
+    info[6] = short_images; info[7] = (int64_t)j->h_tabs.size();
     return BEVW_OK;
 }
 

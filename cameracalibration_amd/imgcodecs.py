@@ -89,6 +89,9 @@ class JpegCodec:
         out = np.empty((n, info["height"], info["width"], 3), np.uint8)
         check(lib().bevw_jpeg_decode_run_device(self.h, self._host_target(out.nbytes), out[0].nbytes, info["width"] * 3))
         check(lib().bevw_jpeg_sync(self.h))
+        short = self.decode_info()["short_images"]
+        if short:
+            raise _ffi.BevwError(f"{short} of the {n} files end before their image is complete (truncated / corrupt entropy-coded data)")
         check(lib().bevw_memcpy_d2h(self.device, ptr(out), self._d_tmp.ptr, out.nbytes))
         return out
 
@@ -103,7 +106,7 @@ class JpegCodec:
         info = (C.c_int64 * 8)()
         check(lib().bevw_jpeg_decode_info(self.h, info))
         return dict(images=info[0], width=info[1], height=info[2], subsequences=info[3], rounds=info[4], entropy_bytes=info[5],
-                    blocks_per_image=info[6], table_sets=info[7])
+                    short_images=info[6], table_sets=info[7])
 
     def planes(self, index: int, nbytes: int) -> np.ndarray:
         out = np.empty(nbytes, np.uint8)

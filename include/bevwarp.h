@@ -281,7 +281,9 @@ int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h
  *                              [batch][4][FH][FW][3] frame sets bevw_run_device reads (files ordered front, back, left, right per set)
  *   bevw_jpeg_decode           both + copy to a dense host array [n][h][w][3]  (= [cv2.imread(f) for f in files])
  *   bevw_jpeg_decode_info      info = images, width, height, subsequences, fixed-point rounds (max over images), entropy-coded bytes,
- *                              blocks per image, distinct Huffman table sets
+ *                              images whose entropy-coded data ended before the image was complete (truncated / corrupt files: their
+ *                              missing blocks are undefined; bevw_jpeg_decode turns a non-zero count into BEVW_E_INVALID), distinct
+ *                              Huffman table sets
  *   bevw_jpeg_get_planes       test hook: the sample planes of image `index` after the inverse DCT (Y, Cb, Cr; whole MCUs)
  *   bevw_jpeg_encode_run_device  enqueue cv2.imwrite x n of device images (BGR rows of row_pitch_bytes, e.g. the padded rows of
  *                              BEVW_PITCH_ALIGNED); sampling 0x22 = 4:2:0 (cv2's default), 0x21 = 4:2:2, 0x11 = 4:4:4

@@ -166,6 +166,19 @@ def test_refusals_are_loud(IC, codec):
         codec.decode([JC.pil_encode(im), JC.pil_encode(JC.image(32, 40, 2))])
     with pytest.raises(BevwError):
         codec.decode([JC.pil_encode(im)[:300]])
+    big = JC.pil_encode(JC.image(200, 300, 1), 95)
+    with pytest.raises(BevwError, match="before their image is complete"):
+        codec.decode([big, big[: len(big) * 2 // 3] + b"\xff\xd9"])     # the scan stops two thirds in: flagged, not silently grey
+    assert np.array_equal(codec.decode([big])[0], JC.pil_decode(big))      # and the context is usable afterwards
+    # garbage instead of entropy-coded data: no hang, no crash, nothing to compare
+    rng = np.random.default_rng(5)
+    head = big[: big.index(b"\xff\xda") + 14]
+    junk = head + bytes(b if b != 255 else 254 for b in rng.integers(0, 256, 20000, dtype=np.uint8).tobytes()) + b"\xff\xd9"
+    try:
+        codec.decode([junk])
+    except BevwError:
+        pass
+    assert np.array_equal(codec.decode([big])[0], JC.pil_decode(big))
 
 
 def test_main_py_with_files_in_and_a_file_out(IC, JO, repo_rig, oracle):
