@@ -86,6 +86,19 @@ def test_decode_larger_batch_many_rounds(codec):
     assert codec.decode_info()["subsequences"] > 10000
 
 
+def test_4k_camera_files(codec):
+    """BASELINE config 5's frames (3840 x 2160) and the reference's largest sample (ExtrinsicCalibration/data/img_src_back.jpg is 2560 x 2048):
+    ~15 k subsequences per image, several per lane in the per-image kernels."""
+    for h, w, q in ((2160, 3840, 90), (2048, 2560, 97)):
+        files = [JC.pil_encode(JC.image(h, w, k), q, 2) for k in (2, 0)]
+        got = codec.decode(files)
+        for i, f in enumerate(files):
+            assert np.array_equal(got[i], JC.pil_decode(f)), (h, w, i)
+        assert codec.decode_info()["subsequences"] > 8000
+    im = JC.image(2160, 3840, 2)
+    assert codec.encode(im[None])[0] == JC.pil_encode(im)
+
+
 def test_bench_sized_batch_decodes_into_frame_sets(IC, codec):
     """BASELINE's batch: 256 frame sets = 1024 camera files of 1280 x 960 in one call, written as the [256][4][960][1280][3] buffer
     bevw_run_device reads; sampled images against libjpeg-turbo, all of them through a checksum (identical files must give identical frames)."""
