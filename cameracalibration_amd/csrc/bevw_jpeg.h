@@ -354,14 +354,15 @@ __host__ __device__ __forceinline__ void fdct_1d(const int32_t in[8], int32_t ou
     out[7] = descale(t4 + z1 + z3, sh); out[5] = descale(t5 + z2 + z4, sh);
     out[3] = descale(t6 + z2 + z3, sh); out[1] = descale(t7 + z1 + z4, sh);
 }
-// jcdctmgr.c quantize: coef / (8 q), rounded half away from zero
-__host__ __device__ __forceinline__ int32_t quantize(int32_t v, int32_t q)
+// jcdctmgr.c quantize: coef / (8 q), rounded half away from zero.  The division is a multiplication by recip = floor(2^32 / (8 q)) + 1
+// and a shift -- exact here: the numerator stays below 2^16 and 8 q below 2^11, so n * (recip * 8q - 2^32) < 2^32 (libjpeg-turbo's SIMD
+// quantiser does the same with 16-bit reciprocals); an integer division costs ~40 instructions per coefficient on this GPU.
+__host__ __device__ __forceinline__ int32_t quantize(int32_t v, int32_t q, uint32_t recip)
 {
-    const int32_t qv = q << 3;
-    int32_t t = v < 0 ? -v : v;
-    t += qv >> 1;
-    t = t >= qv ? t / qv : 0;
-    return v < 0 ? -t : t;
+    const uint32_t qv = (uint32_t)q << 3;
+    const uint32_t t = (uint32_t)(v < 0 ? -v : v) + (qv >> 1);
+    const int32_t r = (int32_t)(((uint64_t)t * recip) >> 32);
+    return v < 0 ? -r : r;
 }
 
 // ---- colour -------------------------------------------------------------------------------------------------------------------
@@ -412,6 +413,7 @@ struct EncHuff { uint16_t code[256]; uint8_t len[256]; };   // jchuff.c jpeg_mak
 struct EncTables {
     EncHuff dc[2], ac[2];     // luma, chroma
     uint16_t q[2][64];        // quantisers, row-major
+    uint32_t recip[2][64];    // floor(2^32 / (8 q)) + 1 (quantize)
 };
 
 __host__ __device__ __forceinline__ int bit_length(int v) { return v ? 32 - __builtin_clz((unsigned)v) : 0; }
@@ -841,6 +843,7 @@ inline void make_enc_tables(int quality, EncTables &T)
         for (int i = 0; i < 64; ++i) {
             long v = ((long)std_quant(t)[i] * scale + 50L) / 100L;
             T.q[t][i] = (uint16_t)(v <= 0 ? 1 : (v > 255 ? 255 : v));
+            T.recip[t][i] = (uint32_t)((((uint64_t)1 << 32) / ((uint32_t)T.q[t][i] << 3)) + 1u);
         }
     int nv;
     for (int t = 0; t < 2; ++t) {

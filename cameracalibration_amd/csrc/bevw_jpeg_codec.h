@@ -410,10 +410,11 @@ __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__rest
         for (int y = 0; y < 8; ++y) in[y] = ws[wave][b * 72 + y * 8 + c];
         fdct_1d(in, out, 1);
         const uint16_t *q = tabs->q[comp ? 1 : 0];
+        const uint32_t *qr = tabs->recip[comp ? 1 : 0];
         int16_t *o = zz + ((size_t)blockIdx.y * G.nblk + g) * 64;
 #pragma unroll
         for (int y = 0; y < 8; ++y) {
-            int32_t v = quantize(out[y], (int32_t)q[y * 8 + c]);
+            int32_t v = quantize(out[y], (int32_t)q[y * 8 + c], qr[y * 8 + c]);
             if (dc_only && (y | c)) v = 0;
             const int k = zigzag_of(y * 8 + c);
             o[k] = (int16_t)v;

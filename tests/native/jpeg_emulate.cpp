@@ -198,7 +198,7 @@ static int do_encode(const char *in, const char *out)
             for (int r = 0; r < 8; ++r) in8[r] = ws[r * 8 + c];
             fdct_1d(in8, o, 1);
             for (int r = 0; r < 8; ++r) {
-                int32_t v = quantize(o[r], T.q[comp ? 1 : 0][r * 8 + c]);
+                int32_t v = quantize(o[r], T.q[comp ? 1 : 0][r * 8 + c], T.recip[comp ? 1 : 0][r * 8 + c]);
                 if (dc_only && (r | c)) v = 0;
                 zz[(size_t)g * 64 + zigzag_of(r * 8 + c)] = (int16_t)v;
             }
