@@ -14,11 +14,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 @pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipcc")), reason="hipcc not available")
 def test_block_compile_on_synthetic_tables(tmp_path):
     exe = str(tmp_path / "block_compile_check")
-    hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
-    cmd = [hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-inline-asm",
-           "-Wno-unused-result", os.path.join(ROOT, "tests", "native", "block_compile_check.cpp"), "-o", exe]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    from tests import _native_build
+
+    _native_build.build(os.path.join(ROOT, "tests", "native", "block_compile_check.cpp"), exe)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "block_compile ok" in r.stdout

@@ -20,10 +20,9 @@ pytest.importorskip("PIL")
 def emu(tmp_path_factory):
     d = tmp_path_factory.mktemp("jpeg_emulate")
     exe = str(d / "jpeg_emulate")
-    hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
-    r = subprocess.run([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-pass-failed", "-o", exe,
-                        os.path.join(ROOT, "tests", "native", "jpeg_emulate.cpp")], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    from tests import _native_build
+
+    _native_build.build(os.path.join(ROOT, "tests", "native", "jpeg_emulate.cpp"), exe)
 
     class Emu:
         def decode(self, raw):

@@ -27,11 +27,9 @@ pytestmark = pytest.mark.skipif(not (os.path.exists(HIPCC) or shutil.which("hipc
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("unit") / "unit_emulate")
-    hipcc = HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
-    cmd = [hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-pass-failed", "-Wno-inline-asm",
-           "-Wno-unused-result", os.path.join(ROOT, "tests", "native", "unit_emulate.cpp"), "-o", out]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    from tests import _native_build
+
+    _native_build.build(os.path.join(ROOT, "tests", "native", "unit_emulate.cpp"), out)
     return out
 
 
