@@ -393,6 +393,20 @@ def main_jpeg(a, d, w, dev):
     d.barrier()
     wall = d.max(time.perf_counter() - t0)
     ev_ms = d.max(codec.timer_between(0, a.steps))
+    if mode == "pipeline":
+        # the host API on the same data, nothing resident: BevGenerator.jpeg(files) = parse + un-stuff + H2D, decode, stitch, encode, D2H of the
+        # files -- what a caller holding file bytes in host memory gets per call (no overlap between consecutive batches)
+        sets = [tuple(files[4 * b:4 * b + 4]) for b in range(batch)]
+        bev.jpeg(sets)
+        t1 = time.perf_counter()
+        reps = max(2, a.steps // 4)
+        for _ in range(reps):
+            out_files = bev.jpeg(sets)
+        host_s = (time.perf_counter() - t1) / reps
+        extra["host_api_frames_per_s"] = round(batch / host_s)
+        extra["host_api_ms_per_batch"] = round(host_s * 1e3, 3)
+        extra["host_api_note"] = ("BevGenerator.jpeg on host byte strings, PCIe and host staging included (%.1f MB of files in, %.1f MB out per batch); "
+                                  "never `value`" % (sum(len(f) for f in files) / 1e6, sum(len(f) for f in out_files) / 1e6))
     info = codec.decode_info() if mode != "encode" else {}
     sizes = codec.files() if mode != "decode" else []
     if mode != "encode":
