@@ -6,8 +6,10 @@
 // the device side of both directions, bit-exact against that library (oracle/jpegoracle.c, pinned against Pillow's
 // libjpeg-turbo), so that frames can enter and leave HBM compressed:
 //
-//   decode   host: marker parsing + byte un-stuffing inside the staging copy (the bytes have to be gathered for the H2D
-//                  transfer anyway; no entropy decoding on the host);
+//   decode   host: marker parsing and a plain copy of the entropy-coded bytes into pinned memory (the gather the H2D transfer needs);
+//            k_jpeg_find_end / k_jpeg_count_raw / k_jpeg_unstuff / k_jpeg_subs : the 0xFF 0x00 stuffing, RSTn markers and fill bytes
+//                  removed on the GPU (chunk counts + prefix), the restart segments located and cut into subsequences;
+//            k_jpeg_columns : the words of every subsequence laid out as a column (lanes of a wave read neighbouring addresses);
 //            k_jpeg_sync0 / k_jpeg_sync : Huffman decoding is sequential by nature.  The entropy-coded segment is cut into
 //                  subsequences of kSubBits bits; every lane decodes one from a GUESSED state (first bit of the
 //                  subsequence, DC of the first block of an MCU), then again from the exit state of its predecessor,
@@ -117,8 +119,12 @@ struct ImageDesc {
     uint32_t tables;        // TableSet index
     uint32_t quant;         // quantiser triple index (3 x 64 uint16, row-major)
     uint32_t seg_blocks;    // blocks per restart segment (kNoRestart without DRI)
-    uint32_t pad[3];
+    uint32_t raw_bytes;     // entropy-coded bytes as they are in the file (0xFF 0x00 stuffing, RSTn markers, the closing marker behind them)
+    uint32_t chunk_first;   // this image's first entry in the per-chunk counters of the un-stuffing kernels
+    uint32_t error;         // set on the device: the restart markers in the data do not match DRI (nsub is then 0)
 };
+// What the host hands over per image: stream_word (slot of the raw bytes = slot of the un-stuffed bytes), raw_bytes, seg_first, nseg (from
+// DRI), sub_first (from an upper bound of nsub), tables, quant, seg_blocks, chunk_first.  stream_bytes, nsub and error are written by the GPU.
 
 // a state of the sequential decoder between two symbols: bit position | block inside the MCU << 32 | zigzag position << 40
 __host__ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t z, uint32_t k) { return (uint64_t)p | ((uint64_t)z << 32) | ((uint64_t)k << 40); }
@@ -751,8 +757,9 @@ inline bool make_hufftab(const RawHuff &r, HuffTab &T)
     return true;
 }
 
-// The staging copy: entropy-coded bytes of d[off ...) with 0xFF 0x00 -> 0xFF, RSTn markers dropped (their positions recorded) and
-// everything from the next marker on left out.  dst needs n - off + 16 bytes; seg_byte receives nseg + 1 byte offsets.
+// Host statement of what the un-stuffing kernels do (tests/native/jpeg_emulate.cpp uses it; the product un-stuffs on the GPU): entropy-coded
+// bytes of d[off ...) with 0xFF 0x00 -> 0xFF, RSTn markers dropped (their positions recorded) and everything from the next marker on left
+// out.  dst needs n - off + 16 bytes; seg_byte receives nseg + 1 byte offsets.
 inline size_t unstuff_scan(const uint8_t *d, size_t n, size_t off, uint8_t *dst, std::vector<uint32_t> &seg_byte)
 {
     seg_byte.clear();

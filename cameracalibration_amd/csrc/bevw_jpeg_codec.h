@@ -59,6 +59,138 @@ __device__ __forceinline__ uint32_t block256_sum(uint32_t v, uint32_t *lds)
     return t;
 }
 
+// ---- un-stuffing ------------------------------------------------------------------------------------------------------------------
+// The host copies the entropy-coded bytes of every file into its slot as they are.  Here: find where the data ends (the first 0xFF that is
+// followed by anything but 0x00 / 0xFF / RSTn), drop the stuffed zeros, the RSTn markers and fill bytes, record where every restart
+// segment starts, cut the segments into subsequences.  Chunks of kRawChunk bytes, 16 bytes per lane; counts per chunk, then a prefix.
+constexpr uint32_t kRawChunk = 4096;
+
+struct RawBytes {   // a lane's 16 bytes with one byte of context either side
+    uint32_t w[4];
+    uint32_t prev, next;
+    __device__ __forceinline__ uint32_t at(int i) const { return i < 0 ? prev : (i > 15 ? next : (w[i >> 2] >> (8 * (i & 3))) & 255u); }
+};
+__device__ __forceinline__ RawBytes raw_load16(const uint8_t *__restrict__ raw, uint32_t pos, uint32_t raw_bytes)
+{
+    RawBytes R;
+    const uint4 v = *reinterpret_cast<const uint4 *>(raw + pos);   // slots are 16-byte aligned and padded
+    R.w[0] = v.x; R.w[1] = v.y; R.w[2] = v.z; R.w[3] = v.w;
+    R.prev = pos ? raw[pos - 1] : 0u;
+    R.next = pos + 16u < raw_bytes ? raw[pos + 16u] : 0xD9u;      // the end of the buffer closes the data like a marker would
+    return R;
+}
+__device__ __forceinline__ bool is_rst(uint32_t b) { return (b & 0xF8u) == 0xD0u; }
+
+__global__ __launch_bounds__(256) void k_jpeg_find_end(const ImageDesc *__restrict__ img, const uint8_t *__restrict__ raw, uint32_t *__restrict__ term)
+{
+    const ImageDesc D = img[blockIdx.y];
+    const uint32_t pos = blockIdx.x * kRawChunk + threadIdx.x * 16u;
+    if (pos >= D.raw_bytes) return;
+    const RawBytes R = raw_load16(raw + (size_t)D.stream_word * 4, pos, D.raw_bytes);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (pos + i >= D.raw_bytes) break;
+        if (R.at(i) == 255u) {
+            const uint32_t nx = pos + i + 1u < D.raw_bytes ? R.at(i + 1) : 0xD9u;
+            if (nx != 0u && nx != 255u && !is_rst(nx)) { atomicMin(&term[blockIdx.y], pos + i); break; }
+        }
+    }
+}
+
+// bit i of keep: byte i of the lane's 16 stays; bit i of rst: a restart marker starts at byte i (the next kept byte opens a segment)
+__device__ __forceinline__ void raw_classify(const RawBytes &R, uint32_t pos, uint32_t end, uint32_t raw_bytes, uint32_t &keep, uint32_t &rst)
+{
+    keep = rst = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (pos + i >= end) break;
+        const uint32_t b = R.at(i), nx = pos + i + 1u < raw_bytes ? R.at(i + 1) : 0xD9u, pv = (pos + i) ? R.at(i - 1) : 0u;   // nx may be the closing marker's 0xFF
+        bool drop = false;
+        if (b == 255u) {
+            if (is_rst(nx)) { drop = true; rst |= 1u << i; }
+            else if (nx == 255u) drop = true;                       // fill byte
+        } else if (pv == 255u && (b == 0u || is_rst(b))) drop = true;   // stuffed zero / second byte of RSTn
+        if (!drop) keep |= 1u << i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_count_raw(const ImageDesc *__restrict__ img, const uint8_t *__restrict__ raw, const uint32_t *__restrict__ term,
+                                                        uint32_t *__restrict__ chunk_keep, uint32_t *__restrict__ chunk_rst)
+{
+    __shared__ uint32_t lds[4];
+    const ImageDesc D = img[blockIdx.y];
+    const uint32_t end = term[blockIdx.y];
+    if (blockIdx.x * kRawChunk >= D.raw_bytes) return;
+    const uint32_t pos = blockIdx.x * kRawChunk + threadIdx.x * 16u;
+    uint32_t keep = 0, rst = 0;
+    if (pos < end) raw_classify(raw_load16(raw + (size_t)D.stream_word * 4, pos, D.raw_bytes), pos, end, D.raw_bytes, keep, rst);
+    const uint32_t nk = block256_sum(__popc(keep), lds), nr = block256_sum(__popc(rst), lds);
+    if (threadIdx.x == 0) { chunk_keep[D.chunk_first + blockIdx.x] = nk; chunk_rst[D.chunk_first + blockIdx.x] = nr; }
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_unstuff(ImageDesc *__restrict__ img, const uint8_t *__restrict__ raw, const uint32_t *__restrict__ term,
+                                                      const uint32_t *__restrict__ chunk_keep, const uint32_t *__restrict__ chunk_rst,
+                                                      uint8_t *__restrict__ stream, uint32_t *__restrict__ seg_byte, uint32_t *__restrict__ nrst_out)
+{
+    __shared__ uint32_t lds[4], lds2[4];
+    const ImageDesc D = img[blockIdx.y];
+    if (blockIdx.x * kRawChunk >= D.raw_bytes) return;
+    const uint32_t end = term[blockIdx.y];
+    uint32_t kb = 0, rb = 0;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) { kb += chunk_keep[D.chunk_first + i]; rb += chunk_rst[D.chunk_first + i]; }
+    kb = block256_sum(kb, lds);
+    rb = block256_sum(rb, lds);
+    const uint32_t pos = blockIdx.x * kRawChunk + threadIdx.x * 16u;
+    uint32_t keep = 0, rst = 0;
+    RawBytes R;
+    R.w[0] = R.w[1] = R.w[2] = R.w[3] = R.prev = R.next = 0;
+    if (pos < end) { R = raw_load16(raw + (size_t)D.stream_word * 4, pos, D.raw_bytes); raw_classify(R, pos, end, D.raw_bytes, keep, rst); }
+    const uint32_t nk = __popc(keep), nr = __popc(rst);
+    const uint32_t ik = wave_incl_scan(nk), ir = wave_incl_scan(nr);
+    if ((threadIdx.x & 63) == 63) { lds[threadIdx.x >> 6] = ik; lds2[threadIdx.x >> 6] = ir; }
+    __syncthreads();
+    uint32_t ok = kb + ik - nk, orr = rb + ir - nr;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) { ok += lds[w]; orr += lds2[w]; }
+    const uint32_t chunk_k = lds[0] + lds[1] + lds[2] + lds[3], chunk_r = lds2[0] + lds2[1] + lds2[2] + lds2[3];
+    uint8_t *S = stream + (size_t)D.stream_word * 4;
+    uint32_t *SB = seg_byte + D.seg_first;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (rst & (1u << i)) {   // the segment that starts behind this marker
+            ++orr;
+            if (orr < D.nseg) SB[orr] = ok;   // more markers than DRI allows: counted, not stored (k_jpeg_subs flags the image)
+        }
+        if (keep & (1u << i)) S[ok++] = (uint8_t)R.at(i);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) SB[0] = 0;
+    if (threadIdx.x == 0 && (blockIdx.x + 1) * kRawChunk >= D.raw_bytes) {   // the last chunk closes the image
+        const uint32_t total = kb + chunk_k, nrst = rb + chunk_r;
+        nrst_out[blockIdx.y] = nrst;
+        img[blockIdx.y].stream_bytes = total;
+        if (nrst + 1u <= D.nseg) SB[nrst + 1u] = total;
+        for (int i = 0; i < 16; ++i) S[total + i] = 0;   // the bit readers look a few bytes past the end
+    }
+}
+
+// One block per image: the restart markers found against DRI, the segments cut into subsequences.
+__global__ __launch_bounds__(256) void k_jpeg_subs(ImageDesc *__restrict__ img, const uint32_t *__restrict__ nrst, const uint32_t *__restrict__ seg_byte,
+                                                   uint32_t *__restrict__ seg_sub)
+{
+    if (threadIdx.x) return;
+    ImageDesc &D = img[blockIdx.x];
+    const uint32_t *SB = seg_byte + D.seg_first;
+    uint32_t *SS = seg_sub + D.seg_first;
+    if (nrst[blockIdx.x] + 1u != D.nseg) { D.error = 1; D.nsub = 0; return; }
+    D.error = 0;
+    uint32_t subs = 0;
+    for (uint32_t s = 0; s < D.nseg; ++s) {
+        SS[s] = subs;
+        subs += ((SB[s + 1] - SB[s]) * 8u + (uint32_t)kSubBits - 1u) / (uint32_t)kSubBits;
+    }
+    SS[D.nseg] = subs;
+    D.nsub = subs;
+}
+
 // ---- decode ----------------------------------------------------------------------------------------------------------------------
 struct SubArrays {
     uint64_t *entry;    // state at the first symbol of the subsequence
@@ -182,7 +314,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
         if (!__syncthreads_or(changed)) break;
         if (rounds > D.nsub + 2u) break;   // cannot happen (induction); never spin
     }
-    if (threadIdx.x == 0) rounds_out[blockIdx.x] = rounds;
+    if (threadIdx.x == 0) rounds_out[blockIdx.x] = rounds | (D.error ? 0x80000000u : 0u);
     // exclusive prefix of (blocks, dc0, dc1, dc2) with a reset at the first subsequence of every restart segment:
     // thread t owns the subsequences [t L, (t + 1) L)
     const uint32_t L = (D.nsub + kSyncThreads - 1) / kSyncThreads;

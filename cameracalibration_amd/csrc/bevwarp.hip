@@ -1904,10 +1904,10 @@ struct bevw_jpeg {
     uint32_t max_sub = 0;
     PinnedBuf h_stream;
     std::vector<jpg::ImageDesc> h_desc;
-    std::vector<uint32_t> h_seg_byte, h_seg_sub;
+    std::vector<uint32_t> h_term;
     std::vector<jpg::TableSet> h_tabs;
     std::vector<uint16_t> h_quant;
-    DevBuf d_stream, d_desc, d_seg_byte, d_seg_sub, d_tabs, d_quant;
+    DevBuf d_raw, d_stream, d_desc, d_seg_byte, d_seg_sub, d_term, d_nrst, d_chunk_keep, d_chunk_rst, d_tabs, d_quant;
     DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_word0, d_cols, d_rounds, d_coef, d_planes, d_img;
     // encode
     jpg::Geom EG{};
@@ -1972,7 +1972,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     HIP_TRY(hipStreamSynchronize(j->st));   // the staging buffers of the previous batch may still be in flight
     j->staged = j->decoded = false;
     std::vector<jpg::Parsed> P((size_t)n);
-    size_t bound = 0;
+    std::vector<size_t> slot_off((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) {
         std::string why;
         if (!data[i]) return fail(BEVW_E_INVALID, "JPEG %d: null pointer", i);
@@ -1981,18 +1981,21 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
         if (i && (P[i].w != P[0].w || P[i].h != P[0].h || P[i].nc != P[0].nc || P[i].hs != P[0].hs || P[i].vs != P[0].vs))
             return fail(BEVW_E_INVALID, "JPEG %d is %dx%d (%d components, luma %dx%d) but the batch is %dx%d (%d, %dx%d): one geometry per batch", i,
                         P[i].w, P[i].h, P[i].nc, P[i].hs, P[i].vs, P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
-        bound += ((len[i] - P[i].scan_off + 16 + 15) & ~(size_t)15) + 16;
+        slot_off[i + 1] = slot_off[i] + (((len[i] - P[i].scan_off + 32 + 15) & ~(size_t)15) + 16);
     }
+    const size_t bound = slot_off[n];
     if (bound >= ((size_t)1 << 32)) return fail(BEVW_E_INVALID, "batch of %zu entropy-coded bytes: split it (4 GiB per batch)", bound);
     j->G = jpg::make_geom(P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
     const jpg::Geom &G = j->G;
     BEVW_TRY(j->h_stream.reserve(bound));
     j->h_desc.assign((size_t)n, jpg::ImageDesc());
-    j->h_seg_byte.clear();
-    j->h_seg_sub.clear();
+    j->h_term.assign((size_t)n, 0);
     j->h_tabs.clear();
     j->h_quant.assign((size_t)n * 192, 0);
     std::vector<std::string> keys;
+    size_t seg_total = 0, sub_total = 0, chunk_total = 0;
+    uint32_t max_sub = 0, max_chunk = 0;
+    const uint32_t nmcu = (uint32_t)G.mcux * (uint32_t)G.mcuy;
     for (int i = 0; i < n; ++i) {
         jpg::ImageDesc &D = j->h_desc[i];
         // tables: identical table sets are shared (cameras of one rig write the same ones)
@@ -2015,67 +2018,75 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
         D.tables = (uint32_t)t;
         D.quant = (uint32_t)i;
         for (int c = 0; c < P[i].nc; ++c) memcpy(&j->h_quant[(size_t)i * 192 + c * 64], P[i].q[P[i].tq[c]], 128);
+        // what the un-stuffing kernels need: the slot, the raw length, the segments DRI promises, room for the subsequences
+        const uint32_t raw = (uint32_t)(len[i] - P[i].scan_off);
+        D.stream_word = (uint32_t)(slot_off[i] >> 2);
+        D.raw_bytes = raw;
+        D.nseg = P[i].ri ? (nmcu + (uint32_t)P[i].ri - 1) / (uint32_t)P[i].ri : 1u;
+        D.seg_blocks = P[i].ri ? (uint32_t)P[i].ri * (uint32_t)G.bpm : jpg::kNoRestart;
+        D.seg_first = (uint32_t)seg_total;
+        D.sub_first = (uint32_t)sub_total;
+        D.chunk_first = (uint32_t)chunk_total;
+        const uint32_t sub_ub = (raw * 8u + (uint32_t)jpg::kSubBits - 1u) / (uint32_t)jpg::kSubBits + D.nseg;   // every segment rounds up once
+        const uint32_t chunks = std::max(1u, (raw + jpg::kRawChunk - 1u) / jpg::kRawChunk);
+        seg_total += D.nseg + 1;
+        sub_total += sub_ub;
+        chunk_total += chunks;
+        max_sub = std::max(max_sub, sub_ub);
+        max_chunk = std::max(max_chunk, chunks);
+        j->h_term[i] = raw;
     }
-    // The staging copy (un-stuffing, ~2.4 GB/s per core): every file has its own slot in the pinned buffer (sized from the file length, so
-    // the slots are known before any byte is looked at) and the files are dealt over the host threads.
-    std::vector<size_t> slot_off((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) slot_off[i + 1] = slot_off[i] + (((len[i] - P[i].scan_off + 16 + 15) & ~(size_t)15) + 16);
-    std::vector<std::vector<uint32_t>> segs((size_t)n);
-    std::vector<size_t> nbs((size_t)n, 0);
+    if (sub_total >= ((size_t)1 << 31)) return fail(BEVW_E_INVALID, "batch too large");
+    // The staging copy is a plain copy of the entropy-coded bytes (dealt over host threads); the GPU removes the stuffing.
     {
         static const int threads_env = [] { const char *e = getenv("BEVW_JPEG_HOST_THREADS"); return e ? atoi(e) : 0; }();
         int nt = threads_env > 0 ? threads_env : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
         nt = std::max(1, std::min(nt, n / 8));   // a thread per >= 8 files, else not worth starting
         auto work = [&](int t) {
-            for (int i = t; i < n; i += nt) nbs[i] = jpg::unstuff_scan(data[i], len[i], P[i].scan_off, (uint8_t *)j->h_stream.p + slot_off[i], segs[i]);
+            for (int i = t; i < n; i += nt) {
+                uint8_t *dst = (uint8_t *)j->h_stream.p + slot_off[i];
+                const size_t raw = len[i] - P[i].scan_off;
+                memcpy(dst, data[i] + P[i].scan_off, raw);
+                memset(dst + raw, 0, slot_off[i + 1] - slot_off[i] - raw);
+            }
         };
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
         work(0);
         for (std::thread &th : pool) th.join();
     }
-    size_t sub_total = 0;
-    uint32_t max_sub = 0;
-    const size_t off = slot_off[n];
-    for (int i = 0; i < n; ++i) {
-        jpg::ImageDesc &D = j->h_desc[i];
-        const std::vector<uint32_t> &seg = segs[i];
-        const uint32_t nseg = (uint32_t)seg.size() - 1;
-        const uint32_t nmcu = (uint32_t)G.mcux * (uint32_t)G.mcuy;
-        const uint32_t want = P[i].ri ? (nmcu + (uint32_t)P[i].ri - 1) / (uint32_t)P[i].ri : 1u;
-        if (nseg != want) return fail(BEVW_E_INVALID, "JPEG %d: %u restart segments in the data, %u expected from DRI", i, nseg, want);
-        D.stream_word = (uint32_t)(slot_off[i] >> 2);
-        D.stream_bytes = (uint32_t)nbs[i];
-        D.seg_first = (uint32_t)j->h_seg_byte.size();
-        D.nseg = nseg;
-        D.seg_blocks = P[i].ri ? (uint32_t)P[i].ri * (uint32_t)G.bpm : jpg::kNoRestart;
-        D.sub_first = (uint32_t)sub_total;
-        uint32_t subs = 0;
-        for (uint32_t s2 = 0; s2 <= nseg; ++s2) {
-            j->h_seg_byte.push_back(seg[s2]);
-            j->h_seg_sub.push_back(subs);
-            if (s2 < nseg) subs += ((seg[s2 + 1] - seg[s2]) * 8u + (uint32_t)jpg::kSubBits - 1u) / (uint32_t)jpg::kSubBits;
-        }
-        D.nsub = subs;
-        sub_total += subs;
-        if (subs > max_sub) max_sub = subs;
-    }
-    if (sub_total >= ((size_t)1 << 31)) return fail(BEVW_E_INVALID, "batch too large");
     j->n = n;
     j->total_sub = sub_total;
     j->max_sub = max_sub;
-    BEVW_TRY(j->d_stream.reserve(off + 1024));   // k_jpeg_columns copies a fixed kColWords words per subsequence, and a lane finishing a block of corrupt data can run ~250 bytes past the end
+    BEVW_TRY(j->d_raw.reserve(bound + 64));
+    BEVW_TRY(j->d_stream.reserve(bound + 1024));   // k_jpeg_columns copies a fixed kColWords words per subsequence, and a lane finishing a block of corrupt data can run ~250 bytes past the end
     BEVW_TRY(j->d_desc.reserve(j->h_desc.size() * sizeof(jpg::ImageDesc)));
-    BEVW_TRY(j->d_seg_byte.reserve(j->h_seg_byte.size() * 4));
-    BEVW_TRY(j->d_seg_sub.reserve(j->h_seg_sub.size() * 4));
+    BEVW_TRY(j->d_seg_byte.reserve(seg_total * 4));
+    BEVW_TRY(j->d_seg_sub.reserve(seg_total * 4));
+    BEVW_TRY(j->d_term.reserve((size_t)n * 4));
+    BEVW_TRY(j->d_nrst.reserve((size_t)n * 4));
+    BEVW_TRY(j->d_chunk_keep.reserve(chunk_total * 4));
+    BEVW_TRY(j->d_chunk_rst.reserve(chunk_total * 4));
     BEVW_TRY(j->d_tabs.reserve(j->h_tabs.size() * sizeof(jpg::TableSet)));
     BEVW_TRY(j->d_quant.reserve(j->h_quant.size() * 2));
-    HIP_TRY(hipMemcpyAsync(j->d_stream.p, j->h_stream.p, off, hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_raw.p, j->h_stream.p, bound, hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size() * sizeof(jpg::ImageDesc), hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemcpyAsync(j->d_seg_byte.p, j->h_seg_byte.data(), j->h_seg_byte.size() * 4, hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemcpyAsync(j->d_seg_sub.p, j->h_seg_sub.data(), j->h_seg_sub.size() * 4, hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemcpyAsync(j->d_term.p, j->h_term.data(), (size_t)n * 4, hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_tabs.p, j->h_tabs.data(), j->h_tabs.size() * sizeof(jpg::TableSet), hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_quant.p, j->h_quant.data(), j->h_quant.size() * 2, hipMemcpyHostToDevice, j->st));
+    // un-stuffing on the device: where the data ends, what stays, where the restart segments start, the subsequences
+    jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
+    const uint8_t *raw = j->d_raw.as<uint8_t>();
+    const dim3 gc(max_chunk, (unsigned)n);
+    jpg::k_jpeg_find_end<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_find_end"));
+    jpg::k_jpeg_count_raw<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_count_raw"));
+    jpg::k_jpeg_unstuff<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>(),
+                                                j->d_stream.as<uint8_t>(), j->d_seg_byte.as<uint32_t>(), j->d_nrst.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_unstuff"));
+    jpg::k_jpeg_subs<<<(unsigned)n, 256, 0, j->st>>>(img, j->d_nrst.as<uint32_t>(), j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_subs"));
     j->staged = true;
     return BEVW_OK;
 }
@@ -2191,9 +2202,12 @@ int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8])
             short_images += v >> 31;
         }
     }
-    size_t stream_bytes = 0;
-    for (const jpg::ImageDesc &D : j->h_desc) stream_bytes += D.stream_bytes;
-    info[0] = j->n; info[1] = j->G.w; info[2] = j->G.h; info[3] = (int64_t)j->total_sub; info[4] = rounds; info[5] = (int64_t)stream_bytes;
+    std::vector<jpg::ImageDesc> desc((size_t)j->n);   // stream_bytes / nsub are written by the un-stuffing kernels
+    HIP_TRY(hipMemcpyAsync(desc.data(), j->d_desc.p, desc.size() * sizeof(jpg::ImageDesc), hipMemcpyDeviceToHost, j->st));
+    HIP_TRY(hipStreamSynchronize(j->st));
+    size_t stream_bytes = 0, subs = 0;
+    for (const jpg::ImageDesc &D : desc) { stream_bytes += D.stream_bytes; subs += D.nsub; if (D.error && !(j->decoded && j->max_sub)) ++short_images; }
+    info[0] = j->n; info[1] = j->G.w; info[2] = j->G.h; info[3] = (int64_t)subs; info[4] = rounds; info[5] = (int64_t)stream_bytes;
     info[6] = short_images; info[7] = (int64_t)j->h_tabs.size();
     return BEVW_OK;
 }

@@ -268,14 +268,15 @@ int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h
 /* ---- cv2.imwrite (surroundBEV.py:340, Tools/undistort.py:73, extrinsicCalib.py:211) -------------------------------------------------------- */
 /* For ".jpg" both cv2 calls are libjpeg(-turbo) with its defaults; the kernels reproduce that library bit for bit (baseline Huffman,
  * jpeg_idct_islow, fancy upsampling, ycc_rgb_convert; encode: rgb_ycc_convert, h2v2_downsample, jpeg_fdct_islow, Annex-K tables at
- * cv2's quality 95, 4:2:0) -- oracle/jpegoracle.c, pinned against Pillow's libjpeg-turbo.  Entropy decoding runs ON THE GPU
- * (self-synchronising parallel Huffman decoding, csrc/bevw_jpeg.h); the host parses markers and removes the 0xFF 0x00 stuffing inside the
- * staging copy of the H2D transfer.  Supported: baseline / extended-sequential Huffman, 8 bit, one interleaved scan, grey (expanded to BGR,
+ * cv2's quality 95, 4:2:0) -- oracle/jpegoracle.c, pinned against Pillow's libjpeg-turbo.  Un-stuffing and entropy decoding run ON THE GPU
+ * (self-synchronising parallel Huffman decoding, csrc/bevw_jpeg.h); the host parses the markers in front of the scan and copies the
+ * entropy-coded bytes as they are into pinned memory for the H2D transfer.  Supported: baseline / extended-sequential Huffman, 8 bit, one interleaved scan, grey (expanded to BGR,
  * as IMREAD_COLOR does) or YCbCr with luma 1x1 / 2x1 / 2x2, restart intervals.  Progressive, arithmetic, CMYK, 12-bit, multi-scan files and
  * EXIF orientations other than 1 are REFUSED (BEVW_E_INVALID, reason in bevw_last_error()): there is no CPU decoder behind this.
  *
  *   bevw_jpeg_probe            header only: info = width, height, components, luma h, luma v, restart interval, EXIF orientation, 0
- *   bevw_jpeg_decode_stage     n files of ONE geometry: parse, un-stuff into pinned memory, enqueue the H2D copies
+ *   bevw_jpeg_decode_stage     n files of ONE geometry: parse the headers, copy the entropy-coded bytes to pinned memory, enqueue the H2D copies and
+ *                              the un-stuffing kernels (what is resident afterwards is the un-stuffed stream, cut into subsequences)
  *   bevw_jpeg_decode_run_device  enqueue the decode of the staged batch; image i is written as BGR rows of row_pitch_bytes at
  *                              d_out + i * image_stride_bytes -- with image_stride = FH*FW*3 the n = 4*batch images ARE the
  *                              [batch][4][FH][FW][3] frame sets bevw_run_device reads (files ordered front, back, left, right per set)
