@@ -351,7 +351,7 @@ def main_jpeg(a, d, w, dev):
         codec.decode_stage(files)
         codec.sync()
         t0 = time.perf_counter()
-        for _ in range(3):   # the host side of a batch: marker parsing + un-stuffing into pinned memory + the H2D copies (compressed bytes only)
+        for _ in range(3):   # the host side of a batch: header parsing + copy into pinned memory + H2D of the compressed bytes + the un-stuffing kernels
             codec.decode_stage(files)
             codec.sync()
         stage_ms = (time.perf_counter() - t0) / 3 * 1e3
@@ -394,7 +394,7 @@ def main_jpeg(a, d, w, dev):
     wall = d.max(time.perf_counter() - t0)
     ev_ms = d.max(codec.timer_between(0, a.steps))
     if mode == "pipeline":
-        # the host API on the same data, nothing resident: BevGenerator.jpeg(files) = parse + un-stuff + H2D, decode, stitch, encode, D2H of the
+        # the host API on the same data, nothing resident: BevGenerator.jpeg(files) = parse + H2D + un-stuff, decode, stitch, encode, D2H of the
         # files -- what a caller holding file bytes in host memory gets per call (no overlap between consecutive batches)
         sets = [tuple(files[4 * b:4 * b + 4]) for b in range(batch)]
         bev.jpeg(sets)
@@ -417,7 +417,7 @@ def main_jpeg(a, d, w, dev):
     if stage_ms is not None:
         extra["host_stage_ms_per_batch"] = round(stage_ms, 3)
         extra["host_stage_files_per_s"] = round(batch * 4 / (stage_ms * 1e-3))
-        extra["host_stage_note"] = ("marker parsing + un-stuffing into pinned memory (host threads) + H2D of the compressed bytes for one batch; "
+        extra["host_stage_note"] = ("header parsing + copy into pinned memory (host threads) + H2D of the compressed bytes + the un-stuffing kernels for one batch; "
                                     "outside the timed region (inputs resident = staged streams); a pipelined caller overlaps it with the kernels")
     cpu = None
     if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline and mode != "pipeline":

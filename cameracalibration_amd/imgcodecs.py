@@ -68,7 +68,8 @@ class JpegCodec:
 
     # ---- decode --------------------------------------------------------------------------------------------------
     def decode_stage(self, files: Sequence[bytes]) -> dict:
-        """Parse + un-stuff + enqueue the upload of `files` (one geometry).  Returns the probe of the first file."""
+        """Parse the headers, copy the entropy-coded bytes to pinned memory, enqueue their upload and the un-stuffing kernels (one geometry per
+        call).  Returns the probe of the first file."""
         files = [bytes(f) for f in files]
         if not files:
             raise Exception("no files")
