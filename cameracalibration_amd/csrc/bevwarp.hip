@@ -2020,6 +2020,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
         for (int c = 0; c < P[i].nc; ++c) memcpy(&j->h_quant[(size_t)i * 192 + c * 64], P[i].q[P[i].tq[c]], 128);
         // what the un-stuffing kernels need: the slot, the raw length, the segments DRI promises, room for the subsequences
         const uint32_t raw = (uint32_t)(len[i] - P[i].scan_off);
+        if (raw < 2) return fail(BEVW_E_INVALID, "JPEG %d: no entropy-coded data behind the scan header", i);
         D.stream_word = (uint32_t)(slot_off[i] >> 2);
         D.raw_bytes = raw;
         D.nseg = P[i].ri ? (nmcu + (uint32_t)P[i].ri - 1) / (uint32_t)P[i].ri : 1u;
@@ -2072,6 +2073,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     HIP_TRY(hipMemcpyAsync(j->d_raw.p, j->h_stream.p, bound, hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size() * sizeof(jpg::ImageDesc), hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_term.p, j->h_term.data(), (size_t)n * 4, hipMemcpyHostToDevice, j->st));
+    HIP_TRY(hipMemsetAsync(j->d_nrst.p, 0xFF, (size_t)n * 4, j->st));   // an image no kernel closes can never pass k_jpeg_subs' check
     HIP_TRY(hipMemcpyAsync(j->d_tabs.p, j->h_tabs.data(), j->h_tabs.size() * sizeof(jpg::TableSet), hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_quant.p, j->h_quant.data(), j->h_quant.size() * 2, hipMemcpyHostToDevice, j->st));
     // un-stuffing on the device: where the data ends, what stays, where the restart segments start, the subsequences

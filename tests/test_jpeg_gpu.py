@@ -194,6 +194,37 @@ def test_refusals_are_loud(IC, codec):
     assert np.array_equal(codec.decode([big])[0], JC.pil_decode(big))
 
 
+def test_corrupted_entropy_data_never_hangs_or_crashes(IC, codec):
+    """Random damage behind the scan header (bytes flipped, stretches zeroed, 0xFF / RSTn injected, tails cut): every call returns -- pixels or a
+    BevwError -- and the context decodes a good file right afterwards."""
+    from cameracalibration_amd._ffi import BevwError
+
+    rng = np.random.default_rng(11)
+    good = [JC.pil_encode(JC.image(240, 320, 2), 90, 2), JC.pil_encode(JC.image(240, 320, 1), 75, 2, restart_marker_blocks=7)]
+    want = [JC.pil_decode(g) for g in good]
+    outcomes = {"decoded": 0, "refused": 0}
+    for trial in range(40):
+        g = bytearray(good[trial % 2])
+        sos = bytes(g).index(b"\xff\xda") + 14
+        kind = trial % 5
+        for _ in range(int(rng.integers(1, 12))):
+            p = int(rng.integers(sos, len(g) - 2))
+            if kind == 0: g[p] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1: g[p:p + int(rng.integers(1, 400))] = bytes(int(rng.integers(1, 400)))
+            elif kind == 2: g[p:p + 2] = bytes([0xFF, int(rng.choice([0xD0, 0xD3, 0xD7, 0x00, 0xFF]))])
+            elif kind == 3: g = g[:p] + bytearray(b"\xff\xd9")
+            else: g[p] = int(rng.integers(0, 256))
+            if kind == 3: break
+        try:
+            out = codec.decode([bytes(g), good[trial % 2]])
+            outcomes["decoded"] += 1
+            assert np.array_equal(out[1], want[trial % 2])          # the undamaged file of the same batch is unaffected
+        except BevwError:
+            outcomes["refused"] += 1
+        assert np.array_equal(codec.decode([good[trial % 2]])[0], want[trial % 2])
+    assert outcomes["decoded"] + outcomes["refused"] == 40
+
+
 def test_main_py_with_files_in_and_a_file_out(IC, JO, repo_rig, oracle):
     """main.py:72-84 (runBEV) + surroundBEV.py:340 end to end on compressed data: four camera FILES in, the stitched .jpg out, against
     cv2.imwrite(bev(*[cv2.imread(f) ...])) restated by the two oracles."""
