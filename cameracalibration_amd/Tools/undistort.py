@@ -134,7 +134,10 @@ def main(argv=None):
                         print("{}: {}x{} is not {}x{}, skipped".format(f, info["width"], info["height"], args.width, args.height))
                         continue
                     gpu.append((f, raw, (info["components"], info["h_samp"], info["v_samp"])))
-                except _ffi.BevwError:
+                except _ffi.BevwError as e:
+                    # not silent: this file is outside the GPU codec's subset and is decoded on the CPU by Pillow (as every file was before
+                    # the codec existed); the remap itself still runs on the GPU
+                    print("{}: decoded by Pillow, not by the GPU codec ({})".format(f, e))
                     ok = False
             if not ok:
                 import io
