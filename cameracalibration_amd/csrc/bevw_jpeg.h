@@ -600,6 +600,43 @@ __host__ __device__ __forceinline__ void enc_block_root(const Geom &G, int g, in
     }
 }
 
+// ---- per-lane bodies of the un-stuffing kernels (k_jpeg_find_end, k_jpeg_count_raw, k_jpeg_unstuff) --------------------------------------
+struct RawBytes {   // a lane's 16 bytes of the file's entropy-coded data with one byte of context either side
+    uint32_t w[4];
+    uint32_t prev, next;
+    __host__ __device__ __forceinline__ uint32_t at(int i) const { return i < 0 ? prev : (i > 15 ? next : (w[i >> 2] >> (8 * (i & 3))) & 255u); }
+};
+__host__ __device__ __forceinline__ bool is_rst(uint32_t b) { return (b & 0xF8u) == 0xD0u; }
+
+// position of the first 0xFF among the lane's bytes that is followed by anything but 0x00 / 0xFF / RSTn (the marker that ends the data), or ~0
+__host__ __device__ __forceinline__ uint32_t raw_first_terminator(const RawBytes &R, uint32_t pos, uint32_t raw_bytes)
+{
+    for (int i = 0; i < 16; ++i) {
+        if (pos + i >= raw_bytes) break;
+        if (R.at(i) == 255u) {
+            const uint32_t nx = pos + i + 1u < raw_bytes ? R.at(i + 1) : 0xD9u;
+            if (nx != 0u && nx != 255u && !is_rst(nx)) return pos + (uint32_t)i;
+        }
+    }
+    return 0xffffffffu;
+}
+
+// bit i of keep: byte i of the lane's 16 stays; bit i of rst: a restart marker starts at byte i (the next kept byte opens a segment)
+__host__ __device__ __forceinline__ void raw_classify(const RawBytes &R, uint32_t pos, uint32_t end, uint32_t raw_bytes, uint32_t &keep, uint32_t &rst)
+{
+    keep = rst = 0;
+    for (int i = 0; i < 16; ++i) {
+        if (pos + i >= end) break;
+        const uint32_t b = R.at(i), nx = pos + i + 1u < raw_bytes ? R.at(i + 1) : 0xD9u, pv = (pos + i) ? R.at(i - 1) : 0u;   // nx may be the closing marker's 0xFF
+        bool drop = false;
+        if (b == 255u) {
+            if (is_rst(nx)) { drop = true; rst |= 1u << i; }
+            else if (nx == 255u) drop = true;                       // fill byte
+        } else if (pv == 255u && (b == 0u || is_rst(b))) drop = true;   // stuffed zero / second byte of RSTn
+        if (!drop) keep |= 1u << i;
+    }
+}
+
 // ---- host side: marker parsing (jdmarker.c) and the staging copy -----------------------------------------------------------
 struct RawHuff { uint8_t bits[17]; uint8_t vals[256]; bool ok; };
 struct Parsed {

@@ -65,11 +65,6 @@ __device__ __forceinline__ uint32_t block256_sum(uint32_t v, uint32_t *lds)
 // segment starts, cut the segments into subsequences.  Chunks of kRawChunk bytes, 16 bytes per lane; counts per chunk, then a prefix.
 constexpr uint32_t kRawChunk = 4096;
 
-struct RawBytes {   // a lane's 16 bytes with one byte of context either side
-    uint32_t w[4];
-    uint32_t prev, next;
-    __device__ __forceinline__ uint32_t at(int i) const { return i < 0 ? prev : (i > 15 ? next : (w[i >> 2] >> (8 * (i & 3))) & 255u); }
-};
 __device__ __forceinline__ RawBytes raw_load16(const uint8_t *__restrict__ raw, uint32_t pos, uint32_t raw_bytes)
 {
     RawBytes R;
@@ -79,39 +74,14 @@ __device__ __forceinline__ RawBytes raw_load16(const uint8_t *__restrict__ raw, 
     R.next = pos + 16u < raw_bytes ? raw[pos + 16u] : 0xD9u;      // the end of the buffer closes the data like a marker would
     return R;
 }
-__device__ __forceinline__ bool is_rst(uint32_t b) { return (b & 0xF8u) == 0xD0u; }
 
 __global__ __launch_bounds__(256) void k_jpeg_find_end(const ImageDesc *__restrict__ img, const uint8_t *__restrict__ raw, uint32_t *__restrict__ term)
 {
     const ImageDesc D = img[blockIdx.y];
     const uint32_t pos = blockIdx.x * kRawChunk + threadIdx.x * 16u;
     if (pos >= D.raw_bytes) return;
-    const RawBytes R = raw_load16(raw + (size_t)D.stream_word * 4, pos, D.raw_bytes);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (pos + i >= D.raw_bytes) break;
-        if (R.at(i) == 255u) {
-            const uint32_t nx = pos + i + 1u < D.raw_bytes ? R.at(i + 1) : 0xD9u;
-            if (nx != 0u && nx != 255u && !is_rst(nx)) { atomicMin(&term[blockIdx.y], pos + i); break; }
-        }
-    }
-}
-
-// bit i of keep: byte i of the lane's 16 stays; bit i of rst: a restart marker starts at byte i (the next kept byte opens a segment)
-__device__ __forceinline__ void raw_classify(const RawBytes &R, uint32_t pos, uint32_t end, uint32_t raw_bytes, uint32_t &keep, uint32_t &rst)
-{
-    keep = rst = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (pos + i >= end) break;
-        const uint32_t b = R.at(i), nx = pos + i + 1u < raw_bytes ? R.at(i + 1) : 0xD9u, pv = (pos + i) ? R.at(i - 1) : 0u;   // nx may be the closing marker's 0xFF
-        bool drop = false;
-        if (b == 255u) {
-            if (is_rst(nx)) { drop = true; rst |= 1u << i; }
-            else if (nx == 255u) drop = true;                       // fill byte
-        } else if (pv == 255u && (b == 0u || is_rst(b))) drop = true;   // stuffed zero / second byte of RSTn
-        if (!drop) keep |= 1u << i;
-    }
+    const uint32_t t = raw_first_terminator(raw_load16(raw + (size_t)D.stream_word * 4, pos, D.raw_bytes), pos, D.raw_bytes);
+    if (t != 0xffffffffu) atomicMin(&term[blockIdx.y], t);
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_count_raw(const ImageDesc *__restrict__ img, const uint8_t *__restrict__ raw, const uint32_t *__restrict__ term,

@@ -7,6 +7,7 @@
 //
 //   jpeg_emulate decode <in.jpg> <out.bin>       out: int32 w h rounds nsub | uint8 bgr[h][w][3]
 //   jpeg_emulate encode <in.bin> <out.jpg>       in : int32 w h quality sampling | uint8 bgr[h][w][3]
+//   jpeg_emulate unstuff <in.bin>                arbitrary bytes taken as entropy-coded data: the lanes' un-stuffing against the sequential one
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -30,6 +31,55 @@ static std::vector<uint8_t> read_file(const char *p)
     return v;
 }
 
+// k_jpeg_find_end / k_jpeg_count_raw / k_jpeg_unstuff: lanes of 16 bytes over the file's entropy-coded bytes as they are, checked against the
+// sequential statement of the same thing (unstuff_scan)
+static bool lane_unstuff(const std::vector<uint8_t> &raw, size_t scan_off, std::vector<uint8_t> &stream, std::vector<uint32_t> &seg_byte)
+{
+    const uint32_t raw_bytes = (uint32_t)(raw.size() - scan_off);
+    std::vector<uint8_t> slot((size_t)raw_bytes + 64, 0);
+    memcpy(slot.data(), raw.data() + scan_off, raw_bytes);
+    auto load16 = [&](uint32_t pos) {
+        RawBytes R;
+        memcpy(R.w, slot.data() + pos, 16);
+        R.prev = pos ? slot[pos - 1] : 0u;
+        R.next = pos + 16u < raw_bytes ? slot[pos + 16u] : 0xD9u;
+        return R;
+    };
+    uint32_t term = raw_bytes;
+    for (uint32_t pos = 0; pos < raw_bytes; pos += 16) term = std::min(term, raw_first_terminator(load16(pos), pos, raw_bytes));
+    stream.assign(raw.size() + 64, 0);
+    seg_byte.assign(1, 0);
+    uint32_t kept = 0;
+    for (uint32_t pos = 0; pos < term; pos += 16) {
+        const RawBytes R = load16(pos);
+        uint32_t keep, rst;
+        raw_classify(R, pos, term, raw_bytes, keep, rst);
+        for (int i = 0; i < 16; ++i) {
+            if (rst & (1u << i)) seg_byte.push_back(kept);
+            if (keep & (1u << i)) stream[kept++] = (uint8_t)R.at(i);
+        }
+    }
+    seg_byte.push_back(kept);
+    std::vector<uint8_t> ref(raw.size() + 64, 0);
+    std::vector<uint32_t> ref_seg;
+    const size_t nb = unstuff_scan(raw.data(), raw.size(), scan_off, ref.data(), ref_seg);
+    if (nb != kept || ref_seg != seg_byte || memcmp(ref.data(), stream.data(), kept) != 0) {
+        fprintf(stderr, "lane un-stuffing differs from the sequential one (%u vs %zu bytes, %zu vs %zu segments)\n", kept, nb, seg_byte.size() - 1, ref_seg.size() - 1);
+        return false;
+    }
+    return true;
+}
+
+static int do_unstuff(const char *in)
+{
+    const std::vector<uint8_t> raw = read_file(in);
+    std::vector<uint8_t> stream;
+    std::vector<uint32_t> seg;
+    if (!lane_unstuff(raw, 0, stream, seg)) return 3;
+    printf("un-stuffed %zu bytes: %zu segments, %u bytes kept\n", raw.size(), seg.size() - 1, seg.back());
+    return 0;
+}
+
 static int do_decode(const char *in, const char *out)
 {
     const std::vector<uint8_t> raw = read_file(in);
@@ -41,10 +91,9 @@ static int do_decode(const char *in, const char *out)
     TableSet T;
     for (int c = 0; c < P.nc; ++c)
         if (!make_hufftab(P.dc[P.td[c]], T.t[2 * c]) || !make_hufftab(P.ac[P.ta[c]], T.t[2 * c + 1])) { fprintf(stderr, "bad huffman table\n"); return 2; }
-    std::vector<uint8_t> stream(raw.size() + 64);
+    std::vector<uint8_t> stream;
     std::vector<uint32_t> seg_byte;
-    const size_t nbytes = unstuff_scan(raw.data(), raw.size(), P.scan_off, stream.data(), seg_byte);
-    (void)nbytes;
+    if (!lane_unstuff(raw, P.scan_off, stream, seg_byte)) return 3;
     const uint32_t *words = (const uint32_t *)stream.data();
     const int nseg = (int)seg_byte.size() - 1;
     const uint32_t seg_blocks = P.ri ? (uint32_t)P.ri * (uint32_t)G.bpm : kNoRestart;
@@ -255,6 +304,7 @@ int main(int argc, char **argv)
 {
     if (argc == 4 && !strcmp(argv[1], "decode")) return do_decode(argv[2], argv[3]);
     if (argc == 4 && !strcmp(argv[1], "encode")) return do_encode(argv[2], argv[3]);
+    if (argc == 3 && !strcmp(argv[1], "unstuff")) return do_unstuff(argv[2]);
     fprintf(stderr, "usage: jpeg_emulate decode in.jpg out.bin | encode in.bin out.jpg\n");
     return 1;
 }

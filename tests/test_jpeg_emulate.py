@@ -34,6 +34,13 @@ def emu(tmp_path_factory):
             w, h, rounds, nsub = np.frombuffer(buf[:16], np.int32)
             return np.frombuffer(buf[16:], np.uint8).reshape(h, w, 3), int(rounds), int(nsub)
 
+        def unstuff(self, data: bytes):
+            a = str(d / "raw.bin")
+            open(a, "wb").write(data)
+            r = subprocess.run([exe, "unstuff", a], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stdout + r.stderr
+            return r.stdout
+
         def encode(self, im, q=95, samp=0x22):
             a, b = str(d / "in.bin"), str(d / "out.jpg")
             h, w = im.shape[:2]
@@ -80,6 +87,21 @@ def test_emulated_private_huffman_tables_and_long_codes(emu):
         assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f)), (k, q)
     f = JC.pil_encode(JC.image(96, 160, 1), 100, 0)
     assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f))
+
+
+def test_emulated_unstuffing_on_byte_soup(emu):
+    # the un-stuffing kernels' lane code against the sequential statement on bytes rich in 0xFF, stuffed zeros, RSTn, fill bytes and early
+    # terminators -- more than any encoder would write, and placed on every position relative to the 16-byte lanes
+    rng = np.random.default_rng(3)
+    alphabet = np.array([0xFF] * 6 + [0x00] * 4 + [0xD0, 0xD3, 0xD7, 0xD9, 0xC4, 0x01, 0x7F, 0x80], np.uint8)
+    for trial in range(60):
+        n = int(rng.integers(1, 400))
+        soup = alphabet[rng.integers(0, len(alphabet), n)] if trial % 2 else rng.integers(0, 256, n, dtype=np.uint8)
+        emu.unstuff(bytes(soup))
+    # a stream as an encoder writes it: no terminator inside, a marker at the very end
+    body = bytes(b for x in rng.integers(0, 256, 5000, dtype=np.uint8) for b in ((255, 0) if x == 255 else (int(x),)))
+    assert "1 segments" in emu.unstuff(body + b"\xff\xd9")
+    assert "3 segments" in emu.unstuff(body[:1000] + b"\xff\xd0" + body[1000:3001] + b"\xff\xff\xd1" + body[3001:] + b"\xff\xd9")
 
 
 def test_emulated_bev_sized_file(emu):
