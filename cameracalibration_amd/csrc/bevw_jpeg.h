@@ -192,9 +192,9 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
 #endif
     for (;;) {
         const bool go = alive && (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit);
+#if defined(__HIP_DEVICE_COMPILE__)
         bool flush = false;      // WRITE: this lane completed a block of its own in this step (at flush_addr)
         size_t flush_addr = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
         if (WRITE ? !__any(go) : !go) break;
 #else
         if (!go) break;
