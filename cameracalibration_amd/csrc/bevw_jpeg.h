@@ -100,10 +100,9 @@ inline Geom make_geom(int w, int h, int nc, int hs, int vs)
 
 // ---- decoding tables ----------------------------------------------------------------------------------------------------
 struct HuffTab {          // jdhuff.c jpeg_make_d_derived_tbl, 9-bit look-ahead
-    uint16_t fast[512];   // len << 8 | symbol for codes of <= 9 bits, 0 otherwise
-    uint32_t ub[8];       // ub[l - 9], l = 9 .. 16: the first 16-bit window (left-justified) that is NOT a code of length <= l
+    uint16_t fast[256];   // len << 8 | symbol for codes of <= 8 bits, 0 otherwise
+    uint32_t ub[10];      // ub[l - 8], l = 8 .. 16: the first 16-bit window (left-justified) that is NOT a code of length <= l (+ 1 pad)
     int32_t valoff[18];   // index of the first symbol of length l minus its first code
-    uint32_t pad[2];
     uint8_t vals[256];
 };
 static_assert(sizeof(HuffTab) % 16 == 0, "HuffTab is copied to LDS in 16-byte pieces");
@@ -131,7 +130,7 @@ __host__ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t z, 
 
 struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
 
-constexpr int kLaneBlock = 72;                  // int16 per lane of k_jpeg_coef's LDS block slots (64 + padding: 16-byte aligned, 8 banks)
+constexpr int kLaneBlock = 64;                  // int16 per lane of k_jpeg_coef's LDS block slots (64 + padding: 16-byte aligned, 8 banks)
 constexpr int kColWords = kSubBits / 32 + 4;   // words a lane can touch while it stays inside its own subsequence (+ look-ahead)
 
 // Where a lane reads the 32-bit words of the entropy-coded data from.  `words` is the image's un-stuffed stream.  With 64 lanes walking 64
@@ -212,16 +211,16 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
         const uint32_t window = off ? (w0 << off) | (w1 >> (32u - off)) : w0;
         const uint32_t peek = window >> 16;
         uint32_t len, sym;
-        const uint32_t e = T.fast[peek >> 7];
+        const uint32_t e = T.fast[peek >> 8];
         if (e) {
             len = e >> 8;
             sym = e & 255u;
         } else {
             // a code of 10 .. 16 bits: its length is 10 + the number of limits the window has reached (no loop: with 64 lanes some lane
             // is here in most iterations, and every lane of the wave pays for the longest path)
-            len = 10u + (peek >= T.ub[1]) + (peek >= T.ub[2]) + (peek >= T.ub[3]) + (peek >= T.ub[4]) + (peek >= T.ub[5]) + (peek >= T.ub[6]);
+            len = 9u + (peek >= T.ub[1]) + (peek >= T.ub[2]) + (peek >= T.ub[3]) + (peek >= T.ub[4]) + (peek >= T.ub[5]) + (peek >= T.ub[6]) + (peek >= T.ub[7]);
             sym = T.vals[((peek >> (16u - len)) + (uint32_t)T.valoff[len]) & 255u];
-            if (peek >= T.ub[7]) { len = 16; sym = 0; }   // not a code at all (corrupt data): libjpeg warns and yields 0
+            if (peek >= T.ub[8]) { len = 16; sym = 0; }   // not a code at all (corrupt data): libjpeg warns and yields 0
         }
         // the extra bits: a DC symbol IS their count, an AC symbol is run << 4 | count
         const uint32_t s = k == 0 ? (sym > 16u ? 16u : sym) : (sym & 15u);
@@ -779,15 +778,15 @@ inline bool make_hufftab(const RawHuff &r, HuffTab &T)
     for (int l = 1; l <= 16; ++l) {
         T.valoff[l] = p - code;
         for (int i = 0; i < r.bits[l]; ++i) {
-            if (l <= 9) {
-                const int c0 = (code + i) << (9 - l);
-                for (int f = 0; f < (1 << (9 - l)); ++f) T.fast[c0 + f] = (uint16_t)((l << 8) | r.vals[p + i]);
+            if (l <= 8) {
+                const int c0 = (code + i) << (8 - l);
+                for (int f = 0; f < (1 << (8 - l)); ++f) T.fast[c0 + f] = (uint16_t)((l << 8) | r.vals[p + i]);
             }
         }
         p += r.bits[l];
         code += r.bits[l];
         if (code > (1 << l)) return false;
-        if (l >= 9) T.ub[l - 9] = (uint32_t)code << (16 - l);   // canonical codes: windows below this are codes of length <= l
+        if (l >= 8) T.ub[l - 8] = (uint32_t)code << (16 - l);   // canonical codes: windows below this are codes of length <= l
         code <<= 1;
     }
     memcpy(T.vals, r.vals, 256);
