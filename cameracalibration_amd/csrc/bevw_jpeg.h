@@ -99,7 +99,7 @@ inline Geom make_geom(int w, int h, int nc, int hs, int vs)
 }
 
 // ---- decoding tables ----------------------------------------------------------------------------------------------------
-struct HuffTab {          // jdhuff.c jpeg_make_d_derived_tbl, 9-bit look-ahead
+struct HuffTab {          // jdhuff.c jpeg_make_d_derived_tbl, 8-bit look-ahead (libjpeg's own HUFF_LOOKAHEAD)
     uint16_t fast[256];   // len << 8 | symbol for codes of <= 8 bits, 0 otherwise
     uint32_t ub[10];      // ub[l - 8], l = 8 .. 16: the first 16-bit window (left-justified) that is NOT a code of length <= l (+ 1 pad)
     int32_t valoff[18];   // index of the first symbol of length l minus its first code
@@ -130,7 +130,7 @@ __host__ __device__ __forceinline__ uint64_t pack_state(uint32_t p, uint32_t z, 
 
 struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
 
-constexpr int kLaneBlock = 64;                  // int16 per lane of k_jpeg_coef's LDS block slots (64 + padding: 16-byte aligned, 8 banks)
+constexpr int kLaneBlock = 64;                  // int16 per lane of k_jpeg_coef's LDS block slots: with the 8-bit look-ahead tables four work-groups fit a CU
 constexpr int kColWords = kSubBits / 32 + 4;   // words a lane can touch while it stays inside its own subsequence (+ look-ahead)
 
 // Where a lane reads the 32-bit words of the entropy-coded data from.  `words` is the image's un-stuffed stream.  With 64 lanes walking 64
