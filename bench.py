@@ -86,6 +86,9 @@ def parse_args():
                          "(1080 -> 1088 pixels, cv::cuda::GpuMat style), dense = the reference's host layout; the other layout is measured "
                          "too and reported beside the headline")
     ap.add_argument("--single-layout", action="store_true", help="skip the measurement of the other device-image layout (profiling runs)")
+    ap.add_argument("--jpeg-source", default="synthetic", choices=["synthetic", "repo"],
+                    help="jpeg_decode_b64 only: 'repo' decodes the reference's own four camera files (tests/golden/repo_rig.npz, 1280x1024, real scenes with "
+                         "flat areas -- long mis-phased stretches for the parallel Huffman decoder) replicated over the batch, instead of synthetic files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -339,13 +342,21 @@ def main_jpeg(a, d, w, dev):
     mode = w["mode"]
     codec = imgcodecs.JpegCodec(dev)
     uniq_files = camera_like_jpegs(8, fw, fh, seed=W.SEED + d.rank)
+    if a.jpeg_source == "repo":
+        if mode != "decode":
+            raise SystemExit("--jpeg-source repo is for jpeg_decode_b64")
+        z = np.load(os.path.join(ROOT, "tests", "golden", "repo_rig.npz"))
+        uniq_files = [z[f"{n}_img"].tobytes() for n in W.CAMERA_NAMES]
+        probe = imgcodecs.probe(uniq_files[0])
+        fw, fh = probe["width"], probe["height"]
     files = [uniq_files[i % len(uniq_files)] for i in range(batch * 4)]
     uniq_bev = W.synthetic_frames(1, bw, bh, seed=W.SEED + 17 + d.rank)[0]          # four BEV-sized camera-like images
     bev_images = np.stack([uniq_bev[i % 4] for i in range(batch)])
     d_frames = _ffi.DeviceBuffer(batch * 4 * fh * fw * 3, dev)
     d_bev = _ffi.DeviceBuffer(batch * bh * bw * 3, dev)
-    extra = {"frame": [fw, fh], "bev": [bw, bh], "jpeg_in": "baseline 4:2:0 quality 90, %d bytes per file (synthetic camera-like frames)" % (
-        sum(len(f) for f in uniq_files) // len(uniq_files)), "jpeg_out": "baseline 4:2:0 quality 95 (cv2.imwrite's defaults)"}
+    extra = {"frame": [fw, fh], "bev": [bw, bh], "jpeg_in": ("baseline 4:2:0, %d bytes per file (%s)" % (
+        sum(len(f) for f in uniq_files) // len(uniq_files), "the reference's own camera files, %dx%d" % (fw, fh) if a.jpeg_source == "repo"
+        else "synthetic camera-like frames, quality 90")), "jpeg_out": "baseline 4:2:0 quality 95 (cv2.imwrite's defaults)"}
     stage_ms = None
     if mode in ("decode", "pipeline"):
         codec.decode_stage(files)

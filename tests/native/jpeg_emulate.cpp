@@ -300,11 +300,77 @@ static int do_encode(const char *in, const char *out)
     return 0;
 }
 
+
+// jpeg_emulate stats <in.jpg>: how the synchronisation converges for a few guessing strategies (offline study, not a test)
+static int do_stats(const char *in)
+{
+    const std::vector<uint8_t> raw = read_file(in);
+    Parsed P;
+    std::string why;
+    if (parse_header(raw.data(), raw.size(), P, why)) return 2;
+    const Geom G = make_geom(P.w, P.h, P.nc, P.hs, P.vs);
+    TableSet T;
+    for (int c = 0; c < P.nc; ++c) { make_hufftab(P.dc[P.td[c]], T.t[2 * c]); make_hufftab(P.ac[P.ta[c]], T.t[2 * c + 1]); }
+    std::vector<uint8_t> stream;
+    std::vector<uint32_t> seg_byte;
+    if (!lane_unstuff(raw, P.scan_off, stream, seg_byte)) return 3;
+    const uint32_t *words = (const uint32_t *)stream.data();
+    const uint32_t total_bits = seg_byte.back() * 8;
+    const int nsub = (int)((total_bits + kSubBits - 1) / kSubBits);   // (files without restart markers)
+    const WordSource src{words, nullptr, 0, 0};
+    // the true states at every subsequence start: one sequential walk
+    std::vector<uint64_t> truth(nsub + 1);
+    {
+        uint64_t st = pack_state(0, 0, 0);
+        for (int j = 0; j < nsub; ++j) {
+            truth[j] = st;
+            const uint32_t end = std::min<uint32_t>((uint32_t)(j + 1) * kSubBits, total_bits);
+            st = decode_sub<false>(src, T.t, G, st, end, nullptr, 0, 0, 0, 0, 0).exit;
+        }
+        truth[nsub] = st;
+    }
+    for (int warm : {0, 128, 256, 512, 1024}) {
+        std::vector<uint64_t> entry(nsub), exitst(nsub);
+        for (int j = 0; j < nsub; ++j) {
+            const uint32_t start = (uint32_t)j * kSubBits, end = std::min<uint32_t>(start + kSubBits, total_bits);
+            uint64_t e = pack_state(start, 0, 0);
+            if (j > 0 && warm) {
+                const uint32_t w0 = start > (uint32_t)warm ? start - (uint32_t)warm : 0;
+                e = decode_sub<false>(src, T.t, G, pack_state(w0, 0, 0), start, nullptr, 0, 0, 0, 0, 0).exit;
+            }
+            entry[j] = j == 0 ? truth[0] : e;
+            exitst[j] = decode_sub<false>(src, T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0).exit;
+        }
+        int right_entry = 0, right_exit = 0;
+        for (int j = 0; j < nsub; ++j) { right_entry += entry[j] == truth[j]; right_exit += exitst[j] == truth[j + 1]; }
+        printf("warm-up %4d bits: after the first pass %5.1f %% of the entry guesses and %5.1f %% of the exit states are the true ones; re-decodes per round:", warm,
+               100.0 * right_entry / nsub, 100.0 * right_exit / nsub);
+        int rounds = 0;
+        for (;;) {
+            std::vector<uint64_t> prev = exitst;
+            int redo = 0;
+            for (int j = 1; j < nsub; ++j) {
+                if (prev[j - 1] == entry[j]) continue;
+                entry[j] = prev[j - 1];
+                const uint32_t end = std::min<uint32_t>((uint32_t)(j + 1) * kSubBits, total_bits);
+                exitst[j] = decode_sub<false>(src, T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0).exit;
+                ++redo;
+            }
+            if (!redo) break;
+            ++rounds;
+            printf(" %d", redo);
+        }
+        printf("  (%d rounds, %d subsequences)\n", rounds, nsub);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 4 && !strcmp(argv[1], "decode")) return do_decode(argv[2], argv[3]);
     if (argc == 4 && !strcmp(argv[1], "encode")) return do_encode(argv[2], argv[3]);
     if (argc == 3 && !strcmp(argv[1], "unstuff")) return do_unstuff(argv[2]);
+    if (argc == 3 && !strcmp(argv[1], "stats")) return do_stats(argv[2]);
     fprintf(stderr, "usage: jpeg_emulate decode in.jpg out.bin | encode in.bin out.jpg\n");
     return 1;
 }
