@@ -359,6 +359,12 @@ static int do_stats(const char *in)
             if (!redo) break;
             ++rounds;
             printf(" %d", redo);
+            if (warm == 0 && redo <= 2 && getenv("BEVW_STATS_VERBOSE"))
+                for (int j = 1; j < nsub; ++j)
+                    if (exitst[j] != prev[j])
+                        printf("\n    round %d sub %d: exit was p=%u z=%u k=%u, is p=%u z=%u k=%u (truth p=%u z=%u k=%u)", rounds, j, (uint32_t)prev[j], (uint32_t)(prev[j] >> 32) & 255u,
+                               (uint32_t)(prev[j] >> 40) & 255u, (uint32_t)exitst[j], (uint32_t)(exitst[j] >> 32) & 255u, (uint32_t)(exitst[j] >> 40) & 255u, (uint32_t)truth[j + 1],
+                               (uint32_t)(truth[j + 1] >> 32) & 255u, (uint32_t)(truth[j + 1] >> 40) & 255u);
         }
         printf("  (%d rounds, %d subsequences)\n", rounds, nsub);
     }
