@@ -368,6 +368,49 @@ static int do_stats(const char *in)
         }
         printf("  (%d rounds, %d subsequences)\n", rounds, nsub);
     }
+    // the lever DESIGN.md section 9 names: from round 3 on, a lane that has to walk again also walks the `window` subsequences behind it under all
+    // bpm block phases (same bit / zigzag position as their current entry), and the chain is resolved through those tables as far as the
+    // positions agree -- rounds and walks this would take
+    for (int window : {0, 4, 8, 16}) {
+        std::vector<uint64_t> entry(nsub), exitst(nsub);
+        for (int j = 0; j < nsub; ++j) {
+            const uint32_t start = (uint32_t)j * kSubBits, end = std::min<uint32_t>(start + kSubBits, total_bits);
+            entry[j] = j == 0 ? truth[0] : pack_state(start, 0, 0);
+            exitst[j] = decode_sub<false>(src, T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0).exit;
+        }
+        int rounds = 0;
+        long walks = nsub, ahead = 0, broke = 0;
+        auto pk = [](uint64_t st) { return st & ~((uint64_t)255 << 32); };   // the state without the block index
+        for (;;) {
+            std::vector<uint64_t> prev = exitst;
+            int redo = 0;
+            for (int j = 1; j < nsub; ++j) {
+                if (prev[j - 1] == entry[j]) continue;
+                ++redo;
+                entry[j] = prev[j - 1];
+                const uint32_t end = std::min<uint32_t>((uint32_t)(j + 1) * kSubBits, total_bits);
+                exitst[j] = decode_sub<false>(src, T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0).exit;
+                ++walks;
+                if (window && rounds >= 2) {   // resolve ahead through all-phase tables
+                    uint64_t carry = exitst[j];
+                    for (int t = j + 1; t < std::min(nsub, j + 1 + window); ++t) {
+                        if (pk(carry) != pk(entry[t])) { ++broke; break; }   // the position changed too: that link needs a real round
+                        walks += G.bpm;                          // the table of subsequence t: one walk per phase
+                        if (carry == entry[t]) break;            // the chain ends here
+                        entry[t] = carry;
+                        const uint32_t e2 = std::min<uint32_t>((uint32_t)(t + 1) * kSubBits, total_bits);
+                        exitst[t] = decode_sub<false>(src, T.t, G, carry, e2, nullptr, 0, 0, 0, 0, 0).exit;
+                        prev[t] = exitst[t];                     // later lanes of this round see the resolved state
+                        carry = exitst[t];
+                        ++ahead;
+                    }
+                }
+            }
+            if (!redo) break;
+            ++rounds;
+        }
+        printf("all-phase tables over %2d subsequences ahead (from round 3): %d rounds, %ld walks, %ld links resolved ahead, %ld chains stopped by a position change (%d subsequences)\n", window, rounds, walks, ahead, broke, nsub);
+    }
     return 0;
 }
 
