@@ -62,6 +62,38 @@ def test_grayscale_and_restart_intervals():
         assert np.array_equal(JO.imdecode(f), JC.pil_decode(f)), kw
 
 
+def test_seeded_random_cases_against_libjpeg_turbo():
+    """300 random (size, content, quality, sampling, restart interval, private tables) cases: decode == Pillow's decode, encode == Pillow's file."""
+    import io
+
+    from PIL import Image
+
+    rng = np.random.default_rng(2024)
+    done = 0
+    for case in range(300):
+        h, w = int(rng.integers(1, 260)), int(rng.integers(1, 260))
+        sub, samp = JC.SUBSAMPLINGS[int(rng.integers(0, 3))]
+        q = int(rng.choice([3, 25, 50, 75, 90, 95, 100]))
+        kind = int(rng.integers(0, 4))
+        im = np.full((h, w, 3), rng.integers(0, 256, 3), np.uint8) if kind == 3 else JC.image(h, w, kind, seed=case)
+        kw = {}
+        if rng.random() < 0.3:
+            kw["restart_marker_blocks"] = int(rng.integers(1, 30))
+        if rng.random() < 0.3:
+            kw["optimize"] = True
+        b = io.BytesIO()
+        try:
+            Image.fromarray(np.ascontiguousarray(im[:, :, ::-1])).save(b, "JPEG", quality=q, subsampling=sub, **kw)
+        except OSError:
+            continue   # Pillow's own output buffer is too small for some tiny images with extra markers
+        f = b.getvalue()
+        assert np.array_equal(JO.imdecode(f), JC.pil_decode(f)), (case, h, w, q, sub, kw)
+        if not kw:
+            assert JO.imencode(im, q, samp) == f, (case, h, w, q, sub)
+        done += 1
+    assert done > 250
+
+
 def test_out_of_scope_files_are_refused():
     from PIL import Image
     import io
