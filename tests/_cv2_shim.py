@@ -23,6 +23,7 @@ FONT_HERSHEY_PLAIN = 1
 TERM_CRITERIA_EPS, TERM_CRITERIA_MAX_ITER = 2, 1
 CALIB_CB_ADAPTIVE_THRESH, CALIB_CB_FAST_CHECK, CALIB_CB_NORMALIZE_IMAGE = 1, 8, 2
 CALIB_FIX_K3 = 128
+IMREAD_COLOR, IMWRITE_JPEG_QUALITY = 1, 1
 
 
 class _Any(types.SimpleNamespace):
@@ -130,6 +131,25 @@ def copyMakeBorder(img, top, bottom, left, right, borderType, value=(0, 0, 0)):
 def norm(a, b, normType=NORM_L2):
     assert normType == NORM_L2
     return float(np.sqrt(((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2).sum()))
+
+
+def imdecode(buf, flags=IMREAD_COLOR):
+    from oracle import jpeg as JO
+
+    assert flags == IMREAD_COLOR
+    return JO.imdecode(np.asarray(buf, np.uint8).tobytes())
+
+
+def imencode(ext, img, params=None):
+    from oracle import jpeg as JO
+
+    assert ext == ".jpg"
+    q = 95
+    if params:
+        for k, v in zip(params[0::2], params[1::2]):
+            if k == IMWRITE_JPEG_QUALITY:
+                q = int(v)
+    return True, np.frombuffer(JO.imencode(np.ascontiguousarray(img), q), np.uint8)
 
 
 def install():

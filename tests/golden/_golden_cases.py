@@ -34,3 +34,10 @@ def pack(cases: dict) -> dict:
         blob[name + "__shape"] = np.array(arr.shape, np.int64)
         blob[name + "__probe"] = probe(arr)
     return blob
+
+
+def jpeg_test_image() -> np.ndarray:
+    """A deterministic 1000 x 1000 BGR image (the reference's BEV size: 62.5 MCUs per side, dummy blocks on both edges) for the cv2.imwrite cases."""
+    y, x = np.mgrid[0:1000, 0:1000]
+    a = np.stack([(x * 3 + y) % 256, 128 + 100 * np.sin(x / 37.0) * np.cos(y / 23.0), (x * y // 7) % 256], -1)
+    return np.ascontiguousarray(np.clip(a, 0, 255).astype(np.uint8))

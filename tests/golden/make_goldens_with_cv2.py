@@ -108,6 +108,15 @@ def main() -> int:
     for f in GC.RESIZE_FACTORS:
         cases["resize_%g" % f] = cv2.resize(small, (0, 0), fx=f, fy=f)
 
+    # row f4: cv2's JPEG codec itself (main.py:74-77 cv2.imread of the camera files; surroundBEV.py:340 cv2.imwrite of the stitched image).  The
+    # JPEG oracle is pinned against Pillow's libjpeg-turbo; these cases say whether THIS OpenCV's bundled codec decodes / writes the same bytes.
+    for n in GC.CAMS:
+        cases["imread_" + n] = cv2.imdecode(np.frombuffer(z[n + "_img"].tobytes(), np.uint8), cv2.IMREAD_COLOR)
+    ok, enc = cv2.imencode(".jpg", GC.jpeg_test_image())                       # cv2.imwrite's defaults: quality 95, 4:2:0
+    cases["imwrite_default"] = np.ascontiguousarray(enc).reshape(-1)
+    ok, enc = cv2.imencode(".jpg", GC.jpeg_test_image(), [cv2.IMWRITE_JPEG_QUALITY, 100])   # Tools/undistort.py:73 with its default -quality 100
+    cases["imwrite_q100"] = np.ascontiguousarray(enc).reshape(-1)
+
     blob = GC.pack(cases)
     blob["cv2_version"] = np.array(getattr(cv2, "__version__", "oracle-shim"))
     np.savez_compressed(OUT, **blob)

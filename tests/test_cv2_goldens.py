@@ -139,3 +139,18 @@ def test_calibrator_paths(goldens, oracle, repo_rig):
     check(goldens, "translate", oracle.translate(small, 403 // 2 - 100, 301 // 2 - 250))
     for f in GC.RESIZE_FACTORS:
         check(goldens, "resize_%g" % f, oracle.resize_linear(small, f, f))
+
+
+def test_jpeg_codec_of_this_opencv(goldens, repo_rig):
+    """Row f4 against cv2 itself: cv2.imread of the reference's camera files and the files cv2.imwrite writes (main.py:74-77, surroundBEV.py:340,
+    Tools/undistort.py:73) against the JPEG oracle -- which is already pinned against Pillow's libjpeg-turbo (tests/test_jpeg_oracle.py); a
+    difference here would mean that this OpenCV's bundled codec is configured differently."""
+    from oracle import jpeg as JO
+    from tests import _jpeg_common as JC
+
+    cams = JC.repo_camera_jpegs()
+    for n in GC.CAMS:
+        check(goldens, "imread_" + n, JO.imdecode(cams[n]))
+    im = GC.jpeg_test_image()
+    check(goldens, "imwrite_default", np.frombuffer(JO.imencode(im), np.uint8))
+    check(goldens, "imwrite_q100", np.frombuffer(JO.imencode(im, 100), np.uint8))
