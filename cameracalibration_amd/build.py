@@ -2,40 +2,63 @@
 
     python -m cameracalibration_amd.build [--force]
 
-The shared object is written next to this file (in-tree: it travels to the GPU box with the repo snapshot and is
-git-ignored).  -ffp-contract=off is REQUIRED: the arithmetic being reproduced has no fused multiply-add.
+Three translation units -- bevwarp.hip (handles, table builders, tools, the camera-per-GPU exchange), bevwarp_plan.hip (the tile plan
+and its per-frame kernels) and bevwarp_jpeg.hip (the JPEG codec) -- are compiled in parallel into objects under csrc/build/ and linked;
+only the units whose sources (or headers) changed are recompiled.  The shared object is written next to this file (in-tree: it travels
+to the GPU box with the repo snapshot and is git-ignored).  -ffp-contract=off is REQUIRED: the arithmetic being reproduced has no fused
+multiply-add.
 """
 from __future__ import annotations
 
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbevwarp.so")
-SOURCES = ["bevwarp.hip"]
-HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join("..", "..", "include", "bevwarp.h")]
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
-         "-Wno-pass-failed", "-Wno-inline-asm"]
+COMMON = ["bevw_host.h", os.path.join("..", "..", "include", "bevwarp.h")]
+# translation unit -> the headers it includes (beyond COMMON)
+UNITS = {
+    "bevwarp.hip": ["bevw_device.h", "bevw_kernels.h", "bevw_pair.h", "bevw_plan.h", "bevw_unit.h", "bevw_planapi.h", "bevw_comm.h"],
+    "bevwarp_plan.hip": ["bevw_device.h", "bevw_kernels.h", "bevw_pair.h", "bevw_plan.h", "bevw_unit.h", "bevw_planapi.h"],
+    "bevwarp_jpeg.hip": ["bevw_jpeg.h", "bevw_jpeg_codec.h"],
+}
+CFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm"]
+EXTRA = os.environ.get("BEVW_CFLAGS", "").split()   # experiment builds (e.g. -DBEVW_UNIT_ABLATE_MEMORY_ONLY=1)
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _newer(path: str, deps) -> bool:
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+    os.makedirs(OBJ, exist_ok=True)
+    me = os.path.abspath(__file__)
+    jobs = []
+    for src, hdrs in UNITS.items():
+        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+        deps = [os.path.join(CSRC, f) for f in [src] + hdrs + COMMON] + [me]
+        if force or EXTRA or _newer(obj, deps):
+            jobs.append([hipcc] + CFLAGS + EXTRA + ["-c", os.path.join(CSRC, src), "-o", obj])
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in UNITS]
+    if not jobs and not _newer(LIB, objs):
+        return LIB
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.run(cmd, check=True)
+
+    with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
+        list(pool.map(run, jobs))
+    run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB + ".tmp"])
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

@@ -63,7 +63,7 @@ static inline const RcclApi &rccl()
 
 // per-rank V sums gathered rank-major ([rank][batch][ncams_r], ranks of one group own equally many cameras) -> the
 // [batch][4] layout bevw_shard_run_device expects (group order == ascending camera order)
-__global__ void k_vsums_interleave(const unsigned long long *__restrict__ gathered, int nranks, int per_rank, int batch,
+static __global__ void k_vsums_interleave(const unsigned long long *__restrict__ gathered, int nranks, int per_rank, int batch,
                                    unsigned long long *__restrict__ all4)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

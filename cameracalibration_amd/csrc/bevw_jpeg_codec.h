@@ -151,13 +151,18 @@ __global__ __launch_bounds__(256) void k_jpeg_subs(ImageDesc *__restrict__ img, 
     const uint32_t *SB = seg_byte + D.seg_first;
     uint32_t *SS = seg_sub + D.seg_first;
     if (nrst[blockIdx.x] + 1u != D.nseg) { D.error = 1; D.nsub = 0; return; }
-    D.error = 0;
-    uint32_t subs = 0;
+    uint32_t subs = 0, empty = 0;
     for (uint32_t s = 0; s < D.nseg; ++s) {
         SS[s] = subs;
+        // a restart segment holds at least one MCU = at least one byte: a segment without data (two adjacent RSTn markers, an RSTn right in
+        // front of EOI, a scan that is only FF D9) owns no subsequence, so nothing downstream would ever look at its blocks -- the
+        // image is truncated / corrupt (never stale coefficients of an earlier batch passed off as pixels)
+        if (SB[s + 1] <= SB[s]) ++empty;
         subs += ((SB[s + 1] - SB[s]) * 8u + (uint32_t)kSubBits - 1u) / (uint32_t)kSubBits;
     }
     SS[D.nseg] = subs;
+    if (empty != 0 || subs == 0) { D.error = 1; D.nsub = 0; return; }
+    D.error = 0;
     D.nsub = subs;
 }
 

@@ -23,7 +23,7 @@ struct FisheyeParams {
     double iR4, iR5;        // 1/fy', -cy'/fy'
 };
 
-__global__ void k_fisheye_map(FisheyeParams p, const double *__restrict__ xs, int width, int height,
+static __global__ void k_fisheye_map(FisheyeParams p, const double *__restrict__ xs, int width, int height,
                               int16_t *__restrict__ map1, uint16_t *__restrict__ map2)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -56,7 +56,7 @@ struct PinholeParams {
     double iR4, iR5, iR8;
 };
 
-__global__ void k_pinhole_map(PinholeParams p, const double *__restrict__ xs, int width, int height,
+static __global__ void k_pinhole_map(PinholeParams p, const double *__restrict__ xs, int width, int height,
                               int16_t *__restrict__ map1, uint16_t *__restrict__ map2)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -80,7 +80,7 @@ __global__ void k_pinhole_map(PinholeParams p, const double *__restrict__ xs, in
 // Camera.get_bev_maps (surroundBEV.py:105-108): cv2.warpPerspective over the CV_16SC2 and CV_16UC1 undistort maps.
 struct Mat3 { double m[9]; };
 
-__global__ void k_bev_lut(Mat3 Minv, const int16_t *__restrict__ und1, const uint16_t *__restrict__ und2, int uw,
+static __global__ void k_bev_lut(Mat3 Minv, const int16_t *__restrict__ und1, const uint16_t *__restrict__ und2, int uw,
                           int uh, int bw, int bh, int bw0, int16_t *__restrict__ lut1, uint16_t *__restrict__ lut2)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -148,7 +148,7 @@ __device__ inline bool clip_segment(int w, int h, long long &x1, long long &y1, 
 }
 
 // One thread per polygon edge: 8-connected Bresenham, left-to-right, after clipping to the image.
-__global__ void k_poly_outline(PolyJob job, uint8_t *__restrict__ img, int w, int h, uint8_t color)
+static __global__ void k_poly_outline(PolyJob job, uint8_t *__restrict__ img, int w, int h, uint8_t color)
 {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= job.npts) return;
@@ -177,7 +177,7 @@ __global__ void k_poly_outline(PolyJob job, uint8_t *__restrict__ img, int w, in
 // One thread per scanline.  An edge alive on row y (y0 <= y < y1) sits at x + (y - y0) * dx: the reference advances
 // every paired edge by dx once per row, which is this closed form.  Spans are [xa >> 16, xb >> 16] between
 // x-sorted pairs.
-__global__ void k_poly_fill(PolyJob job, uint8_t *__restrict__ img, int w, int h, uint8_t color)
+static __global__ void k_poly_fill(PolyJob job, uint8_t *__restrict__ img, int w, int h, uint8_t color)
 {
     const int y = blockIdx.x * blockDim.x + threadIdx.x;
     if (y >= h || job.nedges < 2) return;
@@ -229,7 +229,7 @@ __device__ inline double segment_distance(const Seam &s, double px, double py)
     return sqrt(min_num / min_den);
 }
 
-__global__ void k_blend_weights(uint8_t *__restrict__ maskA, const uint8_t *__restrict__ maskB, int w, int h, Seam lineA,
+static __global__ void k_blend_weights(uint8_t *__restrict__ maskA, const uint8_t *__restrict__ maskB, int w, int h, Seam lineA,
                                 Seam lineB)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -249,7 +249,7 @@ __global__ void k_blend_weights(uint8_t *__restrict__ maskA, const uint8_t *__re
 
 // cv2.remap(src, map1, map2, INTER_LINEAR) for a batch: one thread per destination pixel.
 // grid = (ceil(dw / 256), dh, batch)
-__global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int sh, const int16_t *__restrict__ map1,
+static __global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int sh, const int16_t *__restrict__ map1,
                             const uint16_t *__restrict__ map2, int dw, int dh, uint8_t *__restrict__ dst)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,7 +265,7 @@ __global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int sh, con
 }
 
 // cv2.warpPerspective(src_8UC3, H, dsize): coordinates made on the fly (extrinsicCalib.py:166-169).
-__global__ void k_warp_perspective(const uint8_t *__restrict__ src, int sw, int sh, Mat3 Minv, int bw0, int dw, int dh,
+static __global__ void k_warp_perspective(const uint8_t *__restrict__ src, int sw, int sh, Mat3 Minv, int bw0, int dw, int dh,
                                    uint8_t *__restrict__ dst)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,7 +293,7 @@ __device__ __forceinline__ unsigned vsum_piece(const VsumPiece &p)
     auto v = [](unsigned t) { return max(t & 255u, max((t >> 8) & 255u, (t >> 16) & 255u)); };
     return v(p.x) + v(t1) + v(t2) + v(t3);
 }
-__global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, int vec_ok,
+static __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, int vec_ok,
                        unsigned long long *__restrict__ sums)
 {
     const uint8_t *f = frames + (size_t)blockIdx.y * frame_bytes;
@@ -324,7 +324,7 @@ __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, i
 
 // luminance_balance scalars (surroundBEV.py:64-72): delta_c = cvRound(V_mean - V_c), V_mean = (Vf+Vb+Vl+Vr)/4.
 // one thread per 4-camera frame set.
-__global__ void k_lum_delta(const unsigned long long *__restrict__ vsums, double npx, int nsets, int *__restrict__ deltas)
+static __global__ void k_lum_delta(const unsigned long long *__restrict__ vsums, double npx, int nsets, int *__restrict__ deltas)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nsets) return;
@@ -336,7 +336,7 @@ __global__ void k_lum_delta(const unsigned long long *__restrict__ vsums, double
 
 // luminance_balance applied to whole frames (the exported helper; the stitch kernels apply it per fetched texel).
 // grid = (blocks, n_frames)
-__global__ void k_lum_shift(const uint8_t *__restrict__ frames, size_t frame_px, const int *__restrict__ deltas,
+static __global__ void k_lum_shift(const uint8_t *__restrict__ frames, size_t frame_px, const int *__restrict__ deltas,
                             const HsvTables *__restrict__ tab, uint8_t *__restrict__ out)
 {
     __shared__ int sdiv[256], hdiv[256];
@@ -365,7 +365,7 @@ struct StitchTables {
 // (integer, so the result does not depend on the order of the atomics).
 // grid = (ceil(bw / 256), bh, batch)
 template <bool BLEND, bool BAL>
-__global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, int fh, StitchTables T, int bw, int bh,
+static __global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, int fh, StitchTables T, int bw, int bh,
                             const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                             const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
                             uint8_t *__restrict__ out)
@@ -470,7 +470,7 @@ __device__ __forceinline__ bool analytic_project(const AnalyticRig &R, int c, in
 // (bevw_unit.h: kUnitFracBits).  Pixels that sample nothing get sx = sy = INT16_MIN.  Evaluated once per handle and projection mode:
 // the host compiles the unit schedule (bevw_unit.h, wide plan) from it, and the table is dropped again.
 template <typename F>
-__global__ void k_analytic_map(AnalyticRig R, int c, int fw, int fh, int bw, int bh, int16_t *__restrict__ sxy, uint32_t *__restrict__ frac)
+static __global__ void k_analytic_map(AnalyticRig R, int c, int fw, int fh, int bw, int bh, int16_t *__restrict__ sxy, uint32_t *__restrict__ frac)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= bw || y >= bh) return;
@@ -543,7 +543,7 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
 // schedule of the analytic mode leaves over: frame-border footprints)
 constexpr int kAnalyticFrames = 32;   // (8: the projection was a third of a 64-frame call; profiles/r03/sweeps.log)
 template <bool BLEND, bool BAL, typename F>
-__global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh, int batch,
+static __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh, int batch,
                                   const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                                   const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
                                   uint8_t *__restrict__ out, const uint32_t *__restrict__ tiles = nullptr, int tiles_x = 0)
@@ -639,7 +639,7 @@ __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, in
 }
 
 // per-channel sums of a batch of images (color_balance as an exported helper). grid = (blocks, batch)
-__global__ void k_channel_sums(const uint8_t *__restrict__ img, size_t npx, unsigned long long *__restrict__ chsums)
+static __global__ void k_channel_sums(const uint8_t *__restrict__ img, size_t npx, unsigned long long *__restrict__ chsums)
 {
     const uint8_t *p = img + (size_t)blockIdx.y * npx * 3;
     unsigned acc[3] = {0, 0, 0};
@@ -670,7 +670,7 @@ __device__ __forceinline__ int gain_px(int v, double gain, int f32)
 {
     return f32 ? sat_u8(rne_f((float)v * (float)gain + 0.0f * 0.0f + 0.0f)) : sat_u8(rne_d((double)v * gain + 0.0 * 0.0 + 0.0));
 }
-__global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
+static __global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
                        const uint8_t *__restrict__ car, uint8_t *out, int f32 = 0)
 {
     const double n = (double)npx;
@@ -690,7 +690,7 @@ __global__ void k_gain(const uint8_t *in, size_t npx, const unsigned long long *
 // Mask.__call__ = cv2.bitwise_and(img, img, mask=mask) (surroundBEV.py:161-162) and
 // BlendMask.__call__ = (img * float32(mask / 255.0)).astype(uint8) (surroundBEV.py:279-280) as stand-alone operations
 // (inside BevGenerator.__call__ they are fused into the stitch kernels).  grid = (blocks, batch)
-__global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask, size_t npx, int blend,
+static __global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__restrict__ mask, size_t npx, int blend,
                              uint8_t *__restrict__ out)
 {
     const size_t base = (size_t)blockIdx.y * npx * 3;
@@ -708,7 +708,7 @@ __global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8_t *__r
 // k_gain with a per-frame 3 x 256 look-up table (the gain is one fp64 multiply + cvRound per byte VALUE, so 768
 // table entries per frame replace 3.5 M fp64 operations) and 12-byte vector accesses (4 pixels per lane).
 // Needs npx % 4 == 0 and 4-byte aligned images.  grid = (blocks, batch), block = 256; in place when in == out.
-__global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
+static __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
                                                    const uint8_t *__restrict__ car, uint8_t *out, uint32_t blocks_per_frame,
                                                    uint32_t nframes, int f32 = 0, size_t npx_mean = 0)
 {
@@ -756,7 +756,7 @@ __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx,
 
 // deltas of the owned cameras in plan order: out[b][k] = deltas[b][cams[k]]
 struct ShardCams { int cam[4]; int n; };
-__global__ void k_delta_select(const int *__restrict__ deltas, ShardCams sc, int nsets, int *__restrict__ out)
+static __global__ void k_delta_select(const int *__restrict__ deltas, ShardCams sc, int nsets, int *__restrict__ out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsets * 4) return;
@@ -767,7 +767,7 @@ __global__ void k_delta_select(const int *__restrict__ deltas, ShardCams sc, int
 // full BEV [batch][bh][bw][3] -> packed box [batch][y1-y0][x1-x0][3].  U = uint32_t when every row start is dword
 // aligned (bw % 4 == 0 and x0 % 4 == 0), else uint8_t.  grid = (ceil(row units / 256), box rows, batch)
 template <typename U>
-__global__ void k_pack_box(const uint8_t *__restrict__ full, int bw, int bh, int x0, int y0, int x1, int y1, uint8_t *__restrict__ packed)
+static __global__ void k_pack_box(const uint8_t *__restrict__ full, int bw, int bh, int x0, int y0, int x1, int y1, uint8_t *__restrict__ packed)
 {
     const int row_units = (x1 - x0) * 3 / (int)sizeof(U);
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -797,7 +797,7 @@ __device__ inline uint32_t sat_add_u8x4(uint32_t a, uint32_t b)
 // bw % 4 == 0 and boxes aligned to 4 pixels in x); PX = 1: one thread = one pixel, byte accesses.
 // grid = (ceil(bw / PX / 256), bh, batch)
 template <int PX>
-__global__ void k_combine(CombineParts parts, int bw, int bh, const uint8_t *__restrict__ car, uint8_t *__restrict__ out)
+static __global__ void k_combine(CombineParts parts, int bw, int bh, const uint8_t *__restrict__ car, uint8_t *__restrict__ out)
 {
     const int x = (blockIdx.x * blockDim.x + threadIdx.x) * PX, y = blockIdx.y;
     if (x >= bw) return;
@@ -839,7 +839,7 @@ __global__ void k_combine(CombineParts parts, int bw, int bh, const uint8_t *__r
 // ---------------------------------------------------------------------------------------------------------------
 // CenterImage.translate: cv2.warpAffine with an integer shift = one tap per pixel, zeros outside.
 // grid = (ceil(w / 256), h, batch)
-__global__ void k_translate(const uint8_t *__restrict__ src, int w, int h, int shift_x, int shift_y, uint8_t *__restrict__ dst)
+static __global__ void k_translate(const uint8_t *__restrict__ src, int w, int h, int shift_x, int shift_y, uint8_t *__restrict__ dst)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
@@ -871,7 +871,7 @@ __device__ inline void resize_tap(int d, double scale, int n_src, bool clamp_fra
 
 // cv2.resize(src, (0,0), fx, fy), INTER_LINEAR, 8UC3 (ScaleImage.__call__, extrinsicCalib.py:125).
 // grid = (ceil(dw / 256), dh, batch)
-__global__ void k_resize_linear(const uint8_t *__restrict__ src, int w, int h, double scale_x, double scale_y,
+static __global__ void k_resize_linear(const uint8_t *__restrict__ src, int w, int h, double scale_x, double scale_y,
                                 uint8_t *__restrict__ dst, int dw, int dh)
 {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;

@@ -854,16 +854,6 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     }
 }
 
-// block -> (chunk, unit) of a class list
-template <bool BLEND, bool SUMS, int CLS>
-__device__ __forceinline__ void plan_unit_body(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
-{
-    uint32_t chunk, group;
-    if (!plan_block_map(a, block_id, chunk, group)) return;   // uniform over the block
-    if ((int)group >= a.nlist) return;
-    plan_unit_run<BLEND, SUMS, kUnitClassNQ[CLS], kUnitClassGR[CLS], kUnitClassCON[CLS]>(a, chunk, __builtin_amdgcn_readfirstlane(a.tile_list[group]), lds);
-}
-
 // block -> (chunk, unit) of the list of ALL units in the partition's own (spatial) order, class in bits 28..31: neighbouring units run
 // at the same time on the same XCD, whatever their class, so the two halves of a sector that two units share meet in the L2
 template <bool BLEND, bool SUMS>
@@ -885,6 +875,17 @@ __device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_
 #undef BEVW_UNIT_CASE
 }
 
+// THE per-frame kernel of the tile plan: every unit of every class, one launch per step.  3 blocks of 32 KB per CU.
+#ifndef BEVW_PLAN_ALL_WAVES
+#define BEVW_PLAN_ALL_WAVES 3   // waves per SIMD the kernel is compiled for (<= 168 VGPRs; 4 measured no faster: profiles/r03/sweeps.log)
+#endif
+template <bool BLEND, bool SUMS>
+__global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_eu(BEVW_PLAN_ALL_WAVES, BEVW_PLAN_ALL_WAVES))) k_plan_units(PlanArgs a)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
+    plan_unit_any<BLEND, SUMS>(a, blockIdx.x, patch);
+}
+
 // wide plans (analytic projection): every unit class in one launch, partition order, as plan_unit_any
 template <bool BLEND>
 __global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_eu(3, 3))) k_plan_unit_wide(PlanArgs a)
@@ -902,14 +903,6 @@ __global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_
         default: plan_unit_run<BLEND, false, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6], true>(a, chunk, unit, patch); break;
     }
 #undef BEVW_UNIT_CASE
-}
-
-// the unit classes as kernels of their own (per-class launches: BEVW_PLAN_ONELAUNCH=0, and the unit the per-class profiles are taken on)
-template <bool BLEND, bool SUMS, int CLS>
-__global__ void __launch_bounds__(kUnitThreads) k_plan_unit(PlanArgs a)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
-    if (!(BLEND && CLS == 4)) plan_unit_body<BLEND && CLS != 4, SUMS, CLS>(a, blockIdx.x, patch);   // (no class-4 units in a blend plan)
 }
 
 }  // namespace bevw

@@ -1,147 +1,25 @@
 // bevwarp.hip -- libbevwarp.so: the C-ABI of include/bevwarp.h over the HIP kernels (gfx950 / MI355X only).
 //
-// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared   (cameracalibration_amd/build.py)
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared   (cameracalibration_amd/build.py: this file, bevwarp_plan.hip --
+// the tile plan and its per-frame kernels -- and bevwarp_jpeg.hip -- the JPEG codec -- are compiled in parallel and linked together)
 // There is no CPU path in this library: every pixel and every table entry is produced by a kernel.  The host
 // code below only derives a handful of scalars per calibration (3x3 inverses, polygon vertices and edge slopes,
 // the 512-entry HSV divisor tables, the per-column fp64 chain of the fisheye map) exactly the way the reference's
 // Python / OpenCV host code does.
-#include "../../include/bevwarp.h"
-
-#include <hip/hip_runtime.h>
+#include "bevw_host.h"
 
 #include <algorithm>
 #include <atomic>
 #include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <new>
 #include <string>
 #include <thread>
-#include <vector>
 
 #include "bevw_kernels.h"
-#include "bevw_plan.h"
+#include "bevw_planapi.h"
 #include "bevw_comm.h"
-#include "bevw_jpeg_codec.h"
 
 using namespace bevw;
-
-// ---------------------------------------------------------------------------------------------------------------
-// errors
-// ---------------------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char *fmt, ...)
-{
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof g_err, fmt, ap);
-    va_end(ap);
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                                      \
-    do {                                                                                                   \
-        hipError_t _e = (expr);                                                                            \
-        if (_e != hipSuccess)                                                                              \
-            return fail(BEVW_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-
-#define BEVW_TRY(expr)             \
-    do {                           \
-        int _s = (expr);           \
-        if (_s != BEVW_OK) return _s; \
-    } while (0)
-
-static int use_device(int device)
-{
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
-        (void)hipGetLastError();
-        return fail(BEVW_E_NO_DEVICE, "no HIP device is visible: libbevwarp has no CPU path");
-    }
-    if (device < 0 || device >= n) return fail(BEVW_E_NO_DEVICE, "device %d requested, %d visible", device, n);
-    HIP_TRY(hipSetDevice(device));
-    return BEVW_OK;
-}
-
-static UnitTuning unit_tuning_env()
-{
-    UnitTuning t;
-    if (const char *s = getenv("BEVW_UNIT_GROUPS")) t.max_groups = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_ROOT_W")) t.root_w = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_ROOT_H")) t.root_h = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_MIN_W")) t.min_w = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_LINE_COST")) t.line_cost = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_SECTOR_COST")) t.sector_cost = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_ALIGN_LINES")) t.align_lines = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_OWN_EMPTY")) t.own_empty = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_OWN_DOUBLE")) t.own_double = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_SKEW")) t.skew = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_ROW_ORDER")) t.row_order = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_OWN_PADDING")) t.own_padding = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_STAGGER")) t.stagger = atoi(s);
-    if (const char *s = getenv("BEVW_UNIT_RUN_COST")) t.run_cost = atoi(s);
-    return t;
-}
-
-static int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, int bw, int bh, int ncams = 4, bool seam_tiles = true,
-                      int out_pitch = 0, bool blend = false)
-{
-    static const int lx_env = [] { const char *s = getenv("BEVW_PLAN_LX"); return s ? atoi(s) : 0; }();
-    static const int orient_env = [] { const char *s = getenv("BEVW_PLAN_ORIENT"); return s ? atoi(s) : 0; }();
-    static const int inter_env = [] { const char *s = getenv("BEVW_PLAN_INTERLEAVE"); return s ? atoi(s) : 1; }();
-    static const int colmajor_env = [] { const char *s = getenv("BEVW_PLAN_COLMAJOR"); return s ? atoi(s) : 1; }();
-    static const int super_env = [] { const char *s = getenv("BEVW_PLAN_SUPER"); return s ? atoi(s) : 1; }();
-    static const int block_env = [] { const char *s = getenv("BEVW_PLAN_BLOCK"); return s ? atoi(s) : 1; }();   // block tiles (bevw_block.h)
-    static const int seam_env = [] { const char *s = getenv("BEVW_PLAN_SEAM"); return s ? atoi(s) : 1; }();      // seam block tiles
-    static const int unit_env = [] { const char *s = getenv("BEVW_PLAN_UNITS"); return s ? atoi(s) : 1; }();     // unit schedule (bevw_unit.h)
-    static const UnitTuning unit_tune = unit_tuning_env();
-    UnitTuning tune = unit_tune;
-    if (blend) tune.wide_double = 0;   // the blend kernels carry no two-quad two-contributor class (bevw_unit.h: plan_unit_any)
-    // balance handles (seam_tiles == false): two-contributor units measured 4 % slower under the per-unit channel sums than the per-wave
-    // pair classes (profiles/r03/sweeps.log), as the seam block tiles of round 2 did
-    if (!seam_tiles && !getenv("BEVW_UNIT_OWN_DOUBLE")) tune.own_double = 0;
-    // rows of whole sectors (an output pitch): column cuts on sector boundaries are free, all others split a sector for good -> a higher
-    // price per write sector (3 -> 8: -0.4 ... -2 % on config 3, -2 % on the 4K rig, nothing slower; profiles/r03/sweeps.log).  The dense
-    // layout keeps 3: there every cut shares sectors and the price only drives the source lines up (40 k -> 50 k per frame)
-    if (out_pitch > 0 && !getenv("BEVW_UNIT_SECTOR_COST")) tune.sector_cost = 8;
-    hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, lx_env, orient_env, inter_env, colmajor_env != 0, super_env, ncams,
-                                   block_env != 0, seam_tiles && seam_env != 0, unit_env != 0, tune, out_pitch);
-    if (e != hipSuccess) return fail(BEVW_E_HIP, "contributor-plan build failed: %s", hipGetErrorString(e));
-    return BEVW_OK;
-}
-
-// tuning knobs for experiments (defaults are the shipped configuration)
-static const PlanTuning &plan_tuning()
-{
-    static const PlanTuning tune = [] {
-        PlanTuning t;
-        if (const char *s = getenv("BEVW_PLAN_NB")) t.nb = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_LEAN")) t.lean = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_XCDMAP")) t.xcd_map = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_STAGED")) t.staged = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_LDSPAD")) t.lds_pad = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_ONELAUNCH")) t.one_launch = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_BT_MERGED")) t.bt_merged = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_GROUPMAJOR")) t.group_major = atoi(s);
-        if (const char *s = getenv("BEVW_PLAN_SPATIAL")) t.unit_spatial = atoi(s);
-        return t;
-    }();
-    return tune;
-}
-
-static int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
-                       const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car, unsigned long long *d_chsums,
-                       uint8_t *d_out, bool sums = false)
-{
-    const PlanTuning &tune = plan_tuning();
-    hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, tune, sums);
-    if (e != hipSuccess) return fail(BEVW_E_HIP, "tile-plan stitch launch failed: %s", hipGetErrorString(e));
-    return BEVW_OK;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // small host-side scalars
@@ -317,57 +195,6 @@ struct MaskGeometry {
 // ---------------------------------------------------------------------------------------------------------------
 // device buffer helper
 // ---------------------------------------------------------------------------------------------------------------
-// Lap timer: HIP events recorded on an engine's own stream WITHOUT synchronising, read back after the caller's final sync
-// (bench.py: one mark in front of every step -> per-step durations, median instead of one mean over a 13 ms region).
-struct LapTimer {
-    std::vector<hipEvent_t> ev;
-    int mark(int slot, hipStream_t st)
-    {
-        if (slot < 0 || slot >= 65536) return fail(BEVW_E_INVALID, "timer slot %d out of range", slot);
-        if ((size_t)slot >= ev.size()) ev.resize((size_t)slot + 1, nullptr);
-        if (!ev[slot]) HIP_TRY(hipEventCreate(&ev[slot]));
-        HIP_TRY(hipEventRecord(ev[slot], st));
-        return BEVW_OK;
-    }
-    int between(int a, int b, float *ms)
-    {
-        if (!ms || a < 0 || b < 0 || (size_t)a >= ev.size() || (size_t)b >= ev.size() || !ev[a] || !ev[b])
-            return fail(BEVW_E_INVALID, "timer slots %d / %d were not marked", a, b);
-        HIP_TRY(hipEventSynchronize(ev[b]));
-        HIP_TRY(hipEventElapsedTime(ms, ev[a], ev[b]));
-        return BEVW_OK;
-    }
-    void release() { for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e); ev.clear(); }
-};
-
-// owns one device allocation: released on every exit path (early HIP_TRY / BEVW_TRY returns included)
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    DevBuf() = default;
-    DevBuf(const DevBuf &) = delete;
-    DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { release(); }
-    int reserve(size_t n)
-    {
-        if (n <= cap) return BEVW_OK;
-        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) { p = nullptr; return fail(BEVW_E_NOMEM, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
-        cap = n;
-        return BEVW_OK;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <typename T> T *as() const { return static_cast<T *>(p); }
-};
-
-static int launch_check(const char *what)
-{
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return fail(BEVW_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
-    return BEVW_OK;
-}
-
 // cv2.fisheye.initUndistortRectifyMap on the device (see k_fisheye_map for why xs[] is a host-made chain).
 static int build_fisheye_maps(hipStream_t st, const double K[9], const double D[4], const double Knew[9], int w, int h,
                               int16_t *d_map1, uint16_t *d_map2)
@@ -453,7 +280,7 @@ static int remapper_build_plan(bevw_remapper *r)
     HIP_TRY(hipMemsetAsync(r->ones.p, 0xff, npx, r->stream));
     StitchTables T;
     for (int i = 0; i < 4; ++i) { T.lut1[i] = r->map1.as<int16_t>(); T.lut2[i] = r->map2.as<uint16_t>(); T.mask[i] = r->ones.as<uint8_t>(); }
-    BEVW_TRY(plan_build(r->plan, r->stream, T, r->sw, r->sh, r->dw, r->dh, 1));
+    BEVW_TRY(plan_build(r->plan, r->stream, T, r->sw, r->sh, r->dw, r->dh, 1, 0, false));
     r->ones.release();
     r->plan_ready = r->plan.usable;
     return BEVW_OK;
@@ -510,7 +337,7 @@ int bevw_get_compat(int key)
     return g_compat[key].load();
 }
 
-const char *bevw_last_error(void) { return g_err; }
+const char *bevw_last_error(void) { return g_bevw_err; }
 
 int bevw_device_count(void)
 {
@@ -805,7 +632,9 @@ int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h
 struct bevw_handle {
     bevw_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;    // balance: the odd slices of a batch (balance_plan_run)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_skew = nullptr, ev_join = nullptr;
     LapTimer laps;
     bool cam_set[4] = {false, false, false, false};
     double K[4][9], D[4][4], H[4][9];
@@ -895,8 +724,7 @@ static int stitch_per_pixel(bevw_handle *h, const uint8_t *d_frames, int batch, 
 static int analytic_units_build(bevw_handle *h)
 {
     const bevw_config &c = h->cfg;
-    Plan &p = h->aplan;
-    plan_release(p);
+    plan_release(h->aplan);
     h->aplan_mode = h->projection;
     static const int units_env = [] { const char *s = getenv("BEVW_ANALYTIC_UNITS"); return s ? atoi(s) : 1; }();
     const int fw = c.frame_width, fh = c.frame_height, bw = c.bev_width, bh = c.bev_height;
@@ -906,7 +734,6 @@ static int analytic_units_build(bevw_handle *h)
     BEVW_TRY(d_sxy.reserve(bpx * 4));
     BEVW_TRY(d_frac.reserve(bpx * 8));
     std::vector<int16_t> h1[4];
-    std::vector<uint16_t> h2[4];
     std::vector<uint8_t> hm[4];
     std::vector<uint32_t> hf[4];
     for (int cam = 0; cam < 4; ++cam) {
@@ -922,31 +749,7 @@ static int analytic_units_build(bevw_handle *h)
         HIP_TRY(hipMemcpyAsync(hm[cam].data(), h->mask[cam].p, bpx, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
-    p.lx = 8; p.ncams = 4;
-    p.fw = fw; p.fh = fh; p.bw = bw; p.bh = bh; p.pitch = bw;
-    p.tiles_x = (bw + 31) / 32; p.tiles_y = (bh + 7) / 8; p.ntiles = p.tiles_x * p.tiles_y;
-    std::vector<uint32_t> hdr = unit_host_headers(h1, hm, 4, fw, fh, bw, bh, p.tiles_x, p.tiles_y);
-    UnitTuning tune = unit_tuning_env();
-    if (tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // one group slot stays free: the zeros of pixels without a contributor
-    tune.skew = 0;
-    if (c.blend) tune.wide_double = 0;
-    UnitPlanHost up;
-    unit_compile(h1, h2, hm, 4, fw, fh, bw, bh, bw, p.tiles_x, p.tiles_y, hdr, up, tune, hf);
-    if (up.desc.empty()) return BEVW_OK;
-    HIP_TRY(hipMalloc(&p.un_desc, up.desc.size() * sizeof(UnitDesc)));
-    HIP_TRY(hipMemcpy(p.un_desc, up.desc.data(), up.desc.size() * sizeof(UnitDesc), hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc(&p.un_entries, up.entries.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(p.un_entries, up.entries.data(), up.entries.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(plan_upload_list(up.gsrc, &p.un_gsrc));
-    HIP_TRY(plan_upload_list(up.all, &p.list_un_all));
-    p.n_un_all = (int)up.all.size();
-    p.un_lines = up.lines; p.un_sectors = up.sectors; p.un_skew = 0;
-    std::vector<uint32_t> left;
-    for (size_t t = 0; t < hdr.size(); ++t)
-        if (!(hdr[t] & kHdrBlock)) left.push_back((uint32_t)t);
-    HIP_TRY(plan_upload_list(left, &p.list_slow));
-    p.n_slow = (int)left.size();
-    return BEVW_OK;
+    return plan_build_wide(h->aplan, h1, hf, hm, fw, fh, bw, bh, c.blend != 0);
 }
 
 // BEVW_PROJ_ANALYTIC(_F32): the unit schedule compiled from the projection (analytic_units_build), or -- balance handles, odd geometry,
@@ -959,8 +762,7 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
     if (!c.balance && ((((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) == 0)) {
         if (h->aplan_mode != h->projection) BEVW_TRY(analytic_units_build(h));
         if (h->aplan.n_un_all) {
-            hipError_t e = plan_unit_wide_launch(h->aplan, h->stream, d_frames, batch, c.blend != 0, d_car, d_out, plan_tuning());
-            if (e != hipSuccess) return fail(BEVW_E_HIP, "k_plan_unit_wide launch failed: %s", hipGetErrorString(e));
+            BEVW_TRY(plan_stitch_wide(h->aplan, h->stream, d_frames, batch, c.blend != 0, d_car, d_out));
             if (h->aplan.n_slow == 0) return BEVW_OK;
             left_tiles = static_cast<const uint32_t *>(h->aplan.list_slow);
             n_left = h->aplan.n_slow;
@@ -1022,45 +824,110 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
     return launch_check("k_vsum/k_lum_delta");
 }
 
-// (Round 2 measured, then removed: walking a balance batch in sub-batches of 16 / 32 / 64 / 128 frame sets so that every producer's
-// output is still in the 256 MB Infinity Cache when its consumer runs is SLOWER -- 3.02 / 2.63 / 2.42 / 2.36 ms against 2.29 ms for
-// the whole 256-set batch: the small grids cost more than the cache returns.  profiles/r02/sweeps.log)
+// The gain pass of frame sets [b0, b0 + n) (color_balance + car, surroundBEV.py:43-55, 323-324) on `st`
+static int gain_pass(bevw_handle *h, hipStream_t st, const uint8_t *gain_in, const uint8_t *gain_car, const uint8_t *d_car, uint8_t *d_out, int b0, int n,
+                     bool lut_ok)
+{
+    const bevw_config &c = h->cfg;
+    const size_t npx_true = (size_t)c.bev_width * c.bev_height, npx = (size_t)h->pitch_px * c.bev_height;
+    for (int k0 = b0; k0 < b0 + n; k0 += 65535) {
+        const int nb = b0 + n - k0 < 65535 ? b0 + n - k0 : 65535;
+        if (lut_ok)
+            hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, st, gain_in + (size_t)k0 * npx * 3, npx,
+                               h->chsums.as<unsigned long long>() + (size_t)k0 * 3, gain_car, d_out + (size_t)k0 * npx * 3, 32u,
+                               (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1, npx_true);
+        else
+            hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, st, d_out + (size_t)k0 * npx * 3, npx,
+                               h->chsums.as<unsigned long long>() + (size_t)k0 * 3, d_car, d_out + (size_t)k0 * npx * 3,
+                               h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
+    }
+    return launch_check("k_gain");
+}
+
+// blend + balance on the tile plan (BASELINE config 4), `parts` slices of the batch alternating over the handle's two streams.
+// Per slice: V sums of the raw frames (k_vsum: HBM-bound, reads every byte of the four frames) -> deltas -> luminance round trip of the
+// sampled texel groups into the scratch frame set (k_lum_groups: VALU-bound) -> the unit stitch with per-unit channel sums (HBM-bound)
+// -> the gain pass (copy rate).  In one stream these run strictly one after the other, a memory-bound kernel while the VALUs idle and a
+// VALU-bound one while the memory idles; every quantity is per frame set, so slices are independent, and a slice's kernels overlap
+// the neighbouring slice's kernels of the OTHER kind (round 4: profiles/r04/config4_overlap.md; same idea as the two slices of a JPEG
+// decode batch, bevwarp_jpeg.hip).  The second stream starts one V-sum pass late so that the two streams stay out of phase.
+// (Round 2 measured sub-batches of 16 ... 128 frame sets run ONE AFTER THE OTHER for Infinity-Cache residency: slower, the small grids
+// cost more than the cache returns; profiles/r02/sweeps.log.)
+static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
+{
+    const bevw_config &c = h->cfg;
+    const bool pitched = h->pitch_px != c.bev_width;
+    const size_t npx = (size_t)h->pitch_px * c.bev_height;
+    const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
+    BEVW_TRY(ensure_stats(h, batch));
+    BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
+    // the gain pass reads the pre-gain BEV from a buffer of its own instead of rewriting the output in place: a read stream
+    // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
+    // one more BEV batch of HBM (0.9 GB at batch 256).  No room for it: the gain pass runs in place -- never an error
+    static const int oop = [] { const char *s = getenv("BEVW_GAIN_OOP"); return s ? atoi(s) : 1; }();
+    uint8_t *gain_in = d_out;
+    if (oop && npx % 4 == 0 && h->pre.reserve(npx * 3 * (size_t)batch) == BEVW_OK) gain_in = h->pre.as<uint8_t>();
+    const uint8_t *gain_car = d_car;
+    if (pitched && d_car) {   // the gain pass walks the image as a flat array: the sprite needs the same row pitch
+        BEVW_TRY(h->car_pitched.reserve(npx * 3));
+        BEVW_TRY(plan_pad_image(h->stream, d_car, c.bev_width, h->pitch_px, c.bev_height, h->car_pitched.as<uint8_t>()));
+        gain_car = h->car_pitched.as<uint8_t>();
+    }
+    static const int parts_env = [] { const char *s = getenv("BEVW_BAL_PARTS"); return s ? atoi(s) : 0; }();
+    static const int skew_env = [] { const char *s = getenv("BEVW_BAL_SKEW"); return s ? atoi(s) : 1; }();
+    // slices share the plan's padded scratch image when the BEV width is not a multiple of 4 pixels: one slice then
+    const bool scratch = h->plan.pitch != h->plan.bw && !h->plan.out_pitched;
+    int parts = parts_env > 0 ? parts_env : (batch >= 64 ? 4 : (batch >= 16 ? 2 : 1));
+    if (scratch || !h->stream2) parts = 1;
+    if (parts > batch) parts = batch;
+    if (parts > 1) {
+        HIP_TRY(hipEventRecord(h->ev_fork, h->stream));          // the caller's uploads (and the padded sprite) were enqueued on stream
+        HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
+    }
+    for (int part = 0; part < parts; ++part) {
+        const int b0 = (int)((long long)batch * part / parts), n = (int)((long long)batch * (part + 1) / parts) - b0;
+        if (!n) continue;
+        hipStream_t st = (part & 1) ? h->stream2 : h->stream;
+        const uint8_t *fr = d_frames + (size_t)b0 * set_bytes;
+        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, h->vsums.as<unsigned long long>() + (size_t)b0 * 4, h->deltas.as<int>() + (size_t)b0 * 4));
+        if (part == 0 && parts > 1 && skew_env) {   // the other stream's first slice starts when this one's V sums are done
+            HIP_TRY(hipEventRecord(h->ev_skew, h->stream));
+            HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_skew, 0));
+        }
+        BEVW_TRY(plan_lum_groups(h->plan, st, fr, h->tmp.as<uint8_t>() + (size_t)b0 * set_bytes, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>()));
+        BEVW_TRY(plan_stitch(h->plan, st, h->tmp.as<uint8_t>() + (size_t)b0 * set_bytes, n, c.blend != 0, false, nullptr, nullptr, nullptr,
+                             h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0));
+        BEVW_TRY(gain_pass(h, st, gain_in, gain_car, d_car, d_out, b0, n, npx % 4 == 0));   // (odd image sizes: the byte-wise gain kernel, in place)
+    }
+    if (parts > 1) {   // everything the caller enqueues on the handle's stream afterwards sees the whole batch
+        HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
+        HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    }
+    return BEVW_OK;
+}
+
 static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
 {
     const bevw_config &c = h->cfg;
-    const size_t npx_true = (size_t)c.bev_width * c.bev_height;
     const bool pitched = h->pitch_px != c.bev_width;
     const size_t npx = (size_t)h->pitch_px * c.bev_height;   // pixels per device image, padding columns included
     if (pitched && (h->projection != BEVW_PROJ_LUT || h->schedule_in_use != BEVW_SCHED_TILE_PLAN ||
                     ((((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) != 0)))
         return fail(BEVW_E_INVALID, "an output pitch needs the tile-plan schedule, the table projection and 4-byte aligned buffers");
+    const bool aligned4 = (((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) == 0;
+    // balance schedule of the tile plan: 1 = shift the sampled texel groups of the raw frames once (k_lum_groups), then the units;
+    // 0 = luminance round trip per fetched texel inside the per-tap kernel
+    static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
+    if (h->projection == BEVW_PROJ_LUT && h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok)
+        return balance_plan_run(h, d_frames, batch, d_car, d_out);
     if (c.balance) {
         BEVW_TRY(ensure_stats(h, batch));
         BEVW_TRY(luminance_stats(h->stream, d_frames, batch, c.frame_width, c.frame_height,
                                  h->vsums.as<unsigned long long>(), h->deltas.as<int>()));
         HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
     }
-    const bool aligned4 = (((uintptr_t)d_out | (uintptr_t)d_car | (uintptr_t)d_frames) & 3u) == 0;
-    // balance schedule of the tile plan: 1 = shift the sampled band of the raw frames once (k_lum_band), then the lean
-    // kernels; 0 = luminance round trip per fetched texel inside the generic kernel
-    static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
-    uint8_t *gain_in = d_out;   // where the pre-gain BEV is written (the gain pass is in place unless stated otherwise)
     if (h->projection != BEVW_PROJ_LUT) {
         BEVW_TRY(stitch_analytic(h, d_frames, batch, d_car, d_out));
-    } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok) {
-        const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
-        BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
-        hipError_t e = plan_lum_band(h->plan, h->stream, d_frames, h->tmp.as<uint8_t>(), batch, h->deltas.as<int>(),
-                                     h->hsv.as<HsvTables>());
-        if (e != hipSuccess) return fail(BEVW_E_HIP, "k_lum_band launch failed: %s", hipGetErrorString(e));
-        // the gain pass reads the pre-gain BEV from a buffer of its own instead of rewriting the output in place: a read stream
-        // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
-        // one more BEV batch of HBM (0.9 GB at batch 256)
-        static const int oop = [] { const char *s = getenv("BEVW_GAIN_OOP"); return s ? atoi(s) : 1; }();
-        // (no room for it: the gain pass runs in place, as before round 2 -- never an error)
-        if (oop && npx % 4 == 0 && h->pre.reserve(npx * 3 * (size_t)batch) == BEVW_OK) gain_in = h->pre.as<uint8_t>();
-        BEVW_TRY(plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr,
-                             h->chsums.as<unsigned long long>(), gain_in, true));
     } else if (h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4) {
         BEVW_TRY(plan_stitch(h->plan, h->stream, d_frames, batch, c.blend != 0, c.balance != 0, h->deltas.as<int>(),
                              h->hsv.as<HsvTables>(), d_car, h->chsums.as<unsigned long long>(), d_out));
@@ -1071,22 +938,10 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
         const uint8_t *gain_car = d_car;
         if (pitched && d_car) {   // the gain pass walks the image as a flat array: the sprite needs the same row pitch
             BEVW_TRY(h->car_pitched.reserve(npx * 3));
-            hipLaunchKernelGGL(k_plan_pad, dim3((unsigned)((npx * 3 + 255) / 256)), dim3(256), 0, h->stream, d_car, c.bev_width, h->pitch_px,
-                               c.bev_height, h->car_pitched.as<uint8_t>());
+            BEVW_TRY(plan_pad_image(h->stream, d_car, c.bev_width, h->pitch_px, c.bev_height, h->car_pitched.as<uint8_t>()));
             gain_car = h->car_pitched.as<uint8_t>();
         }
-        for (int b0 = 0; b0 < batch; b0 += 65535) {
-            const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-            if (npx % 4 == 0 && aligned4)
-                hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, h->stream, gain_in + (size_t)b0 * npx * 3, npx,
-                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_car, d_out + (size_t)b0 * npx * 3, 32u,
-                                   (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1, npx_true);
-            else
-                hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, h->stream, d_out + (size_t)b0 * npx * 3, npx,
-                                   h->chsums.as<unsigned long long>() + (size_t)b0 * 3, d_car, d_out + (size_t)b0 * npx * 3,
-                                   h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1);
-        }
-        BEVW_TRY(launch_check("k_gain"));
+        BEVW_TRY(gain_pass(h, h->stream, d_out, gain_car, d_car, d_out, 0, batch, npx % 4 == 0 && aligned4));
     }
     return BEVW_OK;
 }
@@ -1112,8 +967,9 @@ int bevw_create(const bevw_config *cfg, bevw_handle **out)
     bevw_handle *h = new (std::nothrow) bevw_handle();
     if (!h) return fail(BEVW_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
-    if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
-        hipEventCreate(&h->ev1) != hipSuccess) {
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+        hipEventCreate(&h->ev1) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_skew, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         bevw_destroy(h);
         return fail(BEVW_E_HIP, "stream/event creation failed");
     }
@@ -1224,7 +1080,7 @@ int bevw_build(bevw_handle *h)
     }
     // (seam block tiles: measured +0.7 % slower under the per-tile channel sums of the balance path, -1.4 .. -1.8 % without: sweeps.log)
     h->pitch_px = h->pitch_request == BEVW_PITCH_DENSE ? bw : (h->pitch_request == BEVW_PITCH_ALIGNED ? (bw + 63) / 64 * 64 : h->pitch_request);
-    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams, cfg.balance == 0, h->pitch_px != bw ? h->pitch_px : 0, cfg.blend != 0));
+    BEVW_TRY(plan_build(h->plan, st, T, cfg.frame_width, cfg.frame_height, bw, bh, ncams, h->pitch_px != bw ? h->pitch_px : 0, cfg.blend != 0));
     if (h->shard_n) {
         if (!h->plan.usable) return fail(BEVW_E_INVALID, "camera shard needs the tile plan: %d contributors on some pixel", h->plan.max_contrib);
         // bounding box of the owned masks, widened to multiples of 4 pixels in x so that packed rows stay dword aligned
@@ -1279,6 +1135,8 @@ void bevw_destroy(bevw_handle *h)
         h->laps.release();
         if (h->ev0) (void)hipEventDestroy(h->ev0);
         if (h->ev1) (void)hipEventDestroy(h->ev1);
+        for (hipEvent_t e : {h->ev_fork, h->ev_skew, h->ev_join}) if (e) (void)hipEventDestroy(e);
+        if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
         if (h->stream) (void)hipStreamDestroy(h->stream);
     }
     delete h;
@@ -1337,13 +1195,8 @@ int bevw_plan_info(bevw_handle *h, int32_t info[8])
     info[2] = h->schedule_in_use;
     info[3] = h->plan.tiles_x;
     info[4] = h->plan.tiles_y;
-    if (plan_tuning().staged && h->plan.paired_ok) {
-        for (int c = 0; c < Plan::kPairClasses; ++c) info[5] += h->plan.n_pr[c];   // tiles on the pair-staged schedules (bevw_pair.h, bevw_block.h)
-        info[5] += h->plan.n_bt_tiles;
-        info[6] = h->plan.n_rp_single + h->plan.n_rp_double;      // single / double tiles left on the L1-gather kernels
-    } else {
-        info[6] = h->plan.n_single + h->plan.n_double;
-    }
+    info[5] = h->plan.n_unit_tiles;   // base tiles on the unit schedule (bevw_unit.h)
+    info[6] = 0;                      // (rounds 1 - 3: tiles on the L1-gather kernels; retired)
     info[7] = h->plan.n_slow;
     return BEVW_OK;
 }
@@ -1555,9 +1408,7 @@ int bevw_shard_run_device(bevw_handle *h, const void *d_frames, int batch, const
     if (bal_mode == 1 && h->plan.band_ok) {
         const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 3 * h->shard_n;
         BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
-        hipError_t e = plan_lum_band(h->plan, h->stream, frames, h->tmp.as<uint8_t>(), batch, h->sdeltas.as<int>(),
-                                     h->hsv.as<HsvTables>());
-        if (e != hipSuccess) return fail(BEVW_E_HIP, "k_lum_groups launch failed: %s", hipGetErrorString(e));
+        BEVW_TRY(plan_lum_groups(h->plan, h->stream, frames, h->tmp.as<uint8_t>(), batch, h->sdeltas.as<int>(), h->hsv.as<HsvTables>()));
         return plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr, nullptr,
                            (uint8_t *)d_out);
     }
@@ -1868,498 +1719,3 @@ int bevw_timer_stop(bevw_handle *h, float *elapsed_ms)
 }
 
 }  // extern "C"
-
-// ---------------------------------------------------------------------------------------------------------------
-// JPEG either side of the path: cv2.imread (main.py:74-77) / cv2.imwrite (surroundBEV.py:340)
-// ---------------------------------------------------------------------------------------------------------------
-struct PinnedBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    PinnedBuf() = default;
-    PinnedBuf(const PinnedBuf &) = delete;
-    PinnedBuf &operator=(const PinnedBuf &) = delete;
-    ~PinnedBuf() { release(); }
-    int reserve(size_t n)
-    {
-        if (n <= cap) return BEVW_OK;
-        release();
-        hipError_t e = hipHostMalloc(&p, n, hipHostMallocDefault);
-        if (e != hipSuccess) { p = nullptr; return fail(BEVW_E_NOMEM, "hipHostMalloc(%zu) failed: %s", n, hipGetErrorString(e)); }
-        cap = n;
-        return BEVW_OK;
-    }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
-};
-
-struct bevw_jpeg {
-    int device = 0;
-    hipStream_t st = nullptr, st2 = nullptr;   // st2: the odd slices of a decode batch
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    LapTimer timer;
-    // decode: what bevw_jpeg_decode_stage left on the device
-    jpg::Geom G{};
-    int n = 0;
-    bool staged = false, decoded = false;
-    size_t total_sub = 0;
-    uint32_t max_sub = 0;
-    PinnedBuf h_stream;
-    std::vector<jpg::ImageDesc> h_desc;
-    std::vector<uint32_t> h_term;
-    std::vector<jpg::TableSet> h_tabs;
-    std::vector<uint16_t> h_quant;
-    DevBuf d_raw, d_stream, d_desc, d_seg_byte, d_seg_sub, d_term, d_nrst, d_chunk_keep, d_chunk_rst, d_tabs, d_quant;
-    DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_word0, d_cols, d_rounds, d_coef, d_planes, d_img;
-    // encode
-    jpg::Geom EG{};
-    int en = 0, e_quality = -1, e_sampling = -1;
-    jpg::EncTables etabs;
-    std::vector<uint8_t> header;
-    DevBuf d_etabs, d_header, d_eplanes, d_zz, d_acbits, d_dcq, d_bitlen, d_bitbuf, d_totals, d_chunk_ff, d_files, d_sizes, d_src;
-    size_t buf_words = 0, file_cap = 0;
-    std::vector<uint32_t> sizes;
-    bool encoded = false, sizes_valid = false;
-};
-
-static int jpeg_parse_fail(int st, int index, const std::string &why)
-{
-    return fail(BEVW_E_INVALID, "JPEG %d: %s%s", index, st == jpg::kParseUnsupported ? "outside the supported subset: " : "", why.c_str());
-}
-
-int bevw_jpeg_probe(const uint8_t *data, size_t len, int32_t info[8])
-{
-    if (!data || !info) return fail(BEVW_E_INVALID, "bevw_jpeg_probe: null argument");
-    jpg::Parsed P;
-    std::string why;
-    const int st = jpg::parse_header(data, len, P, why);
-    if (st) return jpeg_parse_fail(st, 0, why);
-    info[0] = P.w; info[1] = P.h; info[2] = P.nc; info[3] = P.hs; info[4] = P.vs; info[5] = P.ri; info[6] = P.orientation; info[7] = 0;
-    return BEVW_OK;
-}
-
-int bevw_jpeg_create(int device, bevw_jpeg **out)
-{
-    if (!out) return fail(BEVW_E_INVALID, "bevw_jpeg_create: null out");
-    *out = nullptr;
-    BEVW_TRY(use_device(device));
-    bevw_jpeg *j = new (std::nothrow) bevw_jpeg();
-    if (!j) return fail(BEVW_E_NOMEM, "out of host memory");
-    j->device = device;
-    hipError_t e = hipStreamCreateWithFlags(&j->st, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&j->st2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_a, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_b, hipEventDisableTiming);
-    if (e != hipSuccess) { bevw_jpeg_destroy(j); return fail(BEVW_E_HIP, "stream / event creation failed: %s", hipGetErrorString(e)); }
-    *out = j;
-    return BEVW_OK;
-}
-
-void bevw_jpeg_destroy(bevw_jpeg *j)
-{
-    if (!j) return;
-    (void)hipSetDevice(j->device);
-    if (j->st2) { (void)hipStreamSynchronize(j->st2); (void)hipStreamDestroy(j->st2); }
-    if (j->st) { (void)hipStreamSynchronize(j->st); (void)hipStreamDestroy(j->st); }
-    if (j->ev_a) (void)hipEventDestroy(j->ev_a);
-    if (j->ev_b) (void)hipEventDestroy(j->ev_b);
-    j->timer.release();
-    delete j;
-}
-
-int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_t *len, int n)
-{
-    if (!j || !data || !len || n <= 0 || n > 65535) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_stage: bad argument (1 <= n <= 65535)");
-    BEVW_TRY(use_device(j->device));
-    HIP_TRY(hipStreamSynchronize(j->st));   // the staging buffers of the previous batch may still be in flight
-    j->staged = j->decoded = false;
-    std::vector<jpg::Parsed> P((size_t)n);
-    std::vector<size_t> slot_off((size_t)n + 1, 0);
-    for (int i = 0; i < n; ++i) {
-        std::string why;
-        if (!data[i]) return fail(BEVW_E_INVALID, "JPEG %d: null pointer", i);
-        const int st = jpg::parse_header(data[i], len[i], P[i], why);
-        if (st) return jpeg_parse_fail(st, i, why);
-        if (i && (P[i].w != P[0].w || P[i].h != P[0].h || P[i].nc != P[0].nc || P[i].hs != P[0].hs || P[i].vs != P[0].vs))
-            return fail(BEVW_E_INVALID, "JPEG %d is %dx%d (%d components, luma %dx%d) but the batch is %dx%d (%d, %dx%d): one geometry per batch", i,
-                        P[i].w, P[i].h, P[i].nc, P[i].hs, P[i].vs, P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
-        slot_off[i + 1] = slot_off[i] + (((len[i] - P[i].scan_off + 32 + 15) & ~(size_t)15) + 16);
-    }
-    const size_t bound = slot_off[n];
-    if (bound >= ((size_t)1 << 32)) return fail(BEVW_E_INVALID, "batch of %zu entropy-coded bytes: split it (4 GiB per batch)", bound);
-    j->G = jpg::make_geom(P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
-    const jpg::Geom &G = j->G;
-    BEVW_TRY(j->h_stream.reserve(bound));
-    j->h_desc.assign((size_t)n, jpg::ImageDesc());
-    j->h_term.assign((size_t)n, 0);
-    j->h_tabs.clear();
-    j->h_quant.assign((size_t)n * 192, 0);
-    std::vector<std::string> keys;
-    size_t seg_total = 0, sub_total = 0, chunk_total = 0;
-    uint32_t max_sub = 0, max_chunk = 0;
-    const uint32_t nmcu = (uint32_t)G.mcux * (uint32_t)G.mcuy;
-    for (int i = 0; i < n; ++i) {
-        jpg::ImageDesc &D = j->h_desc[i];
-        // tables: identical table sets are shared (cameras of one rig write the same ones)
-        std::string key;
-        for (int c = 0; c < P[i].nc; ++c) {
-            key.append((const char *)&P[i].dc[P[i].td[c]], sizeof(jpg::RawHuff));
-            key.append((const char *)&P[i].ac[P[i].ta[c]], sizeof(jpg::RawHuff));
-        }
-        size_t t = 0;
-        while (t < keys.size() && keys[t] != key) ++t;
-        if (t == keys.size()) {
-            jpg::TableSet T;
-            memset(&T, 0, sizeof T);
-            for (int c = 0; c < P[i].nc; ++c)
-                if (!jpg::make_hufftab(P[i].dc[P[i].td[c]], T.t[2 * c]) || !jpg::make_hufftab(P[i].ac[P[i].ta[c]], T.t[2 * c + 1]))
-                    return fail(BEVW_E_INVALID, "JPEG %d: over-subscribed Huffman table", i);
-            keys.push_back(key);
-            j->h_tabs.push_back(T);
-        }
-        D.tables = (uint32_t)t;
-        D.quant = (uint32_t)i;
-        for (int c = 0; c < P[i].nc; ++c) memcpy(&j->h_quant[(size_t)i * 192 + c * 64], P[i].q[P[i].tq[c]], 128);
-        // what the un-stuffing kernels need: the slot, the raw length, the segments DRI promises, room for the subsequences
-        const uint32_t raw = (uint32_t)(len[i] - P[i].scan_off);
-        if (raw < 2) return fail(BEVW_E_INVALID, "JPEG %d: no entropy-coded data behind the scan header", i);
-        D.stream_word = (uint32_t)(slot_off[i] >> 2);
-        D.raw_bytes = raw;
-        D.nseg = P[i].ri ? (nmcu + (uint32_t)P[i].ri - 1) / (uint32_t)P[i].ri : 1u;
-        D.seg_blocks = P[i].ri ? (uint32_t)P[i].ri * (uint32_t)G.bpm : jpg::kNoRestart;
-        D.seg_first = (uint32_t)seg_total;
-        D.sub_first = (uint32_t)sub_total;
-        D.chunk_first = (uint32_t)chunk_total;
-        const uint32_t sub_ub = (raw * 8u + (uint32_t)jpg::kSubBits - 1u) / (uint32_t)jpg::kSubBits + D.nseg;   // every segment rounds up once
-        const uint32_t chunks = std::max(1u, (raw + jpg::kRawChunk - 1u) / jpg::kRawChunk);
-        seg_total += D.nseg + 1;
-        sub_total += sub_ub;
-        chunk_total += chunks;
-        max_sub = std::max(max_sub, sub_ub);
-        max_chunk = std::max(max_chunk, chunks);
-        j->h_term[i] = raw;
-    }
-    if (sub_total >= ((size_t)1 << 31)) return fail(BEVW_E_INVALID, "batch too large");
-    // The staging copy is a plain copy of the entropy-coded bytes (dealt over host threads); the GPU removes the stuffing.
-    {
-        static const int threads_env = [] { const char *e = getenv("BEVW_JPEG_HOST_THREADS"); return e ? atoi(e) : 0; }();
-        int nt = threads_env > 0 ? threads_env : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-        nt = std::max(1, std::min(nt, n / 8));   // a thread per >= 8 files, else not worth starting
-        auto work = [&](int t) {
-            for (int i = t; i < n; i += nt) {
-                uint8_t *dst = (uint8_t *)j->h_stream.p + slot_off[i];
-                const size_t raw = len[i] - P[i].scan_off;
-                memcpy(dst, data[i] + P[i].scan_off, raw);
-                memset(dst + raw, 0, slot_off[i + 1] - slot_off[i] - raw);
-            }
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
-        work(0);
-        for (std::thread &th : pool) th.join();
-    }
-    j->n = n;
-    j->total_sub = sub_total;
-    j->max_sub = max_sub;
-    BEVW_TRY(j->d_raw.reserve(bound + 64));
-    BEVW_TRY(j->d_stream.reserve(bound + 1024));   // k_jpeg_columns copies a fixed kColWords words per subsequence, and a lane finishing a block of corrupt data can run ~250 bytes past the end
-    BEVW_TRY(j->d_desc.reserve(j->h_desc.size() * sizeof(jpg::ImageDesc)));
-    BEVW_TRY(j->d_seg_byte.reserve(seg_total * 4));
-    BEVW_TRY(j->d_seg_sub.reserve(seg_total * 4));
-    BEVW_TRY(j->d_term.reserve((size_t)n * 4));
-    BEVW_TRY(j->d_nrst.reserve((size_t)n * 4));
-    BEVW_TRY(j->d_chunk_keep.reserve(chunk_total * 4));
-    BEVW_TRY(j->d_chunk_rst.reserve(chunk_total * 4));
-    BEVW_TRY(j->d_tabs.reserve(j->h_tabs.size() * sizeof(jpg::TableSet)));
-    BEVW_TRY(j->d_quant.reserve(j->h_quant.size() * 2));
-    HIP_TRY(hipMemcpyAsync(j->d_raw.p, j->h_stream.p, bound, hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size() * sizeof(jpg::ImageDesc), hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemcpyAsync(j->d_term.p, j->h_term.data(), (size_t)n * 4, hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemsetAsync(j->d_nrst.p, 0xFF, (size_t)n * 4, j->st));   // an image no kernel closes can never pass k_jpeg_subs' check
-    HIP_TRY(hipMemcpyAsync(j->d_tabs.p, j->h_tabs.data(), j->h_tabs.size() * sizeof(jpg::TableSet), hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemcpyAsync(j->d_quant.p, j->h_quant.data(), j->h_quant.size() * 2, hipMemcpyHostToDevice, j->st));
-    // un-stuffing on the device: where the data ends, what stays, where the restart segments start, the subsequences
-    jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
-    const uint8_t *raw = j->d_raw.as<uint8_t>();
-    const dim3 gc(max_chunk, (unsigned)n);
-    jpg::k_jpeg_find_end<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_find_end"));
-    jpg::k_jpeg_count_raw<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_count_raw"));
-    jpg::k_jpeg_unstuff<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>(),
-                                                j->d_stream.as<uint8_t>(), j->d_seg_byte.as<uint32_t>(), j->d_nrst.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_unstuff"));
-    jpg::k_jpeg_subs<<<(unsigned)n, 256, 0, j->st>>>(img, j->d_nrst.as<uint32_t>(), j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_subs"));
-    j->staged = true;
-    return BEVW_OK;
-}
-
-int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_bytes, size_t row_pitch_bytes)
-{
-    if (!j || !d_out) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_run_device: null argument");
-    if (!j->staged) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_run_device before bevw_jpeg_decode_stage");
-    const jpg::Geom &G = j->G;
-    if (row_pitch_bytes < (size_t)G.w * 3 || image_stride_bytes < row_pitch_bytes * (size_t)G.h)
-        return fail(BEVW_E_INVALID, "output layout (pitch %zu, stride %zu) too small for %dx%d BGR", row_pitch_bytes, image_stride_bytes, G.w, G.h);
-    BEVW_TRY(use_device(j->device));
-    const size_t ns = j->total_sub ? j->total_sub : 1, n = (size_t)j->n;
-    BEVW_TRY(j->d_entry.reserve(ns * 8));
-    BEVW_TRY(j->d_exit.reserve(ns * 8));
-    BEVW_TRY(j->d_exit2.reserve(ns * 8));
-    BEVW_TRY(j->d_sums.reserve(ns * 16));
-    BEVW_TRY(j->d_base.reserve(ns * 16));
-    BEVW_TRY(j->d_endbit.reserve(ns * 4));
-    BEVW_TRY(j->d_meta.reserve(ns * 4));
-    BEVW_TRY(j->d_word0.reserve(ns * 4));
-    BEVW_TRY(j->d_cols.reserve(ns * 4 * (size_t)jpg::kColWords));
-    BEVW_TRY(j->d_rounds.reserve(n * 4));
-    BEVW_TRY(j->d_coef.reserve(n * (size_t)G.nblk * 128));
-    BEVW_TRY(j->d_planes.reserve(n * (size_t)G.plane_bytes));
-    jpg::SubArrays A{j->d_entry.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_sums.as<int4>(), j->d_base.as<int4>(), j->d_endbit.as<uint32_t>(),
-                     j->d_meta.as<uint32_t>(), j->d_word0.as<uint32_t>(), j->d_cols.as<uint32_t>()};
-    const jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
-    const uint32_t *stream = j->d_stream.as<uint32_t>();
-    const jpg::TableSet *tabs = j->d_tabs.as<jpg::TableSet>();
-    // (no zero fill of the coefficient buffer: k_jpeg_coef stores every block whole)
-    // The batch runs as `parts` independent slices alternating over two streams: the tail of the synchronisation (a few lanes per image
-    // walking their subsequences again, the rest of the chip idle) of one slice overlaps the throughput-bound kernels of the other.
-    static const int parts_env = [] { const char *e = getenv("BEVW_JPEG_PARTS"); return e ? atoi(e) : 0; }();
-    const size_t parts = parts_env > 0 ? std::min<size_t>((size_t)parts_env, n) : (n >= 32 ? 2 : 1);   // measured: 2 slices -6 %, 4 and more lose (launches too small)
-    const bool aligned = (uintptr_t)d_out % 4 == 0 && image_stride_bytes % 4 == 0 && row_pitch_bytes % 4 == 0;
-    if (parts > 1) {
-        HIP_TRY(hipEventRecord(j->ev_a, j->st));          // the staging copies were enqueued on st
-        HIP_TRY(hipStreamWaitEvent(j->st2, j->ev_a, 0));
-    }
-    for (size_t part = 0; part < parts; ++part) {
-        const size_t first = n * part / parts, m = n * (part + 1) / parts - first;
-        if (!m) continue;
-        hipStream_t st = (part & 1) ? j->st2 : j->st;
-        const jpg::ImageDesc *im = img + first;
-        int16_t *coef = j->d_coef.as<int16_t>() + first * (size_t)G.nblk * 64;
-        uint8_t *planes = j->d_planes.as<uint8_t>() + first * (size_t)G.plane_bytes;
-        if (j->max_sub) {
-            const dim3 gs((j->max_sub + 255) / 256, (unsigned)m);
-            jpg::k_jpeg_columns<<<gs, 256, 0, st>>>(im, stream, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>(), A);
-            BEVW_TRY(launch_check("k_jpeg_columns"));
-            jpg::k_jpeg_sync0<<<gs, 256, 0, st>>>(im, stream, tabs, G, A);
-            BEVW_TRY(launch_check("k_jpeg_sync0"));
-            // two full-occupancy rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
-            jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit.as<uint64_t>(), j->d_exit2.as<uint64_t>());
-            BEVW_TRY(launch_check("k_jpeg_sync_round"));
-            jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>());
-            BEVW_TRY(launch_check("k_jpeg_sync_round"));
-            jpg::k_jpeg_sync<<<(unsigned)m, jpg::kSyncThreads, 0, st>>>(im, stream, tabs, G, A, j->d_rounds.as<uint32_t>() + first);
-            BEVW_TRY(launch_check("k_jpeg_sync"));
-            jpg::k_jpeg_coef<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, coef);
-            BEVW_TRY(launch_check("k_jpeg_coef"));
-        }
-        jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)m), 256, 0, st>>>(im, G, coef, j->d_quant.as<uint16_t>(), planes);
-        BEVW_TRY(launch_check("k_jpeg_idct"));
-        uint8_t *dst = (uint8_t *)d_out + first * image_stride_bytes;
-        if (aligned && G.nc == 3 && G.hs == 2 && G.vs == 2 && G.dw > 2) {
-            jpg::k_jpeg_color_h2v2<<<dim3(((G.w + 7) / 8 + 63) / 64, (G.h + 3) / 4, (unsigned)m), dim3(64, 4), 0, st>>>(G, planes, dst, image_stride_bytes,
-                                                                                                                           row_pitch_bytes);
-            BEVW_TRY(launch_check("k_jpeg_color_h2v2"));
-        } else {
-            jpg::k_jpeg_color<<<dim3(((G.w + 3) / 4 + 63) / 64, (G.h + 3) / 4, (unsigned)m), dim3(64, 4), 0, st>>>(G, planes, dst, image_stride_bytes,
-                                                                                                                      row_pitch_bytes);
-            BEVW_TRY(launch_check("k_jpeg_color"));
-        }
-    }
-    if (parts > 1) {   // everything the caller enqueues on st afterwards (and bevw_jpeg_sync) sees the whole batch
-        HIP_TRY(hipEventRecord(j->ev_b, j->st2));
-        HIP_TRY(hipStreamWaitEvent(j->st, j->ev_b, 0));
-    }
-    j->decoded = true;
-    return BEVW_OK;
-}
-
-int bevw_jpeg_decode(bevw_jpeg *j, const uint8_t *const *data, const size_t *len, int n, uint8_t *out)
-{
-    if (!out) return fail(BEVW_E_INVALID, "bevw_jpeg_decode: null out");
-    BEVW_TRY(bevw_jpeg_decode_stage(j, data, len, n));
-    const size_t image = (size_t)j->G.w * j->G.h * 3;
-    BEVW_TRY(j->d_img.reserve(image * (size_t)n));
-    BEVW_TRY(bevw_jpeg_decode_run_device(j, j->d_img.p, image, (size_t)j->G.w * 3));
-    HIP_TRY(hipMemcpyAsync(out, j->d_img.p, image * (size_t)n, hipMemcpyDeviceToHost, j->st));
-    HIP_TRY(hipStreamSynchronize(j->st));
-    int64_t info[8];
-    BEVW_TRY(bevw_jpeg_decode_info(j, info));
-    if (info[6])
-        return fail(BEVW_E_INVALID, "%lld of the %d files end before their image is complete (truncated / corrupt entropy-coded data)", (long long)info[6], n);
-    return BEVW_OK;
-}
-
-int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8])
-{
-    if (!j || !info) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_info: null argument");
-    if (!j->staged) return fail(BEVW_E_INVALID, "nothing staged");
-    BEVW_TRY(use_device(j->device));
-    int64_t rounds = 0, short_images = 0;
-    if (j->decoded && j->max_sub) {
-        std::vector<uint32_t> r((size_t)j->n);
-        HIP_TRY(hipMemcpyAsync(r.data(), j->d_rounds.p, r.size() * 4, hipMemcpyDeviceToHost, j->st));
-        HIP_TRY(hipStreamSynchronize(j->st));
-        for (uint32_t v : r) {
-            rounds = std::max<int64_t>(rounds, v & 0x7fffffffu);
-            short_images += v >> 31;
-        }
-    }
-    std::vector<jpg::ImageDesc> desc((size_t)j->n);   // stream_bytes / nsub are written by the un-stuffing kernels
-    HIP_TRY(hipMemcpyAsync(desc.data(), j->d_desc.p, desc.size() * sizeof(jpg::ImageDesc), hipMemcpyDeviceToHost, j->st));
-    HIP_TRY(hipStreamSynchronize(j->st));
-    size_t stream_bytes = 0, subs = 0;
-    for (const jpg::ImageDesc &D : desc) { stream_bytes += D.stream_bytes; subs += D.nsub; if (D.error && !(j->decoded && j->max_sub)) ++short_images; }
-    info[0] = j->n; info[1] = j->G.w; info[2] = j->G.h; info[3] = (int64_t)subs; info[4] = rounds; info[5] = (int64_t)stream_bytes;
-    info[6] = short_images; info[7] = (int64_t)j->h_tabs.size();
-    return BEVW_OK;
-}
-
-int bevw_jpeg_get_planes(bevw_jpeg *j, int index, uint8_t *planes)
-{
-    if (!j || !planes || !j->decoded || index < 0 || index >= j->n) return fail(BEVW_E_INVALID, "bevw_jpeg_get_planes: nothing decoded / bad index");
-    BEVW_TRY(use_device(j->device));
-    HIP_TRY(hipMemcpyAsync(planes, j->d_planes.as<uint8_t>() + (size_t)index * j->G.plane_bytes, (size_t)j->G.plane_bytes, hipMemcpyDeviceToHost, j->st));
-    HIP_TRY(hipStreamSynchronize(j->st));
-    return BEVW_OK;
-}
-
-int bevw_jpeg_encode_bound(int width, int height, int sampling, size_t *bound)
-{
-    const int hs = sampling >> 4, vs = sampling & 15;
-    if (!bound || width <= 0 || height <= 0 || width > 65500 || height > 65500 || !((hs == 1 && vs == 1) || (hs == 2 && vs == 1) || (hs == 2 && vs == 2)))
-        return fail(BEVW_E_INVALID, "bevw_jpeg_encode_bound: bad size / sampling (0x11, 0x21, 0x22)");
-    const jpg::Geom G = jpg::make_geom(width, height, 3, hs, vs);
-    *bound = 1024 + (size_t)G.nblk * 209 * 2;   // header + every block at its longest, every byte stuffed
-    return BEVW_OK;
-}
-
-int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int width, int height, size_t image_stride_bytes, size_t row_pitch_bytes,
-                                int quality, int sampling)
-{
-    if (!j || !d_bgr || n <= 0 || n > 65535) return fail(BEVW_E_INVALID, "bevw_jpeg_encode_run_device: bad argument (1 <= n <= 65535)");
-    size_t bound = 0;
-    BEVW_TRY(bevw_jpeg_encode_bound(width, height, sampling, &bound));
-    if (quality < 1 || quality > 100) return fail(BEVW_E_INVALID, "JPEG quality %d outside 1..100", quality);
-    if (row_pitch_bytes < (size_t)width * 3 || image_stride_bytes < row_pitch_bytes * (size_t)height)
-        return fail(BEVW_E_INVALID, "input layout (pitch %zu, stride %zu) too small for %dx%d BGR", row_pitch_bytes, image_stride_bytes, width, height);
-    BEVW_TRY(use_device(j->device));
-    j->encoded = j->sizes_valid = false;
-    const jpg::Geom G = jpg::make_geom(width, height, 3, sampling >> 4, sampling & 15);
-    if (quality != j->e_quality || sampling != j->e_sampling || width != j->EG.w || height != j->EG.h) {
-        HIP_TRY(hipStreamSynchronize(j->st));
-        jpg::make_enc_tables(quality, j->etabs);
-        j->header = jpg::make_file_header(width, height, G.hs, G.vs, j->etabs);
-        BEVW_TRY(j->d_etabs.reserve(sizeof(jpg::EncTables)));
-        BEVW_TRY(j->d_header.reserve(j->header.size()));
-        HIP_TRY(hipMemcpyAsync(j->d_etabs.p, &j->etabs, sizeof(jpg::EncTables), hipMemcpyHostToDevice, j->st));
-        HIP_TRY(hipMemcpyAsync(j->d_header.p, j->header.data(), j->header.size(), hipMemcpyHostToDevice, j->st));
-        j->e_quality = quality;
-        j->e_sampling = sampling;
-    }
-    j->EG = G;
-    j->en = n;
-    const size_t N = (size_t)n;
-    j->buf_words = ((size_t)G.nblk * 209 + 3) / 4 + 4;
-    j->file_cap = (j->header.size() + j->buf_words * 8 + 16 + 15) & ~(size_t)15;   // every byte stuffed + EOI: cannot overflow
-    BEVW_TRY(j->d_eplanes.reserve(N * (size_t)G.plane_bytes));
-    BEVW_TRY(j->d_zz.reserve(N * (size_t)G.nblk * 128));
-    BEVW_TRY(j->d_bitlen.reserve(N * (size_t)G.nblk * 4));
-    BEVW_TRY(j->d_bitbuf.reserve(N * j->buf_words * 4));
-    BEVW_TRY(j->d_totals.reserve(N * 8));
-    BEVW_TRY(j->d_files.reserve(N * j->file_cap));
-    BEVW_TRY(j->d_sizes.reserve(N * 4));
-    const jpg::EncTables *tabs = j->d_etabs.as<jpg::EncTables>();
-    jpg::k_jenc_ycc<<<dim3((G.wb[1] * 8 + 63) / 64, (G.hb[1] * 8 + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
-        G, (const uint8_t *)d_bgr, image_stride_bytes, row_pitch_bytes, j->d_eplanes.as<uint8_t>());
-    BEVW_TRY(launch_check("k_jenc_ycc"));
-    BEVW_TRY(j->d_acbits.reserve(N * (size_t)G.nblk * 2));
-    BEVW_TRY(j->d_dcq.reserve(N * (size_t)G.nblk * 2));
-    const uint32_t nchunk = (uint32_t)((j->buf_words * 4 + jpg::kStuffChunk - 1) / jpg::kStuffChunk);
-    BEVW_TRY(j->d_chunk_ff.reserve(N * nchunk * 4));
-    jpg::k_jenc_fdct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(G, j->d_eplanes.as<uint8_t>(), tabs, j->d_zz.as<int16_t>(),
-                                                                                 j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>());
-    BEVW_TRY(launch_check("k_jenc_fdct"));
-    jpg::k_jenc_scan<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(G, j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>(),
-                                                                    j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jenc_scan"));
-    jpg::k_jenc_bits<<<dim3((G.nblk + 255) / 256, (unsigned)n), 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), j->d_dcq.as<int16_t>(), tabs,
-                                                                                   j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words);
-    BEVW_TRY(launch_check("k_jenc_bits"));
-    jpg::k_jenc_ffcount<<<dim3(nchunk, (unsigned)n), 256, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
-                                                                        j->d_chunk_ff.as<uint32_t>(), nchunk);
-    BEVW_TRY(launch_check("k_jenc_ffcount"));
-    jpg::k_jenc_stuff<<<dim3(nchunk, (unsigned)n), 256, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
-                                                                      j->d_chunk_ff.as<uint32_t>(), nchunk, j->d_header.as<uint8_t>(),
-                                                                      (uint32_t)j->header.size(), j->d_files.as<uint8_t>(), j->file_cap,
-                                                                      j->d_sizes.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jenc_stuff"));
-    j->encoded = true;
-    return BEVW_OK;
-}
-
-int bevw_jpeg_encoded_sizes(bevw_jpeg *j, size_t *sizes)
-{
-    if (!j || !sizes || !j->encoded) return fail(BEVW_E_INVALID, "bevw_jpeg_encoded_sizes: nothing encoded");
-    BEVW_TRY(use_device(j->device));
-    if (!j->sizes_valid) {
-        j->sizes.assign((size_t)j->en, 0);
-        HIP_TRY(hipMemcpyAsync(j->sizes.data(), j->d_sizes.p, (size_t)j->en * 4, hipMemcpyDeviceToHost, j->st));
-        HIP_TRY(hipStreamSynchronize(j->st));
-        j->sizes_valid = true;
-    }
-    for (int i = 0; i < j->en; ++i) {
-        if (!j->sizes[i]) return fail(BEVW_E_HIP, "image %d overflowed its file buffer (internal error)", i);
-        sizes[i] = j->sizes[i];
-    }
-    return BEVW_OK;
-}
-
-int bevw_jpeg_encoded_copy(bevw_jpeg *j, int index, uint8_t *dst, size_t cap)
-{
-    if (!j || !dst || !j->encoded || index < 0 || index >= j->en) return fail(BEVW_E_INVALID, "bevw_jpeg_encoded_copy: nothing encoded / bad index");
-    if (!j->sizes_valid) {
-        std::vector<size_t> tmp((size_t)j->en);
-        BEVW_TRY(bevw_jpeg_encoded_sizes(j, tmp.data()));
-    }
-    if (cap < j->sizes[index]) return fail(BEVW_E_INVALID, "file %d needs %u bytes, %zu given", index, j->sizes[index], cap);
-    BEVW_TRY(use_device(j->device));
-    HIP_TRY(hipMemcpyAsync(dst, j->d_files.as<uint8_t>() + (size_t)index * j->file_cap, j->sizes[index], hipMemcpyDeviceToHost, j->st));
-    HIP_TRY(hipStreamSynchronize(j->st));
-    return BEVW_OK;
-}
-
-int bevw_jpeg_encode(bevw_jpeg *j, const uint8_t *bgr, int n, int width, int height, int quality, int sampling, uint8_t *out, size_t cap_each,
-                     size_t *sizes)
-{
-    if (!j || !bgr || !out || !sizes || n <= 0) return fail(BEVW_E_INVALID, "bevw_jpeg_encode: bad argument");
-    BEVW_TRY(use_device(j->device));
-    const size_t image = (size_t)width * height * 3;
-    BEVW_TRY(j->d_src.reserve(image * (size_t)n));
-    HIP_TRY(hipMemcpyAsync(j->d_src.p, bgr, image * (size_t)n, hipMemcpyHostToDevice, j->st));
-    BEVW_TRY(bevw_jpeg_encode_run_device(j, j->d_src.p, n, width, height, image, (size_t)width * 3, quality, sampling));
-    BEVW_TRY(bevw_jpeg_encoded_sizes(j, sizes));
-    for (int i = 0; i < n; ++i) BEVW_TRY(bevw_jpeg_encoded_copy(j, i, out + (size_t)i * cap_each, cap_each));
-    return BEVW_OK;
-}
-
-int bevw_jpeg_sync(bevw_jpeg *j)
-{
-    if (!j) return fail(BEVW_E_INVALID, "null jpeg context");
-    BEVW_TRY(use_device(j->device));
-    HIP_TRY(hipStreamSynchronize(j->st));
-    return BEVW_OK;
-}
-
-int bevw_jpeg_timer_mark(bevw_jpeg *j, int slot)
-{
-    if (!j) return fail(BEVW_E_INVALID, "null jpeg context");
-    BEVW_TRY(use_device(j->device));
-    return j->timer.mark(slot, j->st);
-}
-
-int bevw_jpeg_timer_between(bevw_jpeg *j, int slot_a, int slot_b, float *elapsed_ms)
-{
-    if (!j) return fail(BEVW_E_INVALID, "null jpeg context");
-    BEVW_TRY(use_device(j->device));
-    return j->timer.between(slot_a, slot_b, elapsed_ms);
-}

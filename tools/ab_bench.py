@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--workload", default="direct_stitch_b256")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--bench-args", default="", help="extra bench.py arguments for every variant, e.g. '--placements 2 --single-layout'")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
     variants = []
@@ -33,7 +34,7 @@ def main():
             e = dict(os.environ)
             e.update(env)
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", a.workload, "--steps", str(a.steps), "--warmup", "5",
-                                  "--no-cpu-baseline"], env=e, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+                                  "--no-cpu-baseline"] + a.bench_args.split(), env=e, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
             try:
                 d = json.loads(out[-1])
                 res[label].append(d["roofline"].get("kernel_ms_median") or d["roofline"]["kernel_ms"])
