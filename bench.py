@@ -83,13 +83,14 @@ def parse_args():
                          "on each; the MEDIAN placement is reported (0 = 5 for the single-engine workloads, 1 for the camera-shard one)")
     ap.add_argument("--output-pitch", default="aligned", choices=["aligned", "dense"],
                     help="row pitch of the device-resident BEV images (bevw_set_output_pitch): aligned = rows of whole 64-byte sectors "
-                         "(1080 -> 1088 pixels, cv::cuda::GpuMat style), dense = the reference's host layout; the other layout is measured "
-                         "too and reported beside the headline")
+                         "(1080 -> 1088 pixels, cv::cuda::GpuMat style; what BevGenerator's default output_pitch='auto' selects on the tile "
+                         "plan), dense = the reference's host layout; the other layout is measured too and reported beside the headline")
     ap.add_argument("--single-layout", action="store_true", help="skip the measurement of the other device-image layout (profiling runs)")
     ap.add_argument("--jpeg-source", default="synthetic", choices=["synthetic", "repo"],
                     help="jpeg_decode_b64 only: 'repo' decodes the reference's own four camera files (tests/golden/repo_rig.npz, 1280x1024, real scenes with "
                          "flat areas -- long mis-phased stretches for the parallel Huffman decoder) replicated over the batch, instead of synthetic files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f4", action="store_true", help="skip the JPEG summary (`f4`) the default single-GPU run appends to its line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -329,10 +330,24 @@ def jpeg_cpu_baseline(mode, files, images, seconds):
             "sample": f"{n} images {mode}d in {dt:.1f} s by Pillow's libjpeg-turbo (SIMD), {cores} threads"}
 
 
-def main_jpeg(a, d, w, dev):
-    """Row f4 workloads.  One step = one batch through the JPEG kernels (decode: staged streams -> frame sets; encode: device images ->
-    files in HBM; pipeline: decode + stitch + encode with the host synchronisations the three streams need)."""
-    import ctypes as C
+VALU_CLOCK_HZ = 2.4e9        # MI355X peak engine clock
+VALU_PEAK_GINST = 256 * 4 * VALU_CLOCK_HZ / 4 / 1e9   # wave64 VALU instructions per second the chip can issue: 1024 SIMDs, 4 clocks each (16 lanes wide)
+
+
+def jpeg_valu_profile(workload: str):
+    """Static per-unit instruction counts of the JPEG workloads from the committed rocprofv3 PMC pass (profiles/jpeg_valu.json: SQ_INSTS_VALU
+    summed over the kernels of one step / the units of the step), or None.  Like roofline.traffic it is a figure of the round it was
+    collected in, not a measurement of this run."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "jpeg_valu.json"))).get(workload)
+    except (OSError, ValueError):
+        return None
+
+
+def jpeg_measure(a, d, w, dev, workload, steps, warmup, cpu_seconds, host_api=True):
+    """Row f4 workloads.  One step = one batch through the JPEG kernels with the inputs resident in HBM: decode = the files' entropy-coded bytes
+    AS THEY ARE IN THE FILES -> frame sets (un-stuffing, entropy decoding, inverse DCT, colour: everything a decode needs is inside the timed
+    region); encode = device images -> complete files in HBM; pipeline = decode + stitch + encode chained by events on their streams."""
     from cameracalibration_amd import _ffi, imgcodecs, workloads as W
     from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
 
@@ -358,11 +373,12 @@ def main_jpeg(a, d, w, dev):
         sum(len(f) for f in uniq_files) // len(uniq_files), "the reference's own camera files, %dx%d" % (fw, fh) if a.jpeg_source == "repo"
         else "synthetic camera-like frames, quality 90")), "jpeg_out": "baseline 4:2:0 quality 95 (cv2.imwrite's defaults)"}
     stage_ms = None
+    bev = None
     if mode in ("decode", "pipeline"):
         codec.decode_stage(files)
         codec.sync()
         t0 = time.perf_counter()
-        for _ in range(3):   # the host side of a batch: header parsing + copy into pinned memory + H2D of the compressed bytes + the un-stuffing kernels
+        for _ in range(3):   # the host side of a batch: header parsing + copy into pinned memory + H2D of the compressed bytes
             codec.decode_stage(files)
             codec.sync()
         stage_ms = (time.perf_counter() - t0) / 3 * 1e3
@@ -382,44 +398,57 @@ def main_jpeg(a, d, w, dev):
         for k, v in cfg.items():
             setattr(ns, k, v)
         bev = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=W.rig_s(), device=dev)
+        d_bev.free()
+        d_bev = _ffi.DeviceBuffer(batch * bh * bev.out_pitch * 3, dev)
+        image = bh * bev.out_pitch * 3
 
-        def step():
+        def step():   # one asynchronous chain: the streams are ordered by events, the host does not wait in between
             codec.decode_run_device(d_frames.ptr, fh * fw * 3, fw * 3)
-            codec.sync()
+            codec.engine_waits(bev._engine.h)
             bev.run_device(d_frames.ptr, batch, None, d_bev.ptr)
-            bev.sync()
-            codec.encode_run_device(d_bev.ptr, batch, bw, bh, bh * bw * 3, bw * 3)
+            codec.wait_engine(bev._engine.h)
+            codec.encode_run_device(d_bev.ptr, batch, bw, bh, image, bev.out_pitch * 3)
         step()
         alg = 4 * (sum(len(f) for f in files) // len(files)) + sum(len(f) for f in codec.files()) // batch
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     codec.sync()
     d.barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(steps):
         codec.timer_mark(i)
         step()
-    codec.timer_mark(a.steps)
+    codec.timer_mark(steps)
     codec.sync()
     d.barrier()
     wall = d.max(time.perf_counter() - t0)
-    ev_ms = d.max(codec.timer_between(0, a.steps))
-    if mode == "pipeline":
-        # the host API on the same data, nothing resident: BevGenerator.jpeg(files) = parse + H2D + un-stuff, decode, stitch, encode, D2H of the
-        # files -- what a caller holding file bytes in host memory gets per call (no overlap between consecutive batches)
-        sets = [tuple(files[4 * b:4 * b + 4]) for b in range(batch)]
-        bev.jpeg(sets)
-        t1 = time.perf_counter()
-        reps = max(2, a.steps // 4)
-        for _ in range(reps):
-            out_files = bev.jpeg(sets)
-        host_s = (time.perf_counter() - t1) / reps
-        extra["host_api_frames_per_s"] = round(batch / host_s)
-        extra["host_api_ms_per_batch"] = round(host_s * 1e3, 3)
-        extra["host_api_note"] = ("BevGenerator.jpeg on host byte strings, PCIe and host staging included (%.1f MB of files in, %.1f MB out per batch); "
-                                  "never `value`" % (sum(len(f) for f in files) / 1e6, sum(len(f) for f in out_files) / 1e6))
+    ev_ms = d.max(codec.timer_between(0, steps))
     info = codec.decode_info() if mode != "encode" else {}
     sizes = codec.files() if mode != "decode" else []
+    if mode == "pipeline" and host_api and not os.environ.get("BEVW_BENCH_NO_HOST_API"):   # (profiling passes count the kernels of the resident steps only)
+        # the host API on the same data, nothing resident: host byte strings in, host byte strings out (PCIe and host staging included; never
+        # `value`).  jpeg_stream = consecutive batches pipelined (a host thread stages batch i + 1 and this thread fetches batch i - 1 while the
+        # GPU runs batch i); jpeg = one synchronous call per batch
+        sets = [tuple(files[4 * b:4 * b + 4]) for b in range(batch)]
+        bev.jpeg(sets)
+        reps = max(3, steps // 3)
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            out_files = bev.jpeg(sets)
+        call_s = (time.perf_counter() - t1) / reps
+        list(bev.jpeg_stream([sets] * 3))
+        nb = max(6, steps)
+        t1 = time.perf_counter()
+        for out_files in bev.jpeg_stream(sets for _ in range(nb)):
+            pass
+        stream_s = (time.perf_counter() - t1) / nb
+        extra["host_api_frames_per_s"] = round(batch / stream_s)
+        extra["host_api_ms_per_batch"] = round(stream_s * 1e3, 3)
+        extra["host_api_unpipelined_frames_per_s"] = round(batch / call_s)
+        extra["host_api_unpipelined_ms_per_batch"] = round(call_s * 1e3, 3)
+        extra["host_api_note"] = ("BevGenerator.jpeg_stream (pipelined over %d batches) / BevGenerator.jpeg (one synchronous call per batch) on host byte "
+                                  "strings, PCIe and host staging included (%.1f MB of files in, %.1f MB out per batch); never `value`" % (
+                                      nb, sum(len(f) for f in files) / 1e6, sum(len(f) for f in out_files) / 1e6))
     if mode != "encode":
         extra.update(subsequences_per_image=info["subsequences"] // info["images"], fixed_point_rounds_max=info["rounds"],
                      huffman_table_sets=info["table_sets"])
@@ -428,26 +457,63 @@ def main_jpeg(a, d, w, dev):
     if stage_ms is not None:
         extra["host_stage_ms_per_batch"] = round(stage_ms, 3)
         extra["host_stage_files_per_s"] = round(batch * 4 / (stage_ms * 1e-3))
-        extra["host_stage_note"] = ("header parsing + copy into pinned memory (host threads) + H2D of the compressed bytes + the un-stuffing kernels for one batch; "
-                                    "outside the timed region (inputs resident = staged streams); a pipelined caller overlaps it with the kernels")
+        extra["host_stage_note"] = ("header parsing + copy into pinned memory (host threads) + H2D of the compressed bytes for one batch; outside the timed "
+                                    "region (inputs resident = the files' entropy-coded bytes in HBM); jpeg_stream overlaps it with the kernels")
     cpu = None
-    if d.rank == 0 and d.world == 1 and not a.no_cpu_baseline and mode != "pipeline":
-        cpu = jpeg_cpu_baseline(mode, uniq_files, list(uniq_bev), min(a.cpu_seconds, 8.0))
-    launch_ms = ev_ms / a.steps
+    if d.rank == 0 and d.world == 1 and cpu_seconds > 0 and mode != "pipeline":
+        cpu = jpeg_cpu_baseline(mode, uniq_files, list(uniq_bev), cpu_seconds)
+    launch_ms = ev_ms / steps
     achieved = alg * units / (launch_ms * 1e-3) / 1e9
-    out = {"metric": w["metric"], "value": units * d.world * a.steps / wall, "unit": w["unit"], "n_gpus": min(d.world, max(1, _ffi.device_count())),
-           "ranks": d.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+    hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_unit": alg}
+    prof = jpeg_valu_profile(workload if a.jpeg_source != "repo" else workload + "_repo")
+    if prof:
+        ginst = prof["valu_wave_insts_per_unit"] * units / (launch_ms * 1e-3) / 1e9
+        roof = {"bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s", "frac": ginst / VALU_PEAK_GINST,
+                "traffic": None, "kernel_ms": launch_ms, "units_per_launch": units, "valu_wave_insts_per_unit": prof["valu_wave_insts_per_unit"],
+                "source": prof.get("source"), "hbm": hbm,
+                "note": "the entropy stages are bound by VALU issue slots (every lane walks its own bit stream), not by HBM: achieved = wave-level VALU "
+                        "instructions of one step (static figure of the committed PMC pass) / the step's measured time; peak = 1024 SIMDs x 2.4 GHz / 4 clocks"}
+    else:
+        roof = dict({"bound": "hbm", "traffic": None, "kernel_ms": launch_ms, "units_per_launch": units,
+                     "note": "compressed bytes + pixels per unit; the entropy stages are VALU-issue bound, not HBM bound (DESIGN.md section 9); no "
+                             "profiles/jpeg_valu.json entry for this workload"}, **hbm)
+    out = {"metric": w["metric"], "value": units * d.world * steps / wall, "unit": w["unit"], "n_gpus": min(d.world, max(1, _ffi.device_count())),
+           "ranks": d.world, "steps": steps, "warmup": warmup, "ms_per_step": wall / steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-           "config": dict({"workload": a.workload, "batch_per_gpu": batch, "units_per_step": units, "device": _ffi.device_name(dev),
+           "config": dict({"workload": workload, "batch_per_gpu": batch, "units_per_step": units, "device": _ffi.device_name(dev),
                            "sharding": "files across ranks, no data-path collective"}, **extra),
-           "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel_ms": launch_ms, "algorithmic_bytes_per_unit": alg, "units_per_launch": units,
-                        "note": "compressed bytes + pixels per unit; the entropy stages are latency / ALU bound, not HBM bound (DESIGN.md section 9)"},
-           "cpu_baseline": cpu}
+           "roofline": roof, "cpu_baseline": cpu}
+    codec.close()
+    d_frames.free()
+    d_bev.free()
+    return out
+
+
+def main_jpeg(a, d, w, dev):
+    out = jpeg_measure(a, d, w, dev, a.workload, a.steps, a.warmup, 0.0 if a.no_cpu_baseline else min(a.cpu_seconds, 8.0))
     if d.rank == 0:
         print(json.dumps(out), flush=True)
-    codec.close()
     d.close()
+
+
+def f4_summary(a, d, dev):
+    """The JPEG wire format either side of the path in the DEFAULT run, so that the driver's bench record carries it:
+    decode / encode / files-in-file-out rates with their roofline and the libjpeg-turbo CPU baseline.  Short legs (about 10 s in all)."""
+    res = {}
+    for name, cpu_s in (("jpeg_decode_b64", 2.5), ("jpeg_encode_b64", 2.0), ("jpeg_bev_jpeg_b64", 0.0)):
+        o = jpeg_measure(a, d, WORKLOADS[name], dev, name, 8, 2, cpu_s)
+        keep = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
+                "units_per_step": o["config"]["units_per_step"],
+                "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")},
+                "cpu_baseline": o["cpu_baseline"] and {k: o["cpu_baseline"].get(k) for k in ("value", "unit", "cores", "kind", "sample")}}
+        for k in ("fixed_point_rounds_max", "host_api_frames_per_s", "host_api_ms_per_batch", "host_api_unpipelined_frames_per_s", "host_stage_ms_per_batch",
+                  "bytes_per_output_file"):
+            if k in o["config"]:
+                keep[k] = o["config"][k]
+        res[name] = keep
+    res["note"] = ("reference wire format: cv2.imread x 4 (main.py:74-77), cv2.imwrite (surroundBEV.py:340); inputs resident = compressed bytes / device images; "
+                   "full lines: bench.py --workload jpeg_decode_b64 | jpeg_encode_b64 | jpeg_bev_jpeg_b64")
+    return res
 
 
 def main():
@@ -662,6 +728,11 @@ def main():
         "other_output_layout": other,
         "cpu_baseline": cpu,
     }
+    if a.workload == "direct_stitch_b256" and d.world == 1 and not a.no_f4 and not a.single_layout:
+        try:
+            out["f4"] = f4_summary(a, d, dev)
+        except Exception as e:   # the headline must not depend on the JPEG legs
+            out["f4"] = {"error": repr(e)}
     if d.rank == 0:
         print(json.dumps(out), flush=True)
     d.close()

@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
 PROJ_LUT, PROJ_ANALYTIC, PROJ_ANALYTIC_F32 = 0, 1, 2   # bevw_set_projection
@@ -113,6 +113,9 @@ SIGNATURES = {
     "bevw_jpeg_encode_run_device": (_i, [_vp, _vp, _i, _i, _i, _sz, _sz, _i, _i]),
     "bevw_jpeg_encoded_sizes": (_i, [_vp, _vp]),
     "bevw_jpeg_encoded_copy": (_i, [_vp, _i, _vp, _sz]),
+    "bevw_jpeg_encoded_fetch": (_i, [_vp, _vp, _sz, _vp]),
+    "bevw_jpeg_wait_engine": (_i, [_vp, _vp]),
+    "bevw_wait_jpeg": (_i, [_vp, _vp]),
     "bevw_jpeg_encode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "bevw_jpeg_sync": (_i, [_vp]),
     "bevw_jpeg_timer_mark": (_i, [_vp, _i]),

@@ -122,3 +122,7 @@ struct PinnedBuf {
     }
     void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
 };
+
+// (internal, C++ linkage) what other translation units may know of an engine handle: its stream and device
+hipStream_t bevw_internal_handle_stream(bevw_handle *h);
+int bevw_internal_handle_device(bevw_handle *h);

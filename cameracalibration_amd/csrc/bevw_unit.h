@@ -612,6 +612,19 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 #else
 #define BEVW_UNIT_PRIO(x) ((void)0)
 #endif
+// sum of v over the 64 lanes of the wave, uniform result: four DPP adds inside the rows of 16 lanes (quad swaps, half-row and row mirrors),
+// two row broadcasts (gfx9 wave64: lane 15 of every row into the next row, lane 31 into rows 2 and 3), then lane 63 holds the total
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1, 0, 3, 2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2, 3, 0, 1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);    // row_mirror: every lane of a row has the row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 template <bool BLEND, bool SUMS, int NQ, int GR, int NCON, bool WIDE = false>
 __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
 {
@@ -800,19 +813,13 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                         P[p] = px;
                     }
                 }
-                if (SUMS) {
-                    // a lane's 4 pixels sum to <= 1020 per channel and a wave to <= 65280: B and G travel packed through the butterfly
-                    uint32_t sb = 0, sg = 0, sr = 0;
+                if (SUMS) {   // the lane's own sums over its quad slots; the wave reduction follows the loop
 #pragma unroll
                     for (int p = 0; p < 4; ++p) {
-                        sb = __builtin_amdgcn_udot4(P[p], 0x00000001u, sb, false);
-                        sg = __builtin_amdgcn_udot4(P[p], 0x00000100u, sg, false);
-                        sr = __builtin_amdgcn_udot4(P[p], 0x00010000u, sr, false);
+                        tb = __builtin_amdgcn_udot4(P[p], 0x00000001u, tb, false);
+                        tg = __builtin_amdgcn_udot4(P[p], 0x00000100u, tg, false);
+                        tr = __builtin_amdgcn_udot4(P[p], 0x00010000u, tr, false);
                     }
-                    uint32_t bg = sb | (sg << 16);
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) { bg += __shfl_xor(bg, o, 64); sr += __shfl_xor(sr, o, 64); }
-                    tb += bg & 0xffffu; tg += bg >> 16; tr += sr;
                 }
                 if (car_any) {     // uniform over the wave; the sprite is not kept in registers across the frame loop
                     const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
@@ -821,10 +828,15 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                 pack_pixels(P, d[j][0], d[j][1], d[j][2]);
             }
         }
-        if (SUMS && lane == 0 && b < b_end) {
-            // skipped quads and lanes without a quad have zero entries: they add 0.  psums is zeroed per call (plan_stitch_impl)
-            uint32_t *ps = a.psums + ((size_t)frame_of(b) * a.ntiles + sum_tile) * 3;
-            atomicAdd(ps + 0, tb); atomicAdd(ps + 1, tg); atomicAdd(ps + 2, tr);
+        if (SUMS) {
+            // One wave reduction per frame, on the VALU (DPP adds): round 3 reduced every quad slot with __shfl_xor = 12 ds_bpermute_b32 per
+            // slot, more LDS-pipe instructions than the slot's pixel reads.  A lane's NQ x 4 pixels sum to <= 4080 per channel, a wave to
+            // <= 261120.  Skipped quads and lanes without a quad have zero entries: they add 0.  psums is zeroed per call (plan_stitch_impl)
+            const uint32_t wb = wave_sum_dpp(tb), wg = wave_sum_dpp(tg), wr = wave_sum_dpp(tr);
+            if (lane == 0 && b < b_end) {
+                uint32_t *ps = a.psums + ((size_t)frame_of(b) * a.ntiles + sum_tile) * 3;
+                atomicAdd(ps + 0, wb); atomicAdd(ps + 1, wg); atomicAdd(ps + 2, wr);
+            }
         }
         if (DB) land(ring ^ 1);    // frame b+1 into the other half: nobody reads it before the barrier
         {

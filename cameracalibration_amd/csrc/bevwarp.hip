@@ -668,6 +668,9 @@ struct bevw_handle {
     }
 };
 
+hipStream_t bevw_internal_handle_stream(bevw_handle *h) { return h->stream; }
+int bevw_internal_handle_device(bevw_handle *h) { return h->cfg.device; }
+
 static int fill_poly_device(hipStream_t st, const MaskGeometry &g, int cam, bool blend, uint8_t *d_mask, bool modern)
 {
     int pts[8][2];
@@ -849,8 +852,8 @@ static int gain_pass(bevw_handle *h, hipStream_t st, const uint8_t *gain_in, con
 // sampled texel groups into the scratch frame set (k_lum_groups: VALU-bound) -> the unit stitch with per-unit channel sums (HBM-bound)
 // -> the gain pass (copy rate).  In one stream these run strictly one after the other, a memory-bound kernel while the VALUs idle and a
 // VALU-bound one while the memory idles; every quantity is per frame set, so slices are independent, and a slice's kernels overlap
-// the neighbouring slice's kernels of the OTHER kind (round 4: profiles/r04/config4_overlap.md; same idea as the two slices of a JPEG
-// decode batch, bevwarp_jpeg.hip).  The second stream starts one V-sum pass late so that the two streams stay out of phase.
+// the neighbouring slice's kernels of the OTHER kind (round 4: profiles/r04/ab_config4_slices.log; same idea as the two slices of a JPEG
+// decode batch, bevwarp_jpeg.hip).  BEVW_BAL_SKEW=1 starts the second stream one V-sum pass late (measured: no better).
 // (Round 2 measured sub-batches of 16 ... 128 frame sets run ONE AFTER THE OTHER for Infinity-Cache residency: slower, the small grids
 // cost more than the cache returns; profiles/r02/sweeps.log.)
 static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, const uint8_t *d_car, uint8_t *d_out)
@@ -874,10 +877,13 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
         gain_car = h->car_pitched.as<uint8_t>();
     }
     static const int parts_env = [] { const char *s = getenv("BEVW_BAL_PARTS"); return s ? atoi(s) : 0; }();
-    static const int skew_env = [] { const char *s = getenv("BEVW_BAL_SKEW"); return s ? atoi(s) : 1; }();
+    static const int skew_env = [] { const char *s = getenv("BEVW_BAL_SKEW"); return s ? atoi(s) : 0; }();
     // slices share the plan's padded scratch image when the BEV width is not a multiple of 4 pixels: one slice then
     const bool scratch = h->plan.pitch != h->plan.bw && !h->plan.out_pitched;
-    int parts = parts_env > 0 ? parts_env : (batch >= 64 ? 4 : (batch >= 16 ? 2 : 1));
+    // measured (profiles/r04/ab_config4_slices.log, batch 256): 1 slice 2.172 ms, 2 slices 2.142 (2.171 with the second stream one V-sum pass late),
+    // 4 slices 2.22 - 2.24, 8 slices 2.30: three of the four kernels are HBM-bound and the VALU-bound one still moves 1.35 GB, so running
+    // them side by side shares the memory instead of filling idle time -- the overlap is worth 1.4 %, more slices cost it again in small grids
+    int parts = parts_env > 0 ? parts_env : (batch >= 32 ? 2 : 1);
     if (scratch || !h->stream2) parts = 1;
     if (parts > batch) parts = batch;
     if (parts > 1) {

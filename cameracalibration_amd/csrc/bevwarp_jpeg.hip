@@ -22,7 +22,8 @@ struct bevw_jpeg {
     int n = 0;
     bool staged = false, decoded = false;
     size_t total_sub = 0;
-    uint32_t max_sub = 0;
+    uint32_t max_sub = 0, max_chunk = 0;
+    hipEvent_t ev_x = nullptr;                 // ordering against an engine's stream (bevw_jpeg_wait_engine / bevw_wait_jpeg)
     PinnedBuf h_stream;
     std::vector<jpg::ImageDesc> h_desc;
     std::vector<uint32_t> h_term;
@@ -36,6 +37,7 @@ struct bevw_jpeg {
     jpg::EncTables etabs;
     std::vector<uint8_t> header;
     DevBuf d_etabs, d_header, d_eplanes, d_zz, d_acbits, d_dcq, d_bitlen, d_bitbuf, d_totals, d_chunk_ff, d_files, d_sizes, d_src;
+    DevBuf d_packed, d_offsets;                // bevw_jpeg_encoded_fetch: the files of a batch back to back
     size_t buf_words = 0, file_cap = 0;
     std::vector<uint32_t> sizes;
     bool encoded = false, sizes_valid = false;
@@ -69,6 +71,7 @@ int bevw_jpeg_create(int device, bevw_jpeg **out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&j->st2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_a, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_b, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&j->ev_x, hipEventDisableTiming);
     if (e != hipSuccess) { bevw_jpeg_destroy(j); return fail(BEVW_E_HIP, "stream / event creation failed: %s", hipGetErrorString(e)); }
     *out = j;
     return BEVW_OK;
@@ -82,6 +85,7 @@ void bevw_jpeg_destroy(bevw_jpeg *j)
     if (j->st) { (void)hipStreamSynchronize(j->st); (void)hipStreamDestroy(j->st); }
     if (j->ev_a) (void)hipEventDestroy(j->ev_a);
     if (j->ev_b) (void)hipEventDestroy(j->ev_b);
+    if (j->ev_x) (void)hipEventDestroy(j->ev_x);
     j->timer.release();
     delete j;
 }
@@ -194,22 +198,9 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     HIP_TRY(hipMemcpyAsync(j->d_raw.p, j->h_stream.p, bound, hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_desc.p, j->h_desc.data(), j->h_desc.size() * sizeof(jpg::ImageDesc), hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_term.p, j->h_term.data(), (size_t)n * 4, hipMemcpyHostToDevice, j->st));
-    HIP_TRY(hipMemsetAsync(j->d_nrst.p, 0xFF, (size_t)n * 4, j->st));   // an image no kernel closes can never pass k_jpeg_subs' check
     HIP_TRY(hipMemcpyAsync(j->d_tabs.p, j->h_tabs.data(), j->h_tabs.size() * sizeof(jpg::TableSet), hipMemcpyHostToDevice, j->st));
     HIP_TRY(hipMemcpyAsync(j->d_quant.p, j->h_quant.data(), j->h_quant.size() * 2, hipMemcpyHostToDevice, j->st));
-    // un-stuffing on the device: where the data ends, what stays, where the restart segments start, the subsequences
-    jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
-    const uint8_t *raw = j->d_raw.as<uint8_t>();
-    const dim3 gc(max_chunk, (unsigned)n);
-    jpg::k_jpeg_find_end<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_find_end"));
-    jpg::k_jpeg_count_raw<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_count_raw"));
-    jpg::k_jpeg_unstuff<<<gc, 256, 0, j->st>>>(img, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>(),
-                                                j->d_stream.as<uint8_t>(), j->d_seg_byte.as<uint32_t>(), j->d_nrst.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_unstuff"));
-    jpg::k_jpeg_subs<<<(unsigned)n, 256, 0, j->st>>>(img, j->d_nrst.as<uint32_t>(), j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_subs"));
+    j->max_chunk = max_chunk;
     j->staged = true;
     return BEVW_OK;
 }
@@ -240,6 +231,23 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     const jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
     const uint32_t *stream = j->d_stream.as<uint32_t>();
     const jpg::TableSet *tabs = j->d_tabs.as<jpg::TableSet>();
+    // Un-stuffing on the device, part of every decode (round 4: inside the run, so that a timed decode counts it -- what is RESIDENT after
+    // bevw_jpeg_decode_stage is the files' entropy-coded bytes as they are in the files): where the data ends, what stays, where the restart
+    // segments start, the subsequences
+    HIP_TRY(hipMemcpyAsync(j->d_term.p, j->h_term.data(), (size_t)j->n * 4, hipMemcpyHostToDevice, j->st));   // (k_jpeg_find_end lowers it: a fresh copy per run)
+    HIP_TRY(hipMemsetAsync(j->d_nrst.p, 0xFF, (size_t)j->n * 4, j->st));   // an image no kernel closes can never pass k_jpeg_subs' check
+    jpg::ImageDesc *imgw = j->d_desc.as<jpg::ImageDesc>();
+    const uint8_t *raw = j->d_raw.as<uint8_t>();
+    const dim3 gc(j->max_chunk, (unsigned)j->n);
+    jpg::k_jpeg_find_end<<<gc, 256, 0, j->st>>>(imgw, raw, j->d_term.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_find_end"));
+    jpg::k_jpeg_count_raw<<<gc, 256, 0, j->st>>>(imgw, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_count_raw"));
+    jpg::k_jpeg_unstuff<<<gc, 256, 0, j->st>>>(imgw, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>(),
+                                                j->d_stream.as<uint8_t>(), j->d_seg_byte.as<uint32_t>(), j->d_nrst.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_unstuff"));
+    jpg::k_jpeg_subs<<<(unsigned)j->n, 256, 0, j->st>>>(imgw, j->d_nrst.as<uint32_t>(), j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>());
+    BEVW_TRY(launch_check("k_jpeg_subs"));
     // (no zero fill of the coefficient buffer: k_jpeg_coef stores every block whole)
     // The batch runs as `parts` independent slices alternating over two streams: the tail of the synchronisation (a few lanes per image
     // walking their subsequences again, the rest of the chip idle) of one slice overlaps the throughput-bound kernels of the other.
@@ -460,6 +468,69 @@ int bevw_jpeg_encode(bevw_jpeg *j, const uint8_t *bgr, int n, int width, int hei
     BEVW_TRY(bevw_jpeg_encode_run_device(j, j->d_src.p, n, width, height, image, (size_t)width * 3, quality, sampling));
     BEVW_TRY(bevw_jpeg_encoded_sizes(j, sizes));
     for (int i = 0; i < n; ++i) BEVW_TRY(bevw_jpeg_encoded_copy(j, i, out + (size_t)i * cap_each, cap_each));
+    return BEVW_OK;
+}
+
+// every file of the last encode, back to back: a device-side gather + ONE device-to-host copy (bevw_jpeg_encoded_copy costs a
+// synchronising copy per file -- 64 round trips per batch of the files-in / file-out pipeline)
+namespace bevw { namespace jpg {
+static __global__ void k_jenc_pack(const uint8_t *__restrict__ files, size_t file_cap, const uint32_t *__restrict__ sizes,
+                                   const unsigned long long *__restrict__ offsets, uint8_t *__restrict__ packed)
+{
+    const uint32_t size = sizes[blockIdx.y];
+    const uint8_t *src = files + (size_t)blockIdx.y * file_cap;
+    uint8_t *dst = packed + offsets[blockIdx.y];
+    for (uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 16u; i < size; i += gridDim.x * 256u * 16u) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + i);   // file slots are 16-byte aligned and padded
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t n = size - i < 16u ? size - i : 16u;
+        for (uint32_t k = 0; k < n; ++k) dst[i + k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+    }
+}
+} }
+
+int bevw_jpeg_encoded_fetch(bevw_jpeg *j, uint8_t *dst, size_t cap, size_t *offsets)
+{
+    if (!j || !dst || !offsets || !j->encoded) return fail(BEVW_E_INVALID, "bevw_jpeg_encoded_fetch: nothing encoded / null argument");
+    std::vector<size_t> sz((size_t)j->en);
+    BEVW_TRY(bevw_jpeg_encoded_sizes(j, sz.data()));
+    std::vector<unsigned long long> off((size_t)j->en + 1, 0);
+    for (int i = 0; i < j->en; ++i) off[(size_t)i + 1] = off[(size_t)i] + sz[(size_t)i];
+    for (int i = 0; i <= j->en; ++i) offsets[i] = (size_t)off[(size_t)i];
+    const size_t total = (size_t)off[(size_t)j->en];
+    if (cap < total) return fail(BEVW_E_INVALID, "the %d files need %zu bytes, %zu given", j->en, total, cap);
+    BEVW_TRY(use_device(j->device));
+    BEVW_TRY(j->d_packed.reserve(total + 16));
+    BEVW_TRY(j->d_offsets.reserve(off.size() * 8));
+    HIP_TRY(hipMemcpyAsync(j->d_offsets.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, j->st));
+    jpg::k_jenc_pack<<<dim3(16, (unsigned)j->en), 256, 0, j->st>>>(j->d_files.as<uint8_t>(), j->file_cap, j->d_sizes.as<uint32_t>(),
+                                                                    j->d_offsets.as<unsigned long long>(), j->d_packed.as<uint8_t>());
+    BEVW_TRY(launch_check("k_jenc_pack"));
+    HIP_TRY(hipMemcpyAsync(dst, j->d_packed.p, total, hipMemcpyDeviceToHost, j->st));
+    HIP_TRY(hipStreamSynchronize(j->st));
+    return BEVW_OK;
+}
+
+// Ordering between a codec context's stream and an engine's stream WITHOUT the host: decode -> stitch -> encode as one chain.
+//   bevw_jpeg_wait_engine: what is enqueued on the codec afterwards starts when everything enqueued on the engine so far is done;
+//   bevw_wait_jpeg:        the engine waits for the codec (e.g. bevw_run_device behind bevw_jpeg_decode_run_device).
+int bevw_jpeg_wait_engine(bevw_jpeg *j, bevw_handle *h)
+{
+    if (!j || !h) return fail(BEVW_E_INVALID, "bevw_jpeg_wait_engine: null argument");
+    if (bevw_internal_handle_device(h) != j->device) return fail(BEVW_E_INVALID, "codec context and engine live on different devices");
+    BEVW_TRY(use_device(j->device));
+    HIP_TRY(hipEventRecord(j->ev_x, bevw_internal_handle_stream(h)));
+    HIP_TRY(hipStreamWaitEvent(j->st, j->ev_x, 0));
+    return BEVW_OK;
+}
+
+int bevw_wait_jpeg(bevw_handle *h, bevw_jpeg *j)
+{
+    if (!j || !h) return fail(BEVW_E_INVALID, "bevw_wait_jpeg: null argument");
+    if (bevw_internal_handle_device(h) != j->device) return fail(BEVW_E_INVALID, "codec context and engine live on different devices");
+    BEVW_TRY(use_device(j->device));
+    HIP_TRY(hipEventRecord(j->ev_x, j->st));
+    HIP_TRY(hipStreamWaitEvent(bevw_internal_handle_stream(h), j->ev_x, 0));
     return BEVW_OK;
 }
 

@@ -68,8 +68,8 @@ class JpegCodec:
 
     # ---- decode --------------------------------------------------------------------------------------------------
     def decode_stage(self, files: Sequence[bytes]) -> dict:
-        """Parse the headers, copy the entropy-coded bytes to pinned memory, enqueue their upload and the un-stuffing kernels (one geometry per
-        call).  Returns the probe of the first file."""
+        """Parse the headers, copy the entropy-coded bytes to pinned memory, enqueue their upload (one geometry per call).  Returns the probe
+        of the first file."""
         files = [bytes(f) for f in files]
         if not files:
             raise Exception("no files")
@@ -120,17 +120,21 @@ class JpegCodec:
         check(lib().bevw_jpeg_encode_run_device(self.h, d_bgr, n, width, height, image_stride_bytes, row_pitch_bytes, quality, sampling))
         self._n_enc = n
 
-    def files(self) -> list:
-        """The files of the last ``encode_run_device`` (synchronises)."""
+    def files(self, copy: bool = True) -> list:
+        """The files of the last ``encode_run_device`` (synchronises): one gather on the device, ONE device-to-host copy
+        (``bevw_jpeg_encoded_fetch``).  ``copy=True``: a list of ``bytes``; ``copy=False``: ``memoryview`` slices of one host buffer that
+        belongs to the returned views (no per-file copy on the host)."""
         n = self._n_enc
         sizes = (C.c_size_t * n)()
-        check(lib().bevw_jpeg_encoded_sizes(self.h, sizes))
-        out = []
-        for i in range(n):
-            buf = np.empty(sizes[i], np.uint8)
-            check(lib().bevw_jpeg_encoded_copy(self.h, i, ptr(buf), buf.nbytes))
-            out.append(buf.tobytes())
-        return out
+        check(lib().bevw_jpeg_encoded_sizes(self.h, sizes))       # (waits for the encode; the sizes are cached for the fetch)
+        total = sum(sizes)
+        buf = np.empty(total, np.uint8)
+        offsets = (C.c_size_t * (n + 1))()
+        check(lib().bevw_jpeg_encoded_fetch(self.h, ptr(buf), buf.nbytes, offsets))
+        view = memoryview(buf)
+        if copy:
+            return [view[offsets[i]:offsets[i + 1]].tobytes() for i in range(n)]
+        return [view[offsets[i]:offsets[i + 1]] for i in range(n)]
 
     def encode(self, images, quality: int = _DEFAULT_QUALITY, sampling: int = SAMPLING_420) -> list:
         """``[cv2.imencode('.jpg', im)[1].tobytes() for im in images]``: images uint8 [n, h, w, 3] (BGR) -> complete files."""
@@ -144,6 +148,14 @@ class JpegCodec:
         return self.files()
 
     # ---- stream ---------------------------------------------------------------------------------------------------
+    def wait_engine(self, engine_handle) -> None:
+        """What is enqueued on this context afterwards starts when everything enqueued on the engine (a ``bevw_handle``) so far is done."""
+        check(lib().bevw_jpeg_wait_engine(self.h, engine_handle))
+
+    def engine_waits(self, engine_handle) -> None:
+        """The engine's stream waits for everything enqueued on this context so far (no host synchronisation)."""
+        check(lib().bevw_wait_jpeg(engine_handle, self.h))
+
     def sync(self) -> None:
         check(lib().bevw_jpeg_sync(self.h))
 

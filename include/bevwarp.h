@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BEVW_ABI_VERSION 3
+#define BEVW_ABI_VERSION 4
 
 typedef enum bevw_status {
     BEVW_OK = 0,
@@ -275,9 +275,9 @@ int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h
  * EXIF orientations other than 1 are REFUSED (BEVW_E_INVALID, reason in bevw_last_error()): there is no CPU decoder behind this.
  *
  *   bevw_jpeg_probe            header only: info = width, height, components, luma h, luma v, restart interval, EXIF orientation, 0
- *   bevw_jpeg_decode_stage     n files of ONE geometry: parse the headers, copy the entropy-coded bytes to pinned memory, enqueue the H2D copies and
- *                              the un-stuffing kernels (what is resident afterwards is the un-stuffed stream, cut into subsequences)
- *   bevw_jpeg_decode_run_device  enqueue the decode of the staged batch; image i is written as BGR rows of row_pitch_bytes at
+ *   bevw_jpeg_decode_stage     n files of ONE geometry: parse the headers, copy the entropy-coded bytes to pinned memory, enqueue the H2D copies
+ *                              (what is resident afterwards is the files' entropy-coded data as it is in the files)
+ *   bevw_jpeg_decode_run_device  enqueue the decode of the staged batch (un-stuffing, entropy decoding, inverse DCT, colour); image i is written as BGR rows of row_pitch_bytes at
  *                              d_out + i * image_stride_bytes -- with image_stride = FH*FW*3 the n = 4*batch images ARE the
  *                              [batch][4][FH][FW][3] frame sets bevw_run_device reads (files ordered front, back, left, right per set)
  *   bevw_jpeg_decode           both + copy to a dense host array [n][h][w][3]  (= [cv2.imread(f) for f in files])
@@ -289,6 +289,10 @@ int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h
  *   bevw_jpeg_encode_run_device  enqueue cv2.imwrite x n of device images (BGR rows of row_pitch_bytes, e.g. the padded rows of
  *                              BEVW_PITCH_ALIGNED); sampling 0x22 = 4:2:0 (cv2's default), 0x21 = 4:2:2, 0x11 = 4:4:4
  *   bevw_jpeg_encoded_sizes / _copy   synchronise; byte count of every file; one complete file (SOI ... EOI) to host memory
+ *   bevw_jpeg_encoded_fetch    synchronise; ALL files of the last encode back to back in dst (file i at dst + offsets[i], offsets[n] = total):
+ *                              a gather on the device and one device-to-host copy
+ *   bevw_jpeg_wait_engine / bevw_wait_jpeg   order the codec's stream behind an engine's stream / the engine's behind the codec's without the
+ *                              host: decode -> bevw_run_device -> encode as one asynchronous chain (BevGenerator.jpeg_stream)
  *   bevw_jpeg_encode           host images in, files out (out + i * cap_each, sizes[i]); cap_each >= bevw_jpeg_encode_bound
  * All "run" calls are asynchronous on the context's own stream; bevw_jpeg_sync waits; timer marks as for handles. */
 #define BEVW_JPEG_420 0x22
@@ -307,6 +311,9 @@ int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int widt
                                 size_t row_pitch_bytes, int quality, int sampling);
 int bevw_jpeg_encoded_sizes(bevw_jpeg *j, size_t *sizes);
 int bevw_jpeg_encoded_copy(bevw_jpeg *j, int index, uint8_t *dst, size_t cap);
+int bevw_jpeg_encoded_fetch(bevw_jpeg *j, uint8_t *dst, size_t cap, size_t *offsets);
+int bevw_jpeg_wait_engine(bevw_jpeg *j, bevw_handle *h);
+int bevw_wait_jpeg(bevw_handle *h, bevw_jpeg *j);
 int bevw_jpeg_encode(bevw_jpeg *j, const uint8_t *bgr, int n, int width, int height, int quality, int sampling, uint8_t *out,
                      size_t cap_each, size_t *sizes);
 int bevw_jpeg_sync(bevw_jpeg *j);

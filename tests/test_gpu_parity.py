@@ -462,13 +462,15 @@ def test_full_size_batch_properties(ffi, SB, oracle, blend, balance):
     bev, ref = make_pair(SB, oracle, rig, cfg, blend, balance)
     assert bev.plan_info()["schedule"] == 2
     d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
-    d_out = ffi.DeviceBuffer(batch * 1080 * 1080 * 3)
+    pitch = bev.out_pitch   # the default device layout: rows of whole 64-byte sectors (1088 pixels) on the tile plan
+    assert pitch == 1088
+    d_out = ffi.DeviceBuffer(batch * 1080 * pitch * 3)
     d_out.fill(0xA5)
     for b in range(batch):
         d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
     bev.run_device(d_in.ptr, batch, None, d_out.ptr)
     bev.sync()
-    out = d_out.download((batch, 1080, 1080, 3))
+    out = np.ascontiguousarray(d_out.download((batch, 1080, pitch, 3))[:, :, :1080])
     # a frame's BEV does not depend on its position in the batch (XCD / chunk mapping, batch loop)
     for b in range(uniq, batch):
         assert np.array_equal(out[b], out[b % uniq]), b
@@ -494,18 +496,19 @@ def test_bench_configuration_batch_256_all_random(ffi, SB, oracle, blend):
     bev, ref = make_pair(SB, oracle, rig, cfg, blend, False)
     assert bev.plan_info()["schedule"] == 2
     d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
-    d_out = ffi.DeviceBuffer(batch * 1080 * 1080 * 3)
+    pitch = bev.out_pitch   # the bench's layout = the product's default: rows of 1088 pixels on the device
+    d_out = ffi.DeviceBuffer(batch * 1080 * pitch * 3)
     d_out.fill(0x5A)
     for b in range(batch):
         d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
     bev.run_device(d_in.ptr, batch, None, d_out.ptr)
     bev.sync()
     want = [ref(*frames[u]) for u in range(uniq)]
-    per = 1080 * 1080 * 3
+    per = 1080 * pitch * 3
     for b0 in range(0, batch, 32):   # download in slices: the whole batch is 0.9 GB
-        out = d_out.download((32, 1080, 1080, 3), offset=b0 * per)
+        out = d_out.download((32, 1080, pitch, 3), offset=b0 * per)
         for k in range(32):
-            assert np.array_equal(out[k], want[(b0 + k) % uniq]), "frame %d of the batch differs from the oracle" % (b0 + k)
+            assert np.array_equal(out[k][:, :1080], want[(b0 + k) % uniq]), "frame %d of the batch differs from the oracle" % (b0 + k)
     d_in.free()
     d_out.free()
 

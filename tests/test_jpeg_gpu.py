@@ -245,3 +245,63 @@ def test_main_py_with_files_in_and_a_file_out(IC, JO, repo_rig, oracle):
         got = bev.jpeg([files, files[::-1]], car)
         assert len(got) == 2 and got[0] == want, (blend, balance, pitch)
         assert got[1] == JO.imencode(ref(*frames[::-1], car))
+
+
+def test_empty_restart_segments_are_flagged(IC, codec):
+    """a restart segment without a single entropy-coded byte (two adjacent RSTn markers, an RSTn right in front of EOI, a scan that
+    is only EOI) owns no subsequence, so nothing downstream would look at its blocks -- such a file must be refused, never decoded from stale
+    coefficients of an earlier batch."""
+    from cameracalibration_amd._ffi import BevwError
+
+    good = JC.pil_encode(JC.image(96, 128, 2), 90, 2, restart_marker_blocks=4)
+    assert np.array_equal(codec.decode([good])[0], JC.pil_decode(good))      # (fills the coefficient buffer: the stale data a bad file would show)
+    sos = good.index(b"\xff\xda") + 14
+    body = good[sos:-2]
+    first = body.index(b"\xff\xd0")
+    second = body.index(b"\xff\xd1")
+    # the segment between RST0 and RST1 removed: RST0 RST1 back to back (the marker count still matches DRI)
+    adjacent = good[:sos] + body[:first + 2] + body[second:] + b"\xff\xd9"
+    # the last segment removed: an RSTn right in front of EOI
+    last = max(body.rfind(bytes([0xFF, 0xD0 + k])) for k in range(8))
+    tail = good[:sos] + body[:last + 2] + b"\xff\xd9"
+    plain = JC.pil_encode(JC.image(96, 128, 2), 90, 2)
+    psos = plain.index(b"\xff\xda") + 14
+    only_eoi = plain[:psos] + b"\xff\xd9"
+    for bad in (adjacent, tail, only_eoi):
+        with pytest.raises(BevwError):
+            codec.decode([bad])
+        with pytest.raises(BevwError):
+            codec.decode([good, bad])
+    assert np.array_equal(codec.decode([good])[0], JC.pil_decode(good))
+
+
+def test_jpeg_pipeline_refuses_truncated_files_and_streams_identically(IC, JO, repo_rig, oracle):
+    """BevGenerator.jpeg raises on a truncated camera file (it used to stitch undefined pixels), and jpeg_stream -- staging,
+    kernels and fetch of consecutive batches overlapped, three codec contexts -- yields exactly what jpeg() returns batch by batch."""
+    from cameracalibration_amd._ffi import BevwError
+    from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+
+    cams = JC.repo_camera_jpegs()
+    files = [cams[n] for n in W.CAMERA_NAMES]
+    cfg = dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350)
+    ns = SB.BevGenerator.get_args()
+    for k, v in cfg.items():
+        setattr(ns, k, v)
+    car = SB.padding(repo_rig.image("car"), cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"])
+    bev = SB.BevGenerator(blend=True, balance=True, rig=repo_rig.rig)
+    cut = files[2][: len(files[2]) * 3 // 5] + b"\xff\xd9"
+    with pytest.raises(BevwError, match="before their image is complete"):
+        bev.jpeg([files, [files[0], files[1], cut, files[3]]], car)
+    # batches of different sizes and contents; the stream must reproduce the unpipelined calls in order
+    perms = [files, files[::-1], [files[1], files[0], files[3], files[2]], [files[2], files[3], files[0], files[1]]]
+    batches = [[perms[0], perms[1]], [perms[2]], [perms[3], perms[0], perms[1]], [perms[1]], [perms[2], perms[3]]]
+    want = [bev.jpeg(b, car) for b in batches]
+    got = list(bev.jpeg_stream(iter(batches), car))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g == w
+    views = list(bev.jpeg_stream(batches[:2], car, copy=False))
+    assert [[bytes(v) for v in b] for b in views] == want[:2]
+    assert list(bev.jpeg_stream([], car)) == []
+    ref = oracle.RefBevGenerator(repo_rig.rig, cfg, blend=True, balance=True)
+    assert want[0][0] == JO.imencode(ref(*[JO.imdecode(f) for f in files], car))
