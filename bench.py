@@ -501,7 +501,7 @@ def f4_summary(a, d, dev):
     decode / encode / files-in-file-out rates with their roofline and the libjpeg-turbo CPU baseline.  Short legs (about 10 s in all)."""
     res = {}
     for name, cpu_s in (("jpeg_decode_b64", 2.5), ("jpeg_encode_b64", 2.0), ("jpeg_bev_jpeg_b64", 0.0)):
-        o = jpeg_measure(a, d, WORKLOADS[name], dev, name, 8, 2, cpu_s)
+        o = jpeg_measure(a, d, WORKLOADS[name], dev, name, 12, 4, cpu_s)
         keep = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
                 "units_per_step": o["config"]["units_per_step"],
                 "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")},

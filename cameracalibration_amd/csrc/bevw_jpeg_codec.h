@@ -256,6 +256,52 @@ __global__ __launch_bounds__(256) void k_jpeg_sync_round(const ImageDesc *__rest
     xout[slot] = out;
 }
 
+// Round 2 and later touch a shrinking minority of the subsequences (1219, 387, 174, 78 ... of 1224 on the reference's camera files), but a wave
+// runs for as long as its slowest lane: scattered over the image, 32 % of the lanes keep every wave busy for a full walk.  k_jpeg_mark lists,
+// per image, the subsequences whose entry state is not their predecessor's exit state (and copies every exit state to the other ping-pong
+// buffer, so that the listed lanes are the only ones k_jpeg_sync_list has to write); k_jpeg_sync_list walks exactly those, densely packed.
+__global__ __launch_bounds__(256) void k_jpeg_mark(const ImageDesc *__restrict__ img, SubArrays A, const uint64_t *__restrict__ xin,
+                                                   uint64_t *__restrict__ xout, uint32_t *__restrict__ list, uint32_t *__restrict__ count)
+{
+    const ImageDesc D = img[blockIdx.y];
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    const bool live = j < D.nsub;
+    const size_t slot = (size_t)D.sub_first + (live ? j : 0u);
+    bool need = false;
+    if (live) {
+        xout[slot] = xin[slot];
+        need = !(A.meta[slot] & 0x80000000u) && xin[slot - 1] != A.entry[slot];
+    }
+    const unsigned long long m = __ballot(need);
+    if (!m) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&count[blockIdx.y], (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, 0, 64);
+    if (need) list[(size_t)D.sub_first + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = j;
+}
+
+__global__ __launch_bounds__(256) void k_jpeg_sync_list(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
+                                                        const TableSet *__restrict__ tabs, Geom G, SubArrays A, const uint64_t *__restrict__ xin,
+                                                        uint64_t *__restrict__ xout, const uint32_t *__restrict__ list, const uint32_t *__restrict__ count)
+{
+    __shared__ TableSet T;
+    const uint32_t n = count[blockIdx.y];
+    if (blockIdx.x * 256u >= n) return;   // (uniform over the block)
+    const ImageDesc D = img[blockIdx.y];
+    lds_copy(&T, tabs + D.tables);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = list[(size_t)D.sub_first + i];
+    const size_t slot = (size_t)D.sub_first + j;
+    const uint64_t in = xin[slot - 1];
+    A.entry[slot] = in;
+    const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+    A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
+    xout[slot] = R.exit;
+}
+
 __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // One block per image: re-decode every subsequence whose entry state is not its predecessor's exit state until nothing changes, then
@@ -273,12 +319,27 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     volatile uint64_t *vexit = A.exitst + D.sub_first;
     uint64_t *entry = A.entry + D.sub_first;
     uint32_t rounds = 0;
+    // Every round first LISTS the subsequences that have to walk again (their entry state is not their predecessor's exit state) and then
+    // walks them densely packed: a round costs as many wave-walks as its list fills waves (174, 78, 37 ... subsequences: 3, 2, 1 waves),
+    // not one per wave that holds a straggler (all 16 waves of the block for as long as some lane of each has work).
+    __shared__ uint32_t s_list[kSyncThreads];
+    __shared__ uint32_t s_n;
     for (;;) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
         int changed = 0;
         for (uint32_t j = threadIdx.x; j < D.nsub; j += kSyncThreads) {
             if (j == 0 || (A.meta[D.sub_first + j] & 0x80000000u)) continue;
+            if (vexit[j - 1] == entry[j]) continue;
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < (uint32_t)kSyncThreads) s_list[at] = j;
+            else changed = 1;   // more than one block-load of work: the rest is found again in the next round
+        }
+        __syncthreads();
+        const uint32_t n = min(s_n, (uint32_t)kSyncThreads);
+        if (threadIdx.x < n) {
+            const uint32_t j = s_list[threadIdx.x];
             const uint64_t in = vexit[j - 1];
-            if (in == entry[j]) continue;
             entry[j] = in;
             const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[D.sub_first + j], nullptr, 0, 0, 0, 0, 0);
             A.sums[D.sub_first + j] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
@@ -362,12 +423,14 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
 
 // jpeg_idct_islow: a wave transforms 8 blocks; lane = (block, column) for the column pass, (block, row) for the row pass, the 8 x 8
 // intermediate goes through LDS (row pitch 8, block pitch 72 words: conflict-free for the 32-bit writes of a half wave).
+// first: the first block (scan-order index inside the image's coefficient buffer) of the launch -- 0, or G.blk_off[1] when the luma blocks are
+// transformed by k_jpeg_idct_color_h2v2
 __global__ __launch_bounds__(256) void k_jpeg_idct(const ImageDesc *__restrict__ img, Geom G, const int16_t *__restrict__ coef,
-                                                   const uint16_t *__restrict__ quant, uint8_t *__restrict__ planes)
+                                                   const uint16_t *__restrict__ quant, uint8_t *__restrict__ planes, int first)
 {
     __shared__ int32_t ws[4][8 * 72];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane >> 3, c = lane & 7;
-    const int g = (blockIdx.x * 4 + wave) * 8 + b;
+    const int g = first + (blockIdx.x * 4 + wave) * 8 + b;
     const bool valid = g < G.nblk;
     int comp = 0;
     if (G.nc == 3) comp = g >= G.blk_off[2] ? 2 : (g >= G.blk_off[1] ? 1 : 0);
@@ -462,6 +525,81 @@ __global__ __launch_bounds__(256) void k_jpeg_color_h2v2(Geom G, const uint8_t *
 #pragma unroll
     for (int i = 0; i < 8; ++i) px[i] = ycc_to_bgr((int)(((i < 4 ? yv.x : yv.y) >> (8 * (i & 3))) & 255u), up[0][i], up[1][i]);
     uint32_t *o32 = reinterpret_cast<uint32_t *>(o);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        o32[3 * h + 0] = px[4 * h] | (px[4 * h + 1] << 24);
+        o32[3 * h + 1] = (px[4 * h + 1] >> 8) | (px[4 * h + 2] << 16);
+        o32[3 * h + 2] = (px[4 * h + 2] >> 16) | (px[4 * h + 3] << 8);
+    }
+}
+
+// The camera case in ONE pass over the luma coefficients (round 4): 4:2:0, dword-aligned destination, width a multiple of 8.  A work-group owns
+// 8 MCUs of one MCU row = 128 x 16 pixels = 32 luma blocks, 8 per wave: jpeg_idct_islow exactly as k_jpeg_idct (column pass, transpose through
+// LDS, row pass), the samples go to a 16 x 128 tile in LDS instead of a luma plane in memory, and the 256 lanes then convert the tile as
+// k_jpeg_color_h2v2 does (8 pixels per lane, chroma from the planes k_jpeg_idct wrote for the chroma blocks -- a sixth of the sample bytes
+// each).  Saves the luma plane's round trip through HBM (2/3 of the plane bytes written and read) and a launch per slice.
+__global__ __launch_bounds__(256) void k_jpeg_idct_color_h2v2(const ImageDesc *__restrict__ img, Geom G, const int16_t *__restrict__ coef,
+                                                              const uint16_t *__restrict__ quant, const uint8_t *__restrict__ planes,
+                                                              uint8_t *__restrict__ out, size_t image_stride, size_t row_pitch)
+{
+    __shared__ int32_t ws[4][8 * 72];
+    __shared__ __attribute__((aligned(8))) uint8_t ytile[16][136];   // row pitch 136: the 8-byte row pieces of a wave's 8 blocks fall into different banks
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = lane >> 3, c = lane & 7;
+    const int mrow = blockIdx.y, mx0 = blockIdx.x * 8;
+    const int q = wave * 8 + b, ty = q >> 4, tx = q & 15;               // the tile is 16 blocks wide, 2 tall
+    const int bx = mx0 * 2 + tx, by = mrow * 2 + ty;
+    const bool valid = bx < G.wb[0];
+    int32_t in[8], o8[8];
+    if (valid) {
+        const int16_t *cf = coef + ((size_t)blockIdx.z * G.nblk + (size_t)by * G.wb[0] + bx) * 64;   // (luma blocks start at 0)
+        const uint16_t *qt = quant + (size_t)img[blockIdx.z].quant * 192;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) in[r] = (int32_t)cf[r * 8 + c] * (int32_t)qt[r * 8 + c];
+        idct_1d(in, o8, 11);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ws[wave][b * 72 + r * 8 + c] = o8[r];
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int x = 0; x < 8; ++x) in[x] = ws[wave][b * 72 + c * 8 + x];   // row c of block q
+        idct_1d(in, o8, 18);
+        uint2 v;
+        v.x = range_limit(o8[0]) | (range_limit(o8[1]) << 8) | (range_limit(o8[2]) << 16) | (range_limit(o8[3]) << 24);
+        v.y = range_limit(o8[4]) | (range_limit(o8[5]) << 8) | (range_limit(o8[6]) << 16) | (range_limit(o8[7]) << 24);
+        *reinterpret_cast<uint2 *>(&ytile[ty * 8 + c][tx * 8]) = v;
+    }
+    __syncthreads();
+    // colour: lane t -> 8 pixels of row t / 16 of the tile, from column (t % 16) * 8 on: a wave stores 4 row pieces of 384 contiguous bytes
+    const int row = (int)threadIdx.x >> 4, oct = (int)threadIdx.x & 15;
+    const int x0 = mx0 * 16 + oct * 8, y = mrow * 16 + row;
+    if (x0 >= G.w || y >= G.h) return;   // (G.w % 8 == 0: no lane straddles the right edge)
+    const uint8_t *P = planes + (size_t)blockIdx.z * G.plane_bytes;
+    const int cy = y >> 1, cx = x0 >> 1, cp = G.wb[1] * 8;
+    int ny = (y & 1) ? cy + 1 : cy - 1;
+    ny = ny < 0 ? 0 : (ny > G.dh - 1 ? G.dh - 1 : ny);
+    const int li = cx > 0 ? cx - 1 : 0, ri = cx + 4 > G.dw - 1 ? G.dw - 1 : cx + 4;
+    int up[2][8];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint8_t *r0 = P + G.plane_off[1 + k] + (size_t)cy * cp, *r1 = P + G.plane_off[1 + k] + (size_t)ny * cp;
+        const uint32_t a = *reinterpret_cast<const uint32_t *>(r0 + cx), bb = *reinterpret_cast<const uint32_t *>(r1 + cx);
+        int cs[6];
+        cs[0] = 3 * r0[li] + r1[li];
+        cs[5] = 3 * r0[ri] + r1[ri];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[1 + i] = 3 * (int)((a >> (8 * i)) & 255u) + (int)((bb >> (8 * i)) & 255u);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            up[k][2 * i] = (3 * cs[1 + i] + cs[i] + 8) >> 4;
+            up[k][2 * i + 1] = (3 * cs[1 + i] + cs[2 + i] + 7) >> 4;
+        }
+    }
+    const uint2 yv = *reinterpret_cast<const uint2 *>(&ytile[row][oct * 8]);
+    uint32_t px[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) px[i] = ycc_to_bgr((int)(((i < 4 ? yv.x : yv.y) >> (8 * (i & 3))) & 255u), up[0][i], up[1][i]);
+    uint32_t *o32 = reinterpret_cast<uint32_t *>(out + (size_t)blockIdx.z * image_stride + (size_t)y * row_pitch + (size_t)x0 * 3);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         o32[3 * h + 0] = px[4 * h] | (px[4 * h + 1] << 24);

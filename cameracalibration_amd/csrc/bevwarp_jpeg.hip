@@ -21,6 +21,7 @@ struct bevw_jpeg {
     jpg::Geom G{};
     int n = 0;
     bool staged = false, decoded = false;
+    bool luma_planes = true;                   // the last decode wrote the luma sample planes (false: fused luma IDCT + colour conversion)
     size_t total_sub = 0;
     uint32_t max_sub = 0, max_chunk = 0;
     hipEvent_t ev_x = nullptr;                 // ordering against an engine's stream (bevw_jpeg_wait_engine / bevw_wait_jpeg)
@@ -30,6 +31,7 @@ struct bevw_jpeg {
     std::vector<jpg::TableSet> h_tabs;
     std::vector<uint16_t> h_quant;
     DevBuf d_raw, d_stream, d_desc, d_seg_byte, d_seg_sub, d_term, d_nrst, d_chunk_keep, d_chunk_rst, d_tabs, d_quant;
+    DevBuf d_list, d_count;   // round 2: per image, the subsequences that walk again
     DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_word0, d_cols, d_rounds, d_coef, d_planes, d_img;
     // encode
     jpg::Geom EG{};
@@ -224,6 +226,8 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     BEVW_TRY(j->d_word0.reserve(ns * 4));
     BEVW_TRY(j->d_cols.reserve(ns * 4 * (size_t)jpg::kColWords));
     BEVW_TRY(j->d_rounds.reserve(n * 4));
+    BEVW_TRY(j->d_list.reserve(ns * 4));
+    BEVW_TRY(j->d_count.reserve(n * 4));
     BEVW_TRY(j->d_coef.reserve(n * (size_t)G.nblk * 128));
     BEVW_TRY(j->d_planes.reserve(n * (size_t)G.plane_bytes));
     jpg::SubArrays A{j->d_entry.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_sums.as<int4>(), j->d_base.as<int4>(), j->d_endbit.as<uint32_t>(),
@@ -271,19 +275,37 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
             BEVW_TRY(launch_check("k_jpeg_columns"));
             jpg::k_jpeg_sync0<<<gs, 256, 0, st>>>(im, stream, tabs, G, A);
             BEVW_TRY(launch_check("k_jpeg_sync0"));
-            // two full-occupancy rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
+            // two whole-batch rounds (ping-pong of the exit states, back in d_exit afterwards), then the per-image fixed point
             jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit.as<uint64_t>(), j->d_exit2.as<uint64_t>());
             BEVW_TRY(launch_check("k_jpeg_sync_round"));
-            jpg::k_jpeg_sync_round<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>());
-            BEVW_TRY(launch_check("k_jpeg_sync_round"));
+            // round 2 walks a third of the subsequences: listed per image and walked densely packed (bevw_jpeg_codec.h: k_jpeg_mark)
+            uint32_t *cnt = j->d_count.as<uint32_t>() + first;
+            HIP_TRY(hipMemsetAsync(cnt, 0, m * 4, st));
+            jpg::k_jpeg_mark<<<gs, 256, 0, st>>>(im, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_list.as<uint32_t>(), cnt);
+            BEVW_TRY(launch_check("k_jpeg_mark"));
+            jpg::k_jpeg_sync_list<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, j->d_exit2.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_list.as<uint32_t>(), cnt);
+            BEVW_TRY(launch_check("k_jpeg_sync_list"));
             jpg::k_jpeg_sync<<<(unsigned)m, jpg::kSyncThreads, 0, st>>>(im, stream, tabs, G, A, j->d_rounds.as<uint32_t>() + first);
             BEVW_TRY(launch_check("k_jpeg_sync"));
             jpg::k_jpeg_coef<<<gs, 256, 0, st>>>(im, stream, tabs, G, A, coef);
             BEVW_TRY(launch_check("k_jpeg_coef"));
         }
-        jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)m), 256, 0, st>>>(im, G, coef, j->d_quant.as<uint16_t>(), planes);
-        BEVW_TRY(launch_check("k_jpeg_idct"));
         uint8_t *dst = (uint8_t *)d_out + first * image_stride_bytes;
+        static const int fuse_env = [] { const char *e = getenv("BEVW_JPEG_FUSE"); return e ? atoi(e) : 1; }();
+        if (fuse_env && aligned && G.nc == 3 && G.hs == 2 && G.vs == 2 && G.dw > 2 && G.w % 8 == 0) {
+            // the camera case: chroma blocks -> sample planes, then luma inverse DCT + colour conversion in one kernel (no luma plane in memory)
+            const int nchroma = G.nblk - G.blk_off[1];
+            jpg::k_jpeg_idct<<<dim3((nchroma + 31) / 32, (unsigned)m), 256, 0, st>>>(im, G, coef, j->d_quant.as<uint16_t>(), planes, G.blk_off[1]);
+            BEVW_TRY(launch_check("k_jpeg_idct"));
+            jpg::k_jpeg_idct_color_h2v2<<<dim3((G.mcux + 7) / 8, G.mcuy, (unsigned)m), 256, 0, st>>>(im, G, coef, j->d_quant.as<uint16_t>(), planes, dst,
+                                                                                                     image_stride_bytes, row_pitch_bytes);
+            BEVW_TRY(launch_check("k_jpeg_idct_color_h2v2"));
+            j->luma_planes = false;
+            continue;
+        }
+        jpg::k_jpeg_idct<<<dim3((G.nblk + 31) / 32, (unsigned)m), 256, 0, st>>>(im, G, coef, j->d_quant.as<uint16_t>(), planes, 0);
+        BEVW_TRY(launch_check("k_jpeg_idct"));
+        j->luma_planes = true;
         if (aligned && G.nc == 3 && G.hs == 2 && G.vs == 2 && G.dw > 2) {
             jpg::k_jpeg_color_h2v2<<<dim3(((G.w + 7) / 8 + 63) / 64, (G.h + 3) / 4, (unsigned)m), dim3(64, 4), 0, st>>>(G, planes, dst, image_stride_bytes,
                                                                                                                            row_pitch_bytes);
@@ -347,6 +369,12 @@ int bevw_jpeg_get_planes(bevw_jpeg *j, int index, uint8_t *planes)
 {
     if (!j || !planes || !j->decoded || index < 0 || index >= j->n) return fail(BEVW_E_INVALID, "bevw_jpeg_get_planes: nothing decoded / bad index");
     BEVW_TRY(use_device(j->device));
+    if (!j->luma_planes) {   // the fused path keeps no luma plane: transform this image's blocks once more (the coefficients are still there)
+        jpg::k_jpeg_idct<<<dim3((j->G.nblk + 31) / 32, 1), 256, 0, j->st>>>(j->d_desc.as<jpg::ImageDesc>() + index, j->G,
+                                                                              j->d_coef.as<int16_t>() + (size_t)index * j->G.nblk * 64, j->d_quant.as<uint16_t>(),
+                                                                              j->d_planes.as<uint8_t>() + (size_t)index * j->G.plane_bytes, 0);
+        BEVW_TRY(launch_check("k_jpeg_idct"));
+    }
     HIP_TRY(hipMemcpyAsync(planes, j->d_planes.as<uint8_t>() + (size_t)index * j->G.plane_bytes, (size_t)j->G.plane_bytes, hipMemcpyDeviceToHost, j->st));
     HIP_TRY(hipStreamSynchronize(j->st));
     return BEVW_OK;
