@@ -243,6 +243,57 @@ def test_rccl_transport_world_1_self_test():
         gen.close()
 
 
+def rccl_world_n_parity(out_dir, world):
+    """Spawns one worker per GPU (tests/_rccl_worker.py, the product's native RCCL transport, no torch) and compares what the stitch ranks
+    wrote with BevGenerator(blend=True, balance=True) on the same 4K frame sets -- bit-exact.  Also used by bench.py before it times the
+    camera-shard workload on more than one GPU."""
+    import _rccl_worker as RW
+    from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), str(out_dir)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the RCCL workers did not finish: " + "\n".join(logs))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    cfg, rig, frames, car = RW.inputs()
+    SC.apply_cfg(cfg)
+    try:
+        bev = SB.BevGenerator(blend=True, balance=True, rig=rig)
+        want_car, want = bev.batch(frames, car), bev.batch(frames)
+    finally:
+        SC.apply_cfg()
+    for rnd in range(4):
+        got = np.load(os.path.join(str(out_dir), "group0_round%d.npy" % rnd))
+        assert np.array_equal(got, want_car if rnd in (0, 2) else want), "round %d of world %d differs from BevGenerator" % (rnd, world)
+    return logs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_rccl_world_n_parity(tmp_path, world):
+    """the rank > 0 branches of the native RCCL exchange (bevw_shard_gather_parts, bevw_shard_allgather_vsums,
+    k_vsums_interleave) run the moment two GPUs are visible: one process per GPU on the 4K rig with blend + balance, bit-exact against
+    BevGenerator.  World 1 runs everywhere (same worker, no exchange) so that the harness itself stays tested on 1-GPU boxes."""
+    from cameracalibration_amd import _ffi
+
+    if _ffi.device_count() < world:
+        pytest.skip("needs %d GPUs, %d visible" % (world, _ffi.device_count()))
+    if world > 1:
+        assert _ffi.lib().bevw_comm_available() == 1
+    rccl_world_n_parity(tmp_path, world)
+
+
 def test_control_channel_over_sockets():
     """SocketGroup (the out-of-band channel that carries the RCCL unique id and the mask boxes): 3 ranks as threads."""
     import threading
