@@ -570,7 +570,24 @@ def main():
             _ffi.check(_ffi.lib().bevw_timer_between(e.h, a_, b_, C.byref(ms)))
             return float(ms.value)
         units_world = max(1, d.world // 4)
-        extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"], "schedule": "tile_plan",
+        parity = None
+        if d.world > 1:
+            # Before anything is timed on more than one GPU: the same ranks, the same native RCCL exchange, two seeded frame sets through the
+            # host-array call, and every group's stitch rank compares with BevGenerator on its own GPU -- bit-exact or the run stops.  (The rank > 0
+            # branches of bevw_shard_gather_parts / bevw_shard_allgather_vsums can only execute on a multi-GPU box: tests/test_camera_shard.py::
+            # test_rccl_world_n_parity is the same check under pytest.)
+            rng = np.random.default_rng(W.SEED + 1000 + gen.group)
+            pf = rng.integers(0, 256, (2, 4, fh, fw, 3), dtype=np.uint8)
+            got = gen(np.ascontiguousarray(pf[:, list(gen.cams)]), None, root=gen.ranks[0])
+            bad = 0.0
+            if got is not None:
+                ref = SB.BevGenerator(blend=w["blend"], balance=w["balance"], rig=rig, device=dev)
+                bad = 0.0 if np.array_equal(got, ref.batch(pf)) else 1.0
+                del ref
+            if d.max(bad) > 0:
+                raise SystemExit("camera-shard parity check FAILED: the RCCL exchange does not reproduce BevGenerator's bytes")
+            parity = "passed: 2 frame sets per camera group over the native RCCL exchange == BevGenerator on the stitch rank's GPU, bit-exact"
+        extra = {"frame": [fw, fh], "bev": [bw, bh], "blend": w["blend"], "balance": w["balance"], "schedule": "tile_plan", "parity_check": parity,
                  "table_build_s": round(t_build, 3), "cameras_per_rank": len(gen.cams), "camera_groups": units_world,
                  "part_boxes": [list(b) for b in gen.boxes],
                  "transport": "single rank" if d.world == 1 else "rccl (native: ncclAllGather + grouped ncclSend/ncclRecv on the engine stream)"}

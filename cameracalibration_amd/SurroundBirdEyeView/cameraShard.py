@@ -232,7 +232,7 @@ class HubDirectory:
                     c = None
                 if c is not None:
                     try:
-                        c.settimeout(5.0)
+                        c.settimeout(1.0)     # connections are served one after the other: a silent one may hold the directory for a second, not five
                         kind = _recv_exact(c, 1)
                         group = int.from_bytes(_recv_exact(c, 4), "little")
                         if kind == b"R" and 0 <= group < ngroups:
@@ -325,12 +325,19 @@ class SocketGroup:
                 deadline = time.time() + timeout
                 while len(got) < self.world - 1:
                     srv.settimeout(max(0.05, deadline - time.time()))
-                    c, _ = srv.accept()          # socket.timeout when a member never shows up
-                    c.settimeout(timeout)
-                    r = int.from_bytes(_recv_exact(c, 4), "little")
-                    if not (0 < r < self.world) or r in got:
-                        c.close()                # not a member of this group (a stray connection, another job)
+                    c, _ = srv.accept()          # socket.timeout when a member never shows up: the overall deadline
+                    # the 4-byte rank hello gets a short deadline of its own: a stray connection that sends nothing (a port scanner, another
+                    # job) is dropped after 2 s and the hub keeps accepting, instead of eating the whole membership timeout and aborting
+                    c.settimeout(min(2.0, max(0.05, deadline - time.time())))
+                    try:
+                        r = int.from_bytes(_recv_exact(c, 4), "little")
+                    except Exception:
+                        c.close()
                         continue
+                    if not (0 < r < self.world) or r in got:
+                        c.close()                # not a member of this group
+                        continue
+                    c.settimeout(timeout)
                     got[r] = c
             except Exception:
                 for c in got.values():

@@ -117,7 +117,17 @@ def main() -> int:
     ok, enc = cv2.imencode(".jpg", GC.jpeg_test_image(), [cv2.IMWRITE_JPEG_QUALITY, 100])   # Tools/undistort.py:73 with its default -quality 100
     cases["imwrite_q100"] = np.ascontiguousarray(enc).reshape(-1)
 
+    # implementation probes (OpenCV >= 4.11 rewrote warpPerspective and reworked remap): small cases stored whole, see _golden_cases.py
+    u16, s16, u8 = GC.probe_images()
+    Hp = np.array(GC.PROBE_H)
+    full = {"probe_warp_16uc1": cv2.warpPerspective(u16, Hp, GC.PROBE_DSIZE),      # surroundBEV.py:105-108: the map2 half of the BEV LUT
+            "probe_warp_16sc2": cv2.warpPerspective(s16, Hp, GC.PROBE_DSIZE),      #                          the map1 half
+            "probe_warp_8uc3": cv2.warpPerspective(u8, Hp, GC.PROBE_DSIZE)}        # extrinsicCalib.py:166-169
+    pm1, pm2 = GC.probe_maps()
+    full["probe_remap_8uc3"] = cv2.remap(u8, pm1, pm2, interpolation=cv2.INTER_LINEAR)   # surroundBEV.py:113-117
+
     blob = GC.pack(cases)
+    blob.update(GC.pack_full(full))
     blob["cv2_version"] = np.array(getattr(cv2, "__version__", "oracle-shim"))
     np.savez_compressed(OUT, **blob)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(cases), "cases, OpenCV", blob["cv2_version"])

@@ -328,3 +328,34 @@ def test_product_package_is_free_of_pytorch():
                 if "torch" in open(os.path.join(d, f), errors="replace").read():
                     hits.append(os.path.relpath(os.path.join(d, f), ROOT))
     assert not hits, hits
+
+
+def test_control_hub_survives_a_silent_connection():
+    """a connection that never sends its rank hello is dropped after a short per-connection deadline; the hub keeps accepting
+    and the group still forms."""
+    import socket
+    import threading
+    import time
+
+    from cameracalibration_amd.SurroundBirdEyeView import cameraShard as CS
+
+    port, out = free_port(), {}
+
+    def run(r, delay):
+        time.sleep(delay)
+        g = CS.SocketGroup(r, 2, "127.0.0.1", port, timeout=20.0)
+        out[r] = g.all_gather(bytes([r]) * 4)
+        g.close()
+
+    hub = threading.Thread(target=run, args=(0, 0.0))
+    hub.start()
+    time.sleep(0.3)
+    stray = socket.create_connection(("127.0.0.1", port), timeout=5.0)   # connects first, says nothing
+    member = threading.Thread(target=run, args=(1, 0.2))
+    member.start()
+    t0 = time.time()
+    hub.join(15)
+    member.join(15)
+    stray.close()
+    assert not hub.is_alive() and not member.is_alive() and time.time() - t0 < 10
+    assert out[0] == out[1] == [b"\x00" * 4, b"\x01" * 4]

@@ -141,6 +141,33 @@ def test_calibrator_paths(goldens, oracle, repo_rig):
         check(goldens, "resize_%g" % f, oracle.resize_linear(small, f, f))
 
 
+def test_implementation_probes(goldens, oracle):
+    """Which warpPerspective / remap IMPLEMENTATION the golden file's OpenCV runs.  The oracle restates the classic kernels (fixed-point
+    5-bit x 5-bit weights for 8U sources, float weights for 16-bit sources: every OpenCV from 2.4 to 4.10); OpenCV >= 4.11 ships new
+    warpPerspective kernels (8U / 16U / 32F) and a reworked remap.  The probes are stored whole, so a mismatch is reported with its
+    size: how many elements differ and by how much -- 'classic' (0 differences) or 'another implementation' (sub-LSB rounding
+    differences on a large share of the pixels), not just 'differs'."""
+    names = [n for n in ("probe_warp_16uc1", "probe_warp_16sc2", "probe_warp_8uc3", "probe_remap_8uc3") if n + "__full" in goldens]
+    if not names:
+        if os.environ.get("BEVW_REQUIRE_GOLDENS"):
+            pytest.fail("the golden file has no probe_* cases (regenerate it with the current make_goldens_with_cv2.py)")
+        pytest.skip("no probe_* cases in the golden file")
+    u16, s16, u8 = GC.probe_images()
+    Hp = np.array(GC.PROBE_H)
+    pm1, pm2 = GC.probe_maps()
+    mine = {"probe_warp_16uc1": oracle.warp_perspective(u16, Hp, GC.PROBE_DSIZE), "probe_warp_16sc2": oracle.warp_perspective(s16, Hp, GC.PROBE_DSIZE),
+            "probe_warp_8uc3": oracle.warp_perspective(u8, Hp, GC.PROBE_DSIZE), "probe_remap_8uc3": oracle.remap(u8, pm1, pm2)}
+    report = []
+    for n in names:
+        want = goldens[n + "__full"]
+        d = np.abs(want.astype(np.int64) - mine[n].astype(np.int64))
+        report.append("%s: %d of %d elements differ, max |diff| %d" % (n, int(np.count_nonzero(d)), d.size, int(d.max())))
+    print("OpenCV %s implementation probes: %s" % (goldens.get("cv2_version", "?"), "; ".join(report)))
+    bad = [r for r in report if ": 0 of" not in r]
+    assert not bad, ("this OpenCV does not run the classic warpPerspective / remap kernels the oracle restates (expected for opencv-python >= 4.11): "
+                     + "; ".join(bad))
+
+
 def test_jpeg_codec_of_this_opencv(goldens, repo_rig):
     """Row f4 against cv2 itself: cv2.imread of the reference's camera files and the files cv2.imwrite writes (main.py:74-77, surroundBEV.py:340,
     Tools/undistort.py:73) against the JPEG oracle -- which is already pinned against Pillow's libjpeg-turbo (tests/test_jpeg_oracle.py); a
