@@ -132,36 +132,21 @@ struct SubOut { uint64_t exit; int32_t cnt, dc0, dc1, dc2; };
 
 constexpr int kLaneBlock = 64;                  // int16 per lane of k_jpeg_coef's LDS block slots: with the 8-bit look-ahead tables four work-groups fit a CU
 constexpr int kColWords = kSubBits / 32 + 4;   // words a lane can touch while it stays inside its own subsequence (+ look-ahead)
-constexpr int kColGroups = kColWords / 4;      // ... as 16-byte groups of four words
-static_assert(kColWords % 4 == 0, "columns are stored in groups of four words");
 
 // Where a lane reads the 32-bit words of the entropy-coded data from.  `words` is the image's un-stuffed stream.  With 64 lanes walking 64
 // different 128-byte stretches of it, every word load of a wave touches 64 cache lines, the lines of 32 waves do not fit the L1 and the
 // stream was fetched from memory 14 x (profiles/r03_jpeg/pmc_decode_v3.txt).  k_jpeg_columns therefore lays the kColWords words of every
-// subsequence out as a COLUMN of 16-byte groups (group g = words 4g .. 4g + 3 of subsequence j at col[g * stride + j]): lanes of a wave, which
-// advance at about the same pace, read neighbouring addresses, one dwordx4 per 128 bits.  Round 4: groups instead of single words -- a walk
-// used to wait for a word load every 32 bits (the compiler cannot count outstanding loads across the divergent refill, so every refill
-// waited for the load issued at the previous one: ~1 us of exposed latency per 5 symbols in the sparse synchronisation rounds); now the
-// NEXT group is in flight while the current one is consumed, i.e. a load is waited for 128 bits (~20 symbols) after it was issued.
-// Groups beyond the column (a lane finishing a long block past its range) come from the stream itself.
+// subsequence out as a COLUMN (word w of subsequence j at col[w * stride + j]): lanes of a wave, which advance at about the same pace, then
+// read neighbouring addresses.  Words beyond the column (a lane finishing a long block past its range) come from the stream itself.
 struct WordSource {
     const uint32_t *words;   // the image's stream (32-bit words)
-    const uint4 *col;        // this lane's column, or nullptr
+    const uint32_t *col;     // this lane's column, or nullptr
     uint32_t stride;         // subsequences of the image
-    uint32_t word0;          // stream index of the column's first word (0 without a column)
-    __host__ __device__ __forceinline__ uint4 group(uint32_t g) const   // words word0 + 4 g ... + 3
-    {
-        if (col && g < (uint32_t)kColGroups) return col[(size_t)g * stride];
-        const uint32_t *q = words + word0 + 4u * g;
-        return make_uint4(q[0], q[1], q[2], q[3]);
-    }
+    uint32_t word0;          // stream index of the column's first word
     __host__ __device__ __forceinline__ uint32_t at(uint32_t w) const
     {
         const uint32_t d = w - word0;
-        if (!(col && d < (uint32_t)kColWords)) return words[w];
-        const uint4 v = col[(size_t)(d >> 2) * stride];
-        const uint32_t k = d & 3u;
-        return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w));
+        return (col && d < (uint32_t)kColWords) ? col[(size_t)d * stride] : words[w];
     }
 };
 
@@ -185,13 +170,11 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
     SubOut R;
     R.cnt = 0; R.dc0 = R.dc1 = R.dc2 = 0;
-    // bit window: w0 | w1 = the two (big-endian) words around the read position, `off` = bits of w0 already used; the words behind them come
-    // out of a 16-byte group in registers (Gc) while the next group (Gn) is in flight.  One 32-bit window holds a whole symbol (code <= 16
-    // bits + <= 16 extra bits).
-    uint32_t off = p & 31u;
-    uint32_t w0 = __builtin_bswap32(src.at(p >> 5)), w1 = __builtin_bswap32(src.at((p >> 5) + 1));
-    uint32_t nx = (p >> 5) + 2u - src.word0;   // the next word to take, relative to the column's first (p >= the subsequence's first bit)
-    uint4 Gc = src.group(nx >> 2), Gn = src.group((nx >> 2) + 1u);   // the group that holds it, and the one behind (in flight while Gc is consumed)
+    // bit window: w0 | w1 = the two (big-endian) words around the read position, `off` = bits of w0 already used; the word after them
+    // is always in flight (nraw): a wave meets a refill in nearly every iteration, and waiting for a load where it is issued would cost
+    // the whole wave a memory latency per symbol.  One 32-bit window holds a whole symbol (code <= 16 bits + <= 16 extra bits).
+    uint32_t widx = p >> 5, off = p & 31u;
+    uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
     // position of the block in progress (WRITE)
     int mx = 0, my = 0;
     size_t baddr = 0;
@@ -285,13 +268,9 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
         if (off >= 32u) {
             off -= 32u;
             w0 = w1;
-            const uint32_t kk = nx & 3u;
-            w1 = __builtin_bswap32(kk == 0 ? Gc.x : (kk == 1 ? Gc.y : (kk == 2 ? Gc.z : Gc.w)));
-            ++nx;
-            if ((nx & 3u) == 0) {
-                Gc = Gn;
-                Gn = src.group((nx >> 2) + 1u);
-            }
+            w1 = __builtin_bswap32(nraw);
+            ++widx;
+            nraw = src.at(widx + 2);
         }
       }   // if (go)
 #if defined(__HIP_DEVICE_COMPILE__)

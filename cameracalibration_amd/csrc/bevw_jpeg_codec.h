@@ -175,12 +175,12 @@ struct SubArrays {
     uint32_t *endbit;   // last bit (exclusive) the subsequence owns
     uint32_t *meta;     // restart segment | first-of-segment << 31
     uint32_t *word0;    // stream index of the first word of the subsequence's column
-    uint4 *cols;        // the columns: group g (words 4g .. 4g + 3) of subsequence j of an image at cols[kColGroups * sub_first + g * nsub + j]
+    uint32_t *cols;     // the columns: word w of subsequence j of an image at cols[kColWords * sub_first + w * nsub + j]
 };
 
 __device__ __forceinline__ WordSource word_source(const SubArrays &A, const ImageDesc &D, const uint32_t *__restrict__ stream, uint32_t j)
 {
-    return WordSource{stream + D.stream_word, A.cols + (size_t)kColGroups * D.sub_first + j, D.nsub, A.word0[(size_t)D.sub_first + j]};
+    return WordSource{stream + D.stream_word, A.cols + (size_t)kColWords * D.sub_first + j, D.nsub, A.word0[(size_t)D.sub_first + j]};
 }
 
 // Lays the words of every subsequence out as a column (see WordSource) and records where it starts; also the per-subsequence constants
@@ -206,12 +206,12 @@ __global__ __launch_bounds__(256) void k_jpeg_columns(const ImageDesc *__restric
     A.meta[slot] = lo | (j == ss[lo] ? 0x80000000u : 0u);
     A.word0[slot] = start >> 5;
     const uint32_t *src = stream + D.stream_word + (start >> 5);
-    uint4 *dst = A.cols + (size_t)kColGroups * D.sub_first + j;
+    uint32_t *dst = A.cols + (size_t)kColWords * D.sub_first + j;
     uint32_t v[kColWords];
 #pragma unroll
     for (int w = 0; w < kColWords; ++w) v[w] = src[w];   // (the stream buffer is padded: the last subsequence of a batch may read past its data)
 #pragma unroll
-    for (int g = 0; g < kColGroups; ++g) dst[(size_t)g * D.nsub] = make_uint4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+    for (int w = 0; w < kColWords; ++w) dst[(size_t)w * D.nsub] = v[w];
 }
 
 __global__ __launch_bounds__(256) void k_jpeg_sync0(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,

@@ -334,8 +334,9 @@ __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, u
 
 // The per-tap tile kernel.  grid: blocks of 4 waves = 4 base tiles of the list; one tile per wave.
 // LUM: luminance round trip per fetched texel (raw frames); SUMS: emit per-tile channel sums and leave the car to the gain pass
+// (two waves per SIMD: the 128-VGPR budget of rounds 1 - 3 spilled 0.5 - 1.2 KB per lane to scratch -- tools/kernel_resources.sh)
 template <bool BLEND, bool LUM, bool SUMS = LUM>
-__global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) k_stitch_plan(PlanArgs a)
 {
     constexpr bool BAL = LUM;
     __shared__ int sdiv[BAL ? 256 : 1], hdiv[BAL ? 256 : 1];
@@ -373,7 +374,7 @@ __global__ void __launch_bounds__(256) k_stitch_plan(PlanArgs a)
     const bool car_any = __builtin_amdgcn_ballot_w64((car0 | car1 | car2) != 0) != 0;
 
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
-#pragma unroll 2
+#pragma unroll 1
     for (int b = b_begin; b < b_end; ++b) {
         const uint8_t *fb = a.frames + (size_t)b * set_bytes;
         const int *fdeltas = BAL ? a.deltas + b * 4 : nullptr;

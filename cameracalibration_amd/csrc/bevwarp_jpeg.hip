@@ -231,7 +231,7 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     BEVW_TRY(j->d_coef.reserve(n * (size_t)G.nblk * 128));
     BEVW_TRY(j->d_planes.reserve(n * (size_t)G.plane_bytes));
     jpg::SubArrays A{j->d_entry.as<uint64_t>(), j->d_exit.as<uint64_t>(), j->d_sums.as<int4>(), j->d_base.as<int4>(), j->d_endbit.as<uint32_t>(),
-                     j->d_meta.as<uint32_t>(), j->d_word0.as<uint32_t>(), j->d_cols.as<uint4>()};
+                     j->d_meta.as<uint32_t>(), j->d_word0.as<uint32_t>(), j->d_cols.as<uint32_t>()};
     const jpg::ImageDesc *img = j->d_desc.as<jpg::ImageDesc>();
     const uint32_t *stream = j->d_stream.as<uint32_t>();
     const jpg::TableSet *tabs = j->d_tabs.as<jpg::TableSet>();

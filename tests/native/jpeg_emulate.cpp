@@ -101,16 +101,12 @@ static int do_decode(const char *in, const char *out)
     std::vector<uint32_t> seg_sub(nseg + 1, 0);
     for (int s = 0; s < nseg; ++s) seg_sub[s + 1] = seg_sub[s] + ((seg_byte[s + 1] - seg_byte[s]) * 8 + kSubBits - 1) / kSubBits;
     const int nsub = (int)seg_sub[nseg];
-    // k_jpeg_columns: group g (words 4g .. 4g + 3) of subsequence j at col[g * nsub + j]
-    std::vector<uint4> col((size_t)kColGroups * std::max(nsub, 1));
-    std::vector<uint32_t> word0(nsub);
+    // k_jpeg_columns: word w of subsequence j at col[w * nsub + j]
+    std::vector<uint32_t> col((size_t)kColWords * std::max(nsub, 1)), word0(nsub);
     for (int s = 0; s < nseg; ++s)
         for (uint32_t j = seg_sub[s]; j < seg_sub[s + 1]; ++j) {
             word0[j] = (seg_byte[s] * 8 + (j - seg_sub[s]) * kSubBits) >> 5;
-            for (int g = 0; g < kColGroups; ++g) {
-                const uint32_t *q = words + word0[j] + 4 * g;
-                col[(size_t)g * nsub + j] = make_uint4(q[0], q[1], q[2], q[3]);
-            }
+            for (int w = 0; w < kColWords; ++w) col[(size_t)w * nsub + j] = words[word0[j] + w];
         }
     auto source = [&](int j) { return WordSource{words, col.data() + j, (uint32_t)nsub, word0[j]}; };
     std::vector<uint64_t> entry(nsub), exitst(nsub);

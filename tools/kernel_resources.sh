@@ -1,11 +1,11 @@
 #!/bin/bash
 # VGPR / SGPR / LDS / occupancy of every kernel of libbevwarp.so matching a pattern (default: the per-frame plan kernels):
-#   bash tools/kernel_resources.sh [regex]
+#   bash tools/kernel_resources.sh [regex] [translation unit under csrc/, default bevwarp_plan.hip]
 # Compiles to /tmp (the in-tree .so is not touched).
 PAT=${1:-k_plan_}
 cd "$(dirname "$0")/.."
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -Wno-pass-failed -Wno-inline-asm \
-  -Rpass-analysis=kernel-resource-usage cameracalibration_amd/csrc/bevwarp.hip -o /tmp/libbevwarp_res.so 2>&1 |
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-pass-failed -Wno-inline-asm \
+  -Rpass-analysis=kernel-resource-usage -c cameracalibration_amd/csrc/${2:-bevwarp_plan.hip} -o /tmp/libbevwarp_res.o 2>&1 |
 python3 -c '
 import re, sys, subprocess
 pat = re.compile(sys.argv[1])
