@@ -63,7 +63,7 @@ struct Plan {
     void *un_desc = nullptr, *un_entries = nullptr, *un_gsrc = nullptr;
     void *list_un_all = nullptr;             // every unit in partition order, class in bits 28..31
     int n_un_all = 0;
-    int n_un[7] = {0, 0, 0, 0, 0, 0, 0};     // units per class (diagnostics)
+    int n_un[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // units per class (diagnostics)
     int n_unit_tiles = 0;                    // base tiles the units own
     size_t un_lines = 0, un_sectors = 0;     // request arithmetic of the partition (per frame)
     int un_skew = 0;

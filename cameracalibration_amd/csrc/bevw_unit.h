@@ -54,10 +54,11 @@ constexpr int kUnitMaxNQ = 4;                // pixel quads per lane
 constexpr int kUnitMaxGR = 4;                // rounds of kUnitThreads groups
 constexpr int kUnitMaxGroups = kUnitMaxGR * kUnitThreads;        // 1024 group slots = 32 KB of pair entries
 constexpr int kUnitMaxWidth = 256;           // pixels: 64 quads = one wave-store per row
-constexpr int kUnitClasses = 7;               // four single-contributor classes, three for units with up to two contributors per pixel
-constexpr int kUnitClassNQ[kUnitClasses] = {4, 4, 2, 1, 2, 1, 1};
-constexpr int kUnitClassGR[kUnitClasses] = {1, 2, 4, 4, 1, 4, 1};
-constexpr int kUnitClassCON[kUnitClasses] = {1, 1, 1, 1, 2, 2, 2};
+constexpr int kUnitClasses = 8;               // five single-contributor classes (7 = the big one), three for units with up to two contributors per pixel
+constexpr int kUnitClassNQ[kUnitClasses] = {4, 4, 2, 1, 2, 1, 1, 4};
+constexpr int kUnitClassGR[kUnitClasses] = {1, 2, 4, 4, 1, 4, 1, 4};
+constexpr int kUnitClassCON[kUnitClasses] = {1, 1, 1, 1, 2, 2, 2, 1};
+constexpr int kUnitClassBig = 7;              // 4096 pixels AND 1024 groups (round 4: rounds 2 - 3 could not afford its ~160 VGPRs beside the retired schedules)
 constexpr uint32_t kUnitSkip = 1u << 22;     // entry of pixel 0 of a quad, with equal slots: the quad's base tile belongs to another class -> not stored
 
 // unit descriptor: 8 dwords, read with scalar loads
@@ -162,6 +163,7 @@ struct UnitTuning {
     int own_padding = 1;             // the padding columns of a pitched output are written (zeros) by the units at the right edge
     int run_cost = 0;                // cost of one more row run (experiment: wider units write longer runs; profiles/r03/sweeps.log)
     int stagger = 0;                 // pixels the column grid of the root cells shifts per row of cells (0: the same columns in every row)
+    int big_class = 1;               // the (4 quads, 4 rounds) class: fewer cuts where a cell has many pixels AND many groups
 };
 
 // Host-side plan compiler of the units.  tables: host copies of the LUTs of every camera.  hdr: base-tile headers (32 x 8 tiles,
@@ -349,6 +351,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         for (int c = 0; c < kUnitClasses; ++c) {
             if (kUnitClassCON[c] != pass || kUnitClassNQ[c] * kUnitWaves < slots || kUnitClassGR[c] * kUnitThreads < (int)used + (wide ? 1 : 0)) continue;
             if (c == 4 && !tune.wide_double) continue;
+            if (c == kUnitClassBig && !tune.big_class) continue;
             const int cost = kUnitClassNQ[c] * 64 + kUnitClassGR[c] * 14;
             if (cost < best) { best = cost; cls = c; }
         }
@@ -421,7 +424,7 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         if (st.quads == 0) continue;              // nothing a unit owns in here
         bool fits = false;   // some class holds the rectangle (emit decides finally: line-aligned slots may need a few more)
         for (int k = 0; k < kUnitClasses; ++k)
-            fits = fits || (kUnitClassCON[k] == pass && !(k == 4 && !tune.wide_double) && st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads - (wide ? 1 : 0)) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
+            fits = fits || (kUnitClassCON[k] == pass && !(k == 4 && !tune.wide_double) && !(k == kUnitClassBig && !tune.big_class) && st.groups <= std::min(tune.max_groups, kUnitClassGR[k] * kUnitThreads - (wide ? 1 : 0)) && slots_needed(c.w, c.h) <= kUnitClassNQ[k] * kUnitWaves);
         // a rectangle that is mostly other classes' quads (a seam crossing it diagonally) idles most of its lanes: cut it further
         if (fits && (long)st.quads * 8 < (long)(c.w / 4) * c.h * 3 && (long)c.w * c.h > 1024) fits = false;
         if (fits && emit(c.x0, c.y0, c.w, c.h, st)) continue;
@@ -881,7 +884,7 @@ __device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_
         // class 4 (two quads per lane, two contributors): its blend variant would set the kernel's register budget (177 .. 197 VGPRs);
         // plans of blend handles are compiled without it (UnitTuning::wide_double)
         case 4: if (!BLEND) plan_unit_run<false, SUMS, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4]>(a, chunk, unit, lds); break;
-        BEVW_UNIT_CASE(5)
+        BEVW_UNIT_CASE(5) BEVW_UNIT_CASE(7)
         default: plan_unit_run<BLEND, SUMS, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6]>(a, chunk, unit, lds); break;
     }
 #undef BEVW_UNIT_CASE
@@ -911,7 +914,7 @@ __global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_
     switch (e >> 28) {
         BEVW_UNIT_CASE(0) BEVW_UNIT_CASE(1) BEVW_UNIT_CASE(2) BEVW_UNIT_CASE(3)
         case 4: if (!BLEND) plan_unit_run<false, false, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4], true>(a, chunk, unit, patch); break;
-        BEVW_UNIT_CASE(5)
+        BEVW_UNIT_CASE(5) BEVW_UNIT_CASE(7)
         default: plan_unit_run<BLEND, false, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6], true>(a, chunk, unit, patch); break;
     }
 #undef BEVW_UNIT_CASE

@@ -20,6 +20,7 @@ static UnitTuning unit_tuning_env()
     if (const char *s = getenv("BEVW_UNIT_OWN_PADDING")) t.own_padding = atoi(s);
     if (const char *s = getenv("BEVW_UNIT_STAGGER")) t.stagger = atoi(s);
     if (const char *s = getenv("BEVW_UNIT_RUN_COST")) t.run_cost = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_BIG")) t.big_class = atoi(s);
     return t;
 }
 

@@ -98,6 +98,7 @@ static int run(const Rig &r, const char *out_path)
     if (const char *e = getenv("BEVW_UNIT_STAGGER")) tune.stagger = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_RUN_COST")) tune.run_cost = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_ROW_ORDER")) tune.row_order = atoi(e);
+    if (const char *e = getenv("BEVW_UNIT_BIG")) tune.big_class = atoi(e);
     if (r.wide && tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // as analytic_units_build (csrc/bevwarp.hip)
     unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune, r.wide ? r.fr : nullptr);
     if (up.desc.empty() && g_allow_no_units) { printf("unit schedule ok: no unit (every base tile left to the other classes)\n"); return 0; }

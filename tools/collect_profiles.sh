@@ -1,17 +1,25 @@
 #!/bin/bash
 # Round-end evidence, run on the GPU box from the repo root:  gpurun -- 'bash tools/collect_profiles.sh'
-# Everything lands under gpurun_out/final/; copy what should be judged into profiles/.
+# Everything lands under gpurun_out/final/; copy what should be judged into profiles/r04_final/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -n "passed\|failed" $O/pytest_gpu.log | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# the driver's own command: the default line with its f4 summary
+( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.time; tail -3 $O/bench_default.time | head -1
 for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k direct_stitch_analytic_f32_b64 direct_stitch_analytic_f64_b64; do
-  timeout 600 python bench.py --workload $w 2>/dev/null | tail -1 > $O/bench_$w.json
+  timeout 600 python bench.py --workload $w --no-f4 2>/dev/null | tail -1 > $O/bench_$w.json
   python -c "import json;d=json.load(open('$O/bench_$w.json'));o=d.get('other_output_layout');print('$w',round(d['value']),d['unit'],'ms',round(d['ms_per_step'],4),'frac',round(d['roofline']['frac'],3),'placements',d['placements']['ms_per_step'],'| other layout',o and (o['output_layout'],round(o['ms_per_step'],4)),'| cpu',d['cpu_baseline'] and round(d['cpu_baseline']['value'],1))"
 done
+for w in jpeg_decode_b64 jpeg_encode_b64 jpeg_bev_jpeg_b64; do
+  timeout 600 python bench.py --workload $w 2>/dev/null | tail -1 > $O/bench_$w.json
+  python -c "import json;d=json.load(open('$O/bench_$w.json'));c=d['config'];print('$w',round(d['value']),d['unit'],'ms',round(d['ms_per_step'],3),'frac',round(d['roofline']['frac'],3),d['roofline']['bound'],'rounds',c.get('fixed_point_rounds_max'),'host_api',c.get('host_api_frames_per_s'),c.get('host_api_unpipelined_frames_per_s'),'| cpu',d['cpu_baseline'] and round(d['cpu_baseline']['value'],1))"
+done
+timeout 600 python bench.py --workload jpeg_decode_b64 --jpeg-source repo 2>/dev/null | tail -1 > $O/bench_jpeg_decode_b64_repo_files.json
+python -c "import json;d=json.load(open('$O/bench_jpeg_decode_b64_repo_files.json'));c=d['config'];print('jpeg_decode repo files',round(d['value']),'ms',round(d['ms_per_step'],3),'rounds',c.get('fixed_point_rounds_max'))"
 BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
   bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 --placements 1 --single-layout 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
 python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
@@ -26,15 +34,25 @@ for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k
     cp $(find /tmp/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${w}_$c.csv 2>/dev/null
   done
 done
-# per-class times of config 3: the same step launched class by class (BEVW_PLAN_ONELAUNCH=0)
-rm -rf /tmp/kt_classes
-BEVW_PLAN_ONELAUNCH=0 timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_classes -- python $R/bench.py --workload direct_stitch_b256 --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline > /tmp/kt_classes.log 2>&1
-cp $(find /tmp/kt_classes -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_direct_stitch_b256_per_class.csv
+# row f4: kernel statistics and the VALU instruction counts behind roofline.bound = valu_issue of the JPEG lines
+for w in jpeg_decode_b64 jpeg_encode_b64 jpeg_bev_jpeg_b64; do
+  rm -rf /tmp/kt_$w /tmp/pv_$w
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
+  cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
+  BEVW_BENCH_NO_HOST_API=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_$w -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_$w.log 2>&1
+  cp $(find /tmp/pv_$w -name "*counter_collection.csv" | head -1) $O/pmc_valu_$w.csv
+done
+rm -rf /tmp/kt_rep /tmp/pv_rep
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_rep.log 2>&1
+cp $(find /tmp/kt_rep -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_jpeg_decode_b64_repo_files.csv
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_rep.log 2>&1
+cp $(find /tmp/pv_rep -name "*counter_collection.csv" | head -1) $O/pmc_valu_jpeg_decode_b64_repo.csv
 cd $R
 python tools/summarize_pmc.py $O
-# request / latency counters of the merged stitch kernel (config 3, both device-image layouts) and of config 4's kernels
-bash tools/r03/pmc_merged.sh final/pmc_direct_stitch_aligned direct_stitch_b256 "" --single-layout > /dev/null 2>&1
-bash tools/r03/pmc_merged.sh final/pmc_direct_stitch_dense direct_stitch_b256 "" --single-layout --output-pitch dense > /dev/null 2>&1
-bash tools/r03/pmc_merged.sh final/pmc_blend_balance blend_balance_b256 "" --single-layout > /dev/null 2>&1
+python tools/r04/jpeg_valu.py $O
+# request / latency counters of the stitch kernel (config 3, both device-image layouts) and of config 4's kernels
+bash tools/pmc_merged.sh final/pmc_direct_stitch_aligned direct_stitch_b256 "" > /dev/null 2>&1
+bash tools/pmc_merged.sh final/pmc_direct_stitch_dense direct_stitch_b256 "" --output-pitch dense > /dev/null 2>&1
+bash tools/pmc_merged.sh final/pmc_blend_balance blend_balance_b256 "" > /dev/null 2>&1
 for t in pmc_direct_stitch_aligned pmc_direct_stitch_dense pmc_blend_balance; do cp $O/$t/summary.txt $O/$t.txt; rm -rf $O/$t; done
 tail -30 $O/pmc_direct_stitch_aligned.txt

@@ -1,5 +1,5 @@
 #!/bin/bash
-# counters of the merged stitch kernel for one workload / env: gpurun -- 'bash tools/r03/pmc_merged.sh tag workload "ENV=.. ENV=.." [bench args]'
+# counters of the merged stitch kernel for one workload / env: gpurun -- 'bash tools/pmc_merged.sh tag workload "ENV=.. ENV=.." [bench args]'
 TAG=${1:-pmc}; W=${2:-direct_stitch_b256}; E=${3:-}; shift 3
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG

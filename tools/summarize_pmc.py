@@ -26,8 +26,8 @@ try:
     CAL = json.load(open(os.path.join(ROOT, "profiles", "pmc_calibration.json")))["factors"]
 except (OSError, ValueError, KeyError):
     CAL = None
-GROUP_LOADERS = ("k_plan_all", "k_plan_pair", "k_plan_block", "k_plan_unit")   # pair-staged stitch kernels
-PER_STEP = ("k_plan_all", "k_plan_unit", "k_plan_block", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
+GROUP_LOADERS = ("k_plan_units", "k_plan_unit_wide", "k_plan_all", "k_plan_pair", "k_plan_block", "k_plan_unit")   # the staged stitch kernels (texel-group loads)
+PER_STEP = ("k_plan_units", "k_plan_all", "k_plan_unit", "k_plan_block", "k_plan_lean", "k_plan_empty", "k_stitch_", "k_vsum", "k_lum_", "k_reduce_psums", "k_gain", "k_remap")
 
 
 def kernel_sums(path):
@@ -51,7 +51,7 @@ def main(d):
           "WRITE_SIZE is exact (x%.2f for the 8 x 96-byte tile stores), so write traffic above the output bytes is real (partial-sector evictions)." %
           (CAL or {}).get("tile_stores", 1.0), ""]
     traffic = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes "
-                           "(profiles/r03_final/rocprofv3_pmc_hbm_traffic.md, tools/collect_profiles.sh), corrected with the factors of "
+                           "(profiles/r04_final/rocprofv3_pmc_hbm_traffic.md, tools/collect_profiles.sh), corrected with the factors of "
                            "profiles/pmc_calibration.json (measured on known byte counts); bench.py copies the "
                            "figure of the workload it runs into roofline.traffic."}
     for w, units in UNITS.items():
@@ -77,7 +77,7 @@ def main(d):
             tw += b
             md.append("| `%s` | %.0f | %.0f |" % (k[:90], a, b))
         md += ["| **sum** | %.0f (%.0f MB) | %.0f (%.0f MB) |" % (tf, tf * 1024 / 1e6, tw, tw * 1024 / 1e6), ""]
-        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 3,
+        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 4,
                       "corrected": bool(CAL)}
     open(os.path.join(d, "rocprofv3_pmc_hbm_traffic.md"), "w").write("\n".join(md) + "\n")
     json.dump(traffic, open(os.path.join(d, "hbm_traffic.json"), "w"), indent=1)
