@@ -133,7 +133,7 @@ def main(argv=None):
                     if (info["height"], info["width"]) != (args.height, args.width):
                         print("{}: {}x{} is not {}x{}, skipped".format(f, info["width"], info["height"], args.width, args.height))
                         continue
-                    gpu.append((f, raw, (info["components"], info["h_samp"], info["v_samp"])))
+                    gpu.append((f, raw, (info["components"], info["h_samp"], info["v_samp"], info["orientation"])))
                 except _ffi.BevwError as e:
                     # not silent: this file is outside the GPU codec's subset and is decoded on the CPU by Pillow (as every file was before
                     # the codec existed); the remap itself still runs on the GPU
@@ -141,12 +141,13 @@ def main(argv=None):
                     ok = False
             if not ok:
                 import io
-                img = np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(raw)).convert("RGB"))[:, :, ::-1])
+                from PIL import ImageOps
+                img = np.ascontiguousarray(np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(raw))).convert("RGB"))[:, :, ::-1])   # (cv2.imread applies the EXIF orientation)
                 if img.shape != (args.height, args.width, 3):
                     print("{}: {}x{} is not {}x{}, skipped".format(f, img.shape[1], img.shape[0], args.width, args.height))
                     continue
                 out[f] = img
-        for geom in sorted({g for _, _, g in gpu}):   # one geometry (components, sampling) per decode batch
+        for geom in sorted({g for _, _, g in gpu}):   # one geometry (components, sampling, EXIF orientation) per decode batch
             group = [(f, raw) for f, raw, g in gpu if g == geom]
             dec = codec.decode([raw for _, raw in group])
             for (f, _), img in zip(group, dec):

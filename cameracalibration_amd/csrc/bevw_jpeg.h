@@ -767,7 +767,7 @@ inline int parse_header(const uint8_t *d, size_t n, Parsed &P, std::string &why)
     }
     for (int c = 0; c < P.nc; ++c)
         if (!P.qok[P.tq[c]] || !P.dc[P.td[c]].ok || !P.ac[P.ta[c]].ok) { why = "a table the scan refers to is missing"; return kParseFormat; }
-    if (P.orientation > 1) { why = "EXIF orientation other than 1 (cv2.imread would rotate the image)"; return kParseUnsupported; }
+    if (P.orientation < 1 || P.orientation > 8) P.orientation = 1;   // (an invalid tag is ignored, as cv2.imread does)
     return kParseOk;
 }
 

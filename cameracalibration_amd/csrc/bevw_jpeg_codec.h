@@ -608,6 +608,32 @@ __global__ __launch_bounds__(256) void k_jpeg_idct_color_h2v2(const ImageDesc *_
     }
 }
 
+// cv2.imread applies the EXIF orientation tag (OpenCV's ExifTransform: 2 = flip horizontally, 3 = rotate by 180, 4 = flip vertically,
+// 5 = transpose, 6 = transpose + horizontal flip (90 degrees clockwise), 7 = transpose + both flips, 8 = transpose + vertical flip).  src: the
+// decoded image as stored, dense [h][w][3]; dst: the oriented image (ow x oh = w x h, or h x w for 5 .. 8) in the caller's layout.  One thread
+// per output pixel: files with an orientation tag are the exception, not the camera path.
+__global__ __launch_bounds__(256) void k_jpeg_orient(const uint8_t *__restrict__ src, int w, int h, int orientation, uint8_t *__restrict__ dst,
+                                                     size_t image_stride, size_t row_pitch)
+{
+    const int ow = orientation >= 5 ? h : w, oh = orientation >= 5 ? w : h;
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= ow || y >= oh) return;
+    int sx, sy;
+    switch (orientation) {
+        case 2: sx = w - 1 - x; sy = y; break;
+        case 3: sx = w - 1 - x; sy = h - 1 - y; break;
+        case 4: sx = x; sy = h - 1 - y; break;
+        case 5: sx = y; sy = x; break;
+        case 6: sx = y; sy = h - 1 - x; break;
+        case 7: sx = w - 1 - y; sy = h - 1 - x; break;
+        case 8: sx = w - 1 - y; sy = x; break;
+        default: sx = x; sy = y; break;
+    }
+    const uint8_t *s = src + (size_t)blockIdx.z * w * h * 3 + ((size_t)sy * w + sx) * 3;
+    uint8_t *d = dst + (size_t)blockIdx.z * image_stride + (size_t)y * row_pitch + (size_t)x * 3;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+}
+
 // ---- encode ----------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_jenc_ycc(Geom G, const uint8_t *__restrict__ bgr, size_t image_stride, size_t row_pitch,
                                                   uint8_t *__restrict__ planes)

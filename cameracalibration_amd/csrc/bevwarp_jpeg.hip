@@ -21,6 +21,7 @@ struct bevw_jpeg {
     jpg::Geom G{};
     int n = 0;
     bool staged = false, decoded = false;
+    int orientation = 1;                       // EXIF orientation of the staged batch (cv2.imread applies it)
     bool luma_planes = true;                   // the last decode wrote the luma sample planes (false: fused luma IDCT + colour conversion)
     size_t total_sub = 0;
     uint32_t max_sub = 0, max_chunk = 0;
@@ -31,6 +32,7 @@ struct bevw_jpeg {
     std::vector<jpg::TableSet> h_tabs;
     std::vector<uint16_t> h_quant;
     DevBuf d_raw, d_stream, d_desc, d_seg_byte, d_seg_sub, d_term, d_nrst, d_chunk_keep, d_chunk_rst, d_tabs, d_quant;
+    DevBuf d_turn;            // files with an EXIF orientation: the images as stored, before k_jpeg_orient
     DevBuf d_list, d_count;   // round 2: per image, the subsequences that walk again
     DevBuf d_entry, d_exit, d_exit2, d_sums, d_base, d_endbit, d_meta, d_word0, d_cols, d_rounds, d_coef, d_planes, d_img;
     // encode
@@ -105,6 +107,8 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
         if (!data[i]) return fail(BEVW_E_INVALID, "JPEG %d: null pointer", i);
         const int st = jpg::parse_header(data[i], len[i], P[i], why);
         if (st) return jpeg_parse_fail(st, i, why);
+        if (i && P[i].orientation != P[0].orientation)
+            return fail(BEVW_E_INVALID, "JPEG %d has EXIF orientation %d but the batch has %d: one orientation per batch", i, P[i].orientation, P[0].orientation);
         if (i && (P[i].w != P[0].w || P[i].h != P[0].h || P[i].nc != P[0].nc || P[i].hs != P[0].hs || P[i].vs != P[0].vs))
             return fail(BEVW_E_INVALID, "JPEG %d is %dx%d (%d components, luma %dx%d) but the batch is %dx%d (%d, %dx%d): one geometry per batch", i,
                         P[i].w, P[i].h, P[i].nc, P[i].hs, P[i].vs, P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
@@ -113,6 +117,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     const size_t bound = slot_off[n];
     if (bound >= ((size_t)1 << 32)) return fail(BEVW_E_INVALID, "batch of %zu entropy-coded bytes: split it (4 GiB per batch)", bound);
     j->G = jpg::make_geom(P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
+    j->orientation = P[0].orientation;
     const jpg::Geom &G = j->G;
     BEVW_TRY(j->h_stream.reserve(bound));
     j->h_desc.assign((size_t)n, jpg::ImageDesc());
@@ -212,9 +217,20 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     if (!j || !d_out) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_run_device: null argument");
     if (!j->staged) return fail(BEVW_E_INVALID, "bevw_jpeg_decode_run_device before bevw_jpeg_decode_stage");
     const jpg::Geom &G = j->G;
-    if (row_pitch_bytes < (size_t)G.w * 3 || image_stride_bytes < row_pitch_bytes * (size_t)G.h)
-        return fail(BEVW_E_INVALID, "output layout (pitch %zu, stride %zu) too small for %dx%d BGR", row_pitch_bytes, image_stride_bytes, G.w, G.h);
+    const bool oriented = j->orientation != 1;
+    const int ow = j->orientation >= 5 ? G.h : G.w, oh = j->orientation >= 5 ? G.w : G.h;   // what cv2.imread returns
+    if (row_pitch_bytes < (size_t)ow * 3 || image_stride_bytes < row_pitch_bytes * (size_t)oh)
+        return fail(BEVW_E_INVALID, "output layout (pitch %zu, stride %zu) too small for %dx%d BGR", row_pitch_bytes, image_stride_bytes, ow, oh);
     BEVW_TRY(use_device(j->device));
+    // files with an EXIF orientation: decoded as stored into a scratch batch, then turned into the caller's layout (k_jpeg_orient)
+    void *const d_final = d_out;
+    const size_t final_stride = image_stride_bytes, final_pitch = row_pitch_bytes;
+    if (oriented) {
+        BEVW_TRY(j->d_turn.reserve((size_t)j->n * G.w * G.h * 3));
+        d_out = j->d_turn.p;
+        image_stride_bytes = (size_t)G.w * G.h * 3;
+        row_pitch_bytes = (size_t)G.w * 3;
+    }
     const size_t ns = j->total_sub ? j->total_sub : 1, n = (size_t)j->n;
     BEVW_TRY(j->d_entry.reserve(ns * 8));
     BEVW_TRY(j->d_exit.reserve(ns * 8));
@@ -320,6 +336,11 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
         HIP_TRY(hipEventRecord(j->ev_b, j->st2));
         HIP_TRY(hipStreamWaitEvent(j->st, j->ev_b, 0));
     }
+    if (oriented) {
+        jpg::k_jpeg_orient<<<dim3((ow + 255) / 256, (unsigned)oh, (unsigned)j->n), 256, 0, j->st>>>(j->d_turn.as<uint8_t>(), G.w, G.h, j->orientation,
+                                                                                                     (uint8_t *)d_final, final_stride, final_pitch);
+        BEVW_TRY(launch_check("k_jpeg_orient"));
+    }
     j->decoded = true;
     return BEVW_OK;
 }
@@ -330,7 +351,7 @@ int bevw_jpeg_decode(bevw_jpeg *j, const uint8_t *const *data, const size_t *len
     BEVW_TRY(bevw_jpeg_decode_stage(j, data, len, n));
     const size_t image = (size_t)j->G.w * j->G.h * 3;
     BEVW_TRY(j->d_img.reserve(image * (size_t)n));
-    BEVW_TRY(bevw_jpeg_decode_run_device(j, j->d_img.p, image, (size_t)j->G.w * 3));
+    BEVW_TRY(bevw_jpeg_decode_run_device(j, j->d_img.p, image, (size_t)(j->orientation >= 5 ? j->G.h : j->G.w) * 3));
     HIP_TRY(hipMemcpyAsync(out, j->d_img.p, image * (size_t)n, hipMemcpyDeviceToHost, j->st));
     HIP_TRY(hipStreamSynchronize(j->st));
     int64_t info[8];
@@ -360,7 +381,7 @@ int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8])
     HIP_TRY(hipStreamSynchronize(j->st));
     size_t stream_bytes = 0, subs = 0;
     for (const jpg::ImageDesc &D : desc) { stream_bytes += D.stream_bytes; subs += D.nsub; if (D.error && !(j->decoded && j->max_sub)) ++short_images; }
-    info[0] = j->n; info[1] = j->G.w; info[2] = j->G.h; info[3] = (int64_t)subs; info[4] = rounds; info[5] = (int64_t)stream_bytes;
+    info[0] = j->n; info[1] = j->orientation >= 5 ? j->G.h : j->G.w; info[2] = j->orientation >= 5 ? j->G.w : j->G.h;   // the size cv2.imread returns info[3] = (int64_t)subs; info[4] = rounds; info[5] = (int64_t)stream_bytes;
     info[6] = short_images; info[7] = (int64_t)j->h_tabs.size();
     return BEVW_OK;
 }

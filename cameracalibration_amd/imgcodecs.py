@@ -8,7 +8,7 @@ device images encoded into complete ``.jpg`` files, without the pixels ever visi
 
 Everything is computed by libbevwarp's HIP kernels (include/bevwarp.h, ``bevw_jpeg_*``), bit-exact against libjpeg-turbo, the library
 behind cv2's JPEG codec.  There is no CPU decoder here: files outside the supported subset (progressive, arithmetic, CMYK, 12-bit,
-multi-scan, EXIF-rotated) and non-JPEG files raise.
+multi-scan) and non-JPEG files raise.  EXIF orientations are applied on the GPU, as cv2.imread applies them.
 """
 from __future__ import annotations
 
@@ -27,12 +27,16 @@ _DEFAULT_QUALITY = 95               # cv2.imwrite's default for .jpg
 
 
 def probe(raw: bytes) -> dict:
-    """Header of a JPEG file: size, components, luma sampling, restart interval, EXIF orientation.  Raises on unsupported files."""
+    """Header of a JPEG file: size AS cv2.imread RETURNS IT (EXIF orientation applied; stored_width / stored_height are the frame header's),
+    components, luma sampling, restart interval, EXIF orientation.  Raises on unsupported files."""
     info = (C.c_int32 * 8)()
     raw = bytes(raw)
     check(lib().bevw_jpeg_probe(raw, len(raw), info))
-    return dict(width=info[0], height=info[1], components=info[2], h_samp=info[3], v_samp=info[4], restart_interval=info[5],
-                orientation=info[6])
+    d = dict(width=info[0], height=info[1], components=info[2], h_samp=info[3], v_samp=info[4], restart_interval=info[5],
+             orientation=info[6], stored_width=info[0], stored_height=info[1])
+    if d["orientation"] >= 5:   # cv2.imread applies the EXIF orientation: 5 .. 8 turn the image by 90 degrees
+        d["width"], d["height"] = d["height"], d["width"]
+    return d
 
 
 class JpegCodec:

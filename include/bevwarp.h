@@ -271,8 +271,10 @@ int bevw_resize_linear_u8c3(int device, const uint8_t *src, int src_w, int src_h
  * cv2's quality 95, 4:2:0) -- oracle/jpegoracle.c, pinned against Pillow's libjpeg-turbo.  Un-stuffing and entropy decoding run ON THE GPU
  * (self-synchronising parallel Huffman decoding, csrc/bevw_jpeg.h); the host parses the markers in front of the scan and copies the
  * entropy-coded bytes as they are into pinned memory for the H2D transfer.  Supported: baseline / extended-sequential Huffman, 8 bit, one interleaved scan, grey (expanded to BGR,
- * as IMREAD_COLOR does) or YCbCr with luma 1x1 / 2x1 / 2x2, restart intervals.  Progressive, arithmetic, CMYK, 12-bit, multi-scan files and
- * EXIF orientations other than 1 are REFUSED (BEVW_E_INVALID, reason in bevw_last_error()): there is no CPU decoder behind this.
+ * as IMREAD_COLOR does) or YCbCr with luma 1x1 / 2x1 / 2x2, restart intervals.  Progressive, arithmetic, CMYK, 12-bit and multi-scan files
+ * are REFUSED (BEVW_E_INVALID, reason in bevw_last_error()): there is no CPU decoder behind this.  An EXIF orientation tag is applied on the GPU as
+ * cv2.imread applies it (one orientation per batch; orientations 5 .. 8 swap width and height of the decoded images: bevw_jpeg_decode_info reports
+ * the size of the result, bevw_jpeg_probe the stored size and the tag).
  *
  *   bevw_jpeg_probe            header only: info = width, height, components, luma h, luma v, restart interval, EXIF orientation, 0
  *   bevw_jpeg_decode_stage     n files of ONE geometry: parse the headers, copy the entropy-coded bytes to pinned memory, enqueue the H2D copies

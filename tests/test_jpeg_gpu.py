@@ -305,3 +305,28 @@ def test_jpeg_pipeline_refuses_truncated_files_and_streams_identically(IC, JO, r
     assert list(bev.jpeg_stream([], car)) == []
     ref = oracle.RefBevGenerator(repo_rig.rig, cfg, blend=True, balance=True)
     assert want[0][0] == JO.imencode(ref(*[JO.imdecode(f) for f in files], car))
+
+
+def test_exif_orientations_are_applied_like_cv2_imread(IC, codec):
+    """cv2.imread turns an image by its EXIF orientation tag (OpenCV's ExifTransform); so does the decoder, on the GPU.  Reference: the same
+    file decoded by libjpeg-turbo (Pillow) and turned by Pillow's exif_transpose -- the EXIF specification's eight cases, odd sizes included."""
+    from PIL import Image, ImageOps
+    from cameracalibration_amd._ffi import BevwError
+
+    for h, w in ((48, 64), (37, 53), (1, 7)):
+        im = JC.image(h, w, 2)
+        rgb = Image.fromarray(np.ascontiguousarray(im[:, :, ::-1]))
+        files = {}
+        for o in range(1, 9):
+            exif = Image.Exif()
+            exif[0x0112] = o
+            b = io.BytesIO()
+            rgb.save(b, "JPEG", quality=90, subsampling=2, exif=exif)
+            files[o] = b.getvalue()
+            want = np.ascontiguousarray(np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(files[o]))).convert("RGB"))[:, :, ::-1])
+            got = codec.decode([files[o], files[o]])
+            assert got.shape[1:] == want.shape and np.array_equal(got[0], want) and np.array_equal(got[1], want), (h, w, o)
+            assert np.array_equal(IC.imdecode(np.frombuffer(files[o], np.uint8)), want)
+        with pytest.raises(BevwError, match="one orientation per batch"):
+            codec.decode([files[1], files[6]])
+

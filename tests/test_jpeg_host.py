@@ -53,10 +53,15 @@ def test_probe_refuses_by_name(IC):
     with pytest.raises(BevwError, match="component count"):
         IC.probe(b.getvalue())
     exif = Image.Exif()
-    exif[0x0112] = 6     # rotated: cv2.imread would turn the image, this engine does not
-    with pytest.raises(BevwError, match="orientation"):
-        IC.probe(save(exif=exif))
+    exif[0x0112] = 6     # turned by 90 degrees: the decoder applies the tag as cv2.imread does, and the probe reports the size of the RESULT
+    info = IC.probe(save(exif=exif))
+    assert (info["orientation"], info["width"], info["height"], info["stored_width"], info["stored_height"]) == (6, 48, 64, 64, 48)
+    exif[0x0112] = 3
+    info = IC.probe(save(exif=exif))
+    assert (info["orientation"], info["width"], info["height"]) == (3, 64, 48)
     exif[0x0112] = 1
+    assert IC.probe(save(exif=exif))["orientation"] == 1
+    exif[0x0112] = 9     # not a valid orientation: ignored
     assert IC.probe(save(exif=exif))["orientation"] == 1
     good = save()
     with pytest.raises(BevwError, match="not a JPEG"):
