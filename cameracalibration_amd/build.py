@@ -27,7 +27,11 @@ UNITS = {
     "bevwarp_jpeg.hip": ["bevw_jpeg.h", "bevw_jpeg_codec.h"],
 }
 CFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm"]
-EXTRA = os.environ.get("BEVW_CFLAGS", "").split()   # experiment builds (e.g. -DBEVW_UNIT_ABLATE_MEMORY_ONLY=1)
+EXTRA = os.environ.get("BEVW_CFLAGS", "").split()   # experiment builds (e.g. -DBEVW_UNIT_DEPTH=4)
+TAG = os.environ.get("BEVW_BUILD_TAG", "")            # ... land in build_var/libbevwarp_<tag>.so (objects in csrc/build_<tag>/); A/B through BEVW_LIB_PATH
+if TAG:
+    OBJ = os.path.join(CSRC, "build_" + TAG)
+    LIB = os.path.join(os.path.dirname(HERE), "build_var", "libbevwarp_%s.so" % TAG)
 
 
 def _newer(path: str, deps) -> bool:
@@ -40,12 +44,13 @@ def _newer(path: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     me = os.path.abspath(__file__)
     jobs = []
     for src, hdrs in UNITS.items():
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
         deps = [os.path.join(CSRC, f) for f in [src] + hdrs + COMMON] + [me]
-        if force or EXTRA or _newer(obj, deps):
+        if force or (EXTRA and not TAG) or _newer(obj, deps):
             jobs.append([hipcc] + CFLAGS + EXTRA + ["-c", os.path.join(CSRC, src), "-o", obj])
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in UNITS]
     if not jobs and not _newer(LIB, objs):

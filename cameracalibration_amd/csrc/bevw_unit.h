@@ -610,6 +610,9 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 // WIDE: the plan carries 21-bit fractions and the pixels are interpolated in fp32 (the analytic projection mode); wxa / wy then hold the
 // bit patterns of fx / fy.
 // (experiment: -DBEVW_UNIT_PRIO_ON raises the wave priority around the memory instructions of a frame; profiles/r03/sweeps.log)
+#ifndef BEVW_UNIT_DEPTH
+#define BEVW_UNIT_DEPTH 2
+#endif
 #ifdef BEVW_UNIT_PRIO_ON
 #define BEVW_UNIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -714,7 +717,10 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 
     // (Dealing the frames of a chunk strided over the batch, or rotating the class lists per XCD, changes nothing: profiles/r03/placement.md)
     auto frame_of = [&](int b) { return min(b, b_end - 1); };   // past the chunk: the last frame once more
-    constexpr int D = 2;
+    // frames whose groups are in flight in registers.  BEVW_UNIT_DEPTH (even) deepens it for the classes with <= 2 rounds of groups (8 registers per
+    // round and frame); measured: profiles/r04/README.md
+    constexpr int D = (GR <= 2) ? BEVW_UNIT_DEPTH : 2;
+    static_assert(D >= 2 && D % 2 == 0, "the patch halves alternate with the ring");
     pair_u32x4 pf[D][GR];
     auto issue = [&](int b, int ring) {
         const uint8_t *src = a.frames + (size_t)frame_of(b) * set_bytes;
@@ -727,7 +733,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         for (int r = 0; r < GR; ++r) {
             uint4 A, B;
             pair_convert(pf[ring][r].x, pf[ring][r].y, pf[ring][r].z, pf[ring][r].w, A, B);
-            uint4 *sp = reinterpret_cast<uint4 *>(lds + (DB ? ring * kPatch : 0)) + (r * kUnitThreads + (int)threadIdx.x) * 2;
+            uint4 *sp = reinterpret_cast<uint4 *>(lds + (DB ? (ring & 1) * kPatch : 0)) + (r * kUnitThreads + (int)threadIdx.x) * 2;
             sp[0] = A;
             sp[1] = B;
         }
@@ -757,7 +763,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             land(ring);            // every wave finished reading the previous frame: barrier at the end of its step
             block_lds_barrier();
         }
-        const uint2 *const pw = reinterpret_cast<const uint2 *>(lds + (DB ? ring * kPatch : 0));
+        const uint2 *const pw = reinterpret_cast<const uint2 *>(lds + (DB ? (ring & 1) * kPatch : 0));
         BEVW_UNIT_PRIO(3);
         issue(b + D, ring);        // the ring slot of frame b has been converted
         BEVW_UNIT_PRIO(0);
@@ -841,7 +847,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                 atomicAdd(ps + 0, wb); atomicAdd(ps + 1, wg); atomicAdd(ps + 2, wr);
             }
         }
-        if (DB) land(ring ^ 1);    // frame b+1 into the other half: nobody reads it before the barrier
+        if (DB) land((ring + 1) % D);    // frame b+1 into the other half: nobody reads it before the barrier
         {
             uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
