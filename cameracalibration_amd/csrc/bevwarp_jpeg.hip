@@ -381,7 +381,8 @@ int bevw_jpeg_decode_info(bevw_jpeg *j, int64_t info[8])
     HIP_TRY(hipStreamSynchronize(j->st));
     size_t stream_bytes = 0, subs = 0;
     for (const jpg::ImageDesc &D : desc) { stream_bytes += D.stream_bytes; subs += D.nsub; if (D.error && !(j->decoded && j->max_sub)) ++short_images; }
-    info[0] = j->n; info[1] = j->orientation >= 5 ? j->G.h : j->G.w; info[2] = j->orientation >= 5 ? j->G.w : j->G.h;   // the size cv2.imread returns info[3] = (int64_t)subs; info[4] = rounds; info[5] = (int64_t)stream_bytes;
+    info[0] = j->n; info[1] = j->orientation >= 5 ? j->G.h : j->G.w; info[2] = j->orientation >= 5 ? j->G.w : j->G.h;   // (the size cv2.imread returns)
+    info[3] = (int64_t)subs; info[4] = rounds; info[5] = (int64_t)stream_bytes;
     info[6] = short_images; info[7] = (int64_t)j->h_tabs.size();
     return BEVW_OK;
 }
