@@ -44,7 +44,12 @@ def main():
     codec = imgcodecs.JpegCodec(0)
     bad = files_total = skipped = 0
     t0 = time.time()
+    done = 0
+    t_end = t0 + float(os.environ.get("BEVW_SOAK_SECONDS", "1e9"))   # stop there and report what was done
     for case in range(a.cases):
+        if time.time() > t_end:
+            break
+        done += 1
         if rng.random() < 0.03:
             h, w = int(rng.choice([960, 1024, 1080])), int(rng.choice([1280, 1080]))
         else:
@@ -76,7 +81,7 @@ def main():
         if not ok:
             bad += 1
             print("MISMATCH case", case, dict(h=h, w=w, sub=sub, q=q, n=n, **kw), flush=True)
-    print(f"soak_jpeg: seed {a.seed}, {a.cases} cases, {files_total} files ({skipped} cases Pillow could not write), {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"soak_jpeg: seed {a.seed}, {done} of {a.cases} cases run, {files_total} files ({skipped} cases Pillow could not write), {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     return 1 if bad else 0
 
 

@@ -6,8 +6,10 @@ from cameracalibration_amd import workloads as W
 from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
 from oracle import oracle as O
 O.build()
-bad = 0
+import os, time
+bad, done, t_end = 0, 0, time.time() + float(os.environ.get("BEVW_SOAK_SECONDS", "1e9"))   # BEVW_SOAK_SECONDS: stop there and report what was done
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
+    if time.time() > t_end: break
     rng = np.random.default_rng(50000 + seed)
     fw = int(rng.choice([96, 160, 200, 236, 320, 322, 400, 512, 640])); fh = int(rng.choice([64, 128, 150, 256, 258, 384, 480]))
     bw = int(rng.choice([64, 96, 124, 125, 200, 248, 250, 300, 400])); bh = int(rng.choice([64, 96, 130, 201, 250, 333, 400]))
@@ -39,4 +41,5 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         if not np.array_equal(got[b], want):
             bad += 1; print("MISMATCH seed", seed, cfg, blend, balance, b, np.count_nonzero(got[b] != want)); break
     del bev
-print("soak", sys.argv[1], sys.argv[2], "mismatches", bad)
+    done += 1
+print("soak", sys.argv[1], sys.argv[2], "cases run", done, "mismatches", bad)
