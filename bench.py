@@ -498,10 +498,22 @@ def main_jpeg(a, d, w, dev):
 
 def f4_summary(a, d, dev):
     """The JPEG wire format either side of the path in the DEFAULT run, so that the driver's bench record carries it:
-    decode / encode / files-in-file-out rates with their roofline and the libjpeg-turbo CPU baseline.  Short legs (about 10 s in all)."""
+    decode / encode / files-in-file-out rates with their roofline and the libjpeg-turbo CPU baseline.  Each leg is this script run on its JPEG
+    workload in a process of its own (about 8 s each): HIP multiplexes a process's streams onto a few hardware queues, and next to the streams
+    the stitch measurement has left behind the decoder's two slices landed on one queue and ran one after the other (3.7 instead of 2.8 ms)."""
+    import subprocess
+
     res = {}
     for name, cpu_s in (("jpeg_decode_b64", 2.5), ("jpeg_encode_b64", 2.0), ("jpeg_bev_jpeg_b64", 0.0)):
-        o = jpeg_measure(a, d, WORKLOADS[name], dev, name, 12, 4, cpu_s)
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", "12", "--warmup", "4", "--cpu-seconds", str(cpu_s)]
+        if cpu_s <= 0:
+            cmd.append("--no-cpu-baseline")
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        try:
+            o = json.loads(r.stdout.strip().splitlines()[-1])
+        except (IndexError, ValueError):
+            res[name] = {"error": (r.stderr or r.stdout)[-400:]}
+            continue
         keep = {"metric": o["metric"], "value": o["value"], "unit": o["unit"], "ms_per_step": o["ms_per_step"], "steps": o["steps"],
                 "units_per_step": o["config"]["units_per_step"],
                 "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms")},
@@ -512,7 +524,7 @@ def f4_summary(a, d, dev):
                 keep[k] = o["config"][k]
         res[name] = keep
     res["note"] = ("reference wire format: cv2.imread x 4 (main.py:74-77), cv2.imwrite (surroundBEV.py:340); inputs resident = compressed bytes / device images; "
-                   "full lines: bench.py --workload jpeg_decode_b64 | jpeg_encode_b64 | jpeg_bev_jpeg_b64")
+                   "each leg = `bench.py --workload <name> --steps 12 --warmup 4` in its own process")
     return res
 
 

@@ -884,8 +884,9 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
     // 4 slices 2.22 - 2.24, 8 slices 2.30: three of the four kernels are HBM-bound and the VALU-bound one still moves 1.35 GB, so running
     // them side by side shares the memory instead of filling idle time -- the overlap is worth 1.4 %, more slices cost it again in small grids
     int parts = parts_env > 0 ? parts_env : (batch >= 32 ? 2 : 1);
-    if (scratch || !h->stream2) parts = 1;
+    if (scratch) parts = 1;
     if (parts > batch) parts = batch;
+    if (parts > 1 && !h->stream2 && hipStreamCreate(&h->stream2) != hipSuccess) { (void)hipGetLastError(); h->stream2 = nullptr; parts = 1; }
     if (parts > 1) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->stream));          // the caller's uploads (and the padded sprite) were enqueued on stream
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
@@ -973,7 +974,9 @@ int bevw_create(const bevw_config *cfg, bevw_handle **out)
     bevw_handle *h = new (std::nothrow) bevw_handle();
     if (!h) return fail(BEVW_E_NOMEM, "out of host memory");
     h->cfg = *cfg;
-    if (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->stream2) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
+    // (stream2 is created by the first balance step that wants it: HIP multiplexes a process's streams onto a handful of hardware queues --
+    // 4 by default -- and every stream that merely exists makes it likelier that two streams meant to overlap share one)
+    if (hipStreamCreate(&h->stream) != hipSuccess || hipEventCreate(&h->ev0) != hipSuccess ||
         hipEventCreate(&h->ev1) != hipSuccess || hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_skew, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) {
         bevw_destroy(h);
