@@ -10,6 +10,12 @@ import os
 
 import numpy as np
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); streams that share a queue do not overlap.  The
+# compressed pipeline (BevGenerator.jpeg_stream: an engine stream + three codec contexts of two streams each) measured 14.7 k frame sets/s
+# with 4 queues and 16.5 k with 8 (profiles/r04/hw_queues_jpeg_stream.log); nothing else changed.  Only a default: the caller's own setting wins,
+# and it must be in the environment before the HIP runtime initialises, i.e. before libbevwarp.so is loaded.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
 ABI_VERSION = 4
