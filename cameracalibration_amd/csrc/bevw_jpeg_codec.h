@@ -337,7 +337,23 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
         }
         __syncthreads();
         const uint32_t n = min(s_n, (uint32_t)kSyncThreads);
-        if (threadIdx.x < n) {
+        constexpr uint32_t kWaves = kSyncThreads / 64;
+        if (n <= kWaves) {
+            // The tail (the reference's camera files: 13 of 16 rounds list <= 16 subsequences): one subsequence per WAVE, every lane walking the
+            // same bits.  A wave whose lanes walk different subsequences executes both sides of every branch of the symbol loop; a uniform
+            // walk executes its own path only, and a lone wave is bound by exactly that instruction count.
+            const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+            if (w < n) {
+                const uint32_t j = __builtin_amdgcn_readfirstlane(s_list[w]);
+                const uint64_t in = vexit[j - 1];
+                const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[D.sub_first + j], nullptr, 0, 0, 0, 0, 0);
+                if ((threadIdx.x & 63u) == 0) {
+                    entry[j] = in;
+                    A.sums[D.sub_first + j] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
+                    if (R.exit != vexit[j]) { vexit[j] = R.exit; changed = 1; }
+                }
+            }
+        } else if (threadIdx.x < n) {
             const uint32_t j = s_list[threadIdx.x];
             const uint64_t in = vexit[j - 1];
             entry[j] = in;
