@@ -279,7 +279,9 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             while (done) {
                 const int srcl = __ffsll((long long)done) - 1;
                 done &= done - 1ull;
-                const uint32_t alo = (uint32_t)__shfl((int)(uint32_t)flush_addr, srcl, 64), ahi = (uint32_t)__shfl((int)(uint32_t)((unsigned long long)flush_addr >> 32), srcl, 64);
+                // (v_readlane_b32 with the scalar lane index: __shfl here compiled to two ds_bpermute_b32 + an LDS wait in front of every block store)
+                const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)flush_addr, srcl);
+                const uint32_t ahi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)flush_addr >> 32), srcl);
                 const size_t a = (size_t)(((unsigned long long)ahi << 32) | alo);
                 int16_t *blk_l = wave_lbuf + (size_t)srcl * kLaneBlock;
                 coef[a + lane] = blk_l[lane];
