@@ -157,7 +157,8 @@ struct WordSource {
 template <bool WRITE>
 __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTab *tabs, const Geom &G, uint64_t entry,
                                              uint32_t end_bit, int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0,
-                                             int32_t pred1, int32_t pred2, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr, bool alive = true)
+                                             int32_t pred1, int32_t pred2, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr, bool alive = true,
+                                             uint32_t *wlist = nullptr)
 {
     // WRITE: a block belongs to the lane in whose range it STARTS.  The owner assembles it in lbuf (64 int16 of its own, LDS on the device,
     // zero at entry), keeps decoding past end_bit until the block is complete, and the block is stored whole -- no read-modify-write of
@@ -175,25 +176,30 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
     // the whole wave a memory latency per symbol.  One 32-bit window holds a whole symbol (code <= 16 bits + <= 16 extra bits).
     uint32_t widx = p >> 5, off = p & 31u;
     uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
-    // position of the block in progress (WRITE)
-    int mx = 0, my = 0;
-    size_t baddr = 0;
+    // position of the block in progress (WRITE): MCU (mx, my), luma block (zx, zy) inside it; bidx = its index in the image's coefficient buffer.
+    // Everything in the loop is a select between scalars: an indexed read of G's arrays is a memory load on the device, and on gfx950 a wait
+    // for ANY load is a wait for every block store issued before it (one counter).
+    int mx = 0, my = 0, zx = 0, zy = 0;
+    uint32_t bidx = 0;
+    const int wb0 = G.wb[0], wb1 = G.wb[1], off1 = G.blk_off[1], off2 = G.blk_off[2];   // (read HERE: selects between loads come back as loads of a selected address)
     if (WRITE) {
         const uint32_t mcu = blk / (uint32_t)G.bpm;
         mx = (int)(mcu % (uint32_t)G.mcux);
         my = (int)(mcu / (uint32_t)G.mcux);
+        if ((int)z < G.nY) { zx = (int)z % G.hs; zy = (int)z / G.hs; }
     }
-    bool fresh = true;   // baddr must be recomputed
+    bool fresh = true;   // bidx must be recomputed
     bool own = k == 0;   // WRITE: the block in progress started inside this lane's range
 #if defined(__HIP_DEVICE_COMPILE__)
     const int lane = (int)(threadIdx.x & 63u);
     int16_t *const wave_lbuf = WRITE ? lbuf - (size_t)lane * kLaneBlock : nullptr;   // lbuf of lane 0 of this wave
+    uint32_t *const wave_list = WRITE ? wlist : nullptr;                             // 64 entries of this wave
 #endif
     for (;;) {
         const bool go = alive && (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit);
 #if defined(__HIP_DEVICE_COMPILE__)
-        bool flush = false;      // WRITE: this lane completed a block of its own in this step (at flush_addr)
-        size_t flush_addr = 0;
+        bool flush = false;      // WRITE: this lane completed a block of its own in this step (block flush_idx of the image)
+        uint32_t flush_idx = 0;
         if (WRITE ? !__any(go) : !go) break;
 #else
         if (!go) break;
@@ -201,10 +207,10 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
       if (go) {
         const int c = (int)z < G.nY ? 0 : 1 + (int)z - G.nY;
         if (WRITE && fresh) {
-            int bx, by;
-            if (c == 0) { bx = mx * G.hs + (int)z % G.hs; by = my * G.vs + (int)z / G.hs; }
-            else { bx = mx; by = my; }
-            baddr = ((size_t)G.blk_off[c] + (size_t)by * G.wb[c] + bx) * 64;
+            const int bx = c == 0 ? mx * G.hs + zx : mx, by = c == 0 ? my * G.vs + zy : my;
+            const int wbc = c == 0 ? wb0 : wb1;   // (the chroma planes have one size)
+            const int first = c == 0 ? 0 : (c == 1 ? off1 : off2);
+            bidx = (uint32_t)(first + by * wbc + bx);
             fresh = false;
         }
         const HuffTab &T = tabs[2 * c + (k ? 1 : 0)];
@@ -237,7 +243,11 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             k = 1;
         } else if (s) {
             k += sym >> 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (WRITE && own && k <= 63u) lbuf[(int)nat[k]] = (int16_t)v;   // (nat is never null here: a second, global-memory path would put a wait for all stores in front of this write)
+#else
             if (WRITE && own && k <= 63u) lbuf[nat ? (int)nat[k] : natural_of((int)k)] = (int16_t)v;
+#endif
             ++k;
         } else {
             k = (sym >> 4) == 15u ? k + 16u : 64u;   // ZRL : EOB
@@ -246,9 +256,9 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             if (WRITE && own) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 flush = true;
-                flush_addr = baddr;
+                flush_idx = bidx;
 #else
-                memcpy(coef + baddr, lbuf, 128);
+                memcpy(coef + (size_t)bidx * 64, lbuf, 128);
                 memset(lbuf, 0, 128);
 #endif
             }
@@ -259,7 +269,13 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             fresh = true;
             if (++z == (uint32_t)G.bpm) {
                 z = 0;
-                if (WRITE && ++mx == G.mcux) { mx = 0; ++my; }
+                if (WRITE) {
+                    zx = zy = 0;
+                    if (++mx == G.mcux) { mx = 0; ++my; }
+                }
+            } else if (WRITE && ++zx == G.hs) {
+                zx = 0;
+                ++zy;
             }
         }
         const uint32_t used = len + s;
@@ -275,17 +291,23 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
       }   // if (go)
 #if defined(__HIP_DEVICE_COMPILE__)
         if (WRITE) {
-            unsigned long long done = __ballot(flush);
-            while (done) {
-                const int srcl = __ffsll((long long)done) - 1;
-                done &= done - 1ull;
-                // (v_readlane_b32 with the scalar lane index: __shfl here compiled to two ds_bpermute_b32 + an LDS wait in front of every block store)
-                const uint32_t alo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)flush_addr, srcl);
-                const uint32_t ahi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)flush_addr >> 32), srcl);
-                const size_t a = (size_t)(((unsigned long long)ahi << 32) | alo);
-                int16_t *blk_l = wave_lbuf + (size_t)srcl * kLaneBlock;
-                coef[a + lane] = blk_l[lane];
-                blk_l[lane] = 0;
+            // Eight blocks per pass: lanes 8 g .. 8 g + 7 take the g-th completed block, 16 bytes each (one 128-byte line per block, as
+            // before, but one LDS round trip and one store instruction per EIGHT blocks instead of per block).  Who completed the g-th
+            // block is found through a 64-entry list in LDS (wave_list): the owners write `block index << 6 | lane` at their rank.
+            const unsigned long long done = __ballot(flush);
+            if (done) {
+                const int nf = __popcll(done);
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done, 0u));
+                if (flush) wave_list[rank] = (flush_idx << 6) | (uint32_t)lane;
+                for (int g0 = 0; g0 < nf; g0 += 8) {
+                    const int g = g0 + (lane >> 3);
+                    if (g < nf) {
+                        const uint32_t e = wave_list[g];
+                        uint4 *blk_l = reinterpret_cast<uint4 *>(wave_lbuf + (size_t)(e & 63u) * kLaneBlock) + (lane & 7);
+                        *(reinterpret_cast<uint4 *>(coef + (size_t)(e >> 6) * 64) + (lane & 7)) = *blk_l;
+                        *blk_l = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
             }
         }
 #endif

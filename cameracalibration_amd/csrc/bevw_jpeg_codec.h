@@ -417,6 +417,7 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
     __shared__ TableSet T;
     __shared__ __attribute__((aligned(16))) int16_t lbuf[256][kLaneBlock];
     __shared__ uint8_t nat[64];
+    __shared__ uint32_t wlist[4][64];   // decode_sub: the blocks a wave completed in one step
     const ImageDesc D = img[blockIdx.y];
     if (blockIdx.x * 256u >= D.nsub) return;
     lds_copy(&T, tabs + D.tables);
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
         if (c2 < cap) cap = (uint32_t)c2;
     }
     decode_sub<true>(word_source(A, D, stream, jj), T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
-                     b.z, b.w, nat, lbuf[threadIdx.x], alive);
+                     b.z, b.w, nat, lbuf[threadIdx.x], alive, wlist[threadIdx.x >> 6]);
 }
 
 // jpeg_idct_islow: a wave transforms 8 blocks; lane = (block, column) for the column pass, (block, row) for the row pass, the 8 x 8

@@ -119,6 +119,7 @@ int bevw_jpeg_decode_stage(bevw_jpeg *j, const uint8_t *const *data, const size_
     j->G = jpg::make_geom(P[0].w, P[0].h, P[0].nc, P[0].hs, P[0].vs);
     j->orientation = P[0].orientation;
     const jpg::Geom &G = j->G;
+    if (G.nblk >= (1 << 26)) return fail(BEVW_E_INVALID, "JPEG of %dx%d: more than 2^26 blocks per image", G.w, G.h);   // (k_jpeg_coef packs block index << 6 | lane)
     BEVW_TRY(j->h_stream.reserve(bound));
     j->h_desc.assign((size_t)n, jpg::ImageDesc());
     j->h_term.assign((size_t)n, 0);
