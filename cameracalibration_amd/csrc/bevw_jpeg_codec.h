@@ -302,6 +302,93 @@ __global__ __launch_bounds__(256) void k_jpeg_sync_list(const ImageDesc *__restr
     xout[slot] = R.exit;
 }
 
+// ---- the scalar walker -------------------------------------------------------------------------------------------------------------
+// decode_sub<false> for ONE subsequence per wave, computed on the scalar unit.  The last synchronisation rounds of a photograph (flat sky,
+// saturated areas: runs of identical short blocks in which a shifted decoder stays consistent for many subsequences) advance one
+// subsequence per round and chain: a serial chain of walks by a lone wave, each bound by the dependent-instruction latency of the vector
+// pipeline (~170 instructions of 4+ cycles per symbol).  Here every state variable is an SGPR, every branch a scalar branch, the Huffman
+// tables are read with s_load_dword from the batch's table sets in memory (the scalar cache holds them) and only the words of the
+// entropy-coded data come through the vector memory path (their own counter: a table look-up never waits for a word in flight).
+typedef const __attribute__((address_space(4))) uint32_t *scalar_words_t;
+__device__ __forceinline__ uint32_t s_word(const void *base, uint32_t dword_index)   // base, index wave-uniform
+{
+    return ((scalar_words_t)(uintptr_t)base)[dword_index];
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t s_bswap(uint32_t x) { return uni(__builtin_bswap32(x)); }   // (v_perm_b32 on the loaded VGPR, then to an SGPR)
+static_assert(offsetof(HuffTab, ub) == 512 && offsetof(HuffTab, valoff) == 552 && offsetof(HuffTab, vals) == 624, "decode_sub_scalar reads HuffTab by dword index");
+
+__device__ inline SubOut decode_sub_scalar(const WordSource &src, const HuffTab *tabs_in_memory, const Geom &G, uint64_t entry, uint32_t end_bit_)
+{
+    const uint32_t e_hi = uni((uint32_t)(entry >> 32));
+    uint32_t p = uni((uint32_t)entry), z = e_hi & 255u, k = (e_hi >> 8) & 255u;
+    const uint32_t end_bit = uni(end_bit_), nY = uni((uint32_t)G.nY), bpm = uni((uint32_t)G.bpm);
+    const uint32_t stride = uni(src.stride), word0 = uni(src.word0);
+    int32_t cnt = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    // the words: vector loads of a uniform address (lane 0's value is taken where it is consumed)
+    auto word_at = [&](uint32_t w) -> uint32_t {
+        const uint32_t d = w - word0;
+        return (src.col && d < (uint32_t)kColWords) ? src.col[(size_t)d * stride] : src.words[w];
+    };
+    uint32_t widx = p >> 5, off = p & 31u;
+    uint32_t w0 = s_bswap(word_at(widx)), w1 = s_bswap(word_at(widx + 1));
+    uint32_t nraw = word_at(widx + 2);   // stays in its VGPR until the refill
+    while (p < end_bit) {
+        const uint32_t c = z < nY ? 0u : 1u + z - nY;
+        const HuffTab *T = tabs_in_memory + (2u * c + ((k + 63u) >> 6));   // (k <= 63: 0 for the DC table, 1 for the AC table; a comparison would detour through a VGPR)
+        const uint32_t window = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - off));   // (off < 32: one s_lshr_b64)
+        const uint32_t peek = window >> 16, hi8 = peek >> 8;
+        const uint32_t e = (s_word(T, hi8 >> 1) >> ((hi8 & 1u) * 16u)) & 0xffffu;
+        uint32_t len, sym;
+        if (e) {
+            len = e >> 8;
+            sym = e & 255u;
+        } else {
+            len = 9u;
+#pragma unroll
+            for (int i = 1; i <= 7; ++i) len += peek >= s_word(T, 128 + i) ? 1u : 0u;
+            const uint32_t vi = ((peek >> (16u - len)) + s_word(T, 138 + len)) & 255u;
+            sym = (s_word(T, 156 + (vi >> 2)) >> ((vi & 3u) * 8u)) & 255u;
+            if (peek >= s_word(T, 128 + 8)) { len = 16; sym = 0; }
+        }
+        const uint32_t s = k == 0 ? (sym > 16u ? 16u : sym) : (sym & 15u);
+        int32_t v = 0;
+        if (s) {
+            v = (int32_t)((window << len) >> (32u - s));
+            v = v < (1 << (s - 1)) ? v - (1 << s) + 1 : v;
+        }
+        if (k == 0) {
+            if (c == 0) dc0 += v;
+            else if (c == 1) dc1 += v;
+            else dc2 += v;
+            k = 1;
+        } else if (s) {
+            k += (sym >> 4) + 1u;
+        } else {
+            k = (sym >> 4) == 15u ? k + 16u : 64u;
+        }
+        if (k >= 64u) {
+            k = 0;
+            ++cnt;
+            if (++z == bpm) z = 0;
+        }
+        const uint32_t used = len + s;
+        p += used;
+        off += used;
+        if (off >= 32u) {
+            off -= 32u;
+            w0 = w1;
+            w1 = s_bswap(nraw);
+            ++widx;
+            nraw = word_at(widx + 2);
+        }
+    }
+    SubOut R;
+    R.exit = pack_state(p, z, k);
+    R.cnt = cnt; R.dc0 = dc0; R.dc1 = dc1; R.dc2 = dc2;
+    return R;
+}
+
 __device__ __forceinline__ int4 add4(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 // One block per image: re-decode every subsequence whose entry state is not its predecessor's exit state until nothing changes, then
@@ -323,7 +410,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     // walks them densely packed: a round costs as many wave-walks as its list fills waves (174, 78, 37 ... subsequences: 3, 2, 1 waves),
     // not one per wave that holds a straggler (all 16 waves of the block for as long as some lane of each has work).
     __shared__ uint32_t s_list[kSyncThreads];
-    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_n, s_lead[kSyncThreads / 64];
     for (;;) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -339,19 +426,44 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
         const uint32_t n = min(s_n, (uint32_t)kSyncThreads);
         constexpr uint32_t kWaves = kSyncThreads / 64;
         if (n <= kWaves) {
-            // The tail (the reference's camera files: 13 of 16 rounds list <= 16 subsequences): one subsequence per WAVE, every lane walking the
-            // same bits.  A wave whose lanes walk different subsequences executes both sides of every branch of the symbol loop; a uniform
-            // walk executes its own path only, and a lone wave is bound by exactly that instruction count.
+            // The tail: one listed subsequence per WAVE, walked on the scalar unit (decode_sub_scalar) -- and the wave goes on with the
+            // successor itself for as long as the successor's recorded entry state is not the exit state just computed.  An unsynchronised
+            // run (the reference's right camera: 10 subsequences of ordinary texture) is ONE serial chain; a round per link adds the
+            // round's listing and barriers to every link, and walks every link twice (the successor of a listed subsequence is listed too,
+            // with a stale entry state).  So a listed subsequence whose predecessor is listed as well is left to the predecessor's wave,
+            // and a wave stops in front of a subsequence that another wave of this round walks.
+            if (threadIdx.x < n) {   // s_lead: this listed subsequence's predecessor is not listed -- it starts a stretch, a wave walks it
+                uint32_t lead = 1u;
+                for (uint32_t i = 0; i < n; ++i) lead = s_list[i] + 1u == s_list[threadIdx.x] ? 0u : lead;
+                s_lead[threadIdx.x] = lead;
+            }
+            __syncthreads();
             const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            if (w < n) {
-                const uint32_t j = __builtin_amdgcn_readfirstlane(s_list[w]);
-                const uint64_t in = vexit[j - 1];
-                const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[D.sub_first + j], nullptr, 0, 0, 0, 0, 0);
-                if ((threadIdx.x & 63u) == 0) {
-                    entry[j] = in;
-                    A.sums[D.sub_first + j] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
-                    if (R.exit != vexit[j]) { vexit[j] = R.exit; changed = 1; }
+            uint32_t j = w < n ? uni(s_list[w]) : 0u;
+            if (w < n && uni(s_lead[w])) {
+                const uint64_t first = vexit[j - 1];
+                uint32_t in_lo = uni((uint32_t)first), in_hi = uni((uint32_t)(first >> 32));
+                for (;;) {
+                    const uint64_t in = ((uint64_t)in_hi << 32) | in_lo;
+                    const SubOut R = decode_sub_scalar(word_source(A, D, stream, j), (tabs + D.tables)->t, G, in, A.endbit[D.sub_first + j]);
+                    const uint32_t x_lo = uni((uint32_t)R.exit), x_hi = uni((uint32_t)(R.exit >> 32));
+                    if ((threadIdx.x & 63u) == 0) {
+                        entry[j] = in;
+                        A.sums[D.sub_first + j] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
+                        vexit[j] = R.exit;
+                    }
+                    ++j;
+                    if (j >= D.nsub || (uni(A.meta[D.sub_first + j]) & 0x80000000u)) break;   // nothing depends on this exit state
+                    const uint64_t next_in = entry[j];
+                    if (uni((uint32_t)next_in) == x_lo && uni((uint32_t)(next_in >> 32)) == x_hi) break;   // synchronised again
+                    bool other = false;   // j starts the stretch of another wave of this round
+                    for (uint32_t i = 0; i < n; ++i) other = other || (uni(s_list[i]) == j && uni(s_lead[i]));
+                    if (other) { changed = 1; break; }
+                    in_lo = x_lo;
+                    in_hi = x_hi;
                 }
+            } else if (w < n) {
+                changed = 1;   // (left to the predecessor's wave; if that wave stops early, the next round lists it again)
             }
         } else if (threadIdx.x < n) {
             const uint32_t j = s_list[threadIdx.x];
