@@ -6,6 +6,11 @@
 namespace bevw {
 namespace jpg {
 
+#ifndef BEVW_JPEG_TAIL
+#define BEVW_JPEG_TAIL 16
+#endif
+constexpr int kSyncTail = BEVW_JPEG_TAIL;   // k_jpeg_sync: rounds that list at most this many subsequences (<= 64) are walked on the scalar unit
+static_assert(kSyncTail <= 64, "k_jpeg_sync keeps the stretch starts of a round one per lane");
 constexpr int kSyncThreads = 1024;   // one block per image in the per-image kernels (fixed point, prefix sums, stuffing)
 
 template <typename T> __device__ __forceinline__ void lds_copy(T *dst, const T *__restrict__ src)
@@ -410,7 +415,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     // walks them densely packed: a round costs as many wave-walks as its list fills waves (174, 78, 37 ... subsequences: 3, 2, 1 waves),
     // not one per wave that holds a straggler (all 16 waves of the block for as long as some lane of each has work).
     __shared__ uint32_t s_list[kSyncThreads];
-    __shared__ uint32_t s_n, s_lead[kSyncThreads / 64];
+    __shared__ uint32_t s_n, s_lead[64];
     for (;;) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
@@ -425,8 +430,8 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
         __syncthreads();
         const uint32_t n = min(s_n, (uint32_t)kSyncThreads);
         constexpr uint32_t kWaves = kSyncThreads / 64;
-        if (n <= kWaves) {
-            // The tail: one listed subsequence per WAVE, walked on the scalar unit (decode_sub_scalar) -- and the wave goes on with the
+        if (n <= (uint32_t)kSyncTail) {
+            // The tail: a wave per listed subsequence (round-robin beyond 16), walked on the scalar unit (decode_sub_scalar) -- and the wave goes on with the
             // successor itself for as long as the successor's recorded entry state is not the exit state just computed.  An unsynchronised
             // run (the reference's right camera: 10 subsequences of ordinary texture) is ONE serial chain; a round per link adds the
             // round's listing and barriers to every link, and walks every link twice (the successor of a listed subsequence is listed too,
@@ -438,9 +443,14 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
                 s_lead[threadIdx.x] = lead;
             }
             __syncthreads();
-            const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-            uint32_t j = w < n ? uni(s_list[w]) : 0u;
-            if (w < n && uni(s_lead[w])) {
+            const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+            const uint32_t lane_lead = lane < n && s_lead[lane] ? s_list[lane] : 0xffffffffu;   // the stretch starts, one per lane (n <= 64)
+            for (uint32_t idx = w; idx < n; idx += kWaves) {
+                if (!uni(s_lead[idx])) {
+                    changed = 1;   // (left to the predecessor's wave; if that wave stops early, the next round lists it again)
+                    continue;
+                }
+                uint32_t j = uni(s_list[idx]);
                 const uint64_t first = vexit[j - 1];
                 uint32_t in_lo = uni((uint32_t)first), in_hi = uni((uint32_t)(first >> 32));
                 for (;;) {
@@ -456,14 +466,10 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
                     if (j >= D.nsub || (uni(A.meta[D.sub_first + j]) & 0x80000000u)) break;   // nothing depends on this exit state
                     const uint64_t next_in = entry[j];
                     if (uni((uint32_t)next_in) == x_lo && uni((uint32_t)(next_in >> 32)) == x_hi) break;   // synchronised again
-                    bool other = false;   // j starts the stretch of another wave of this round
-                    for (uint32_t i = 0; i < n; ++i) other = other || (uni(s_list[i]) == j && uni(s_lead[i]));
-                    if (other) { changed = 1; break; }
+                    if (__any(lane_lead == j)) { changed = 1; break; }   // j starts another stretch of this round
                     in_lo = x_lo;
                     in_hi = x_hi;
                 }
-            } else if (w < n) {
-                changed = 1;   // (left to the predecessor's wave; if that wave stops early, the next round lists it again)
             }
         } else if (threadIdx.x < n) {
             const uint32_t j = s_list[threadIdx.x];
