@@ -188,6 +188,67 @@ __device__ __forceinline__ WordSource word_source(const SubArrays &A, const Imag
     return WordSource{stream + D.stream_word, A.cols + (size_t)kColWords * D.sub_first + j, D.nsub, A.word0[(size_t)D.sub_first + j]};
 }
 
+// ---- the lane walker of the synchronisation passes ---------------------------------------------------------------------------------------
+// decode_sub<false> written for 64 lanes that walk 64 different subsequences: every conditional of the symbol step is taken by SOME lane in
+// nearly every step (a block ends, a DC symbol, a zero run, end of block ...), so a branch only adds its exec-mask bookkeeping to a body
+// that is executed anyway.  Here a step is straight-line selects; the two real branches left are the codes longer than the look-ahead
+// (three dependent table reads) and the refill of the bit window (a memory load).  Same states, same sums, bit for bit.
+__device__ inline SubOut decode_sub_lanes(const WordSource &src, const HuffTab *tabs_lds, const Geom &G, uint64_t entry, uint32_t end_bit)
+{
+    uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
+    int32_t cnt = 0, dc0 = 0, dc1 = 0, dc2 = 0;
+    uint32_t widx = p >> 5, off = p & 31u;
+    uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
+    const uint32_t luma_last = (uint32_t)G.nY - 1u, bpm = (uint32_t)G.bpm;
+    const uint8_t *const lds = reinterpret_cast<const uint8_t *>(tabs_lds);
+    while (p < end_bit) {
+        const uint32_t c = max(z, luma_last) - luma_last;                                   // component of block z of the MCU
+        const uint8_t *T = lds + c * (2u * (uint32_t)sizeof(HuffTab)) + min(k, 1u) * (uint32_t)sizeof(HuffTab);
+        const uint32_t window = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - off));
+        uint32_t e = reinterpret_cast<const uint16_t *>(T)[window >> 24];
+        if (e == 0u) {   // 9 .. 16 bits
+            const HuffTab &H = *reinterpret_cast<const HuffTab *>(T);
+            const uint32_t peek = window >> 16;
+            uint32_t len = 9u + (peek >= H.ub[1]) + (peek >= H.ub[2]) + (peek >= H.ub[3]) + (peek >= H.ub[4]) + (peek >= H.ub[5]) + (peek >= H.ub[6]) + (peek >= H.ub[7]);
+            uint32_t sym = H.vals[((peek >> (16u - len)) + (uint32_t)H.valoff[len]) & 255u];
+            if (peek >= H.ub[8]) { len = 16; sym = 0; }
+            e = (len << 8) | sym;
+        }
+        const uint32_t len = e >> 8, sym = e & 255u;
+        const bool dc = k == 0u;
+        const uint32_t s = dc ? min(sym, 16u) : (sym & 15u);
+        const uint32_t raw = ((window << len) >> 1) >> (31u - s);                           // the s extra bits (0 for s = 0)
+        const uint32_t one_s = 1u << s;
+        const int32_t v = raw < (one_s >> 1) ? (int32_t)(raw + 1u - one_s) : (int32_t)raw;   // HUFF_EXTEND (0 stays 0)
+        const int32_t dcv = dc ? v : 0;
+        dc0 += c == 0u ? dcv : 0;
+        dc1 += c == 1u ? dcv : 0;
+        dc2 += c == 2u ? dcv : 0;
+        const uint32_t run = sym >> 4;
+        const uint32_t k_ac = s ? k + run + 1u : (run == 15u ? k + 16u : 64u);
+        k = dc ? 1u : k_ac;
+        const uint32_t done = k >> 6;                                                       // (k < 128) the block is complete
+        cnt += (int32_t)done;
+        k &= done - 1u;
+        z += done;
+        z = z == bpm ? 0u : z;
+        const uint32_t used = len + s;
+        p += used;
+        off += used;
+        if (off >= 32u) {
+            off -= 32u;
+            w0 = w1;
+            w1 = __builtin_bswap32(nraw);
+            ++widx;
+            nraw = src.at(widx + 2);
+        }
+    }
+    SubOut R;
+    R.exit = pack_state(p, z, k);
+    R.cnt = cnt; R.dc0 = dc0; R.dc1 = dc1; R.dc2 = dc2;
+    return R;
+}
+
 // Lays the words of every subsequence out as a column (see WordSource) and records where it starts; also the per-subsequence constants
 // the later kernels need (last bit owned, restart segment, first-of-segment flag, the guessed entry state).
 __global__ __launch_bounds__(256) void k_jpeg_columns(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
@@ -229,7 +290,7 @@ __global__ __launch_bounds__(256) void k_jpeg_sync0(const ImageDesc *__restrict_
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= D.nsub) return;
     const size_t slot = (size_t)D.sub_first + j;
-    const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, A.entry[slot], A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+    const SubOut R = decode_sub_lanes(word_source(A, D, stream, j), T.t, G, A.entry[slot], A.endbit[slot]);
     A.exitst[slot] = R.exit;
     A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
 }
@@ -253,7 +314,7 @@ __global__ __launch_bounds__(256) void k_jpeg_sync_round(const ImageDesc *__rest
         const uint64_t in = xin[slot - 1];
         if (in != A.entry[slot]) {
             A.entry[slot] = in;
-            const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+            const SubOut R = decode_sub_lanes(word_source(A, D, stream, j), T.t, G, in, A.endbit[slot]);
             A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
             out = R.exit;
         }
@@ -302,7 +363,7 @@ __global__ __launch_bounds__(256) void k_jpeg_sync_list(const ImageDesc *__restr
     const size_t slot = (size_t)D.sub_first + j;
     const uint64_t in = xin[slot - 1];
     A.entry[slot] = in;
-    const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[slot], nullptr, 0, 0, 0, 0, 0);
+    const SubOut R = decode_sub_lanes(word_source(A, D, stream, j), T.t, G, in, A.endbit[slot]);
     A.sums[slot] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
     xout[slot] = R.exit;
 }
@@ -475,7 +536,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
             const uint32_t j = s_list[threadIdx.x];
             const uint64_t in = vexit[j - 1];
             entry[j] = in;
-            const SubOut R = decode_sub<false>(word_source(A, D, stream, j), T.t, G, in, A.endbit[D.sub_first + j], nullptr, 0, 0, 0, 0, 0);
+            const SubOut R = decode_sub_lanes(word_source(A, D, stream, j), T.t, G, in, A.endbit[D.sub_first + j]);
             A.sums[D.sub_first + j] = make_int4(R.cnt, R.dc0, R.dc1, R.dc2);
             if (R.exit != vexit[j]) { vexit[j] = R.exit; changed = 1; }
         }
