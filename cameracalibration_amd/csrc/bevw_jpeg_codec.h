@@ -196,18 +196,23 @@ __device__ __forceinline__ WordSource word_source(const SubArrays &A, const Imag
 __device__ inline SubOut decode_sub_lanes(const WordSource &src, const HuffTab *tabs_lds, const Geom &G, uint64_t entry, uint32_t end_bit)
 {
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
-    int32_t cnt = 0, dc0 = 0, dc1 = 0, dc2 = 0;
-    uint32_t widx = p >> 5, off = p & 31u;
-    uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
+    int32_t cnt = 0, dc_all = 0, dc1 = 0, dc2 = 0;
+    uint32_t off = p & 31u;
+    // the words: this walk never leaves the subsequence's column (it stops at the first symbol at or behind end_bit: <= kColWords - 1 words
+    // from the column's first, look-ahead included), so the next word is one stride further
+    const uint32_t *next = src.col + (size_t)((p >> 5) - src.word0) * src.stride;
+    uint32_t w0 = __builtin_bswap32(next[0]), w1 = __builtin_bswap32(next[src.stride]), nraw = next[2 * (size_t)src.stride];
+    next += 3 * (size_t)src.stride;
     const uint32_t luma_last = (uint32_t)G.nY - 1u, bpm = (uint32_t)G.bpm;
-    const uint8_t *const lds = reinterpret_cast<const uint8_t *>(tabs_lds);
+    const uint16_t *const fast = reinterpret_cast<const uint16_t *>(tabs_lds);   // table t: fast[t * (sizeof(HuffTab) / 2) + i]
+    constexpr uint32_t kTab16 = (uint32_t)sizeof(HuffTab) / 2u;
     while (p < end_bit) {
         const uint32_t c = max(z, luma_last) - luma_last;                                   // component of block z of the MCU
-        const uint8_t *T = lds + c * (2u * (uint32_t)sizeof(HuffTab)) + min(k, 1u) * (uint32_t)sizeof(HuffTab);
+        const uint32_t t = 2u * c + min(k, 1u);
         const uint32_t window = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - off));
-        uint32_t e = reinterpret_cast<const uint16_t *>(T)[window >> 24];
+        uint32_t e = fast[__umul24(t, kTab16) + (window >> 24)];
         if (e == 0u) {   // 9 .. 16 bits
-            const HuffTab &H = *reinterpret_cast<const HuffTab *>(T);
+            const HuffTab &H = *reinterpret_cast<const HuffTab *>(fast + __umul24(t, kTab16));
             const uint32_t peek = window >> 16;
             uint32_t len = 9u + (peek >= H.ub[1]) + (peek >= H.ub[2]) + (peek >= H.ub[3]) + (peek >= H.ub[4]) + (peek >= H.ub[5]) + (peek >= H.ub[6]) + (peek >= H.ub[7]);
             uint32_t sym = H.vals[((peek >> (16u - len)) + (uint32_t)H.valoff[len]) & 255u];
@@ -220,10 +225,12 @@ __device__ inline SubOut decode_sub_lanes(const WordSource &src, const HuffTab *
         const uint32_t raw = ((window << len) >> 1) >> (31u - s);                           // the s extra bits (0 for s = 0)
         const uint32_t one_s = 1u << s;
         const int32_t v = raw < (one_s >> 1) ? (int32_t)(raw + 1u - one_s) : (int32_t)raw;   // HUFF_EXTEND (0 stays 0)
-        const int32_t dcv = dc ? v : 0;
-        dc0 += c == 0u ? dcv : 0;
-        dc1 += c == 1u ? dcv : 0;
-        dc2 += c == 2u ? dcv : 0;
+        const int32_t dcv = dc ? v : 0;                                                     // |dcv| < 2^16: 24-bit multiplies
+        dc_all += dcv;
+        // dc1 += dcv * (c & 1), dc2 += dcv * (c >> 1): one v_mad_i32_i24 each (written out: the compiler turns the products back into
+        // compare + select, or into a 64-bit multiply-add)
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(dc1) : "v"(dcv), "v"(c & 1u));
+        asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(dc2) : "v"(dcv), "v"(c >> 1));
         const uint32_t run = sym >> 4;
         const uint32_t k_ac = s ? k + run + 1u : (run == 15u ? k + 16u : 64u);
         k = dc ? 1u : k_ac;
@@ -239,13 +246,13 @@ __device__ inline SubOut decode_sub_lanes(const WordSource &src, const HuffTab *
             off -= 32u;
             w0 = w1;
             w1 = __builtin_bswap32(nraw);
-            ++widx;
-            nraw = src.at(widx + 2);
+            nraw = *next;
+            next += src.stride;
         }
     }
     SubOut R;
     R.exit = pack_state(p, z, k);
-    R.cnt = cnt; R.dc0 = dc0; R.dc1 = dc1; R.dc2 = dc2;
+    R.cnt = cnt; R.dc0 = dc_all - dc1 - dc2; R.dc1 = dc1; R.dc2 = dc2;
     return R;
 }
 
