@@ -375,6 +375,110 @@ __global__ __launch_bounds__(256) void k_jpeg_sync_list(const ImageDesc *__restr
     xout[slot] = R.exit;
 }
 
+// ---- the lane walker of the final pass ----------------------------------------------------------------------------------------------------
+// decode_sub<true> in the same straight-line form (see decode_sub_lanes): every subsequence is walked from its true entry state and the
+// coefficients are stored.  A block belongs to the lane in whose range it STARTS: the owner assembles it in its LDS slot (lbuf, 64 int16,
+// zero at entry), keeps decoding past end_bit until the block is complete, and the wave stores the blocks completed in a step whole --
+// eight per pass, 16 bytes per lane (wlist: who completed which block).  All 64 lanes stay in the loop until the last one is done.
+// Block position: cidx = index of the MCU = index of its chroma blocks, lidx = index of its first luma block; hs, vs are 1 or 2.
+__device__ inline void decode_sub_store(const WordSource &src, const HuffTab *tabs_lds, const Geom &G, uint64_t entry, uint32_t end_bit,
+                                        int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0, int32_t pred1, int32_t pred2,
+                                        const uint8_t *nat, int16_t *lbuf, bool alive, uint32_t *wave_list)
+{
+    uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
+    uint32_t widx = p >> 5, off = p & 31u;
+    uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
+    const uint32_t luma_last = (uint32_t)G.nY - 1u, bpm = (uint32_t)G.bpm, mcux = (uint32_t)G.mcux;
+    const uint32_t hs = (uint32_t)G.hs, hshift = hs - 1u, wb0 = (uint32_t)G.wb[0], row_step = ((uint32_t)G.vs - 1u) * wb0;
+    const uint32_t off1 = (uint32_t)G.blk_off[1], off2 = (uint32_t)G.blk_off[2];
+    uint32_t cidx = blk / bpm, mx = cidx % mcux;
+    uint32_t lidx = (cidx / mcux) * (uint32_t)G.vs * wb0 + mx * hs;
+    bool own = k == 0u;   // the block in progress started inside this lane's range
+    const int lane = (int)(threadIdx.x & 63u);
+    int16_t *const wave_lbuf = lbuf - (size_t)lane * kLaneBlock;   // lbuf of lane 0 of this wave
+    const uint16_t *const fast = reinterpret_cast<const uint16_t *>(tabs_lds);
+    constexpr uint32_t kTab16 = (uint32_t)sizeof(HuffTab) / 2u;
+    for (;;) {
+        const bool go = alive && (p < end_bit || k != 0u) && blk < blk_cap;
+        if (!__any(go)) break;
+        bool flush = false;      // this lane completed a block of its own in this step (block flush_idx of the image)
+        uint32_t flush_idx = 0;
+        if (go) {
+            const uint32_t c = max(z, luma_last) - luma_last;
+            const uint32_t t = 2u * c + min(k, 1u);
+            const uint32_t window = (uint32_t)(((((uint64_t)w0) << 32) | w1) >> (32u - off));
+            uint32_t e = fast[__umul24(t, kTab16) + (window >> 24)];
+            if (e == 0u) {   // 9 .. 16 bits
+                const HuffTab &H = *reinterpret_cast<const HuffTab *>(fast + __umul24(t, kTab16));
+                const uint32_t peek = window >> 16;
+                uint32_t len = 9u + (peek >= H.ub[1]) + (peek >= H.ub[2]) + (peek >= H.ub[3]) + (peek >= H.ub[4]) + (peek >= H.ub[5]) + (peek >= H.ub[6]) + (peek >= H.ub[7]);
+                uint32_t sym = H.vals[((peek >> (16u - len)) + (uint32_t)H.valoff[len]) & 255u];
+                if (peek >= H.ub[8]) { len = 16; sym = 0; }
+                e = (len << 8) | sym;
+            }
+            const uint32_t len = e >> 8, sym = e & 255u;
+            const bool dc = k == 0u;
+            const uint32_t s = dc ? min(sym, 16u) : (sym & 15u);
+            const uint32_t raw = ((window << len) >> 1) >> (31u - s);
+            const uint32_t one_s = 1u << s;
+            const int32_t v = raw < (one_s >> 1) ? (int32_t)(raw + 1u - one_s) : (int32_t)raw;   // HUFF_EXTEND
+            // the DC prediction of the block's component
+            const int32_t dcv = dc ? v : 0;
+            pred0 += c == 0u ? dcv : 0;
+            pred1 += c == 1u ? dcv : 0;
+            pred2 += c == 2u ? dcv : 0;
+            const int32_t pred = c == 0u ? pred0 : (c == 1u ? pred1 : pred2);
+            // the coefficient goes into the owner's block: the DC value at 0, an AC value at the natural position of k + run
+            const uint32_t run = sym >> 4, kpos = k + run;
+            const bool store = own && (dc || (s != 0u && kpos <= 63u));
+            const uint32_t at = dc ? 0u : (uint32_t)nat[kpos & 63u];
+            if (store) lbuf[at] = (int16_t)(dc ? pred : v);
+            const uint32_t k_ac = s ? kpos + 1u : (run == 15u ? k + 16u : 64u);
+            k = dc ? 1u : k_ac;
+            const uint32_t done = k >> 6;   // (k < 128) the block is complete
+            flush = done != 0u && own;
+            flush_idx = c == 0u ? lidx + (z >> hshift) * wb0 + (z & hshift) : (c == 1u ? off1 : off2) + cidx;
+            own = own || done != 0u;
+            blk += done;
+            k &= done - 1u;
+            z += done;
+            const uint32_t wrap = z == bpm ? 1u : 0u;   // the MCU is complete
+            z = wrap ? 0u : z;
+            cidx += wrap;
+            mx += wrap;
+            lidx += wrap ? hs : 0u;
+            const bool row_end = mx == mcux;             // (only right after a wrap)
+            mx = row_end ? 0u : mx;
+            lidx += row_end ? row_step : 0u;
+            const uint32_t used = len + s;
+            p += used;
+            off += used;
+            if (off >= 32u) {
+                off -= 32u;
+                w0 = w1;
+                w1 = __builtin_bswap32(nraw);
+                ++widx;
+                nraw = src.at(widx + 2);
+            }
+        }
+        const unsigned long long done_mask = __ballot(flush);
+        if (done_mask) {
+            const int nf = __popcll(done_mask);
+            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(done_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done_mask, 0u));
+            if (flush) wave_list[rank] = (flush_idx << 6) | (uint32_t)lane;
+            for (int g0 = 0; g0 < nf; g0 += 8) {
+                const int g = g0 + (lane >> 3);
+                if (g < nf) {
+                    const uint32_t o = wave_list[g];
+                    uint4 *blk_l = reinterpret_cast<uint4 *>(wave_lbuf + (size_t)(o & 63u) * kLaneBlock) + (lane & 7);
+                    *(reinterpret_cast<uint4 *>(coef + (size_t)(o >> 6) * 64) + (lane & 7)) = *blk_l;
+                    *blk_l = make_uint4(0u, 0u, 0u, 0u);
+                }
+            }
+        }
+    }
+}
+
 // ---- the scalar walker -------------------------------------------------------------------------------------------------------------
 // decode_sub<false> for ONE subsequence per wave, computed on the scalar unit.  The last synchronisation rounds of a photograph (flat sky,
 // saturated areas: runs of identical short blocks in which a shifted decoder stays consistent for many subsequences) advance one
@@ -620,7 +724,7 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
         const unsigned long long c2 = (unsigned long long)((A.meta[slot] & 0x7fffffffu) + 1u) * D.seg_blocks;
         if (c2 < cap) cap = (uint32_t)c2;
     }
-    decode_sub<true>(word_source(A, D, stream, jj), T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
+    decode_sub_store(word_source(A, D, stream, jj), T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
                      b.z, b.w, nat, lbuf[threadIdx.x], alive, wlist[threadIdx.x >> 6]);
 }
 
