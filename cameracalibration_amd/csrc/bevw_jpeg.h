@@ -304,9 +304,6 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
                     if (g < nf) {
                         const uint32_t e = wave_list[g];
                         uint4 *blk_l = reinterpret_cast<uint4 *>(wave_lbuf + (size_t)(e & 63u) * kLaneBlock) + (lane & 7);
-#if defined(BEVW_EXP_COEF_NOSTORE)   // timing experiment only (profiles/r04/README.md section 12): what the block stores cost
-                        if (e == 0xffffffffu)
-#endif
                         *(reinterpret_cast<uint4 *>(coef + (size_t)(e >> 6) * 64) + (lane & 7)) = *blk_l;
                         *blk_l = make_uint4(0u, 0u, 0u, 0u);
                     }

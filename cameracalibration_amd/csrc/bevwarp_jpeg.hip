@@ -15,7 +15,8 @@ using namespace bevw;
 struct bevw_jpeg {
     int device = 0;
     hipStream_t st = nullptr, st2 = nullptr;   // st2: the odd slices of a decode batch
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    hipStream_t st_more[2] = {nullptr, nullptr};   // third and fourth slice stream (BEVW_JPEG_STREAMS > 2; created on first use)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_more[2] = {nullptr, nullptr};
     LapTimer timer;
     // decode: what bevw_jpeg_decode_stage left on the device
     jpg::Geom G{};
@@ -86,6 +87,10 @@ void bevw_jpeg_destroy(bevw_jpeg *j)
     if (!j) return;
     (void)hipSetDevice(j->device);
     if (j->st2) { (void)hipStreamSynchronize(j->st2); (void)hipStreamDestroy(j->st2); }
+    for (int i = 0; i < 2; ++i) {
+        if (j->st_more[i]) { (void)hipStreamSynchronize(j->st_more[i]); (void)hipStreamDestroy(j->st_more[i]); }
+        if (j->ev_more[i]) (void)hipEventDestroy(j->ev_more[i]);
+    }
     if (j->st) { (void)hipStreamSynchronize(j->st); (void)hipStreamDestroy(j->st); }
     if (j->ev_a) (void)hipEventDestroy(j->ev_a);
     if (j->ev_b) (void)hipEventDestroy(j->ev_b);
@@ -275,14 +280,24 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     static const int parts_env = [] { const char *e = getenv("BEVW_JPEG_PARTS"); return e ? atoi(e) : 0; }();
     const size_t parts = parts_env > 0 ? std::min<size_t>((size_t)parts_env, n) : (n >= 32 ? 2 : 1);   // measured: 2 slices -6 %, 4 and more lose (launches too small)
     const bool aligned = (uintptr_t)d_out % 4 == 0 && image_stride_bytes % 4 == 0 && row_pitch_bytes % 4 == 0;
+    static const int streams_env = [] { const char *e = getenv("BEVW_JPEG_STREAMS"); return e ? atoi(e) : 0; }();
+    const size_t nstreams = std::min<size_t>(parts, streams_env > 0 ? (size_t)std::min(streams_env, 4) : 2);
+    hipStream_t lanes[4] = {j->st, j->st2, nullptr, nullptr};
+    for (size_t i = 2; i < nstreams; ++i) {
+        if (!j->st_more[i - 2]) {
+            HIP_TRY(hipStreamCreateWithFlags(&j->st_more[i - 2], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&j->ev_more[i - 2], hipEventDisableTiming));
+        }
+        lanes[i] = j->st_more[i - 2];
+    }
     if (parts > 1) {
         HIP_TRY(hipEventRecord(j->ev_a, j->st));          // the staging copies were enqueued on st
-        HIP_TRY(hipStreamWaitEvent(j->st2, j->ev_a, 0));
+        for (size_t i = 1; i < nstreams; ++i) HIP_TRY(hipStreamWaitEvent(lanes[i], j->ev_a, 0));
     }
     for (size_t part = 0; part < parts; ++part) {
         const size_t first = n * part / parts, m = n * (part + 1) / parts - first;
         if (!m) continue;
-        hipStream_t st = (part & 1) ? j->st2 : j->st;
+        hipStream_t st = lanes[part % nstreams];
         const jpg::ImageDesc *im = img + first;
         int16_t *coef = j->d_coef.as<int16_t>() + first * (size_t)G.nblk * 64;
         uint8_t *planes = j->d_planes.as<uint8_t>() + first * (size_t)G.plane_bytes;
@@ -336,6 +351,10 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     if (parts > 1) {   // everything the caller enqueues on st afterwards (and bevw_jpeg_sync) sees the whole batch
         HIP_TRY(hipEventRecord(j->ev_b, j->st2));
         HIP_TRY(hipStreamWaitEvent(j->st, j->ev_b, 0));
+        for (size_t i = 2; i < nstreams; ++i) {
+            HIP_TRY(hipEventRecord(j->ev_more[i - 2], lanes[i]));
+            HIP_TRY(hipStreamWaitEvent(j->st, j->ev_more[i - 2], 0));
+        }
     }
     if (oriented) {
         jpg::k_jpeg_orient<<<dim3((ow + 255) / 256, (unsigned)oh, (unsigned)j->n), 256, 0, j->st>>>(j->d_turn.as<uint8_t>(), G.w, G.h, j->orientation,

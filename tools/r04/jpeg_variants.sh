@@ -7,7 +7,7 @@ O=$R/gpurun_out/r04_jv_$N; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for t in "$@"; do
   if [ $t = base ]; then unset BEVW_LIB_PATH; else export BEVW_LIB_PATH=$R/build_var/libbevwarp_$t.so; fi
-  for src in synthetic repo; do
+  for src in ${JV_SRC:-synthetic repo}; do
     rm -rf /tmp/kt
     timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source $src --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt.log 2>&1
     cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats_${t}_$src.csv
