@@ -395,12 +395,21 @@ __host__ __device__ __forceinline__ int32_t quantize(int32_t v, int32_t q, uint3
 }
 
 // ---- colour -------------------------------------------------------------------------------------------------------------------
+// a * b for |a|, |b| < 2^23 (samples and the 17-bit colour constants): one full-rate 24-bit multiply on the device, where a 32-bit one is quarter rate
+__host__ __device__ __forceinline__ int32_t mul_small(int32_t a, int32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __mul24(a, b);
+#else
+    return a * b;
+#endif
+}
 // jdcolor.c ycc_rgb_convert (SCALEBITS 16) for one pixel, packed B | G << 8 | R << 16
 __host__ __device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
 {
-    const int32_t cr_r = (91881 * (cr - 128) + 32768) >> 16;
-    const int32_t cb_b = (116130 * (cb - 128) + 32768) >> 16;
-    const int32_t g_off = (-22554 * (cb - 128) + 32768 - 46802 * (cr - 128)) >> 16;
+    const int32_t cr_r = (mul_small(91881, cr - 128) + 32768) >> 16;
+    const int32_t cb_b = (mul_small(116130, cb - 128) + 32768) >> 16;
+    const int32_t g_off = (mul_small(-22554, cb - 128) + 32768 - mul_small(46802, cr - 128)) >> 16;
     int r = y + cr_r, g = y + g_off, b = y + cb_b;
     r = r < 0 ? 0 : (r > 255 ? 255 : r);
     g = g < 0 ? 0 : (g > 255 ? 255 : g);
@@ -410,9 +419,9 @@ __host__ __device__ __forceinline__ uint32_t ycc_to_bgr(int y, int cb, int cr)
 // jccolor.c rgb_ycc_convert
 __host__ __device__ __forceinline__ void bgr_to_ycc(int b, int g, int r, int &y, int &cb, int &cr)
 {
-    y = (19595 * r + 38470 * g + 7471 * b + 32768) >> 16;
-    cb = (-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16;
-    cr = (32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16;
+    y = (mul_small(19595, r) + mul_small(38470, g) + mul_small(7471, b) + 32768) >> 16;
+    cb = (mul_small(-11059, r) - mul_small(21709, g) + (b << 15) + (128 << 16) + 32767) >> 16;
+    cr = ((r << 15) - mul_small(27439, g) - mul_small(5329, b) + (128 << 16) + 32767) >> 16;
 }
 
 // jdsample.c: the chroma sample of component plane C (pitch cp, real size dw x dh) seen by luma position (x, y)
