@@ -264,16 +264,7 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
     HIP_TRY(hipMemsetAsync(j->d_nrst.p, 0xFF, (size_t)j->n * 4, j->st));   // an image no kernel closes can never pass k_jpeg_subs' check
     jpg::ImageDesc *imgw = j->d_desc.as<jpg::ImageDesc>();
     const uint8_t *raw = j->d_raw.as<uint8_t>();
-    const dim3 gc(j->max_chunk, (unsigned)j->n);
-    jpg::k_jpeg_find_end<<<gc, 256, 0, j->st>>>(imgw, raw, j->d_term.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_find_end"));
-    jpg::k_jpeg_count_raw<<<gc, 256, 0, j->st>>>(imgw, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_count_raw"));
-    jpg::k_jpeg_unstuff<<<gc, 256, 0, j->st>>>(imgw, raw, j->d_term.as<uint32_t>(), j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>(),
-                                                j->d_stream.as<uint8_t>(), j->d_seg_byte.as<uint32_t>(), j->d_nrst.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_unstuff"));
-    jpg::k_jpeg_subs<<<(unsigned)j->n, 256, 0, j->st>>>(imgw, j->d_nrst.as<uint32_t>(), j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>());
-    BEVW_TRY(launch_check("k_jpeg_subs"));
+    // (these four kernels run per slice, below: a slice's un-stuffing overlaps the other slice's first passes)
     // (no zero fill of the coefficient buffer: k_jpeg_coef stores every block whole)
     // The batch runs as `parts` independent slices alternating over two streams: the tail of the synchronisation (a few lanes per image
     // walking their subsequences again, the rest of the chip idle) of one slice overlaps the throughput-bound kernels of the other.
@@ -299,6 +290,19 @@ int bevw_jpeg_decode_run_device(bevw_jpeg *j, void *d_out, size_t image_stride_b
         if (!m) continue;
         hipStream_t st = lanes[part % nstreams];
         const jpg::ImageDesc *im = img + first;
+        {
+            const dim3 gc(j->max_chunk, (unsigned)m);
+            uint32_t *term = j->d_term.as<uint32_t>() + first, *nrst = j->d_nrst.as<uint32_t>() + first;
+            jpg::k_jpeg_find_end<<<gc, 256, 0, st>>>(imgw + first, raw, term);
+            BEVW_TRY(launch_check("k_jpeg_find_end"));
+            jpg::k_jpeg_count_raw<<<gc, 256, 0, st>>>(imgw + first, raw, term, j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>());
+            BEVW_TRY(launch_check("k_jpeg_count_raw"));
+            jpg::k_jpeg_unstuff<<<gc, 256, 0, st>>>(imgw + first, raw, term, j->d_chunk_keep.as<uint32_t>(), j->d_chunk_rst.as<uint32_t>(),
+                                                     j->d_stream.as<uint8_t>(), j->d_seg_byte.as<uint32_t>(), nrst);
+            BEVW_TRY(launch_check("k_jpeg_unstuff"));
+            jpg::k_jpeg_subs<<<(unsigned)m, 256, 0, st>>>(imgw + first, nrst, j->d_seg_byte.as<uint32_t>(), j->d_seg_sub.as<uint32_t>());
+            BEVW_TRY(launch_check("k_jpeg_subs"));
+        }
         int16_t *coef = j->d_coef.as<int16_t>() + first * (size_t)G.nblk * 64;
         uint8_t *planes = j->d_planes.as<uint8_t>() + first * (size_t)G.plane_bytes;
         if (j->max_sub) {
