@@ -195,6 +195,9 @@ __device__ __forceinline__ WordSource word_source(const SubArrays &A, const Imag
 // (three dependent table reads) and the refill of the bit window (a memory load).  Same states, same sums, bit for bit.
 __device__ inline SubOut decode_sub_lanes(const WordSource &src, const HuffTab *tabs_lds, const Geom &G, uint64_t entry, uint32_t end_bit)
 {
+#if defined(BEVW_EXP_OLD_SYNC)
+    return decode_sub<false>(src, tabs_lds, G, entry, end_bit, nullptr, 0, 0, 0, 0, 0);
+#endif
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
     int32_t cnt = 0, dc_all = 0, dc1 = 0, dc2 = 0;
     uint32_t off = p & 31u;
@@ -636,9 +639,12 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
                     }
                     ++j;
                     if (j >= D.nsub || (uni(A.meta[D.sub_first + j]) & 0x80000000u)) break;   // nothing depends on this exit state
+                    // j starts another stretch of this round: its wave read the exit state in front of it when it started -- maybe before the
+                    // store above.  Whatever entry[j] says right now, only another round can tell (FIRST this test, then the look at entry[j]:
+                    // the other way round a stale walk of j could pass for synchronised and end the fixed point early)
+                    if (__any(lane_lead == j)) { changed = 1; break; }
                     const uint64_t next_in = entry[j];
                     if (uni((uint32_t)next_in) == x_lo && uni((uint32_t)(next_in >> 32)) == x_hi) break;   // synchronised again
-                    if (__any(lane_lead == j)) { changed = 1; break; }   // j starts another stretch of this round
                     in_lo = x_lo;
                     in_hi = x_hi;
                 }
@@ -724,8 +730,13 @@ __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__
         const unsigned long long c2 = (unsigned long long)((A.meta[slot] & 0x7fffffffu) + 1u) * D.seg_blocks;
         if (c2 < cap) cap = (uint32_t)c2;
     }
+#if defined(BEVW_EXP_OLD_COEF)
+    decode_sub<true>(word_source(A, D, stream, jj), T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
+                     b.z, b.w, nat, lbuf[threadIdx.x], alive, wlist[threadIdx.x >> 6]);
+#else
     decode_sub_store(word_source(A, D, stream, jj), T.t, G, A.entry[slot], A.endbit[slot], coef + (size_t)blockIdx.y * G.nblk * 64, (uint32_t)b.x, cap, b.y,
                      b.z, b.w, nat, lbuf[threadIdx.x], alive, wlist[threadIdx.x >> 6]);
+#endif
 }
 
 // jpeg_idct_islow: a wave transforms 8 blocks; lane = (block, column) for the column pass, (block, row) for the row pass, the 8 x 8

@@ -86,6 +86,20 @@ def test_decode_larger_batch_many_rounds(codec):
     assert codec.decode_info()["subsequences"] > 10000
 
 
+def test_noise_at_quality_100_long_unsynchronised_runs(codec):
+    """Noise at quality 100: blocks of ~1000 bits (longer than a subsequence), 40 ... 130 synchronisation rounds per image, many stretches
+    of the in-block tail walked side by side (k_jpeg_sync: a wave that reaches another wave's stretch must ask for another round -- the soak
+    of round 4 caught the version that looked at the successor's entry state first; profiles/r04/soak_jpeg_fail_seed4_case1613.npz is one of those cases)."""
+    rng = np.random.default_rng(20260925)
+    for (h, w, sub, n) in ((84, 542, 2, 5), (413, 256, 0, 4), (200, 333, 1, 3)):
+        files = [JC.pil_encode(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), 100, sub) for _ in range(n)]
+        for _ in range(3):   # (the failure depended on which wave was first)
+            got = codec.decode(files)
+            for i, f in enumerate(files):
+                assert np.array_equal(got[i], JC.pil_decode(f)), (h, w, sub, i)
+        assert codec.decode_info()["rounds"] > 16
+
+
 def test_4k_camera_files(codec):
     """BASELINE config 5's frames (3840 x 2160) and the reference's largest sample (ExtrinsicCalibration/data/img_src_back.jpg is 2560 x 2048):
     ~15 k subsequences per image, several per lane in the per-image kernels."""

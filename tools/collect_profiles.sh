@@ -8,6 +8,29 @@ mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -n "passed\|failed" $O/pytest_gpu.log | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+cd /tmp && export TMPDIR=/tmp
+# row f4: kernel statistics and the VALU instruction counts behind roofline.bound = valu_issue of the JPEG lines
+for w in jpeg_decode_b64 jpeg_encode_b64 jpeg_bev_jpeg_b64; do
+  rm -rf /tmp/kt_$w /tmp/pv_$w
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
+  cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
+  BEVW_BENCH_NO_HOST_API=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_$w -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_$w.log 2>&1
+  cp $(find /tmp/pv_$w -name "*counter_collection.csv" | head -1) $O/pmc_valu_$w.csv
+done
+rm -rf /tmp/kt_rep /tmp/pv_rep
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_rep.log 2>&1
+cp $(find /tmp/kt_rep -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_jpeg_decode_b64_repo_files.csv
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_rep.log 2>&1
+cp $(find /tmp/pv_rep -name "*counter_collection.csv" | head -1) $O/pmc_valu_jpeg_decode_b64_repo.csv
+cd $R
+python tools/r04/jpeg_valu.py $O | grep "wave-level"
+python - <<'P'
+import json
+d=json.load(open('gpurun_out/final/jpeg_valu.json'))
+for k,v in d.items():
+    if isinstance(v,dict): v.pop('per_kernel_per_step',None)
+json.dump(d,open('profiles/jpeg_valu.json','w'),indent=1)   # (on the box: the JPEG lines below price their VALU roofline with THIS build's instruction counts)
+P
 # the driver's own command: the default line with its f4 summary
 ( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.time; tail -3 $O/bench_default.time | head -1
 for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k direct_stitch_analytic_f32_b64 direct_stitch_analytic_f64_b64; do
@@ -34,22 +57,8 @@ for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k
     cp $(find /tmp/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${w}_$c.csv 2>/dev/null
   done
 done
-# row f4: kernel statistics and the VALU instruction counts behind roofline.bound = valu_issue of the JPEG lines
-for w in jpeg_decode_b64 jpeg_encode_b64 jpeg_bev_jpeg_b64; do
-  rm -rf /tmp/kt_$w /tmp/pv_$w
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
-  cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
-  BEVW_BENCH_NO_HOST_API=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_$w -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_$w.log 2>&1
-  cp $(find /tmp/pv_$w -name "*counter_collection.csv" | head -1) $O/pmc_valu_$w.csv
-done
-rm -rf /tmp/kt_rep /tmp/pv_rep
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_rep.log 2>&1
-cp $(find /tmp/kt_rep -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_jpeg_decode_b64_repo_files.csv
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_rep.log 2>&1
-cp $(find /tmp/pv_rep -name "*counter_collection.csv" | head -1) $O/pmc_valu_jpeg_decode_b64_repo.csv
 cd $R
 python tools/summarize_pmc.py $O
-python tools/r04/jpeg_valu.py $O
 # request / latency counters of the stitch kernel (config 3, both device-image layouts) and of config 4's kernels
 bash tools/pmc_merged.sh final/pmc_direct_stitch_aligned direct_stitch_b256 "" > /dev/null 2>&1
 bash tools/pmc_merged.sh final/pmc_direct_stitch_dense direct_stitch_b256 "" --output-pitch dense > /dev/null 2>&1

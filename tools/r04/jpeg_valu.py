@@ -11,12 +11,13 @@ import os
 import sys
 from collections import defaultdict
 
-# workload -> (kernel-name prefixes of one step, the once-per-step kernel, units per step)
+# workload -> (kernel-name prefixes of one step, a kernel with a known number of dispatches per step, that number, units per step)
+# (a decode batch of 256 files runs as 2 slices, each with its own k_jpeg_subs: bevwarp_jpeg.hip, bevw_jpeg_decode_run_device)
 SPEC = {
-    "jpeg_decode_b64": (("k_jpeg_",), "k_jpeg_subs", 256),
-    "jpeg_decode_b64_repo": (("k_jpeg_",), "k_jpeg_subs", 256),
-    "jpeg_encode_b64": (("k_jenc_",), "k_jenc_scan", 64),
-    "jpeg_bev_jpeg_b64": (("k_jpeg_", "k_jenc_", "k_plan_", "k_stitch_plan"), "k_jenc_scan", 64),
+    "jpeg_decode_b64": (("k_jpeg_",), "k_jpeg_subs", 2, 256),
+    "jpeg_decode_b64_repo": (("k_jpeg_",), "k_jpeg_subs", 2, 256),
+    "jpeg_encode_b64": (("k_jenc_",), "k_jenc_scan", 1, 64),
+    "jpeg_bev_jpeg_b64": (("k_jpeg_", "k_jenc_", "k_plan_", "k_stitch_plan"), "k_jenc_scan", 1, 64),
 }
 
 
@@ -31,7 +32,7 @@ def main(d):
     out = {"_comment": "wave-level VALU instructions per unit (SQ_INSTS_VALU summed over the kernels of one step / units per step) from rocprofv3 --pmc "
                        "passes of `bench.py --workload W --steps 3 --warmup 1 --no-cpu-baseline` (tools/r04/run2.sh); static figures of the round they "
                        "were collected in; bench.py: roofline.bound = valu_issue"}
-    for w, (prefixes, marker, units) in SPEC.items():
+    for w, (prefixes, marker, per_step_calls, units) in SPEC.items():
         path = os.path.join(d, "pmc_valu_%s.csv" % w)
         if not os.path.exists(path):
             continue
@@ -43,7 +44,7 @@ def main(d):
                 k = short(row.get("Kernel_Name") or row.get("Kernel Name"))
                 sums[k] += float(row.get("Counter_Value") or row.get("Counter Value"))
                 calls[k] += 1
-        steps = calls.get(marker, 0)
+        steps = calls.get(marker, 0) // per_step_calls
         if not steps:
             continue
         per_step = {k: v / steps for k, v in sums.items() if k.startswith(prefixes)}

@@ -72,7 +72,16 @@ def main():
         except OSError:      # Pillow's own output buffer is too small for some tiny images with extra markers: not a case
             skipped += 1
             continue
-        got = codec.decode(files)
+        try:
+            got = codec.decode(files)
+        except Exception as e:      # a refusal of a valid file is a failure of the case: report it, keep the files, go on
+            bad += 1
+            print("FAILED case", case, dict(h=h, w=w, sub=sub, q=q, n=n, **kw), repr(e), flush=True)
+            out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "soak_jpeg_fail_seed%d_case%d.npz" % (a.seed, case))
+            if bad <= 3:
+                os.makedirs(os.path.dirname(out), exist_ok=True)
+                np.savez(out, **{"f%d" % i: np.frombuffer(f, np.uint8) for i, f in enumerate(files)})
+            continue
         ok = all(np.array_equal(got[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))[:, :, ::-1]) for i, f in enumerate(files))
         if "optimize" not in kw and "restart_marker_blocks" not in kw:      # the engine writes libjpeg's default file: standard tables, no DRI
             enc = codec.encode(np.stack(ims), q, samp)
@@ -80,7 +89,14 @@ def main():
         files_total += n
         if not ok:
             bad += 1
-            print("MISMATCH case", case, dict(h=h, w=w, sub=sub, q=q, n=n, **kw), flush=True)
+            dec_bad = [i for i, f in enumerate(files) if not np.array_equal(got[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))[:, :, ::-1])]
+            print("MISMATCH case", case, dict(h=h, w=w, sub=sub, q=q, n=n, **kw), "decode differs for files", dec_bad, flush=True)
+            if bad <= 3:
+                out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "soak_jpeg_fail_seed%d_case%d.npz" % (a.seed, case))
+                os.makedirs(os.path.dirname(out), exist_ok=True)
+                np.savez(out, **{"f%d" % i: np.frombuffer(f, np.uint8) for i, f in enumerate(files)})
+                again = codec.decode(files)      # (the same files a second time: is the result reproducible?)
+                print("   second decode of the same files: differs for", [i for i, f in enumerate(files) if not np.array_equal(again[i], np.asarray(Image.open(io.BytesIO(f)).convert("RGB"))[:, :, ::-1])], flush=True)
     print(f"soak_jpeg: seed {a.seed}, {done} of {a.cases} cases run, {files_total} files ({skipped} cases Pillow could not write), {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
     return 1 if bad else 0
 
