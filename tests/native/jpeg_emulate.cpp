@@ -2,7 +2,10 @@
 //
 // Every lane function of the JPEG kernels is __host__ __device__; this program drives them in plain loops in the order the kernels
 // do (one loop iteration = one lane), including the synchronisation fixed point of the parallel Huffman decoder, and writes what
-// the device would write.  tests/test_jpeg_emulate.py compares the results with the oracle (oracle/jpegoracle.c) and with Pillow's
+// the device would write.  The walkers the kernels actually run (bevw_jpeg_walk.h: the straight-line lane walker of the synchronisation
+// passes, the scalar walker of the serial tail, the storing walker of the final pass) run NEXT to decode_sub, the plain statement of the
+// algorithm, on every subsequence and every entry state the fixed point goes through: any difference in an exit state, a block count, a DC
+// sum or a coefficient ends the program with an error.  tests/test_jpeg_emulate.py compares the results with the oracle (oracle/jpegoracle.c) and with Pillow's
 // libjpeg-turbo.  Compiled with hipcc (only the host part runs).
 //
 //   jpeg_emulate decode <in.jpg> <out.bin>       out: int32 w h rounds nsub | uint8 bgr[h][w][3]
@@ -14,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../cameracalibration_amd/csrc/bevw_jpeg.h"
+#include "../../cameracalibration_amd/csrc/bevw_jpeg_walk.h"
 
 using namespace bevw::jpg;
 
@@ -80,6 +84,21 @@ static int do_unstuff(const char *in)
     return 0;
 }
 
+static bool same_walk(const SubOut &a, const SubOut &b) { return a.exit == b.exit && a.cnt == b.cnt && a.dc0 == b.dc0 && a.dc1 == b.dc1 && a.dc2 == b.dc2; }
+static long g_walks = 0;
+// decode_sub<false> and the two walkers the synchronisation kernels run, on the same subsequence from the same state
+static bool walk3(const WordSource &src, const TableSet &T, const Geom &G, uint64_t in, uint32_t end, SubOut &R, int j)
+{
+    R = decode_sub<false>(src, T.t, G, in, end, nullptr, 0, 0, 0, 0, 0);
+    const SubOut L = decode_sub_lanes(src, T.t, G, in, end), S = decode_sub_scalar(src, T.t, G, in, end);
+    ++g_walks;
+    if (same_walk(R, L) && same_walk(R, S)) return true;
+    fprintf(stderr, "walkers differ on subsequence %d from state %llx: decode_sub exit %llx cnt %d dc %d %d %d | lanes %llx %d %d %d %d | scalar %llx %d %d %d %d\n", j,
+            (unsigned long long)in, (unsigned long long)R.exit, R.cnt, R.dc0, R.dc1, R.dc2, (unsigned long long)L.exit, L.cnt, L.dc0, L.dc1, L.dc2,
+            (unsigned long long)S.exit, S.cnt, S.dc0, S.dc1, S.dc2);
+    return false;
+}
+
 static int do_decode(const char *in, const char *out)
 {
     const std::vector<uint8_t> raw = read_file(in);
@@ -123,7 +142,7 @@ static int do_decode(const char *in, const char *out)
             endbit[j] = end;
             segof[j] = (uint32_t)s;
             first[j] = j == seg_sub[s];
-            sums[j] = decode_sub<false>(source((int)j), T.t, G, entry[j], end, nullptr, 0, 0, 0, 0, 0);
+            if (!walk3(source((int)j), T, G, entry[j], end, sums[j], (int)j)) return 4;
             exitst[j] = sums[j].exit;
         }
     // k_jpeg_sync: rounds until no exit state changes (lanes of a round read the exit states of the previous round or newer)
@@ -136,7 +155,7 @@ static int do_decode(const char *in, const char *out)
             const uint64_t in = exitst[j - 1];
             if (in == entry[j]) continue;
             entry[j] = in;
-            sums[j] = decode_sub<false>(source(j), T.t, G, in, endbit[j], nullptr, 0, 0, 0, 0, 0);
+            if (!walk3(source(j), T, G, in, endbit[j], sums[j], j)) return 4;
             if (sums[j].exit != exitst[j]) { exitst[j] = sums[j].exit; changed = true; }
         }
         if (!changed) break;
@@ -164,6 +183,22 @@ static int do_decode(const char *in, const char *out)
         if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
         int16_t lbuf[64] = {0};
         decode_sub<true>(source(j), T.t, G, entry[j], endbit[j], coef.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2], nat, lbuf);
+    }
+    {   // k_jpeg_coef's own walker (decode_sub_store) into a second buffer: the same coefficients, every block stored whole
+        std::vector<int16_t> coef2((size_t)G.nblk * 64, 0x7777);
+        for (int j = 0; j < nsub; ++j) {
+            uint32_t cap = (uint32_t)G.nblk;
+            if (seg_blocks != kNoRestart) { const uint64_t c2 = (uint64_t)(segof[j] + 1) * seg_blocks; if (c2 < cap) cap = (uint32_t)c2; }
+            int16_t lbuf[64] = {0};
+            decode_sub_store(source(j), T.t, G, entry[j], endbit[j], coef2.data(), base_blk[j], cap, base_dc[3 * j], base_dc[3 * j + 1], base_dc[3 * j + 2], nat, lbuf,
+                             true, nullptr);
+        }
+        if (coef2 != coef) {
+            size_t d = 0;
+            while (coef2[d] == coef[d]) ++d;
+            fprintf(stderr, "decode_sub_store differs from decode_sub<true>: first at coefficient %zu of block %zu (%d against %d)\n", d % 64, d / 64, coef2[d], coef[d]);
+            return 4;
+        }
     }
     // k_jpeg_idct: lane = (block, column), then (block, row)
     std::vector<uint8_t> planes((size_t)G.plane_bytes);
@@ -208,7 +243,7 @@ static int do_decode(const char *in, const char *out)
     fwrite(hdr, 4, 4, f);
     fwrite(bgr.data(), 1, bgr.size(), f);
     fclose(f);
-    printf("decoded %dx%d nc=%d %dx%d: %d segments, %d subsequences, %d rounds\n", G.w, G.h, G.nc, G.hs, G.vs, nseg, nsub, rounds);
+    printf("decoded %dx%d nc=%d %dx%d: %d segments, %d subsequences, %d rounds, %ld walks by three walkers each\n", G.w, G.h, G.nc, G.hs, G.vs, nseg, nsub, rounds, g_walks);
     return 0;
 }
 

@@ -1,6 +1,8 @@
 """CPU run of the JPEG kernels' per-lane code (tests/native/jpeg_emulate.cpp): the functions in cameracalibration_amd/csrc/bevw_jpeg.h
-are __host__ __device__, so the parallel Huffman decoder's fixed point, the inverse / forward DCT, the colour code and the bit writer
-the GPU runs are checked here, without a GPU, against Pillow's libjpeg-turbo (row f4)."""
+and bevw_jpeg_walk.h are __host__ __device__, so the parallel Huffman decoder's fixed point, the inverse / forward DCT, the colour code and
+the bit writer the GPU runs are checked here, without a GPU, against Pillow's libjpeg-turbo (row f4).  Every decode below also runs the
+three walkers the kernels use (straight-line lane walker, scalar walker, storing walker) next to decode_sub, the plain statement of the
+algorithm, on every subsequence and every entry state of the fixed point, and fails on the first difference."""
 import os
 import shutil
 import subprocess
@@ -30,6 +32,7 @@ def emu(tmp_path_factory):
             open(a, "wb").write(raw)
             r = subprocess.run([exe, "decode", a, b], capture_output=True, text=True, timeout=300)
             assert r.returncode == 0, r.stdout + r.stderr
+            assert "walks by three walkers each" in r.stdout, r.stdout
             buf = open(b, "rb").read()
             w, h, rounds, nsub = np.frombuffer(buf[:16], np.int32)
             return np.frombuffer(buf[16:], np.uint8).reshape(h, w, 3), int(rounds), int(nsub)
@@ -87,6 +90,13 @@ def test_emulated_private_huffman_tables_and_long_codes(emu):
         assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f)), (k, q)
     f = JC.pil_encode(JC.image(96, 160, 1), 100, 0)
     assert np.array_equal(emu.decode(f)[0], JC.pil_decode(f))
+    # uniform noise at quality 100: blocks longer than a 1024-bit subsequence (lanes that own no block; owners walking through their successor)
+    rng = np.random.default_rng(20260925)
+    for h, w, sub in ((84, 542, 2), (120, 96, 0), (64, 200, 1)):
+        f = JC.pil_encode(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), 100, sub)
+        got, rounds, nsub = emu.decode(f)
+        assert np.array_equal(got, JC.pil_decode(f)), (h, w, sub)
+        assert rounds > 8
 
 
 def test_emulated_unstuffing_on_byte_soup(emu):
