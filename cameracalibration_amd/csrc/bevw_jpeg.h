@@ -536,6 +536,28 @@ __host__ __device__ inline uint32_t ac_code_bits(const int16_t *zz, const uint8_
     if (r > 0) bits += aclen[0];
     return bits;
 }
+// ac_code_bits split over the 8 lanes of a block: lane r prices the coefficients at zigzag positions 8 r .. 8 r + 7.  `nonzero` = bit k set
+// for every k >= 1 with zz[k] != 0, and bit 0 set (the DC position stands for "the run starts behind me"): the run in front of a coefficient
+// is its distance to the next lower set bit.  The sum of the eight lanes' results is ac_code_bits (the lane that holds position 63 adds the
+// EOB); tests/native/jpeg_emulate.cpp checks exactly that on every block it encodes.
+__host__ __device__ inline uint32_t ac_code_bits_octet(const int16_t *z8, int r, uint64_t nonzero, const uint8_t *aclen)
+{
+    uint32_t bits = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 8 * r + i;
+        int t = z8[i];
+        if (k == 0 || t == 0) continue;
+        const uint64_t below = nonzero & ((1ull << k) - 1ull);   // (never 0: bit 0)
+        const int prev = 63 - __builtin_clzll(below);
+        const int run = k - prev - 1;
+        if (t < 0) t = -t;
+        const int nb = bit_length(t);
+        bits += (uint32_t)(run >> 4) * aclen[0xF0] + (uint32_t)aclen[((run & 15) << 4) + nb] + (uint32_t)nb;
+    }
+    if (r == 7 && !(nonzero >> 63)) bits += aclen[0];   // zeros behind the last coefficient: EOB
+    return bits;
+}
 __host__ __device__ __forceinline__ uint32_t dc_code_bits(int diff, const uint8_t *dclen)
 {
     const int nb = bit_length(diff < 0 ? -diff : diff);

@@ -745,9 +745,34 @@ __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__rest
         }
     }
     __syncthreads();
+    // the bits of the block's AC codes, eight lanes per block (ac_code_bits_octet; one lane walking all 63 coefficients left 7 of 8 lanes idle
+    // for longer than both DCT passes took): nonzero mask through LDS, eight partial sums through LDS
+    __shared__ uint8_t nzb[4][8][8];
+    __shared__ uint32_t part[4][8][8];
+    int16_t z8[8];
+    if (valid) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(&zl[wave][b][8 * r]);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            z8[i] = (int16_t)(w[i >> 1] >> (16 * (i & 1)));
+            m |= z8[i] != 0 ? 1u << i : 0u;
+        }
+        nzb[wave][b][r] = (uint8_t)(r == 0 ? (m | 1u) : m);
+    }
+    __syncthreads();
+    if (valid) {
+        const uint2 mm = *reinterpret_cast<const uint2 *>(&nzb[wave][b][0]);
+        part[wave][b][r] = ac_code_bits_octet(z8, r, ((uint64_t)mm.y << 32) | mm.x, alen[comp ? 1 : 0]);
+    }
+    __syncthreads();
     if (valid && r == 0) {
         const size_t blk = (size_t)blockIdx.y * G.nblk + g;
-        acbits[blk] = (uint16_t)ac_code_bits(zl[wave][b], alen[comp ? 1 : 0]);
+        uint32_t bits = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) bits += part[wave][b][i];
+        acbits[blk] = (uint16_t)bits;
         dcq[blk] = zl[wave][b][0];
     }
 }

@@ -294,6 +294,14 @@ static int do_encode(const char *in, const char *out)
     for (int g = 0; g < G.nblk; ++g) {
         const int t = (g % G.bpm) < G.nY ? 0 : 1;
         acbits[g] = (uint16_t)ac_code_bits(zz.data() + (size_t)g * 64, T.ac[t].len);
+        {   // k_jenc_fdct prices the block with eight lanes (ac_code_bits_octet): the same number
+            const int16_t *z = zz.data() + (size_t)g * 64;
+            uint64_t nonzero = 1;
+            for (int k = 1; k < 64; ++k) nonzero |= z[k] ? 1ull << k : 0ull;
+            uint32_t sum = 0;
+            for (int r8 = 0; r8 < 8; ++r8) sum += ac_code_bits_octet(z + 8 * r8, r8, nonzero, T.ac[t].len);
+            if (sum != acbits[g]) { fprintf(stderr, "ac_code_bits_octet: block %d: %u against %u\n", g, sum, (unsigned)acbits[g]); return 4; }
+        }
         dcq[g] = zz[(size_t)g * 64];
     }
     std::vector<uint32_t> pos(G.nblk + 1, 0);
