@@ -618,6 +618,52 @@ __host__ __device__ inline void enc_ycc_at(const uint8_t *__restrict__ bgr, size
     Cr[(size_t)yo * cw + xc] = (uint8_t)scr;
 }
 
+// enc_ycc_at for the camera case (4:2:0): one lane = 8 x 2 luma pixels = 4 chroma samples.  Inside the image (and with dword-aligned rows) the two
+// rows are read as 6 dwords each and everything is written as dwords (Y: 2 x 8 bytes, Cb / Cr: 4 bytes each); tiles that touch the right or
+// bottom edge, where jccolor / jcsample replicate pixels, go sample by sample through enc_ycc_at.  Same arithmetic, same planes
+// (tests/native/jpeg_emulate.cpp builds the planes both ways and compares them).
+__host__ __device__ inline void enc_ycc_h2v2_tile(const uint8_t *__restrict__ bgr, size_t pitch, const Geom &G, int t, int yo, uint8_t *__restrict__ Y,
+                                                  uint8_t *__restrict__ Cb, uint8_t *__restrict__ Cr)
+{
+    const int yw = G.wb[0] * 8, cw = G.wb[1] * 8, X0 = 8 * t, Y0 = 2 * yo;
+    if (4 * t >= cw) return;
+    const bool inside = X0 + 8 <= G.w && Y0 + 2 <= G.h && yo < G.dh && pitch % 4 == 0 && ((uintptr_t)bgr & 3u) == 0;
+    if (!inside) {
+        for (int xc = 4 * t; xc < 4 * t + 4 && xc < cw; ++xc) enc_ycc_at(bgr, pitch, G, xc, yo, Y, Cb, Cr);
+        return;
+    }
+    int cb[2][8], cr[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(bgr + (size_t)(Y0 + j) * pitch + (size_t)X0 * 3);
+        uint32_t w[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w[i] = row[i];
+        uint32_t yy[2] = {0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int n = 3 * i;
+            const int b = (int)((w[n >> 2] >> (8 * (n & 3))) & 255u), g = (int)((w[(n + 1) >> 2] >> (8 * ((n + 1) & 3))) & 255u),
+                      r = (int)((w[(n + 2) >> 2] >> (8 * ((n + 2) & 3))) & 255u);
+            int y;
+            bgr_to_ycc(b, g, r, y, cb[j][i], cr[j][i]);
+            yy[i >> 2] |= (uint32_t)y << (8 * (i & 3));
+        }
+        uint32_t *yo32 = reinterpret_cast<uint32_t *>(Y + (size_t)(Y0 + j) * yw + X0);
+        yo32[0] = yy[0];
+        yo32[1] = yy[1];
+    }
+    uint32_t ob = 0, orr = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int bias = 1 + ((4 * t + i) & 1);   // jcsample.c h2v2_downsample: 1, 2, 1, 2, ...
+        ob |= (uint32_t)((cb[0][2 * i] + cb[0][2 * i + 1] + cb[1][2 * i] + cb[1][2 * i + 1] + bias) >> 2) << (8 * i);
+        orr |= (uint32_t)((cr[0][2 * i] + cr[0][2 * i + 1] + cr[1][2 * i] + cr[1][2 * i + 1] + bias) >> 2) << (8 * i);
+    }
+    *reinterpret_cast<uint32_t *>(Cb + (size_t)yo * cw + 4 * t) = ob;
+    *reinterpret_cast<uint32_t *>(Cr + (size_t)yo * cw + 4 * t) = orr;
+}
+
 // k_jenc_fdct: which samples block g (scan order) transforms.  jccoefct.c compress_data: blocks of the last MCU column / row that
 // lie beyond the component's own width_in_blocks / height_in_blocks are dummies -- AC = 0, DC = the quantised DC of the previous
 // block of the MCU (the block to the left; for a dummy ROW the last block of the row above).  The chain always ends at a real

@@ -699,6 +699,15 @@ __global__ __launch_bounds__(256) void k_jenc_ycc(Geom G, const uint8_t *__restr
 // jpeg_fdct_islow + quantisation: lane = (block, row) for the row pass, (block, column) for the column pass; blocks are numbered and
 // stored in scan order (MCU by MCU), coefficients in zigzag order -- what the entropy coder walks.  The quantised block also goes to LDS,
 // where one lane per block counts the bits of its AC codes (jchuff.c encode_one_block without the DC part, which needs the neighbour).
+// the same for 4:2:0, 8 x 2 luma pixels per lane (enc_ycc_h2v2_tile): grid (ceil(chroma width / 4 / 64), ceil(chroma rows / 4), images), block (64, 4)
+__global__ __launch_bounds__(256) void k_jenc_ycc_h2v2(Geom G, const uint8_t *__restrict__ bgr, size_t image_stride, size_t row_pitch,
+                                                       uint8_t *__restrict__ planes)
+{
+    const int t = blockIdx.x * 64 + threadIdx.x, yo = blockIdx.y * 4 + threadIdx.y;
+    if (4 * t >= G.wb[1] * 8 || yo >= G.hb[1] * 8) return;
+    uint8_t *P = planes + (size_t)blockIdx.z * G.plane_bytes;
+    enc_ycc_h2v2_tile(bgr + (size_t)blockIdx.z * image_stride, row_pitch, G, t, yo, P + G.plane_off[0], P + G.plane_off[1], P + G.plane_off[2]);
+}
 __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__restrict__ planes, const EncTables *__restrict__ tabs,
                                                    int16_t *__restrict__ zz, uint16_t *__restrict__ acbits, int16_t *__restrict__ dcq)
 {

@@ -472,8 +472,12 @@ int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int widt
     BEVW_TRY(j->d_files.reserve(N * j->file_cap));
     BEVW_TRY(j->d_sizes.reserve(N * 4));
     const jpg::EncTables *tabs = j->d_etabs.as<jpg::EncTables>();
-    jpg::k_jenc_ycc<<<dim3((G.wb[1] * 8 + 63) / 64, (G.hb[1] * 8 + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
-        G, (const uint8_t *)d_bgr, image_stride_bytes, row_pitch_bytes, j->d_eplanes.as<uint8_t>());
+    if (G.hs == 2 && G.vs == 2 && image_stride_bytes % 4 == 0)   // the camera case: 8 x 2 pixels per lane, dword loads and stores
+        jpg::k_jenc_ycc_h2v2<<<dim3((G.wb[1] * 2 + 63) / 64, (G.hb[1] * 8 + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
+            G, (const uint8_t *)d_bgr, image_stride_bytes, row_pitch_bytes, j->d_eplanes.as<uint8_t>());
+    else
+        jpg::k_jenc_ycc<<<dim3((G.wb[1] * 8 + 63) / 64, (G.hb[1] * 8 + 3) / 4, (unsigned)n), dim3(64, 4), 0, j->st>>>(
+            G, (const uint8_t *)d_bgr, image_stride_bytes, row_pitch_bytes, j->d_eplanes.as<uint8_t>());
     BEVW_TRY(launch_check("k_jenc_ycc"));
     BEVW_TRY(j->d_acbits.reserve(N * (size_t)G.nblk * 2));
     BEVW_TRY(j->d_dcq.reserve(N * (size_t)G.nblk * 2));

@@ -262,6 +262,14 @@ static int do_encode(const char *in, const char *out)
     for (int yo = 0; yo < G.hb[1] * 8; ++yo)
         for (int xc = 0; xc < G.wb[1] * 8; ++xc)
             enc_ycc_at(bgr, (size_t)w * 3, G, xc, yo, planes.data() + G.plane_off[0], planes.data() + G.plane_off[1], planes.data() + G.plane_off[2]);
+    if (G.hs == 2 && G.vs == 2) {   // k_jenc_ycc_h2v2: the same planes, 8 x 2 luma pixels per lane (misaligned rows included: w * 3 need not be a multiple of 4)
+        std::vector<uint8_t> planes2((size_t)G.plane_bytes, 0xA5);
+        std::vector<uint8_t> fill((size_t)G.plane_bytes, 0xA5);
+        for (int yo = 0; yo < G.hb[1] * 8; ++yo)
+            for (int t = 0; 4 * t < G.wb[1] * 8; ++t)
+                enc_ycc_h2v2_tile(bgr, (size_t)w * 3, G, t, yo, planes2.data() + G.plane_off[0], planes2.data() + G.plane_off[1], planes2.data() + G.plane_off[2]);
+        if (planes2 != planes) { fprintf(stderr, "enc_ycc_h2v2_tile differs from enc_ycc_at\n"); return 4; }
+    }
     // k_jenc_fdct: lane = (block, row), then (block, column)
     std::vector<int16_t> zz((size_t)G.nblk * 64);
     for (int g = 0; g < G.nblk; ++g) {
