@@ -460,8 +460,10 @@ __host__ __device__ __forceinline__ int bit_length(int v) { return v ? 32 - __bu
 // EMIT: bits are ORed into `out` (32-bit words, most significant bit first) starting at bit `pos`; the first and the last word a
 // block touches may be shared with its neighbours (atomic), the words in between are its own.
 template <bool EMIT>
+// nonzero: bit k set for every k >= 1 with zz[k] != 0 (bit 0 is ignored) -- the loop visits the coefficients that exist, not all 63 positions
+// (64 lanes = 64 blocks walk in step: the wave runs as long as its fullest block has coefficients)
 __host__ __device__ inline uint32_t encode_block(const int16_t *__restrict__ zz, int last_dc, const EncHuff &D, const EncHuff &A, uint32_t *out,
-                                                 uint32_t pos)
+                                                 uint32_t pos, uint64_t nonzero)
 {
     uint32_t bits = 0;
     uint64_t acc = 0;   // EMIT: pending bits, right-aligned
@@ -493,19 +495,20 @@ __host__ __device__ inline uint32_t encode_block(const int16_t *__restrict__ zz,
     int nb = bit_length(temp);
     put(D.code[nb], D.len[nb]);
     if (nb) put((uint32_t)temp2, nb);
-    int r = 0;
-    for (int k = 1; k < 64; ++k) {
+    int prev = 0;
+    for (uint64_t m = nonzero & ~1ull; m; m &= m - 1ull) {
+        const int k = __builtin_ctzll(m);
+        int r = k - prev - 1;
+        prev = k;
         temp = zz[k];
-        if (temp == 0) { ++r; continue; }
         while (r > 15) { put(A.code[0xF0], A.len[0xF0]); r -= 16; }
         temp2 = temp;
         if (temp < 0) { temp = -temp; --temp2; }
         nb = bit_length(temp);
         put(A.code[(r << 4) + nb], A.len[(r << 4) + nb]);
         put((uint32_t)temp2, nb);
-        r = 0;
     }
-    if (r > 0) put(A.code[0], A.len[0]);
+    if (prev < 63) put(A.code[0], A.len[0]);   // zeros behind the last coefficient: EOB
     if (EMIT && nacc > 0) {   // the tail shares its word with the next block
         const uint32_t w = (uint32_t)(acc & ((1ull << nacc) - 1ull)) << (32 - lead - nacc);
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -519,6 +522,12 @@ __host__ __device__ inline uint32_t encode_block(const int16_t *__restrict__ zz,
 
 // The two halves of encode_block<false>: the bits of the AC coefficients (known as soon as the block is quantised: k_jenc_fdct) and of
 // the DC difference (needs the previous block of the component: k_jenc_scan).  aclen / dclen = EncHuff::len of the component's tables.
+__host__ __device__ inline uint64_t nonzero_mask(const int16_t *zz)   // bit k = zz[k] != 0, k >= 1; bit 0 set (see ac_code_bits_octet)
+{
+    uint64_t m = 1;
+    for (int k = 1; k < 64; ++k) m |= zz[k] ? 1ull << k : 0ull;
+    return m;
+}
 __host__ __device__ inline uint32_t ac_code_bits(const int16_t *zz, const uint8_t *aclen)
 {
     uint32_t bits = 0;

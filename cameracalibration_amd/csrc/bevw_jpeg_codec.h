@@ -709,7 +709,8 @@ __global__ __launch_bounds__(256) void k_jenc_ycc_h2v2(Geom G, const uint8_t *__
     enc_ycc_h2v2_tile(bgr + (size_t)blockIdx.z * image_stride, row_pitch, G, t, yo, P + G.plane_off[0], P + G.plane_off[1], P + G.plane_off[2]);
 }
 __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__restrict__ planes, const EncTables *__restrict__ tabs,
-                                                   int16_t *__restrict__ zz, uint16_t *__restrict__ acbits, int16_t *__restrict__ dcq)
+                                                   int16_t *__restrict__ zz, uint16_t *__restrict__ acbits, int16_t *__restrict__ dcq,
+                                                   uint64_t *__restrict__ nzmask)
 {
     __shared__ int32_t ws[4][8 * 72];
     __shared__ int16_t zl[4][8][64];
@@ -783,6 +784,8 @@ __global__ __launch_bounds__(256) void k_jenc_fdct(Geom G, const uint8_t *__rest
         for (int i = 0; i < 8; ++i) bits += part[wave][b][i];
         acbits[blk] = (uint16_t)bits;
         dcq[blk] = zl[wave][b][0];
+        const uint2 mm = *reinterpret_cast<const uint2 *>(&nzb[wave][b][0]);
+        nzmask[blk] = ((uint64_t)mm.y << 32) | mm.x;   // for k_jenc_bits (encode_block)
     }
 }
 
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jenc_scan(Geom G, const uint16
 // first version slow.
 __global__ __launch_bounds__(256) void k_jenc_bits(Geom G, const int16_t *__restrict__ zz, const int16_t *__restrict__ dcq,
                                                    const EncTables *__restrict__ tabs, const uint32_t *__restrict__ bitpos, uint32_t *__restrict__ bitbuf,
-                                                   size_t buf_words)
+                                                   size_t buf_words, const uint64_t *__restrict__ nzmask)
 {
     __shared__ EncTables T;
     __shared__ uint32_t zl[256 * 33];
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(256) void k_jenc_bits(Geom G, const int16_t *__rest
     const int last = pr < 0 ? 0 : dcq[base + pr];
     const int t = (g % G.bpm) < G.nY ? 0 : 1;
     encode_block<true>(reinterpret_cast<const int16_t *>(zl + threadIdx.x * 33), last, T.dc[t], T.ac[t], bitbuf + (size_t)blockIdx.y * buf_words,
-                       bitpos[base + g]);
+                       bitpos[base + g], nzmask[base + g]);
 }
 
 // The file = header | entropy-coded bytes with a 0x00 after every 0xFF (jchuff.c emit_bits; the last byte is filled with 1-bits first,

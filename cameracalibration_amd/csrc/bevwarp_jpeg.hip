@@ -41,7 +41,7 @@ struct bevw_jpeg {
     int en = 0, e_quality = -1, e_sampling = -1;
     jpg::EncTables etabs;
     std::vector<uint8_t> header;
-    DevBuf d_etabs, d_header, d_eplanes, d_zz, d_acbits, d_dcq, d_bitlen, d_bitbuf, d_totals, d_chunk_ff, d_files, d_sizes, d_src;
+    DevBuf d_etabs, d_header, d_eplanes, d_zz, d_acbits, d_dcq, d_nzmask, d_bitlen, d_bitbuf, d_totals, d_chunk_ff, d_files, d_sizes, d_src;
     DevBuf d_packed, d_offsets;                // bevw_jpeg_encoded_fetch: the files of a batch back to back
     size_t buf_words = 0, file_cap = 0;
     std::vector<uint32_t> sizes;
@@ -481,16 +481,17 @@ int bevw_jpeg_encode_run_device(bevw_jpeg *j, const void *d_bgr, int n, int widt
     BEVW_TRY(launch_check("k_jenc_ycc"));
     BEVW_TRY(j->d_acbits.reserve(N * (size_t)G.nblk * 2));
     BEVW_TRY(j->d_dcq.reserve(N * (size_t)G.nblk * 2));
+    BEVW_TRY(j->d_nzmask.reserve(N * (size_t)G.nblk * 8));
     const uint32_t nchunk = (uint32_t)((j->buf_words * 4 + jpg::kStuffChunk - 1) / jpg::kStuffChunk);
     BEVW_TRY(j->d_chunk_ff.reserve(N * nchunk * 4));
     jpg::k_jenc_fdct<<<dim3((G.nblk + 31) / 32, (unsigned)n), 256, 0, j->st>>>(G, j->d_eplanes.as<uint8_t>(), tabs, j->d_zz.as<int16_t>(),
-                                                                                 j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>());
+                                                                                 j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>(), j->d_nzmask.as<uint64_t>());
     BEVW_TRY(launch_check("k_jenc_fdct"));
     jpg::k_jenc_scan<<<(unsigned)n, jpg::kSyncThreads, 0, j->st>>>(G, j->d_acbits.as<uint16_t>(), j->d_dcq.as<int16_t>(), tabs, j->d_bitlen.as<uint32_t>(),
                                                                     j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>());
     BEVW_TRY(launch_check("k_jenc_scan"));
     jpg::k_jenc_bits<<<dim3((G.nblk + 255) / 256, (unsigned)n), 256, 0, j->st>>>(G, j->d_zz.as<int16_t>(), j->d_dcq.as<int16_t>(), tabs,
-                                                                                   j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words);
+                                                                                   j->d_bitlen.as<uint32_t>(), j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_nzmask.as<uint64_t>());
     BEVW_TRY(launch_check("k_jenc_bits"));
     jpg::k_jenc_ffcount<<<dim3(nchunk, (unsigned)n), 256, 0, j->st>>>(j->d_bitbuf.as<uint32_t>(), j->buf_words, j->d_totals.as<uint32_t>(),
                                                                         j->d_chunk_ff.as<uint32_t>(), nchunk);

@@ -304,8 +304,7 @@ static int do_encode(const char *in, const char *out)
         acbits[g] = (uint16_t)ac_code_bits(zz.data() + (size_t)g * 64, T.ac[t].len);
         {   // k_jenc_fdct prices the block with eight lanes (ac_code_bits_octet): the same number
             const int16_t *z = zz.data() + (size_t)g * 64;
-            uint64_t nonzero = 1;
-            for (int k = 1; k < 64; ++k) nonzero |= z[k] ? 1ull << k : 0ull;
+            const uint64_t nonzero = nonzero_mask(z);
             uint32_t sum = 0;
             for (int r8 = 0; r8 < 8; ++r8) sum += ac_code_bits_octet(z + 8 * r8, r8, nonzero, T.ac[t].len);
             if (sum != acbits[g]) { fprintf(stderr, "ac_code_bits_octet: block %d: %u against %u\n", g, sum, (unsigned)acbits[g]); return 4; }
@@ -318,7 +317,7 @@ static int do_encode(const char *in, const char *out)
         const int last = pr < 0 ? 0 : dcq[pr];
         const int t = z < G.nY ? 0 : 1;
         const uint32_t len = (uint32_t)acbits[g] + dc_code_bits((int)dcq[g] - last, T.dc[t].len);
-        if (len != encode_block<false>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], nullptr, 0)) { fprintf(stderr, "split length differs at block %d\n", g); return 3; }
+        if (len != encode_block<false>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], nullptr, 0, nonzero_mask(zz.data() + (size_t)g * 64))) { fprintf(stderr, "split length differs at block %d\n", g); return 3; }
         pos[g + 1] = pos[g] + len;
     }
     const uint32_t total_bits = pos[G.nblk];
@@ -329,7 +328,7 @@ static int do_encode(const char *in, const char *out)
         const int z = g % G.bpm, pr = dc_predecessor(g, G);
         const int last = pr < 0 ? 0 : zz[(size_t)pr * 64];
         const int t = z < G.nY ? 0 : 1;
-        const uint32_t n = encode_block<true>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], words.data(), pos[g]);
+        const uint32_t n = encode_block<true>(zz.data() + (size_t)g * 64, last, T.dc[t], T.ac[t], words.data(), pos[g], nonzero_mask(zz.data() + (size_t)g * 64));
         if (n != pos[g + 1] - pos[g]) { fprintf(stderr, "length mismatch at block %d\n", g); return 3; }
     }
     // k_jenc_stuff
