@@ -22,20 +22,28 @@ template <typename T> __device__ __forceinline__ void lds_copy(T *dst, const T *
     for (unsigned i = threadIdx.x + threadIdx.y * blockDim.x; i < sizeof(T) / 16; i += blockDim.x * blockDim.y) d[i] = s[i];
 }
 
-// Exclusive prefix over one value per thread of a 1-D block, done the plain way: partials to LDS, thread 0 walks them.  The blocks that
-// use it run one per image and call it a handful of times; a walk over 1024 LDS words is a few microseconds and cannot be wrong.
+// Exclusive prefix over one value per thread of a 1-D block of whole waves, done the plain way in two levels: partials to LDS, lane 0 of every
+// wave walks its wave's 64, thread 0 walks the waves' totals.  (One thread walking all 1024 took ~40 us of the one-block-per-image kernels:
+// a lone lane gets one LDS round trip per step.)  lds: blockDim.x + blockDim.x / 64 + 1 values.
 template <typename V> __device__ __forceinline__ V block_exscan_serial(V v, V *lds, V &total)
 {
+    const unsigned T = blockDim.x, W = T >> 6, w = threadIdx.x >> 6;
     lds[threadIdx.x] = v;
+    __syncthreads();
+    if ((threadIdx.x & 63u) == 0) {
+        V run = V();
+        for (unsigned i = w * 64; i < w * 64 + 64; ++i) { const V t = lds[i]; lds[i] = run; run = run + t; }
+        lds[T + w] = run;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         V run = V();
-        for (unsigned i = 0; i < blockDim.x; ++i) { const V t = lds[i]; lds[i] = run; run = run + t; }
-        lds[blockDim.x] = run;
+        for (unsigned i = 0; i < W; ++i) { const V t = lds[T + i]; lds[T + i] = run; run = run + t; }
+        lds[T + W] = run;
     }
     __syncthreads();
-    const V r = lds[threadIdx.x];
-    total = lds[blockDim.x];
+    const V r = lds[threadIdx.x] + lds[T + w];
+    total = lds[T + W];
     __syncthreads();
     return r;
 }
@@ -415,17 +423,38 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
     part[threadIdx.x] = run;
     s_reset[threadIdx.x] = reset;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    // two levels (a lone lane walking all 1024 entries took a fifth of the kernel): lane 0 of every wave walks its wave's 64 entries, thread 0 the 16
+    // wave totals; an entry behind a reset inside its own wave does not see what came before the wave
+    __shared__ int4 wave_part[kSyncThreads / 64];
+    __shared__ int wave_reset[kSyncThreads / 64];
+    const uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) {
         int4 carry = make_int4(0, 0, 0, 0);
-        for (int i = 0; i < kSyncThreads; ++i) {
+        int seen = 0;
+        for (uint32_t i = wv * 64u; i < wv * 64u + 64u; ++i) {
             const int4 t = part[i];
             const int r = s_reset[i];
-            part[i] = carry;                     // what thread i starts from (void after its first reset)
+            part[i] = carry;                     // what thread i starts from inside its wave (void after its first reset)
+            s_reset[i] = seen;                   // a reset in front of i inside the wave: part[i] is complete
+            carry = r ? t : add4(carry, t);
+            seen |= r;
+        }
+        wave_part[wv] = carry;
+        wave_reset[wv] = seen;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int4 carry = make_int4(0, 0, 0, 0);
+        for (int i = 0; i < kSyncThreads / 64; ++i) {
+            const int4 t = wave_part[i];
+            const int r = wave_reset[i];
+            wave_part[i] = carry;
             carry = r ? t : add4(carry, t);
         }
     }
     __syncthreads();
     run = part[threadIdx.x];
+    if (!s_reset[threadIdx.x]) run = add4(run, wave_part[wv]);
     for (uint32_t j = j0; j < j1; ++j) {
         const uint32_t m = A.meta[D.sub_first + j];
         if (m & 0x80000000u) run = make_int4(0, 0, 0, 0);
@@ -795,7 +824,7 @@ __global__ __launch_bounds__(kSyncThreads) void k_jenc_scan(Geom G, const uint16
                                                              const EncTables *__restrict__ tabs, uint32_t *__restrict__ bitpos,
                                                              uint32_t *__restrict__ bitbuf, size_t buf_words, uint32_t *__restrict__ totals)
 {
-    __shared__ uint32_t lds[kSyncThreads + 1];
+    __shared__ uint32_t lds[kSyncThreads + kSyncThreads / 64 + 1];
     __shared__ uint8_t dlen[2][16];
     if (threadIdx.x < 32) dlen[threadIdx.x >> 4][threadIdx.x & 15] = tabs->dc[threadIdx.x >> 4].len[threadIdx.x & 15];
     __syncthreads();
