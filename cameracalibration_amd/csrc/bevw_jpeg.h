@@ -17,10 +17,12 @@
 //                  this takes 2 - 3 rounds (correctness does not rest on it: the fixed point is reached by induction
 //                  from the first subsequence of every restart segment, whose state is known).  A prefix sum of the blocks
 //                  completed and of the DC differences per component turns the states into output positions;
+//                  (three walkers run these passes -- bevw_jpeg_walk.h; decode_sub below is their plain statement);
 //            k_jpeg_coef  : decodes every subsequence once more from its TRUE entry state and writes the coefficients;
 //            k_jpeg_idct  : jpeg_idct_islow, 8 blocks per wave (lane = block x column, transpose through LDS);
-//            k_jpeg_color : fancy (triangle) chroma upsampling + YCbCr -> BGR, written straight into the caller's frame layout.
-//   encode   k_jenc_ycc   : BGR -> YCbCr + chroma downsampling with libjpeg's edge replication;
+//            k_jpeg_color : fancy (triangle) chroma upsampling + YCbCr -> BGR, written straight into the caller's frame layout
+//                  (the camera case: k_jpeg_idct_color_h2v2, luma inverse DCT and colour in one pass).
+//   encode   k_jenc_ycc   : BGR -> YCbCr + chroma downsampling with libjpeg's edge replication (4:2:0: k_jenc_ycc_h2v2, 8 x 2 pixels per lane);
 //            k_jenc_fdct  : jpeg_fdct_islow + quantisation, dummy blocks of partial MCUs;
 //            k_jenc_len / k_jenc_scan / k_jenc_bits / k_jenc_stuff : Huffman code lengths per block, a prefix sum to bit
 //                  offsets, every block written at its offset (atomic OR on shared words), 0xFF byte stuffing by a
@@ -154,65 +156,36 @@ struct WordSource {
 // in state `entry`.  Returns the state in which the first symbol at or after end_bit is met, the number of blocks completed and
 // the sum of the DC differences per component.  WRITE: the entry state is the true one; `blk` is the index (scan order) of the
 // block in progress, pred the DC predictions; coefficients are written (row-major int16, DC already predicted) until blk_cap.
+//
+// This is the PLAIN statement of what a lane does with a subsequence -- one branch per case, as jdhuff.c reads.  The kernels run the walkers of
+// bevw_jpeg_walk.h (straight-line for 64 divergent lanes, scalar for the serial tail, storing for the final pass); tests/native/jpeg_emulate.cpp
+// runs this function and those walkers side by side on every subsequence and every entry state the fixed point goes through.
 template <bool WRITE>
 __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTab *tabs, const Geom &G, uint64_t entry,
                                              uint32_t end_bit, int16_t *__restrict__ coef, uint32_t blk, uint32_t blk_cap, int32_t pred0,
-                                             int32_t pred1, int32_t pred2, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr, bool alive = true,
-                                             uint32_t *wlist = nullptr)
+                                             int32_t pred1, int32_t pred2, const uint8_t *nat = nullptr, int16_t *lbuf = nullptr)
 {
-    // WRITE: a block belongs to the lane in whose range it STARTS.  The owner assembles it in lbuf (64 int16 of its own, LDS on the device,
-    // zero at entry), keeps decoding past end_bit until the block is complete, and the block is stored whole -- no read-modify-write of
-    // zeroed lines, no zero fill of the coefficient buffer.  The block in progress at a lane's entry (k != 0) is its predecessor's: it is
-    // decoded for the state only.  On the device the STORE is the wave's job: all 64 lanes stay in the loop until the last one is done
-    // (`alive` = false for lanes without a subsequence), and after every symbol the blocks completed in that step are written one after the
-    // other, lane i storing coefficient i -- one 128-byte request per block instead of eight 16-byte ones (the pass was bound by its
-    // 59 M write requests, profiles/r03_jpeg/pmc_decode_v3.txt).  The host build (tests/native/jpeg_emulate.cpp) stores with memcpy.
-    // nat: the natural-order table in memory of the caller's choice (LDS on the device: a global-memory look-up would queue behind the stores)
+    // WRITE: a block belongs to the lane in whose range it STARTS.  The owner assembles it in lbuf (64 int16 of its own, zero at entry),
+    // keeps decoding past end_bit until the block is complete, and the block is stored whole -- no read-modify-write of zeroed lines, no
+    // zero fill of the coefficient buffer.  The block in progress at a lane's entry (k != 0) is its predecessor's: it is decoded for the
+    // state only.
     uint32_t p = (uint32_t)entry, z = (uint32_t)(entry >> 32) & 255u, k = (uint32_t)(entry >> 40) & 255u;
     SubOut R;
     R.cnt = 0; R.dc0 = R.dc1 = R.dc2 = 0;
-    // bit window: w0 | w1 = the two (big-endian) words around the read position, `off` = bits of w0 already used; the word after them
-    // is always in flight (nraw): a wave meets a refill in nearly every iteration, and waiting for a load where it is issued would cost
-    // the whole wave a memory latency per symbol.  One 32-bit window holds a whole symbol (code <= 16 bits + <= 16 extra bits).
+    // bit window: w0 | w1 = the two (big-endian) words around the read position, `off` = bits of w0 already used, nraw = the word after
+    // them.  One 32-bit window holds a whole symbol (code <= 16 bits + <= 16 extra bits).
     uint32_t widx = p >> 5, off = p & 31u;
     uint32_t w0 = __builtin_bswap32(src.at(widx)), w1 = __builtin_bswap32(src.at(widx + 1)), nraw = src.at(widx + 2);
-    // position of the block in progress (WRITE): MCU (mx, my), luma block (zx, zy) inside it; bidx = its index in the image's coefficient buffer.
-    // Everything in the loop is a select between scalars: an indexed read of G's arrays is a memory load on the device, and on gfx950 a wait
-    // for ANY load is a wait for every block store issued before it (one counter).
-    int mx = 0, my = 0, zx = 0, zy = 0;
-    uint32_t bidx = 0;
-    const int wb0 = G.wb[0], wb1 = G.wb[1], off1 = G.blk_off[1], off2 = G.blk_off[2];   // (read HERE: selects between loads come back as loads of a selected address)
+    // position of the block in progress (WRITE): MCU (mx, my)
+    int mx = 0, my = 0;
     if (WRITE) {
         const uint32_t mcu = blk / (uint32_t)G.bpm;
         mx = (int)(mcu % (uint32_t)G.mcux);
         my = (int)(mcu / (uint32_t)G.mcux);
-        if ((int)z < G.nY) { zx = (int)z % G.hs; zy = (int)z / G.hs; }
     }
-    bool fresh = true;   // bidx must be recomputed
     bool own = k == 0;   // WRITE: the block in progress started inside this lane's range
-#if defined(__HIP_DEVICE_COMPILE__)
-    const int lane = (int)(threadIdx.x & 63u);
-    int16_t *const wave_lbuf = WRITE ? lbuf - (size_t)lane * kLaneBlock : nullptr;   // lbuf of lane 0 of this wave
-    uint32_t *const wave_list = WRITE ? wlist : nullptr;                             // 64 entries of this wave
-#endif
-    for (;;) {
-        const bool go = alive && (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit);
-#if defined(__HIP_DEVICE_COMPILE__)
-        bool flush = false;      // WRITE: this lane completed a block of its own in this step (block flush_idx of the image)
-        uint32_t flush_idx = 0;
-        if (WRITE ? !__any(go) : !go) break;
-#else
-        if (!go) break;
-#endif
-      if (go) {
+    while (WRITE ? ((p < end_bit || k != 0) && blk < blk_cap) : p < end_bit) {
         const int c = (int)z < G.nY ? 0 : 1 + (int)z - G.nY;
-        if (WRITE && fresh) {
-            const int bx = c == 0 ? mx * G.hs + zx : mx, by = c == 0 ? my * G.vs + zy : my;
-            const int wbc = c == 0 ? wb0 : wb1;   // (the chroma planes have one size)
-            const int first = c == 0 ? 0 : (c == 1 ? off1 : off2);
-            bidx = (uint32_t)(first + by * wbc + bx);
-            fresh = false;
-        }
         const HuffTab &T = tabs[2 * c + (k ? 1 : 0)];
         const uint32_t window = off ? (w0 << off) | (w1 >> (32u - off)) : w0;
         const uint32_t peek = window >> 16;
@@ -222,8 +195,7 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             len = e >> 8;
             sym = e & 255u;
         } else {
-            // a code of 10 .. 16 bits: its length is 10 + the number of limits the window has reached (no loop: with 64 lanes some lane
-            // is here in most iterations, and every lane of the wave pays for the longest path)
+            // a code of 9 .. 16 bits: its length is 9 + the number of limits the window has reached
             len = 9u + (peek >= T.ub[1]) + (peek >= T.ub[2]) + (peek >= T.ub[3]) + (peek >= T.ub[4]) + (peek >= T.ub[5]) + (peek >= T.ub[6]) + (peek >= T.ub[7]);
             sym = T.vals[((peek >> (16u - len)) + (uint32_t)T.valoff[len]) & 255u];
             if (peek >= T.ub[8]) { len = 16; sym = 0; }   // not a code at all (corrupt data): libjpeg warns and yields 0
@@ -243,39 +215,26 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             k = 1;
         } else if (s) {
             k += sym >> 4;
-#if defined(__HIP_DEVICE_COMPILE__)
-            if (WRITE && own && k <= 63u) lbuf[(int)nat[k]] = (int16_t)v;   // (nat is never null here: a second, global-memory path would put a wait for all stores in front of this write)
-#else
             if (WRITE && own && k <= 63u) lbuf[nat ? (int)nat[k] : natural_of((int)k)] = (int16_t)v;
-#endif
             ++k;
         } else {
             k = (sym >> 4) == 15u ? k + 16u : 64u;   // ZRL : EOB
         }
         if (k >= 64u) {   // block complete
             if (WRITE && own) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                flush = true;
-                flush_idx = bidx;
-#else
-                memcpy(coef + (size_t)bidx * 64, lbuf, 128);
+                int bx, by;
+                if (c == 0) { bx = mx * G.hs + (int)z % G.hs; by = my * G.vs + (int)z / G.hs; }
+                else { bx = mx; by = my; }
+                memcpy(coef + ((size_t)G.blk_off[c] + (size_t)by * G.wb[c] + bx) * 64, lbuf, 128);
                 memset(lbuf, 0, 128);
-#endif
             }
             own = true;
             k = 0;
             ++R.cnt;
             ++blk;
-            fresh = true;
             if (++z == (uint32_t)G.bpm) {
                 z = 0;
-                if (WRITE) {
-                    zx = zy = 0;
-                    if (++mx == G.mcux) { mx = 0; ++my; }
-                }
-            } else if (WRITE && ++zx == G.hs) {
-                zx = 0;
-                ++zy;
+                if (WRITE && ++mx == G.mcux) { mx = 0; ++my; }
             }
         }
         const uint32_t used = len + s;
@@ -288,29 +247,6 @@ __host__ __device__ inline SubOut decode_sub(const WordSource &src, const HuffTa
             ++widx;
             nraw = src.at(widx + 2);
         }
-      }   // if (go)
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (WRITE) {
-            // Eight blocks per pass: lanes 8 g .. 8 g + 7 take the g-th completed block, 16 bytes each (one 128-byte line per block, as
-            // before, but one LDS round trip and one store instruction per EIGHT blocks instead of per block).  Who completed the g-th
-            // block is found through a 64-entry list in LDS (wave_list): the owners write `block index << 6 | lane` at their rank.
-            const unsigned long long done = __ballot(flush);
-            if (done) {
-                const int nf = __popcll(done);
-                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(done >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)done, 0u));
-                if (flush) wave_list[rank] = (flush_idx << 6) | (uint32_t)lane;
-                for (int g0 = 0; g0 < nf; g0 += 8) {
-                    const int g = g0 + (lane >> 3);
-                    if (g < nf) {
-                        const uint32_t e = wave_list[g];
-                        uint4 *blk_l = reinterpret_cast<uint4 *>(wave_lbuf + (size_t)(e & 63u) * kLaneBlock) + (lane & 7);
-                        *(reinterpret_cast<uint4 *>(coef + (size_t)(e >> 6) * 64) + (lane & 7)) = *blk_l;
-                        *blk_l = make_uint4(0u, 0u, 0u, 0u);
-                    }
-                }
-            }
-        }
-#endif
     }
     R.exit = pack_state(p, z, k);
     return R;

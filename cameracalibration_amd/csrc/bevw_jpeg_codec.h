@@ -472,9 +472,9 @@ __global__ __launch_bounds__(kSyncThreads) void k_jpeg_sync(const ImageDesc *__r
 }
 
 // The final pass: every subsequence decoded from its true entry state, coefficients written.  A block is assembled in the LDS slot of the
-// lane in whose range it starts (kLaneBlock int16 per lane) and stored by the whole wave, one coefficient per lane (decode_sub); the
-// natural-order table sits in LDS too (a global-memory look-up would queue behind the stores: on gfx9 loads and stores share one
-// in-order counter).
+// lane in whose range it starts (kLaneBlock int16 per lane) and stored by the whole wave, eight blocks per pass (decode_sub_store,
+// bevw_jpeg_walk.h); the natural-order table sits in LDS too (a global-memory look-up would queue behind the stores: on gfx9 loads and
+// stores share one in-order counter).
 __global__ __launch_bounds__(256) void k_jpeg_coef(const ImageDesc *__restrict__ img, const uint32_t *__restrict__ stream,
                                                    const TableSet *__restrict__ tabs, Geom G, SubArrays A, int16_t *__restrict__ coef)
 {
