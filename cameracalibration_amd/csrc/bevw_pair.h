@@ -16,15 +16,21 @@ namespace bevw {
 
 constexpr uint32_t kPairNoGroup = 0x80000000u;   // source offset of a lane without a group (frame sets are < 2 GB): out of the buffer's range
 constexpr uint32_t kBufferWord3 = 0x00020000u;   // raw buffer descriptor, dword 3 (gfx9 family: DATA_FORMAT 32)
-// cache-policy bits of the group loads / pixel stores (gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1).  Measured (profiles/r02/sweeps.log,
-// "cache policy"): every non-default policy is slower; the defaults are what ships.
+// cache-policy bits of the group loads / pixel stores (gfx94x/95x: 1 = sc0, 2 = nt, 16 = sc1).  Round 2's kernels were slower with every
+// non-default policy (profiles/r02/sweeps.log, "cache policy"); the unit kernel is not: its output is written once and never read, and as
+// streaming stores (nt | sc0) it leaves the L2 to the texel groups and the plan -- config 3 0.439 -> 0.410 ms (nt alone 0.419, nt | sc1
+// 0.410; nt LOADS 0.519: the groups ARE re-read, by the neighbouring units) -- where the rows are whole sectors; the dense layout loses
+// (0.46 -> 0.51) and keeps the default.  profiles/r04/ab_store_policy.log, run16_store_policy.log
 #ifndef BEVW_LOAD_AUX
 #define BEVW_LOAD_AUX 0
 #endif
 #ifndef BEVW_STORE_AUX
 #define BEVW_STORE_AUX 0
 #endif
-constexpr int kPairLoadAux = BEVW_LOAD_AUX, kPairStoreAux = BEVW_STORE_AUX;
+#ifndef BEVW_STREAM_AUX
+#define BEVW_STREAM_AUX 3
+#endif
+constexpr int kPairLoadAux = BEVW_LOAD_AUX, kPairStoreAux = BEVW_STORE_AUX, kPairStreamAux = BEVW_STREAM_AUX;   // (stream: output rows of whole sectors, bevw_unit.h unit_store_quad)
 
 typedef uint32_t pair_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t pair_u32x3 __attribute__((ext_vector_type(3)));

@@ -631,6 +631,15 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// A quad's 12 bytes to the output image.  The output is written once and never read: as a STREAMING store (nt | sc0) it leaves the L2 to the
+// texel groups and the plan (config 3 0.439 -> 0.410 ms, undistort 0.10 -> 0.079; profiles/r04/ab_store_policy.log) -- when its rows are
+// whole 64-byte sectors.  In the dense layout (rows of 3240 bytes) neighbouring quads of two rows share sectors, streaming stores send
+// them to memory in pieces (0.46 -> 0.51 ms): those keep the default policy.  `streaming` is uniform over the launch.
+__device__ __forceinline__ void unit_store_quad(pair_u32x3 v, __amdgpu_buffer_rsrc_t ro, int off, bool streaming)
+{
+    if (streaming) __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, kPairStreamAux);
+    else __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, kPairStoreAux);
+}
 template <bool BLEND, bool SUMS, int NQ, int GR, int NCON, bool WIDE = false>
 __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
 {
@@ -648,6 +657,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ux = (int)(int16_t)(pos & 0xffffu), uy = (int)(pos >> 16), uw = (int)(shape & 0xffffu), uh = (int)(shape >> 16);
     const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
+    const bool streaming = ((uint32_t)a.pitch * 3u) % 64u == 0u;   // rows of whole sectors (see unit_store_quad)
     constexpr int kPatch = GR * kUnitThreads * 32;              // one frame's pair entries
     constexpr bool DB = 2 * kPatch <= kUnitMaxGroups * 32;      // both halves fit the block's 32 KB
 
@@ -707,7 +717,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);   // zeros without a sprite
-                __builtin_amdgcn_raw_buffer_store_b96(c, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+                unit_store_quad(c, ro, (int)ooff_masked[j], streaming);
             }
         }
         return;
@@ -754,7 +764,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #pragma unroll
         for (int j = 0; j < NQ; ++j) {
             if (BEVW_UNIT_ABLATE_MEMORY_ONLY == 2 && keep != 0x12345679u) continue;
-            __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{keep, keep + i0[j][0][0], keep}, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+            unit_store_quad(pair_u32x3{keep, keep + i0[j][0][0], keep}, ro, (int)ooff_masked[j], streaming);
         }
     };
 #else
@@ -854,7 +864,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             BEVW_UNIT_PRIO(3);
 #pragma unroll
             for (int j = 0; j < NQ; ++j)
-                __builtin_amdgcn_raw_buffer_store_b96(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], 0, kPairStoreAux);
+                unit_store_quad(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], streaming);
             BEVW_UNIT_PRIO(0);
         }
         block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
