@@ -9,6 +9,42 @@
 
 namespace bevw {
 
+// ---- cache policy of data that passes exactly once -------------------------------------------------------------------------
+// Round 4's last measurement (profiles/r04/README.md section 17): the unit kernel's output as streaming stores took 5 - 7 % off config 3
+// and 20 % off the undistort -- written once, never read, it only displaced the texel groups from the L2.  The same holds for other
+// once-through streams; these switches put the `nt` policy on them so that one A/B each (BEVW_CFLAGS=-DBEVW_..._NT=1,
+// tools/ab_bench.py with BEVW_LIB_PATH) can tell.  All default to 0: the code below is then exactly the plain load / store.
+//   BEVW_GAIN_NT   k_gain_lut: the pre-gain BEV batch (read once) and the output (written once)      -- config 4, 0.35 of 2.0 ms
+//   BEVW_VSUM_NT   k_vsum: the raw frames of the luminance statistics (3.8 GB read per config-4 step)  -- config 4, 0.65 of 2.0 ms
+//   BEVW_PLAN_NT   k_plan_units: the unit's plan entries and group offsets (read once per block and 16 frames: 110 MB per config-3 step)
+//   BEVW_COEF_NT   JPEG: the coefficient blocks (k_jpeg_coef writes them once, the inverse DCT kernels read them once: 2 x 472 MB per slice)
+#ifndef BEVW_GAIN_NT
+#define BEVW_GAIN_NT 0
+#endif
+#ifndef BEVW_VSUM_NT
+#define BEVW_VSUM_NT 0
+#endif
+#ifndef BEVW_PLAN_NT
+#define BEVW_PLAN_NT 0
+#endif
+#ifndef BEVW_COEF_NT
+#define BEVW_COEF_NT 0
+#endif
+template <int NT, typename T> __host__ __device__ __forceinline__ T once_load(const T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+template <int NT, typename T> __host__ __device__ __forceinline__ void once_store(T *p, T v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
+
 // ---- byte-permute / dot-product instructions of the staged stitch kernels, callable from host code as well ----------
 // On the device these are the gfx950 instructions themselves (v_perm_b32, v_alignbyte_b32, v_dot4_u32_u8, v_dot2_u32_u16).
 // The host versions restate the instructions bit for bit; they exist ONLY so that tests/native/unit_emulate.cpp can run

@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct(const ImageDesc *__restrict__
         const int16_t *cf = coef + ((size_t)blockIdx.y * G.nblk + g) * 64;
         const uint16_t *q = quant + (size_t)img[blockIdx.y].quant * 192 + comp * 64;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int32_t)cf[r * 8 + c] * (int32_t)q[r * 8 + c];
+        for (int r = 0; r < 8; ++r) in[r] = (int32_t)once_load<BEVW_COEF_NT>(cf + r * 8 + c) * (int32_t)q[r * 8 + c];
         idct_1d(in, out, 11);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[wave][b * 72 + r * 8 + c] = out[r];
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void k_jpeg_idct_color_h2v2(const ImageDesc *_
         const int16_t *cf = coef + ((size_t)blockIdx.z * G.nblk + (size_t)by * G.wb[0] + bx) * 64;   // (luma blocks start at 0)
         const uint16_t *qt = quant + (size_t)img[blockIdx.z].quant * 192;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int32_t)cf[r * 8 + c] * (int32_t)qt[r * 8 + c];
+        for (int r = 0; r < 8; ++r) in[r] = (int32_t)once_load<BEVW_COEF_NT>(cf + r * 8 + c) * (int32_t)qt[r * 8 + c];
         idct_1d(in, o8, 11);
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[wave][b * 72 + r * 8 + c] = o8[r];

@@ -5,6 +5,7 @@
 // inline v_mad_i32_i24) have a host form of the same meaning next to them.
 #pragma once
 #include "bevw_jpeg.h"
+#include "bevw_device.h"
 
 namespace bevw {
 namespace jpg {
@@ -219,7 +220,13 @@ __host__ __device__ inline void decode_sub_store(const WordSource &src, const Hu
                 if (g < nf) {
                     const uint32_t o = wave_list[g];
                     uint4 *blk_l = reinterpret_cast<uint4 *>(wave_lbuf + (size_t)(o & 63u) * kLaneBlock) + (lane & 7);
-                    *(reinterpret_cast<uint4 *>(coef + (size_t)(o >> 6) * 64) + (lane & 7)) = *blk_l;
+                    if (BEVW_COEF_NT) {   // (bevw_device.h: the coefficient blocks pass once)
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const uint4 v = *blk_l;
+                        __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4 *>(coef + (size_t)(o >> 6) * 64) + (lane & 7));
+                    } else {
+                        *(reinterpret_cast<uint4 *>(coef + (size_t)(o >> 6) * 64) + (lane & 7)) = *blk_l;
+                    }
                     *blk_l = make_uint4(0u, 0u, 0u, 0u);
                 }
             }

@@ -303,7 +303,15 @@ static __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_b
     unsigned acc = 0;
     size_t i = tid;
     for (; i + 3 * nthreads < npieces; i += 4 * nthreads) {
+#if BEVW_VSUM_NT   // (bevw_device.h: the frames pass once)
+        auto piece = [](const VsumPiece *q) {
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(q);
+            return VsumPiece{once_load<1>(w), once_load<1>(w + 1), once_load<1>(w + 2)};
+        };
+        const VsumPiece a = piece(fp + i), b = piece(fp + i + nthreads), c = piece(fp + i + 2 * nthreads), d = piece(fp + i + 3 * nthreads);
+#else
         const VsumPiece a = fp[i], b = fp[i + nthreads], c = fp[i + 2 * nthreads], d = fp[i + 3 * nthreads];
+#endif
         acc += vsum_piece(a) + vsum_piece(b) + vsum_piece(c) + vsum_piece(d);
     }
     for (; i < npieces; i += nthreads) acc += vsum_piece(fp[i]);
@@ -731,7 +739,7 @@ static __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size
     const size_t base = (size_t)frame * npx * 3, nq = npx / 4;
     for (size_t q = (size_t)blk * blockDim.x + threadIdx.x; q < nq; q += (size_t)blocks_per_frame * blockDim.x) {
         const uint32_t *ip = reinterpret_cast<const uint32_t *>(in + base + q * 12);
-        uint32_t w[3] = {ip[0], ip[1], ip[2]}, cw[3] = {0, 0, 0}, o[3] = {0, 0, 0};
+        uint32_t w[3] = {once_load<BEVW_GAIN_NT>(ip), once_load<BEVW_GAIN_NT>(ip + 1), once_load<BEVW_GAIN_NT>(ip + 2)}, cw[3] = {0, 0, 0}, o[3] = {0, 0, 0};
         if (car != nullptr) {
             const uint32_t *cp = reinterpret_cast<const uint32_t *>(car + q * 12);
             cw[0] = cp[0]; cw[1] = cp[1]; cw[2] = cp[2];
@@ -744,7 +752,7 @@ static __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size
             o[bi >> 2] |= v << ((bi & 3) * 8);
         }
         uint32_t *op = reinterpret_cast<uint32_t *>(out + base + q * 12);
-        op[0] = o[0]; op[1] = o[1]; op[2] = o[2];
+        once_store<BEVW_GAIN_NT>(op, o[0]); once_store<BEVW_GAIN_NT>(op + 1, o[1]); once_store<BEVW_GAIN_NT>(op + 2, o[2]);
     }
 }
 

@@ -635,6 +635,13 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
 // texel groups and the plan (config 3 0.439 -> 0.410 ms, undistort 0.10 -> 0.079; profiles/r04/ab_store_policy.log) -- when its rows are
 // whole 64-byte sectors.  In the dense layout (rows of 3240 bytes) neighbouring quads of two rows share sectors, streaming stores send
 // them to memory in pieces (0.46 -> 0.51 ms): those keep the default policy.  `streaming` is uniform over the launch.
+// a plan entry of the unit (BEVW_PLAN_NT, bevw_device.h: read once per block and chunk of frames)
+__device__ __forceinline__ uint4 unit_plan_load(const uint4 *p)
+{
+    if (!BEVW_PLAN_NT) return *p;
+    const pair_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const pair_u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void unit_store_quad(pair_u32x3 v, __amdgpu_buffer_rsrc_t ro, int off, bool streaming)
 {
     if (streaming) __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, kPairStreamAux);
@@ -677,11 +684,11 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         uint32_t e0 = 0;
 #pragma unroll
         for (int con = 0; con < NCON; ++con) {
-            const uint4 e4 = a.un_entries[((size_t)ent_off + sidx * kParts + con) * 64 + lane];   // the lane's 4 pixels of this slot
+            const uint4 e4 = unit_plan_load(a.un_entries + ((size_t)ent_off + sidx * kParts + con) * 64 + lane);   // the lane's 4 pixels of this slot
             const uint32_t e[4] = {e4.x, e4.y, e4.z, e4.w};
             if (con == 0) e0 = e[0];
             if (WIDE) {
-                const uint4 f4 = a.un_entries[((size_t)ent_off + sidx * kParts + kFPart + con) * 64 + lane];
+                const uint4 f4 = unit_plan_load(a.un_entries + ((size_t)ent_off + sidx * kParts + kFPart + con) * 64 + lane);
                 const uint32_t f[4] = {f4.x, f4.y, f4.z, f4.w};
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -695,7 +702,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             }
         }
         if (kWeights) {
-            const uint4 w4 = a.un_entries[((size_t)ent_off + sidx * kParts + 2) * 64 + lane];
+            const uint4 w4 = unit_plan_load(a.un_entries + ((size_t)ent_off + sidx * kParts + 2) * 64 + lane);
             const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
             for (int p = 0; p < 4; ++p) { wf[j][0][p] = blend_weight_f32((int)(w[p] & 255u)); wf[j][NCON - 1][p] = blend_weight_f32((int)((w[p] >> 8) & 255u)); }
@@ -723,7 +730,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         return;
     }
 #pragma unroll
-    for (int r = 0; r < GR; ++r) gs[r] = a.un_gsrc[((size_t)gs_off + r) * kUnitThreads + threadIdx.x];
+    for (int r = 0; r < GR; ++r) gs[r] = once_load<BEVW_PLAN_NT>(a.un_gsrc + ((size_t)gs_off + r) * kUnitThreads + threadIdx.x);
 
     // (Dealing the frames of a chunk strided over the batch, or rotating the class lists per XCD, changes nothing: profiles/r03/placement.md)
     auto frame_of = [&](int b) { return min(b, b_end - 1); };   // past the chunk: the last frame once more
