@@ -97,3 +97,40 @@ def test_every_interleaving_ends_in_the_sequential_decoders_states(N, S, tail, s
 
 def test_the_model_catches_the_variant_the_soak_caught():
     assert not all(run(seed, 60, 6, 16, False, 0.35) for seed in range(4000))
+
+
+def _prefix_serial(part, reset):
+    """What thread 0 used to do alone (k_jpeg_sync): out[i] = what thread i starts from; a thread whose range holds a reset passes on what it
+    accumulated since its (last) reset."""
+    out, carry = [], 0
+    for t, r in zip(part, reset):
+        out.append(carry)
+        carry = t if r else carry + t
+    return out
+
+
+def _prefix_two_levels(part, reset, wave=64):
+    """The same in two levels, as the kernel does it now: lane 0 of every wave walks its wave's entries from 0, thread 0 walks the waves' totals,
+    and an entry behind a reset inside its own wave does not take the wave's incoming carry."""
+    n = len(part)
+    local, seen_before, totals, any_reset = [0] * n, [False] * n, [], []
+    for w0 in range(0, n, wave):
+        carry, seen = 0, False
+        for i in range(w0, min(w0 + wave, n)):
+            local[i], seen_before[i] = carry, seen
+            carry = part[i] if reset[i] else carry + part[i]
+            seen = seen or reset[i]
+        totals.append(carry)
+        any_reset.append(seen)
+    wave_in = _prefix_serial(totals, any_reset)
+    return [local[i] + (0 if seen_before[i] else wave_in[i // wave]) for i in range(n)]
+
+
+def test_two_level_prefix_with_resets_equals_the_serial_walk():
+    rng = random.Random(5)
+    for trial in range(300):
+        n = 1024
+        p_reset = rng.choice([0.0, 0.002, 0.02, 0.3, 1.0])
+        part = [rng.randrange(-50, 400) for _ in range(n)]
+        reset = [rng.random() < p_reset for _ in range(n)]
+        assert _prefix_two_levels(part, reset) == _prefix_serial(part, reset), trial
