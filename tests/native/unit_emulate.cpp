@@ -13,6 +13,7 @@
 //        | uint8 frames[nframes][ncams][fh][fw][3] | uint8 car[bh][bw][3] if has_car
 //   out: int32 nunits claimed_tiles lines sectors | uint8 written[bh][bw] | uint8 image[nframes][bh][bw][3] (unwritten pixels 0)
 #include <cmath>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
@@ -100,7 +101,14 @@ static int run(const Rig &r, const char *out_path)
     if (const char *e = getenv("BEVW_UNIT_ROW_ORDER")) tune.row_order = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_BIG")) tune.big_class = atoi(e);
     if (r.wide && tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // as analytic_units_build (csrc/bevwarp.hip)
-    unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune, r.wide ? r.fr : nullptr);
+    const double t_compile = [&] {
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        unit_compile(r.l1, r.l2, r.mk, r.ncams, r.fw, r.fh, r.bw, r.bh, pitch, tiles_x, tiles_y, hdr, up, tune, r.wide ? r.fr : nullptr);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        return (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6;
+    }();
+    if (getenv("BEVW_EMU_TIME")) printf("unit_compile: %.1f ms (one host thread)\n", t_compile);
     if (up.desc.empty() && g_allow_no_units) { printf("unit schedule ok: no unit (every base tile left to the other classes)\n"); return 0; }
     CHECK(!up.desc.empty(), "no unit compiled");
     if (getenv("BEVW_EMU_HIST")) {   // owned pixels by unit width (diagnostics: narrow units write short row runs)
