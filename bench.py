@@ -81,7 +81,7 @@ def parse_args():
     ap.add_argument("--placements", type=int, default=0,
                     help="buffer placements: the frame / output buffers are freed and re-allocated this many times and K steps are timed "
                          "on each; the MEDIAN placement is reported (0 = 5 for the single-engine workloads, 1 for the camera-shard one)")
-    ap.add_argument("--output-pitch", default="aligned", choices=["aligned", "dense"],
+    ap.add_argument("--output-pitch", default="aligned", type=lambda v: v if v in ("aligned", "dense") else int(v),
                     help="row pitch of the device-resident BEV images (bevw_set_output_pitch): aligned = rows of whole 64-byte sectors "
                          "(1080 -> 1088 pixels, cv::cuda::GpuMat style; what BevGenerator's default output_pitch='auto' selects on the tile "
                          "plan), dense = the reference's host layout; the other layout is measured too and reported beside the headline")
@@ -90,6 +90,7 @@ def parse_args():
                     help="jpeg_decode_b64 only: 'repo' decodes the reference's own four camera files (tests/golden/repo_rig.npz, 1280x1024, real scenes with "
                          "flat areas -- long mis-phased stretches for the parallel Huffman decoder) replicated over the batch, instead of synthetic files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="skip the two rocprofv3 --pmc child runs behind roofline.traffic (falls back to profiles/hbm_traffic.json)")
     ap.add_argument("--no-f4", action="store_true", help="skip the JPEG summary (`f4`) the default single-GPU run appends to its line")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -154,18 +155,64 @@ def aggregate(world: int, batch: int, steps: int, wall: float, ev_ms: float, alg
             "achieved_gbs": alg_bytes * batch / (launch_ms * 1e-3) / 1e9}
 
 
-def measured_traffic(workload: str, batch: int):
-    """(HBM bytes per launch, where the figure comes from) from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, corrected with profiles/pmc_calibration.json), or
-    (None, None).  It is a STATIC figure of the round it was collected in, not a measurement of this run."""
+def static_traffic(workload: str, batch: int):
+    """(HBM bytes per launch, fetch, write, source) from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json: separate --pmc
+    FETCH_SIZE / WRITE_SIZE runs of this same command, corrected with profiles/pmc_calibration.json), or Nones.  A STATIC figure of the
+    collection it came from -- the fallback when the live measurement below cannot run."""
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(workload)
         if rec and rec.get("units_per_launch") == batch:
-            return rec["fetch_bytes"] + rec["write_bytes"], "profiles/hbm_traffic.json (static, rocprofv3 --pmc passes of round %s%s)" % (
-                rec.get("round", 1), ", counters calibrated on known byte counts" if rec.get("corrected") else "")
+            return rec["fetch_bytes"] + rec["write_bytes"], rec["fetch_bytes"], rec["write_bytes"], (
+                "profiles/hbm_traffic.json (static, rocprofv3 --pmc passes of round %s%s)" % (rec.get("round", 1), ", counters calibrated on known byte counts" if rec.get("corrected") else ""))
     except (OSError, ValueError):
         pass
-    return None, None
+    return None, None, None, None
+
+
+def live_traffic(a, batch: int):
+    """HBM bytes per launch of THIS build on THIS box: two child runs of this script (3 steps + 1 warm-up, one placement, the same layout)
+    under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the two counters do not fit the TCC's slots together;
+    no tracing beside the counters), summed over the step's kernels and corrected as tools/summarize_pmc.py does (the guide's gfx950
+    note: FETCH_SIZE tallies 128-byte requests at 64 bytes; factors measured on known byte counts, profiles/pmc_calibration.json).
+    Returns (total, fetch, write, source) or None when rocprofv3 is missing / fails (the caller falls back to the static file)."""
+    import glob
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    profiled = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))   # already under rocprofv3
+    if os.environ.get("BEVW_BENCH_CHILD") or a.no_live_traffic or profiled or shutil.which("rocprofv3") is None:
+        return None
+    spec = importlib.util.spec_from_file_location("bevw_summarize_pmc", os.path.join(ROOT, "tools", "summarize_pmc.py"))
+    S = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(S)
+    steps, warmup, files = 3, 1, {}
+    env = dict(os.environ, BEVW_BENCH_CHILD="1", TMPDIR="/tmp")
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bevw_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--workload", a.workload,
+               "--steps", str(steps), "--warmup", str(warmup), "--placements", "1", "--single-layout", "--no-cpu-baseline", "--no-f4",
+               "--output-pitch", str(a.output_pitch), "--schedule", a.schedule, "--unique-sets", str(a.unique_sets)] + (["--batch", str(a.batch)] if a.batch else [])
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            found = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not found:
+                return None
+            files[counter] = found[0]
+        except (OSError, subprocess.SubprocessError):
+            return None
+    try:
+        tf, tw, rows = S.per_launch_traffic(files["FETCH_SIZE"], files["WRITE_SIZE"], steps + warmup)
+    except Exception:
+        return None
+    finally:
+        for f in files.values():
+            shutil.rmtree(os.path.dirname(os.path.dirname(f)), ignore_errors=True)
+    if not rows or tf <= 0 or tw <= 0:
+        return None
+    fb, wb = int(tf * 1024), int(tw * 1024)
+    return fb + wb, fb, wb, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child runs of this command on this box (%d launches each), "
+                             "corrected with profiles/pmc_calibration.json%s" % (steps + warmup, "" if S.CAL else " (MISSING: uncorrected)"))
 
 
 def upload_replicated(buf, unique: np.ndarray, batch: int):
@@ -349,6 +396,8 @@ def jpeg_measure(a, d, w, dev, workload, steps, warmup, cpu_seconds, host_api=Tr
     AS THEY ARE IN THE FILES -> frame sets (un-stuffing, entropy decoding, inverse DCT, colour: everything a decode needs is inside the timed
     region); encode = device images -> complete files in HBM; pipeline = decode + stitch + encode chained by events on their streams."""
     from cameracalibration_amd import _ffi, imgcodecs, workloads as W
+
+    _ffi.prefer_hw_queues(8)   # the decoder's slice streams and the engine's streams on hardware queues of their own (before HIP initialises)
     from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
 
     cfg = W.CONFIG_S
@@ -405,7 +454,7 @@ def jpeg_measure(a, d, w, dev, workload, steps, warmup, cpu_seconds, host_api=Tr
         def step():   # one asynchronous chain: the streams are ordered by events, the host does not wait in between
             codec.decode_run_device(d_frames.ptr, fh * fw * 3, fw * 3)
             codec.engine_waits(bev._engine.h)
-            bev.run_device(d_frames.ptr, batch, None, d_bev.ptr)
+            bev.run_device(d_frames.ptr, batch, None, d_bev.ptr, out_bytes=batch * image)
             codec.wait_engine(bev._engine.h)
             codec.encode_run_device(d_bev.ptr, batch, bw, bh, image, bev.out_pitch * 3)
         step()
@@ -535,6 +584,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={d.world}")
     from cameracalibration_amd import _ffi, workloads as W
 
+    _ffi.prefer_hw_queues(8)
     _ffi.require_device()  # loud: this bench has no CPU path
     dev = d.local_rank if _ffi.device_count() > d.local_rank else 0
     w = WORKLOADS[a.workload]
@@ -616,7 +666,7 @@ def main():
         fw, fh, bw, bh = cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
         unique = W.synthetic_frames(a.unique_sets, fw, fh, seed=W.SEED + d.rank)
         proj = w.get("projection", "lut")
-        layouts = [a.output_pitch, "dense" if a.output_pitch == "aligned" else "aligned"] if proj == "lut" else ["dense"]
+        layouts = [a.output_pitch, "dense" if a.output_pitch != "dense" else "aligned"] if proj == "lut" else ["dense"]   # (a number = pixels per row, experiments)
 
         def engine(layout):
             t0 = time.perf_counter()
@@ -629,7 +679,7 @@ def main():
                 b_in = _ffi.DeviceBuffer(batch * unique[0].nbytes, dev)
                 b_out = _ffi.DeviceBuffer(batch * bh * g.out_pitch * 3, dev)
                 upload_replicated(b_in, unique, batch)
-                return (b_in, b_out), (lambda: g.run_device(b_in.ptr, batch, None, b_out.ptr))
+                return (b_in, b_out), (lambda: g.run_device(b_in.ptr, batch, None, b_out.ptr, out_bytes=batch * g.out_image_bytes))
             return make_buffers, g.sync, g.timer_start, g.timer_stop, g.timer_mark, g.timer_between
         bev, t_build = engine(layouts[0])
         make_buffers, sync, tstart, tstop, tmark, tbetween = harness(bev)
@@ -730,7 +780,8 @@ def main():
                  "frac": alg_bytes * batch * a.steps / (o_mid["ev_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "placements_ms_per_step": [round(x["wall"] / a.steps * 1e3, 4) for x in o_draws]}
 
-    traffic, traffic_source = measured_traffic(a.workload, batch)
+    lt = live_traffic(a, batch) if (d.rank == 0 and d.world == 1 and w["kind"] != "camera") else None
+    traffic, traffic_fetch, traffic_write, traffic_source = lt if lt else static_traffic(a.workload, batch)
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
     value, launch_ms, achieved = agg["value"], agg["launch_ms"], agg["achieved_gbs"]
     out = {
@@ -747,7 +798,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "frac_best_placement": alg_bytes * batch * a.steps / (min(x["ev_ms"] for x in draws) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "frac_worst_placement": alg_bytes * batch * a.steps / (max(x["ev_ms"] for x in draws) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_source,
+                     "traffic": traffic, "traffic_fetch": traffic_fetch, "traffic_write": traffic_write, "traffic_source": traffic_source,
+                     "traffic_over_algorithmic": (traffic / (alg_bytes * batch)) if traffic else None,
                      "kernel_ms": launch_ms, "kernel_ms_median": lap_median, "kernel_ms_min": laps[0], "kernel_ms_max": laps[-1],
                      "frac_median": alg_bytes * batch / (lap_median * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},

@@ -447,7 +447,7 @@ class BevGenerator:
         slot.reserve(self, (B * 4 * frame, B * image))
         slot.codec.decode_run_device(slot.bufs[0].ptr, frame, c.frame_width * 3)
         slot.codec.engine_waits(self._engine.h)
-        self.run_device(slot.bufs[0].ptr, B, d_car, slot.bufs[1].ptr)
+        self.run_device(slot.bufs[0].ptr, B, d_car, slot.bufs[1].ptr, out_bytes=B * image)
         slot.codec.wait_engine(self._engine.h)
         slot.codec.encode_run_device(slot.bufs[1].ptr, B, c.bev_width, c.bev_height, image, self.out_pitch * 3, quality)
 
@@ -502,22 +502,62 @@ class BevGenerator:
             except StopIteration:
                 return
             k, inflight = 0, None
-            while nxt is not None:
-                nxt.result()                                  # batch k is staged (its upload is enqueued on its codec's stream)
-                try:
-                    nxt = pool.submit(stage, k + 1, next(it))  # the host side of batch k + 1 runs beside everything below
-                except StopIteration:
-                    nxt = None
-                self._jpeg_enqueue(slots[k % 3], d_car, quality)
+            try:
+                while nxt is not None:
+                    try:
+                        nxt.result()                              # batch k is staged (its upload is enqueued on its codec's stream)
+                    except BaseException:
+                        nxt = None
+                        if inflight is not None:                  # batch k - 1 runs on the GPU and is good work: deliver it, then fail
+                            done, inflight = inflight, None
+                            yield self._jpeg_collect(slots[done % 3], copy)
+                        raise
+                    try:
+                        nxt = pool.submit(stage, k + 1, next(it))  # the host side of batch k + 1 runs beside everything below
+                    except StopIteration:
+                        nxt = None
+                    self._jpeg_enqueue(slots[k % 3], d_car, quality)
+                    done, inflight = inflight, k
+                    k += 1
+                    if done is not None:
+                        yield self._jpeg_collect(slots[done % 3], copy)   # batch k - 1, while the GPU runs batch k
                 if inflight is not None:
-                    yield self._jpeg_collect(slots[inflight % 3], copy)   # batch k - 1, while the GPU runs batch k
-                inflight = k
-                k += 1
-            if inflight is not None:
-                yield self._jpeg_collect(slots[inflight % 3], copy)
+                    done, inflight = inflight, None
+                    yield self._jpeg_collect(slots[done % 3], copy)
+            finally:
+                # leaving early (an exception above, or the consumer dropped the generator): nothing may stay in flight on a slot the next
+                # jpeg() / jpeg_stream() call re-uses -- wait for the staging thread, then for every codec stream
+                if nxt is not None:
+                    try:
+                        nxt.result()
+                    except BaseException:
+                        pass
+                if inflight is not None or nxt is not None:
+                    for sl in slots:
+                        try:
+                            sl.codec.sync()
+                        except Exception:
+                            pass
 
-    def run_device(self, d_frames: int, batch: int, d_car, d_out: int) -> None:
-        """Asynchronous launch on device-resident buffers (raw pointers from DeviceBuffer)."""
+    @property
+    def out_image_bytes(self) -> int:
+        """Bytes of ONE device-side BEV image as run_device() writes it: rows of ``out_pitch`` pixels (padding columns included)."""
+        return self.out_pitch * self._engine.cfg.bev_height * 3
+
+    def run_device(self, d_frames: int, batch: int, d_car, d_out: int, out_bytes: int = None) -> None:
+        """Asynchronous launch on device-resident buffers (raw pointers from DeviceBuffer).
+
+        out_bytes: the size of the buffer behind ``d_out``.  The library sees raw pointers and cannot check it, so a handle whose
+        device images are pitched (``out_pitch != BEV_WIDTH``: the 'auto' / 'aligned' layouts) REQUIRES it -- a caller that sized its
+        buffer for dense images (batch * BEV_HEIGHT * BEV_WIDTH * 3) would otherwise be overrun silently.  Size buffers with
+        ``batch * bev.out_image_bytes`` or construct with ``output_pitch='dense'``."""
+        need = int(batch) * self.out_image_bytes
+        if out_bytes is None:
+            if self.out_pitch != self._engine.cfg.bev_width:
+                raise Exception("this BevGenerator writes device images with rows of {} pixels (output_pitch); pass out_bytes= (>= {} for "
+                                "this batch) or construct it with output_pitch='dense'".format(self.out_pitch, need))
+        elif int(out_bytes) < need:
+            raise Exception("output buffer of {} bytes, {} images of {} bytes need {}".format(int(out_bytes), int(batch), self.out_image_bytes, need))
         check(lib().bevw_run_device(self._engine.h, d_frames, batch, d_car, d_out))
 
     def sync(self) -> None:

@@ -10,12 +10,6 @@ import os
 
 import numpy as np
 
-# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default); streams that share a queue do not overlap.  The
-# compressed pipeline (BevGenerator.jpeg_stream: an engine stream + three codec contexts of two streams each) measured 14.7 k frame sets/s
-# with 4 queues and 16.5 k with 8 (profiles/r04/hw_queues_jpeg_stream.log); nothing else changed.  Only a default: the caller's own setting wins,
-# and it must be in the environment before the HIP runtime initialises, i.e. before libbevwarp.so is loaded.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
 ABI_VERSION = 4
@@ -146,6 +140,23 @@ def lib() -> C.CDLL:
             raise BevwError(f"libbevwarp ABI {L.bevw_abi_version()} != binding ABI {ABI_VERSION}")
         _lib = L
     return _lib
+
+
+def prefer_hw_queues(n: int = 8) -> bool:
+    """Opt-in: ask the HIP runtime for `n` hardware queues (GPU_MAX_HW_QUEUES; 4 by default).  HIP multiplexes a process's streams onto
+    them and streams that share a queue do not overlap: the compressed pipeline (BevGenerator.jpeg_stream: an engine stream + three
+    codec contexts of two streams each) measured 14.7 k frame sets/s with 4 queues and 16.5 k with 8 (profiles/r04/hw_queues_jpeg_stream.log).
+    The variable is read when the HIP runtime initialises, so this must run BEFORE the first libbevwarp call of the process (and before any
+    other HIP user); it changes the process environment (child processes inherit it), which is why importing the package does not do it.
+    The caller's own setting wins.  Returns True when the setting can still take effect; warns and returns False otherwise."""
+    import warnings
+    if "GPU_MAX_HW_QUEUES" in os.environ:
+        return _lib is None
+    if _lib is not None:
+        warnings.warn("prefer_hw_queues() after libbevwarp.so was loaded: the HIP runtime has read GPU_MAX_HW_QUEUES already", RuntimeWarning)
+        return False
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(n))
+    return True
 
 
 def check(status: int) -> None:

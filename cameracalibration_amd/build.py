@@ -4,7 +4,7 @@
 
 Three translation units -- bevwarp.hip (handles, table builders, tools, the camera-per-GPU exchange), bevwarp_plan.hip (the tile plan
 and its per-frame kernels) and bevwarp_jpeg.hip (the JPEG codec) -- are compiled in parallel into objects under csrc/build/ and linked;
-only the units whose sources (or headers) changed are recompiled.  The shared object is written next to this file (in-tree: it travels
+a unit is recompiled when its source, ANY header under csrc/ or the flag set changed.  The shared object is written next to this file (in-tree: it travels
 to the GPU box with the repo snapshot and is git-ignored).  -ffp-contract=off is REQUIRED: the arithmetic being reproduced has no fused
 multiply-add.
 """
@@ -19,13 +19,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libbevwarp.so")
-COMMON = ["bevw_host.h", os.path.join("..", "..", "include", "bevwarp.h")]
-# translation unit -> the headers it includes (beyond COMMON)
-UNITS = {
-    "bevwarp.hip": ["bevw_device.h", "bevw_kernels.h", "bevw_pair.h", "bevw_plan.h", "bevw_unit.h", "bevw_planapi.h", "bevw_comm.h"],
-    "bevwarp_plan.hip": ["bevw_device.h", "bevw_kernels.h", "bevw_pair.h", "bevw_plan.h", "bevw_unit.h", "bevw_planapi.h"],
-    "bevwarp_jpeg.hip": ["bevw_jpeg.h", "bevw_jpeg_codec.h"],
-}
+# translation units; every header under csrc/ (and the public header) is a dependency of every unit: a header edit can never leave a
+# stale object behind (round 4's explicit lists had missed bevw_jpeg_walk.h and bevw_device.h for the JPEG unit)
+UNITS = ["bevwarp.hip", "bevwarp_plan.hip", "bevwarp_jpeg.hip"]
+
+
+def _headers():
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "bevwarp.h")]
+
+
 CFLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-Wno-pass-failed", "-Wno-inline-asm"]
 EXTRA = os.environ.get("BEVW_CFLAGS", "").split()   # experiment builds (e.g. -DBEVW_UNIT_DEPTH=4)
 TAG = os.environ.get("BEVW_BUILD_TAG", "")            # ... land in build_var/libbevwarp_<tag>.so (objects in csrc/build_<tag>/); A/B through BEVW_LIB_PATH
@@ -43,14 +46,22 @@ def _newer(path: str, deps) -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if EXTRA and not TAG:
+        # experiment flags never land in the default objects / libbevwarp.so (a later plain build would keep them: fresh mtimes)
+        raise SystemExit("BEVW_CFLAGS needs BEVW_BUILD_TAG=<tag>: experiment builds go to build_var/libbevwarp_<tag>.so")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     me = os.path.abspath(__file__)
+    # the flag set the objects were compiled with: a different one (another BEVW_CFLAGS under the same tag) rebuilds everything
+    stamp, flags = os.path.join(OBJ, "flags.stamp"), " ".join(CFLAGS + EXTRA)
+    if not os.path.exists(stamp) or open(stamp).read() != flags:
+        force = True
     jobs = []
-    for src, hdrs in UNITS.items():
+    hdrs = _headers()
+    for src in UNITS:
         obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        deps = [os.path.join(CSRC, f) for f in [src] + hdrs + COMMON] + [me]
-        if force or (EXTRA and not TAG) or _newer(obj, deps):
+        deps = [os.path.join(CSRC, src)] + hdrs + [me]
+        if force or _newer(obj, deps):
             jobs.append([hipcc] + CFLAGS + EXTRA + ["-c", os.path.join(CSRC, src), "-o", obj])
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in UNITS]
     if not jobs and not _newer(LIB, objs):
@@ -63,6 +74,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=len(UNITS)) as pool:
         list(pool.map(run, jobs))
+    with open(stamp, "w") as f:
+        f.write(flags)
     run([hipcc, "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB + ".tmp"])
     os.replace(LIB + ".tmp", LIB)
     return LIB

@@ -6,6 +6,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
+#include <string.h>
 
 namespace bevw {
 
@@ -13,16 +15,18 @@ namespace bevw {
 // Round 4's last measurement (profiles/r04/README.md section 17): the unit kernel's output as streaming stores took 5 - 7 % off config 3
 // and 20 % off the undistort -- written once, never read, it only displaced the texel groups from the L2.  The same holds for other
 // once-through streams; these switches put the `nt` policy on them so that one A/B each (BEVW_CFLAGS=-DBEVW_..._NT=1,
-// tools/ab_bench.py with BEVW_LIB_PATH) can tell.  All default to 0: the code below is then exactly the plain load / store.
+// tools/ab_bench.py with BEVW_LIB_PATH) can tell.  With 0 the code below is exactly the plain load / store.
+// Round 5's A/B (profiles/r05/ab_call1_policies_and_maps.log, config 4 at 1.923 ms): GAIN_NT 1.895, VSUM_NT 1.880, both 1.844 -> both ON;
+// PLAN_NT: config 3 0.430 -> 0.433, undistort 0.079 -> 0.104 -> stays OFF (the plan slice of a unit IS re-read, by the block of the next chunk).
 //   BEVW_GAIN_NT   k_gain_lut: the pre-gain BEV batch (read once) and the output (written once)      -- config 4, 0.35 of 2.0 ms
 //   BEVW_VSUM_NT   k_vsum: the raw frames of the luminance statistics (3.8 GB read per config-4 step)  -- config 4, 0.65 of 2.0 ms
 //   BEVW_PLAN_NT   k_plan_units: the unit's plan entries and group offsets (read once per block and 16 frames: 110 MB per config-3 step)
 //   BEVW_COEF_NT   JPEG: the coefficient blocks (k_jpeg_coef writes them once, the inverse DCT kernels read them once: 2 x 472 MB per slice)
 #ifndef BEVW_GAIN_NT
-#define BEVW_GAIN_NT 0
+#define BEVW_GAIN_NT 1
 #endif
 #ifndef BEVW_VSUM_NT
-#define BEVW_VSUM_NT 0
+#define BEVW_VSUM_NT 1
 #endif
 #ifndef BEVW_PLAN_NT
 #define BEVW_PLAN_NT 0
@@ -117,60 +121,109 @@ __device__ __forceinline__ int sat_s16(int v) { return v < -32768 ? -32768 : (v 
 __device__ __forceinline__ int sat_u16(int v) { return v < 0 ? 0 : (v > 65535 ? 65535 : v); }
 
 // ---- cvtColor BGR<->HSV 8-bit + V shift: luminance_balance (SurroundBirdEyeView/surroundBEV.py:57-79) ------
+// Tables of the round trip, built once on the host (make_hsv_tables, csrc/bevwarp.hip), copied into LDS by every kernel that shifts texels.
 struct HsvTables {
-    int sdiv[256];  // cvRound((255 << 12) / (1.0 * i))
-    int hdiv[256];  // cvRound((180 << 12) / (6.0 * i))
+    int sdiv[256];    // cvRound((255 << 12) / (1.0 * i))                                          (BGR2HSV, 8 bit)
+    int hdiv[256];    // cvRound((180 << 12) / (6.0 * i))
+    // HSV2BGR's hue arithmetic, per 8-bit H value, indexed by the LOW BYTE of the signed hue quotient q = (num * hdiv[diff] + 2048) >> 12
+    // (q in [-30, 150]; H = q < 0 ? q + 180 : q, so bytes 226 .. 255 hold H = 150 .. 179):
+    //   .x = bits of the float32 factor g of the middle candidate  v * (1 - s * g):  g = f in odd sectors, 1.f - f in even sectors,
+    //        with h = float(H) * (6.f / 180.f), sector = floor(h), f = h - sector -- the floats OpenCV's HSV2RGB_f computes;
+    //   .y = v_perm_b32 selector that deals the candidates {byte 0: v, byte 1: v (1 - s), byte 2: v (1 - s g)} to (B, G, R): the sector table
+    //        {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} with candidates 2 / 3 (only one of them is ever selected) as "middle".
+    uint2 hue[256];
 };
+static_assert(sizeof(HsvTables) == 4096, "HsvTables is copied as 1024 dwords");
+
+// host side: the table entry of hue byte i (see HsvTables::hue); plain float32 arithmetic, no contraction
+static inline void hsv_hue_entry(int i, uint32_t &gbits, uint32_t &sel)
+{
+    const int H = i < 151 ? i : (i >= 226 ? i - 256 + 180 : 0);   // bytes 151 .. 225 are never produced
+    const float hscale = 6.f / 180.f;
+    float h = (float)H * hscale;
+    if (h >= 6.f) h -= 6.f;                                          // fmod(h, 6): never taken for H < 180
+    int sector = (int)floorf(h);
+    h -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+    const float g = (sector & 1) ? h : 1.f - h;
+    memcpy(&gbits, &g, 4);
+    static const uint32_t kSel[6] = {0x0c000201u, 0x0c020001u, 0x0c010002u, 0x0c010200u, 0x0c020100u, 0x0c000102u};
+    sel = kSel[sector];
+}
+
+// the block's copy of the tables: one 16-byte piece per thread and trip (256 pieces), then the caller synchronises
+__device__ __forceinline__ void hsv_tables_to_lds(HsvTables &lds, const HsvTables *__restrict__ tab)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(tab);
+    uint4 *dst = reinterpret_cast<uint4 *>(&lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(HsvTables) / 16); i += blockDim.x) dst[i] = src[i];
+}
 
 // One texel through BGR2HSV -> V = sat_u8(V + delta) -> HSV2BGR.  The round trip is lossy, so it is applied even
 // when delta == 0, exactly as the reference does.
 // Packed form: texel in, texel out as B | G << 8 | R << 16 (byte 3 of the input is ignored, of the result 0).
-__device__ __forceinline__ uint32_t luminance_shift_bgr(uint32_t texel, int delta, const int *__restrict__ sdiv,
-                                                        const int *__restrict__ hdiv)
+// Round 5: ~45 VALU instructions per texel instead of ~85 (k_lum_groups was VALU-bound).  What went:
+//   * H is never materialised: the low byte of the signed quotient indexes HsvTables::hue, which holds everything HSV2BGR derives
+//     from H (float conversion, * 6/180, floor, fraction, the sector's candidate permutation);
+//   * three candidates instead of four: a sector selects t2 = v (1 - s f) or t3 = v (1 - s (1 - f)), never both;
+//   * the maximum channel comes back as V itself: cvRound(float(V) * (1/255.f) * 255.f) == V for every V in 0 .. 255.
+// Exhaustive check against the oracle (all 2^24 colours x deltas): tests/native/hsv_exhaustive.cpp, tests/test_hsv_exhaustive.py.
+__host__ __device__ __forceinline__ uint32_t luminance_shift_bgr(uint32_t texel, int delta, const HsvTables &T)
 {
     const int b = (int)(texel & 255u), g = (int)((texel >> 8) & 255u), r = (int)((texel >> 16) & 255u);
-    int v = max(b, max(g, r));
-    int vmin = min(b, min(g, r));
-    int diff = v - vmin;
-    int s = (diff * sdiv[v] + (1 << 11)) >> 12;
-    // hue numerator: the channel that holds the maximum picks the formula (R first, then G, as OpenCV's masks do)
-    int h = (v == r) ? (g - b) : ((v == g) ? (b - r + 2 * diff) : (r - g + 4 * diff));
-    h = (h * hdiv[diff] + (1 << 11)) >> 12;
-    h += h < 0 ? 180 : 0;
-    h = sat_u8(h);
-    s = s & 255;  // (uint8_t) store of the oracle / OpenCV
-    v = sat_u8(v + delta);
-    // HSV -> BGR, float path (cvtColor HSV2BGR on 8U: H * 2 degrees / 60, S / 255, V / 255; result * 255 rounded)
-    const float hscale = 6.f / 180.f;
-    float fh = (float)h * hscale;
-    const float fs = (float)s * (1.f / 255.f), fv = (float)v * (1.f / 255.f);
-    // OpenCV wraps H with fmod(h, 6); H <= 255 here, so h * hscale < 8.5 and the wrap is one exact subtraction
-    if (fh >= 6.f) fh -= 6.f;
-    int sector = (int)floorf(fh);
-    fh -= (float)sector;
-    if ((unsigned)sector >= 6u) { sector = 0; fh = 0.f; }
-    // the four candidates of the sector table; S == 0 needs no special case: every candidate is then fv * 1
-    const float t0 = fv;
+    const int mx = b > g ? b : g, mn = b < g ? b : g;
+    const int v = mx > r ? mx : r, vmin = mn < r ? mn : r;
+    const int diff = v - vmin;
+    // 24-bit multiplies (v_mad_u32_u24 / v_mad_i32_i24; a plain 32-bit product compiles to the slow v_mad_u64_u32): diff <= 255, sdiv < 2^20,
+    // |num| <= 1275, hdiv < 2^17
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BEVW_UMUL24(a, b) ((int)__umul24((unsigned)(a), (unsigned)(b)))
+#define BEVW_MUL24(a, b) __mul24((a), (b))
+#else
+#define BEVW_UMUL24(a, b) ((a) * (b))
+#define BEVW_MUL24(a, b) ((a) * (b))
+#endif
+    const int s = (BEVW_UMUL24(diff, T.sdiv[v]) + (1 << 11)) >> 12;   // 0 .. 255
+    // hue numerator: the channel that holds the maximum picks the formula (R first, then G, as OpenCV's masks do).  Masks and bit-selects
+    // (v_bfi_b32) instead of compare + v_cndmask_b32: v >= r, g, so (v - r - 1) >> 31 is all ones exactly when v == r
+    const uint32_t mr = (uint32_t)((v - r - 1) >> 31), mg = (uint32_t)((v - g - 1) >> 31);
+    const uint32_t c0 = (uint32_t)(g - b), c1 = (uint32_t)(b - r + 2 * diff), c2 = (uint32_t)(r - g + 4 * diff);
+    const uint32_t c12 = (c1 & mg) | (c2 & ~mg);
+    const int num = (int)((c0 & mr) | (c12 & ~mr));
+    const uint32_t hi = ((uint32_t)((BEVW_MUL24(num, T.hdiv[diff]) + (1 << 11)) >> 12)) & 255u;
+#undef BEVW_UMUL24
+#undef BEVW_MUL24
+    const uint2 hq = T.hue[hi];
+    int v2 = v + delta;
+    v2 = v2 < 0 ? 0 : (v2 > 255 ? 255 : v2);
+    // HSV -> BGR, float path (cvtColor HSV2BGR on 8U: S / 255, V / 255; candidates * 255 rounded)
+    const float fs = (float)s * (1.f / 255.f), fv = (float)v2 * (1.f / 255.f);
+    float gf;
+#if defined(__HIP_DEVICE_COMPILE__)
+    gf = __uint_as_float(hq.x);
+#else
+    memcpy(&gf, &hq.x, 4);
+#endif
     const float t1 = fv * (1.f - fs);
-    const float t2 = fv * (1.f - fs * fh);
-    const float t3 = fv * (1.f - fs * (1.f - fh));
+    const float tm = fv * (1.f - fs * gf);
     // cvRound(t * 255) for t in [0, 1]: adding 1.5 * 2^23 rounds to nearest-even at unit precision and leaves the integer
-    // (0..255, no saturation possible) in the low mantissa byte -- same rounding as v_rndne + v_cvt, a third of the work
+    // (0..255, no saturation possible) in the low mantissa byte
     const float kMagic = 12582912.f;
-    const uint32_t u0 = __float_as_uint(t0 * 255.f + kMagic), u1 = __float_as_uint(t1 * 255.f + kMagic);
-    const uint32_t u2 = __float_as_uint(t2 * 255.f + kMagic), u3 = __float_as_uint(t3 * 255.f + kMagic);
-    // T = low bytes of (u0, u1, u2, u3)
-    const uint32_t T = __builtin_amdgcn_perm(__builtin_amdgcn_perm(u3, u2, 0x0c0c0400u), __builtin_amdgcn_perm(u1, u0, 0x0c0c0400u), 0x05040100u);
-    // sector table {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} -> candidate index of (b, g, r), as a byte selector
-    const uint32_t sel = sector < 3 ? (sector == 0 ? 0x0c000301u : (sector == 1 ? 0x0c020001u : 0x0c010003u))
-                                    : (sector == 3 ? 0x0c010200u : (sector == 4 ? 0x0c030100u : 0x0c000102u));
-    return __builtin_amdgcn_perm(0u, T, sel);
+    const float r1 = t1 * 255.f + kMagic, rm = tm * 255.f + kMagic;
+    uint32_t u1, um;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u1 = __float_as_uint(r1); um = __float_as_uint(rm);
+#else
+    memcpy(&u1, &r1, 4); memcpy(&um, &rm, 4);
+#endif
+    // candidates: byte 0 = V', byte 1 = low byte of u1, byte 2 = low byte of um
+    const uint32_t C = px_perm(um, px_perm(u1, (uint32_t)v2, 0x0c0c0400u), 0x0c040100u);
+    return px_perm(0u, C, hq.y);
 }
 
-__device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int delta, const int *__restrict__ sdiv,
-                                                   const int *__restrict__ hdiv)
+__host__ __device__ __forceinline__ void luminance_shift_px(int &b, int &g, int &r, int delta, const HsvTables &T)
 {
-    const uint32_t o = luminance_shift_bgr((uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16), delta, sdiv, hdiv);
+    const uint32_t o = luminance_shift_bgr((uint32_t)b | ((uint32_t)g << 8) | ((uint32_t)r << 16), delta, T);
     b = (int)(o & 255u);
     g = (int)((o >> 8) & 255u);
     r = (int)((o >> 16) & 255u);
@@ -193,7 +246,7 @@ static inline unsigned xcd_frame_grid(unsigned blocks_per_frame, unsigned nframe
 // out = (sum p * w15 + 2^14) >> 15 with w15 = 32 * w10  ==  (sum p * w10 + 512) >> 10, w10 = 5-bit x 5-bit products.
 template <bool LUM>
 __device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, int sw, int sh, int sx, int sy,
-                                              unsigned code, int out[3], int delta, const int *sdiv, const int *hdiv)
+                                              unsigned code, int out[3], int delta, const HsvTables *hsv)
 {
     const int fx = code & 31, fy = (code >> 5) & 31;
     const int ax = kQOne - fx, ay = kQOne - fy;
@@ -207,7 +260,7 @@ __device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, i
         for (int k = 0; k < 3; ++k) { t[0][k] = p0[k]; t[1][k] = p0[3 + k]; t[2][k] = p1[k]; t[3][k] = p1[3 + k]; }
         if (LUM) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, sdiv, hdiv);
+            for (int q = 0; q < 4; ++q) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, *hsv);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -224,7 +277,7 @@ __device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, i
             if (ok[q]) {
                 const uint8_t *p = src + ((size_t)(sy + (q >> 1)) * sw + (sx + (q & 1))) * 3;
                 t[q][0] = p[0]; t[q][1] = p[1]; t[q][2] = p[2];
-                if (LUM) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, sdiv, hdiv);
+                if (LUM) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, *hsv);
             } else {
                 t[q][0] = t[q][1] = t[q][2] = 0;  // border value enters after the balance step
             }

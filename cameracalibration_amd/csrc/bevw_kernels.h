@@ -260,7 +260,7 @@ static __global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int 
     uint8_t *d = dst + ((size_t)blockIdx.z * dw * dh + o) * 3;
     const int sx = map1[o * 2], sy = map1[o * 2 + 1];
     int out[3];
-    remap_u8c3_px<false>(s, sw, sh, sx, sy, map2[o] & (kQTab2 - 1), out, 0, nullptr, nullptr);
+    remap_u8c3_px<false>(s, sw, sh, sx, sy, map2[o] & (kQTab2 - 1), out, 0, nullptr);
     d[0] = (uint8_t)out[0]; d[1] = (uint8_t)out[1]; d[2] = (uint8_t)out[2];
 }
 
@@ -277,7 +277,7 @@ static __global__ void k_warp_perspective(const uint8_t *__restrict__ src, int s
     int sx, sy, out[3];
     unsigned code;
     perspective_coord(Minv.m, x, y, bw0, sx, sy, code);
-    remap_u8c3_px<false>(s, sw, sh, sx, sy, code, out, 0, nullptr, nullptr);
+    remap_u8c3_px<false>(s, sw, sh, sx, sy, code, out, 0, nullptr);
     d[0] = (uint8_t)out[0]; d[1] = (uint8_t)out[1]; d[2] = (uint8_t)out[2];
 }
 
@@ -347,14 +347,14 @@ static __global__ void k_lum_delta(const unsigned long long *__restrict__ vsums,
 static __global__ void k_lum_shift(const uint8_t *__restrict__ frames, size_t frame_px, const int *__restrict__ deltas,
                             const HsvTables *__restrict__ tab, uint8_t *__restrict__ out)
 {
-    __shared__ int sdiv[256], hdiv[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+    __shared__ HsvTables hsv;
+    hsv_tables_to_lds(hsv, tab);
     __syncthreads();
     const size_t base = (size_t)blockIdx.y * frame_px * 3;
     const int delta = deltas[blockIdx.y];
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < frame_px; p += (size_t)gridDim.x * blockDim.x) {
         int b = frames[base + p * 3], g = frames[base + p * 3 + 1], r = frames[base + p * 3 + 2];
-        luminance_shift_px(b, g, r, delta, sdiv, hdiv);
+        luminance_shift_px(b, g, r, delta, hsv);
         out[base + p * 3] = (uint8_t)b; out[base + p * 3 + 1] = (uint8_t)g; out[base + p * 3 + 2] = (uint8_t)r;
     }
 }
@@ -378,10 +378,10 @@ static __global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, i
                             const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
                             uint8_t *__restrict__ out)
 {
-    __shared__ int sdiv[256], hdiv[256];
+    __shared__ HsvTables hsv;
     __shared__ unsigned long long part[3][4];
     if (BAL) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+        hsv_tables_to_lds(hsv, tab);
         __syncthreads();
     }
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -398,7 +398,7 @@ static __global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, i
             const uint8_t *src = frames + ((size_t)b * 4 + c) * frame_bytes;
             const int sx = T.lut1[c][o * 2], sy = T.lut1[c][o * 2 + 1];
             int v[3];
-            remap_u8c3_px<BAL>(src, fw, fh, sx, sy, T.lut2[c][o] & (kQTab2 - 1), v, BAL ? deltas[b * 4 + c] : 0, sdiv, hdiv);
+            remap_u8c3_px<BAL>(src, fw, fh, sx, sy, T.lut2[c][o] & (kQTab2 - 1), v, BAL ? deltas[b * 4 + c] : 0, &hsv);
             if (BLEND) {
                 const float wgt = blend_weight_f32(m);
                 v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
@@ -501,7 +501,7 @@ static __global__ void k_analytic_map(AnalyticRig R, int c, int fw, int fh, int 
 // windows, one per footprint row, and realigned with v_alignbyte (two vector loads per contributor instead of twelve byte loads).
 template <bool BAL, typename F>
 __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src, int fw, int fh, const AnalyticTap<F> &tp, int out[3], int delta,
-                                                const int *sdiv, const int *hdiv, bool aligned)
+                                                const HsvTables &hsv, bool aligned)
 {
     F t[4][3];
     const size_t toff = ((size_t)tp.sy * fw + tp.sx) * 3;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
                         {(int)(r1x >> 24), (int)(r1y & 255u), (int)((r1y >> 8) & 255u)}};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (BAL) luminance_shift_px(px[q][0], px[q][1], px[q][2], delta, sdiv, hdiv);
+            if (BAL) luminance_shift_px(px[q][0], px[q][1], px[q][2], delta, hsv);
             t[q][0] = (F)px[q][0]; t[q][1] = (F)px[q][1]; t[q][2] = (F)px[q][2];
         }
     } else {
@@ -531,7 +531,7 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
             if ((unsigned)tx < (unsigned)fw && (unsigned)ty < (unsigned)fh) {
                 const uint8_t *p = src + ((size_t)ty * fw + tx) * 3;
                 int b = p[0], g = p[1], rr = p[2];
-                if (BAL) luminance_shift_px(b, g, rr, delta, sdiv, hdiv);
+                if (BAL) luminance_shift_px(b, g, rr, delta, hsv);
                 t[q][0] = (F)b; t[q][1] = (F)g; t[q][2] = (F)rr;
             } else {
                 t[q][0] = t[q][1] = t[q][2] = (F)0;
@@ -556,10 +556,10 @@ static __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int
                                   const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
                                   uint8_t *__restrict__ out, const uint32_t *__restrict__ tiles = nullptr, int tiles_x = 0)
 {
-    __shared__ int sdiv[256], hdiv[256];
+    __shared__ HsvTables hsv;
     __shared__ unsigned long long part[3][4];
     if (BAL) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
+        hsv_tables_to_lds(hsv, tab);
         __syncthreads();
     }
     int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,7 +602,7 @@ static __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int
                 if (k >= n) break;
                 const uint8_t *src = frames + ((size_t)b * 4 + cam[k]) * frame_bytes;
                 int v[3];
-                analytic_sample<BAL, F>(src, fw, fh, tap[k], v, BAL ? deltas[b * 4 + cam[k]] : 0, sdiv, hdiv, aligned);
+                analytic_sample<BAL, F>(src, fw, fh, tap[k], v, BAL ? deltas[b * 4 + cam[k]] : 0, hsv, aligned);
                 if (BLEND) {
                     const float wgt = blend_weight_f32(msk[k]);
                     v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);

@@ -61,6 +61,8 @@ struct Plan {
     int n_slow = 0;
     // unit schedule (bevw_unit.h): k-d partition compiled on the host
     void *un_desc = nullptr, *un_entries = nullptr, *un_gsrc = nullptr;
+    void *un_gsrc_compact = nullptr;         // the units' group lists for the compact scratch of the balance schedule (unit_gsrc_compact); nullptr: not usable
+    size_t compact_stride = 0;               // bytes between the compact scratch copies of consecutive frame sets
     void *list_un_all = nullptr;             // every unit in partition order, class in bits 28..31
     int n_un_all = 0;
     int n_un[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // units per class (diagnostics)
@@ -185,36 +187,52 @@ static __global__ void k_plan_touch(const uint2 *__restrict__ plan, int ntiles, 
         }
 }
 
-// luminance_balance (surroundBEV.py:57-79) applied to the sampled texel groups of every raw frame:
-// scratch = HSV2BGR(sat(V + delta)).  One lane = one group = 4 texels (12 bytes, one dwordx3 each way); groups[] holds
-// byte offsets inside the frame set in ascending order, so neighbouring lanes touch neighbouring memory.
-// grid = xcd_frame_grid(ceil(ngroups / 256), batch); block = 256.
+// luminance_balance (surroundBEV.py:57-79) applied to the sampled texel groups of every raw frame, into the COMPACT scratch (bevw_unit.h:
+// unit_gsrc_compact): slot i of a frame set's scratch = HSV2BGR(sat(V + delta)) of group groups[i].  One lane = one group = 4 texels
+// (12 bytes, one dwordx3 each way); groups[] holds byte offsets inside the frame set in ascending order, so neighbouring lanes read
+// neighbouring memory, and they WRITE consecutive 12-byte slots: whole sectors, 3 KB per block and trip.  (Rounds 2 - 4 wrote the groups back
+// at their own offsets into a scratch frame set of full size: 12-byte pieces with holes, every run of groups ending in a partially written
+// sector, and the units then re-read that sparse layout.)  A block takes kLumTrips x 256 consecutive groups of one frame set (the 4 KB of
+// tables in LDS are paid once per block); the offsets and the texels of all its trips are requested before the first one is converted.
+// grid = xcd_frame_grid(ceil(ngroups / (256 kLumTrips)), batch); block = 256.
+constexpr int kLumTrips = 8;
 static __global__ void __launch_bounds__(256) k_lum_groups(const uint8_t *__restrict__ frames, uint8_t *__restrict__ scratch, size_t set_bytes,
-                                                            uint32_t frame_bytes, const uint32_t *__restrict__ groups, int ngroups,
+                                                            size_t scratch_stride, uint32_t frame_bytes, const uint32_t *__restrict__ groups, int ngroups,
                                                             const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                                                             uint32_t blocks_per_frame, uint32_t nframes)
 {
-    __shared__ int sdiv[256], hdiv[256];
+    __shared__ HsvTables hsv;
+    __shared__ int cam_delta[4];
     uint32_t frame, blk;
     if (!xcd_frame_map(blockIdx.x, blocks_per_frame, nframes, frame, blk)) return;   // grid: xcd_frame_grid()
-    for (int i = threadIdx.x; i < 256; i += 256) { sdiv[i] = tab->sdiv[i]; hdiv[i] = tab->hdiv[i]; }
-    __syncthreads();
-    const int gi = (int)blk * 256 + threadIdx.x;
-    if (gi >= ngroups) return;
-    const int b = (int)frame;
-    const uint32_t goff = groups[gi];
-    const size_t off = (size_t)b * set_bytes + goff;
-    const AlignedU3 v = *reinterpret_cast<const AlignedU3 *>(frames + off);
-    const uint32_t w[3] = {v.x, v.y, v.z};
-    const int delta = deltas[b * 4 + (int)(goff / frame_bytes)];
-    // the 4 texels of the group as dwords (byte 3 is ignored), shifted, and packed back into the 12 bytes
-    uint32_t P[4] = {w[0], __builtin_amdgcn_alignbyte(w[1], w[0], 3), __builtin_amdgcn_alignbyte(w[2], w[1], 2), w[2] >> 8};
+    hsv_tables_to_lds(hsv, tab);
+    if (threadIdx.x < 4) cam_delta[threadIdx.x] = deltas[frame * 4 + threadIdx.x];
+    const uint8_t *fin = frames + (size_t)frame * set_bytes;
+    uint8_t *fout = scratch + (size_t)frame * scratch_stride;
+    const int g0 = (int)blk * (kLumTrips * 256) + (int)threadIdx.x;
+    uint32_t goff[kLumTrips];
+    AlignedU3 v[kLumTrips];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) P[t] = luminance_shift_bgr(P[t], delta, sdiv, hdiv);
-    uint32_t o[3];
-    pack_pixels(P, o[0], o[1], o[2]);
-    AlignedU3 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2];
-    *reinterpret_cast<AlignedU3 *>(scratch + off) = ov;
+    for (int t = 0; t < kLumTrips; ++t) goff[t] = g0 + t * 256 < ngroups ? groups[g0 + t * 256] : 0u;
+#pragma unroll
+    for (int t = 0; t < kLumTrips; ++t) v[t] = *reinterpret_cast<const AlignedU3 *>(fin + goff[t]);   // (past the list: group 0 once more, not stored)
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < kLumTrips; ++t) {
+        const int gi = g0 + t * 256;
+        if (gi >= ngroups) break;
+        const uint32_t w[3] = {v[t].x, v[t].y, v[t].z};
+        const int cam = (int)(goff[t] >= frame_bytes) + (int)(goff[t] >= 2u * frame_bytes) + (int)(goff[t] >= 3u * frame_bytes);
+        const int delta = cam_delta[cam];
+        // the 4 texels of the group as dwords (byte 3 is ignored), shifted, and packed back into the 12 bytes
+        uint32_t P[4] = {w[0], __builtin_amdgcn_alignbyte(w[1], w[0], 3), __builtin_amdgcn_alignbyte(w[2], w[1], 2), w[2] >> 8};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) P[k] = luminance_shift_bgr(P[k], delta, hsv);
+        uint32_t o[3];
+        pack_pixels(P, o[0], o[1], o[2]);
+        AlignedU3 ov; ov.x = o[0]; ov.y = o[1]; ov.z = o[2];
+        *reinterpret_cast<AlignedU3 *>(fout + (size_t)gi * 12) = ov;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -263,12 +281,12 @@ __device__ __forceinline__ void bilinear_rows(uint2 r0, uint2 r1, uint32_t wx, u
 template <bool BLEND, bool BAL>
 __device__ __forceinline__ void eval_entry(const uint8_t *__restrict__ fb, const EntryRegs &e, uint32_t row_bytes, int fw,
                                            int fh, uint32_t frame_bytes, bool tile_slow, const int *__restrict__ fdeltas,
-                                           const int *sdiv, const int *hdiv, int v[3])
+                                           const HsvTables &hsv, int v[3])
 {
     const int cam = (e.meta >> 18) & 3;
     if (tile_slow && (e.meta & kMetaSlow)) {
         const int sx = (int)(int16_t)(e.off & 0xffffu), sy = (int)(int16_t)(e.off >> 16);
-        remap_u8c3_px<BAL>(fb + (size_t)cam * frame_bytes, fw, fh, sx, sy, e.meta & 1023u, v, BAL ? fdeltas[cam] : 0, sdiv, hdiv);
+        remap_u8c3_px<BAL>(fb + (size_t)cam * frame_bytes, fw, fh, sx, sy, e.meta & 1023u, v, BAL ? fdeltas[cam] : 0, &hsv);
     } else if (!BAL) {
         const uint2 r0 = load_u2_unaligned(fb + e.off), r1 = load_u2_unaligned(fb + e.off + row_bytes);
         bilinear_rows(r0, r1, e.wx, e.wy, v);
@@ -280,7 +298,7 @@ __device__ __forceinline__ void eval_entry(const uint8_t *__restrict__ fb, const
                        {(int)(r1.x >> 24), (int)(r1.y & 255), (int)((r1.y >> 8) & 255)}};
         const int delta = fdeltas[cam];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, sdiv, hdiv);
+        for (int q = 0; q < 4; ++q) luminance_shift_px(t[q][0], t[q][1], t[q][2], delta, hsv);
         const int ax = e.wx & 255, fx = e.wx >> 24, ay = e.wy & 65535, fy = e.wy >> 16;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -312,11 +330,13 @@ struct PlanArgs {
     const uint4 *un_entries;     // one uint4 per lane and quad slot: the plan entries of the lane's 4 pixels
     const uint32_t *un_gsrc;
     int un_skew;                 // unit_skew constant of the plan
+    uint32_t set_stride;         // units: bytes between consecutive frame sets (0: fw * fh * 3 * ncams; else the compact scratch, bevw_unit.h)
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
 // its own L2, so the map decides what an L2 sees:
 //   xcd_affine 1: an XCD owns whole batch chunks (all tiles of frames b0..b0+nb), neighbouring tiles share its L2
+//   xcd_affine 2: as 1, the chunks of an XCD interleaved unit by unit (BEVW_PLAN_XCDMAP=2)
 //   xcd_affine 0: plain chunk-major order (few chunks)
 __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, uint32_t &chunk, uint32_t &group)
 {
@@ -325,6 +345,12 @@ __device__ __forceinline__ bool plan_block_map(const PlanArgs &a, uint32_t id, u
         const uint32_t xcd = id & 7u, k = id >> 3;
         chunk = xcd + 8u * (k / ng);
         group = k % ng;
+    } else if (a.xcd_affine == 2) {
+        // the chunks of an XCD interleaved: unit g of every chunk the XCD owns runs back to back, so the unit's plan slice (entries +
+        // group list) is fetched from memory once per XCD and served from its L2 to the other chunks
+        const uint32_t xcd = id & 7u, k = id >> 3, cpx = ((uint32_t)a.nchunks + 7u) >> 3;
+        chunk = xcd + 8u * (k % cpx);
+        group = k / cpx;
     } else {
         chunk = id / ng;
         group = id % ng;
@@ -339,9 +365,10 @@ template <bool BLEND, bool LUM, bool SUMS = LUM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) k_stitch_plan(PlanArgs a)
 {
     constexpr bool BAL = LUM;
-    __shared__ int sdiv[BAL ? 256 : 1], hdiv[BAL ? 256 : 1];
+    __shared__ uint32_t hsv_words[BAL ? sizeof(HsvTables) / 4 : 1];   // (no LDS for the variants without the luminance round trip)
+    const HsvTables &hsv = *reinterpret_cast<const HsvTables *>(hsv_words);
     if (BAL) {
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) { sdiv[i] = a.tab->sdiv[i]; hdiv[i] = a.tab->hdiv[i]; }
+        hsv_tables_to_lds(*reinterpret_cast<HsvTables *>(hsv_words), a.tab);
         __syncthreads();
     }
     uint32_t chunk, group;
@@ -385,13 +412,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                eval_entry<BLEND, BAL>(fb, e0[j], row_bytes, a.fw, a.fh, frame_bytes, tile_slow, fdeltas, sdiv, hdiv, px[j]);
+                eval_entry<BLEND, BAL>(fb, e0[j], row_bytes, a.fw, a.fh, frame_bytes, tile_slow, fdeltas, hsv, px[j]);
             }
             if (second) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     int w[3];
-                    eval_entry<BLEND, BAL>(fb, e1[j], row_bytes, a.fw, a.fh, frame_bytes, tile_slow, fdeltas, sdiv, hdiv, w);
+                    eval_entry<BLEND, BAL>(fb, e1[j], row_bytes, a.fw, a.fh, frame_bytes, tile_slow, fdeltas, hsv, w);
                     px[j][0] = min(255, px[j][0] + w[0]); px[j][1] = min(255, px[j][1] + w[1]); px[j][2] = min(255, px[j][2] + w[2]);
                 }
             }
@@ -472,7 +499,7 @@ static __global__ void k_plan_unpad(const uint8_t *__restrict__ src, int bw, int
 // ---------------------------------------------------------------------------------------------------------------
 static inline void plan_release(Plan &p)
 {
-    void *ptrs[] = {p.un_desc, p.un_entries, p.un_gsrc, p.list_un_all, p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_slow};
+    void *ptrs[] = {p.un_desc, p.un_entries, p.un_gsrc, p.un_gsrc_compact, p.list_un_all, p.entries, p.hdr, p.groups, p.psums, p.pad_out, p.pad_car, p.d_max, p.list_slow};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     p = Plan();
@@ -526,6 +553,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = hipMemcpyAsync(&p.max_contrib, p.d_max, sizeof(int), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
     p.band_ok = false;
+    std::vector<uint32_t> groups_host;   // the sampled 4-texel groups, ascending (what Plan::groups holds on the device)
     if (fw % 4 == 0) {
         const size_t nbits = (size_t)ncams * fh * (fw / 4), nwords = (nbits + 31) / 32;
         uint32_t *d_bits = nullptr;
@@ -551,6 +579,7 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         p.n_groups = (int)list.size();
         if ((e = plan_upload_list(list, &p.groups)) != hipSuccess) return e;
         p.band_ok = true;
+        groups_host.swap(list);
     }
     std::vector<uint32_t> hdr((size_t)p.ntiles);
     if ((e = hipMemcpyAsync(hdr.data(), p.hdr, hdr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st)) != hipSuccess) return e;
@@ -574,6 +603,11 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
         if (!up.desc.empty()) {
             hdr.swap(hdr_un);
             if ((e = plan_upload_units(p, up)) != hipSuccess) return e;
+            std::vector<uint32_t> gc;
+            if (p.band_ok && unit_gsrc_compact(up.gsrc, groups_host, gc) && unit_compact_stride(groups_host.size()) < (1ull << 31)) {
+                if ((e = plan_upload_list(gc, &p.un_gsrc_compact)) != hipSuccess) return e;
+                p.compact_stride = unit_compact_stride(groups_host.size());
+            }
         }
     }
     // what no unit owns stays on the per-tap kernel
@@ -592,14 +626,17 @@ static inline hipError_t plan_build_impl(Plan &p, hipStream_t st, const StitchTa
 struct PlanTuning { int nb = 0; int xcd_map = 1; int units = 1; };
 
 // One step of the tile plan on `st`.
-//   balance = luminance round trip per tap on RAW frames (per-tap kernel over every tile) + per-tile channel sums;
-//   sums    = the frames are luminance-shifted already (plan_lum_band): units with per-unit channel sums, the car left to the gain pass.
-// Both end with k_reduce_psums into d_chsums.  psums_frames / psums_first: the psums buffer is sized for psums_frames frame sets and this
-// call's frames start at slot psums_first of it (two half-batches of one balance step run concurrently on two streams: run_device).
+//   balance   = luminance round trip per tap on RAW frames (per-tap kernel over every tile) + per-tile channel sums;
+//   d_scratch = the compact scratch plan_lum_band filled from d_frames (balance schedule 1): the units read IT (p.compact_stride bytes per
+//               frame set, group lists p.un_gsrc_compact), the per-tap kernel serves what no unit owns from the RAW frames with the luminance
+//               round trip per tap (d_deltas, d_tab); everything on the per-tap kernel when the units cannot run;
+//   sums      = per-unit / per-tile channel sums, the car left to the gain pass (with d_scratch; or: d_frames are luminance-shifted already).
+// balance and sums end with k_reduce_psums into d_chsums.  psums_frames / psums_first: the psums buffer is sized for psums_frames frame sets
+// and this call's frames start at slot psums_first of it (two half-batches of one balance step run concurrently on two streams: run_device).
 static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance,
                                           const int *d_deltas, const HsvTables *d_tab, const uint8_t *d_car,
                                           unsigned long long *d_chsums, uint8_t *d_out, const PlanTuning &tune, bool sums = false,
-                                          int psums_frames = 0, int psums_first = 0)
+                                          int psums_frames = 0, int psums_first = 0, const uint8_t *d_scratch = nullptr)
 {
     hipError_t e;
     PlanArgs a = {};
@@ -631,7 +668,9 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.un_gsrc = static_cast<const uint32_t *>(p.un_gsrc);
     a.un_skew = p.un_skew;
     // the units need 4-byte aligned frame sets (dword-addressed group loads) and are not combined with the per-tap luminance kernel
-    const bool use_units = !balance && tune.units && p.n_un_all > 0 && (((uintptr_t)d_frames) & 3u) == 0;
+    const bool compact = d_scratch != nullptr;
+    const bool use_units = !balance && tune.units && p.n_un_all > 0 && (((uintptr_t)d_frames) & 3u) == 0 &&
+                           (!compact || (p.un_gsrc_compact != nullptr && (((uintptr_t)d_scratch) & 3u) == 0));
     a.batch = batch;
     // frames per block: enough chunks to give each of the 8 XCDs whole chunks, otherwise one frame per chunk.  A block reads its plan
     // slice (4 bytes per pixel + the group list) once per chunk: 16 frames per block instead of 8 halve that traffic -- 1.8 M of the
@@ -643,7 +682,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     if (nb > batch) nb = batch;
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
-    a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? 1 : 0;
+    a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? tune.xcd_map : 0;
     const bool with_sums = balance || sums;
     if (with_sums) {
         if (psums_frames < batch) { psums_frames = batch; psums_first = 0; }
@@ -660,13 +699,14 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         if ((e = hipMemsetAsync(a.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
     }
     auto grid_blocks = [&]() -> unsigned {
-        if (a.xcd_affine == 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
+        if (a.xcd_affine >= 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
         return (unsigned)(a.ngroups * a.nchunks);
     };
     const dim3 block(256);
     if (use_units) {
         if (sums) a.car = nullptr;   // the car is added behind the gains
         a.tile_list = static_cast<const uint32_t *>(p.list_un_all); a.nlist = p.n_un_all; a.ngroups = p.n_un_all;
+        if (compact) { a.frames = d_scratch; a.set_stride = (uint32_t)p.compact_stride; a.un_gsrc = static_cast<const uint32_t *>(p.un_gsrc_compact); }
         const dim3 grid(grid_blocks());
         if (blend && sums) hipLaunchKernelGGL((k_plan_units<true, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_plan_units<true, false>), grid, block, 0, st, a);
@@ -679,10 +719,14 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         a.tile_list = use_units ? static_cast<const uint32_t *>(p.list_slow) : nullptr;
         a.nlist = n_tap; a.ngroups = (n_tap + 3) / 4;
         if (sums) a.car = nullptr;
+        a.frames = d_frames; a.set_stride = 0;   // the per-tap kernel reads whole frames: RAW ones in the balance modes
         const dim3 grid(grid_blocks());
-        if (balance) {
+        if (balance || (compact && sums)) {
             if (blend) hipLaunchKernelGGL((k_stitch_plan<true, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_stitch_plan<false, true>), grid, block, 0, st, a);
+        } else if (compact) {   // luminance round trip per tap, no channel sums (camera-per-GPU shards: the stitch rank balances the colours)
+            if (blend) hipLaunchKernelGGL((k_stitch_plan<true, true, false>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_stitch_plan<false, true, false>), grid, block, 0, st, a);
         } else if (blend && sums) hipLaunchKernelGGL((k_stitch_plan<true, false, true>), grid, block, 0, st, a);
         else if (blend) hipLaunchKernelGGL((k_stitch_plan<true, false>), grid, block, 0, st, a);
         else if (sums) hipLaunchKernelGGL((k_stitch_plan<false, false, true>), grid, block, 0, st, a);
@@ -723,7 +767,7 @@ static inline hipError_t plan_unit_wide_launch(const Plan &p, hipStream_t st, co
     if (nb > batch) nb = batch;
     a.nb = nb;
     a.nchunks = (batch + nb - 1) / nb;
-    a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? 1 : 0;
+    a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? tune.xcd_map : 0;
     a.tile_list = static_cast<const uint32_t *>(p.list_un_all); a.nlist = p.n_un_all; a.ngroups = p.n_un_all;
     const unsigned grid = a.xcd_affine ? (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8)) : (unsigned)(a.ngroups * a.nchunks);
     if (blend) hipLaunchKernelGGL((k_plan_unit_wide<true>), dim3(grid), dim3(kUnitThreads), 0, st, a);
@@ -731,17 +775,17 @@ static inline hipError_t plan_unit_wide_launch(const Plan &p, hipStream_t st, co
     return hipGetLastError();
 }
 
-// luminance-shift the sampled texel groups of every raw frame of the batch into `scratch` (same layout as `frames`)
+// luminance-shift the sampled texel groups of every raw frame of the batch into the compact scratch (p.compact_stride bytes per frame set)
 static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch,
                                        const int *d_deltas, const HsvTables *d_tab)
 {
-    if (p.n_groups == 0) return hipSuccess;
+    if (p.n_groups == 0 || p.compact_stride == 0) return hipSuccess;
     const size_t set_bytes = (size_t)p.fw * p.fh * 3 * p.ncams;
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
-        const unsigned bpf = (unsigned)(p.n_groups + 255) / 256;
+        const unsigned bpf = (unsigned)(p.n_groups + 256 * kLumTrips - 1) / (256 * kLumTrips);
         hipLaunchKernelGGL(k_lum_groups, dim3(xcd_frame_grid(bpf, (unsigned)nb)), dim3(256), 0, st, d_frames + (size_t)b0 * set_bytes,
-                           d_scratch + (size_t)b0 * set_bytes, set_bytes, (uint32_t)p.fw * p.fh * 3,
+                           d_scratch + (size_t)b0 * p.compact_stride, set_bytes, p.compact_stride, (uint32_t)p.fw * p.fh * 3,
                            static_cast<const uint32_t *>(p.groups), p.n_groups, d_deltas + (size_t)b0 * 4, d_tab, bpf, (uint32_t)nb);
     }
     return hipGetLastError();

@@ -13,9 +13,10 @@ int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, i
 
 // one step: see plan_stitch_impl (bevw_plan.h)
 int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance, const int *d_deltas, const HsvTables *d_tab,
-                const uint8_t *d_car, unsigned long long *d_chsums, uint8_t *d_out, bool sums = false, int psums_frames = 0, int psums_first = 0);
+                const uint8_t *d_car, unsigned long long *d_chsums, uint8_t *d_out, bool sums = false, int psums_frames = 0, int psums_first = 0,
+                const uint8_t *d_scratch = nullptr);
 
-// balance: luminance round trip of the sampled texel groups of the raw frames into a scratch frame set
+// balance: luminance round trip of the sampled texel groups of the raw frames into the compact scratch (p.compact_stride bytes per frame set)
 int plan_lum_groups(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch, const int *d_deltas, const HsvTables *d_tab);
 
 // rows of bw pixels -> rows of pitch pixels (the car sprite of a pitched handle)

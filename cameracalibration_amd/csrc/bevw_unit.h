@@ -494,6 +494,27 @@ static inline void unit_compile(const std::vector<int16_t> lut1[4], const std::v
         if (own[t] != 0) { hdr[t] |= kHdrBlock; ++out.claimed_tiles; }
 }
 
+// The COMPACT scratch of the balance schedule (bevw_plan.h: k_lum_groups): the luminance-shifted copy of a frame set holds ONLY the
+// sampled 4-texel groups, 12 bytes each, in ascending order of their offsets in the frame set (Plan::groups) -- slot i of the scratch is group
+// groups[i].  A unit's group list for that layout is the rank of every group times 12.  The 16-byte load of slot i reaches 4 bytes into
+// slot i + 1; they matter only to a pixel that samples texel pair 3 of the group (texels 4g + 3, 4g + 4), and then texel 4g + 4 lies in the
+// pixel's footprint, i.e. group g + 1 (same row: sx + 1 < fw) is sampled as well and IS slot i + 1.
+// Returns false when a unit loads a group the list does not hold (the compact layout is then not used).
+static inline bool unit_gsrc_compact(const std::vector<uint32_t> &gsrc, const std::vector<uint32_t> &groups, std::vector<uint32_t> &out)
+{
+    out.assign(gsrc.size(), kPairNoGroup);
+    for (size_t i = 0; i < gsrc.size(); ++i) {
+        if (gsrc[i] == kPairNoGroup) continue;
+        const auto it = std::lower_bound(groups.begin(), groups.end(), gsrc[i]);
+        if (it == groups.end() || *it != gsrc[i]) return false;
+        out[i] = (uint32_t)(it - groups.begin()) * 12u;
+    }
+    return true;
+}
+// bytes between the compact scratch copies of consecutive frame sets: the groups + the 4 bytes the last slot's load reaches beyond them,
+// rounded to whole 64-byte sectors
+static inline size_t unit_compact_stride(size_t ngroups) { return (ngroups * 12 + 16 + 63) / 64 * 64; }
+
 static inline std::vector<uint32_t> unit_host_headers(const std::vector<int16_t> lut1[4], const std::vector<uint8_t> mask[4], int ncams, int fw, int fh,
                                                       int bw, int bh, int tiles_x, int tiles_y)
 {
@@ -613,6 +634,9 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 #ifndef BEVW_UNIT_DEPTH
 #define BEVW_UNIT_DEPTH 2
 #endif
+#ifndef BEVW_UNIT_EARLY_STORE
+#define BEVW_UNIT_EARLY_STORE 0
+#endif
 #ifdef BEVW_UNIT_PRIO_ON
 #define BEVW_UNIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -663,7 +687,8 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ux = (int)(int16_t)(pos & 0xffffu), uy = (int)(pos >> 16), uw = (int)(shape & 0xffffu), uh = (int)(shape >> 16);
-    const size_t set_bytes = (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
+    // bytes between consecutive frame sets as this kernel reads them: whole frames, or the compact scratch of the balance schedule (unit_gsrc_compact)
+    const size_t set_bytes = a.set_stride ? (size_t)a.set_stride : (size_t)a.fw * a.fh * 3 * a.ncams, img_bytes = (size_t)a.pitch * a.bh * 3;
     const bool streaming = ((uint32_t)a.pitch * 3u) % 64u == 0u;   // rows of whole sectors (see unit_store_quad)
     constexpr int kPatch = GR * kUnitThreads * 32;              // one frame's pair entries
     constexpr bool DB = 2 * kPatch <= kUnitMaxGroups * 32;      // both halves fit the block's 32 KB
@@ -853,6 +878,13 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                 }
                 pack_pixels(P, d[j][0], d[j][1], d[j][2]);
             }
+#if BEVW_UNIT_EARLY_STORE
+            {   // experiment: a quad is stored as soon as it is interpolated (the store stream spread over the frame's arithmetic)
+                uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;
+                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
+                unit_store_quad(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], streaming);
+            }
+#endif
         }
         if (SUMS) {
             // One wave reduction per frame, on the VALU (DPP adds): round 3 reduced every quad slot with __shfl_xor = 12 ds_bpermute_b32 per
@@ -865,6 +897,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             }
         }
         if (DB) land((ring + 1) % D);    // frame b+1 into the other half: nobody reads it before the barrier
+#if !BEVW_UNIT_EARLY_STORE
         {
             uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
@@ -874,6 +907,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                 unit_store_quad(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], streaming);
             BEVW_UNIT_PRIO(0);
         }
+#endif
         block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
     };
 #endif

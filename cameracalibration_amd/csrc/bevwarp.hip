@@ -70,6 +70,7 @@ static HsvTables make_hsv_tables()
         t.sdiv[i] = host_rne((255 << 12) / (1. * i));
         t.hdiv[i] = host_rne((180 << 12) / (6. * i));
     }
+    for (int i = 0; i < 256; ++i) hsv_hue_entry(i, t.hue[i].x, t.hue[i].y);
     return t;
 }
 
@@ -863,7 +864,8 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
     const size_t npx = (size_t)h->pitch_px * c.bev_height;
     const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
     BEVW_TRY(ensure_stats(h, batch));
-    BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
+    const size_t cstride = h->plan.compact_stride;   // the compact scratch: only the sampled texel groups of a frame set (bevw_unit.h: unit_gsrc_compact)
+    BEVW_TRY(h->tmp.reserve(cstride * (size_t)batch));
     // the gain pass reads the pre-gain BEV from a buffer of its own instead of rewriting the output in place: a read stream
     // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
     // one more BEV batch of HBM (0.9 GB at batch 256).  No room for it: the gain pass runs in place -- never an error
@@ -901,9 +903,10 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
             HIP_TRY(hipEventRecord(h->ev_skew, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_skew, 0));
         }
-        BEVW_TRY(plan_lum_groups(h->plan, st, fr, h->tmp.as<uint8_t>() + (size_t)b0 * set_bytes, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>()));
-        BEVW_TRY(plan_stitch(h->plan, st, h->tmp.as<uint8_t>() + (size_t)b0 * set_bytes, n, c.blend != 0, false, nullptr, nullptr, nullptr,
-                             h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0));
+        uint8_t *scratch = h->tmp.as<uint8_t>() + (size_t)b0 * cstride;
+        BEVW_TRY(plan_lum_groups(h->plan, st, fr, scratch, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>()));
+        BEVW_TRY(plan_stitch(h->plan, st, fr, n, c.blend != 0, false, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>(), nullptr,
+                             h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0, scratch));
         BEVW_TRY(gain_pass(h, st, gain_in, gain_car, d_car, d_out, b0, n, npx % 4 == 0));   // (odd image sizes: the byte-wise gain kernel, in place)
     }
     if (parts > 1) {   // everything the caller enqueues on the handle's stream afterwards sees the whole batch
@@ -925,7 +928,7 @@ static int run_device(bevw_handle *h, const uint8_t *d_frames, int batch, const 
     // balance schedule of the tile plan: 1 = shift the sampled texel groups of the raw frames once (k_lum_groups), then the units;
     // 0 = luminance round trip per fetched texel inside the per-tap kernel
     static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
-    if (h->projection == BEVW_PROJ_LUT && h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.band_ok)
+    if (h->projection == BEVW_PROJ_LUT && h->schedule_in_use == BEVW_SCHED_TILE_PLAN && aligned4 && c.balance && bal_mode == 1 && h->plan.compact_stride != 0)
         return balance_plan_run(h, d_frames, batch, d_car, d_out);
     if (c.balance) {
         BEVW_TRY(ensure_stats(h, batch));
@@ -1414,12 +1417,11 @@ int bevw_shard_run_device(bevw_handle *h, const void *d_frames, int batch, const
                        h->sdeltas.as<int>());
     BEVW_TRY(launch_check("k_lum_delta/k_delta_select"));
     static const int bal_mode = [] { const char *s = getenv("BEVW_BAL_MODE"); return s ? atoi(s) : 1; }();
-    if (bal_mode == 1 && h->plan.band_ok) {
-        const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 3 * h->shard_n;
-        BEVW_TRY(h->tmp.reserve(set_bytes * (size_t)batch));
+    if (bal_mode == 1 && h->plan.compact_stride != 0) {
+        BEVW_TRY(h->tmp.reserve(h->plan.compact_stride * (size_t)batch));
         BEVW_TRY(plan_lum_groups(h->plan, h->stream, frames, h->tmp.as<uint8_t>(), batch, h->sdeltas.as<int>(), h->hsv.as<HsvTables>()));
-        return plan_stitch(h->plan, h->stream, h->tmp.as<uint8_t>(), batch, c.blend != 0, false, nullptr, nullptr, nullptr, nullptr,
-                           (uint8_t *)d_out);
+        return plan_stitch(h->plan, h->stream, frames, batch, c.blend != 0, false, h->sdeltas.as<int>(), h->hsv.as<HsvTables>(), nullptr, nullptr,
+                           (uint8_t *)d_out, false, 0, 0, h->tmp.as<uint8_t>());
     }
     HIP_TRY(hipMemsetAsync(h->chsums.p, 0, sizeof(unsigned long long) * 3 * (size_t)batch, h->stream));
     return plan_stitch(h->plan, h->stream, frames, batch, c.blend != 0, true, h->sdeltas.as<int>(), h->hsv.as<HsvTables>(), nullptr,

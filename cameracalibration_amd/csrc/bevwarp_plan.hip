@@ -54,10 +54,10 @@ int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, i
 }
 
 int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, bool blend, bool balance, const int *d_deltas, const HsvTables *d_tab,
-                const uint8_t *d_car, unsigned long long *d_chsums, uint8_t *d_out, bool sums, int psums_frames, int psums_first)
+                const uint8_t *d_car, unsigned long long *d_chsums, uint8_t *d_out, bool sums, int psums_frames, int psums_first, const uint8_t *d_scratch)
 {
     hipError_t e = plan_stitch_impl(p, st, d_frames, batch, blend, balance, d_deltas, d_tab, d_car, d_chsums, d_out, plan_tuning(), sums, psums_frames,
-                                    psums_first);
+                                    psums_first, d_scratch);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "tile-plan stitch launch failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }

@@ -20,6 +20,9 @@ SAMPLING_420, SAMPLING_422, SAMPLING_444 = 0x22, 0x21, 0x11
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("BEVW_ORACLE_SANITIZE") == "1":   # ASan + UBSan build (tests/test_sanitizers.py); see oracle.sanitized_build
+        from oracle import oracle as _O
+        return _O.sanitized_build("jpegoracle")
     src = os.path.join(_HERE, "jpegoracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.run(["make", "-C", _HERE, "-s", "libjpegoracle.so"] + (["-B"] if force else []), check=True)

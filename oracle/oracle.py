@@ -20,8 +20,24 @@ _LIB_PATH = os.path.join(_HERE, "libbevoracle.so")
 CAMERAS = ("front", "back", "left", "right")
 
 
+def sanitized_build(name: str) -> str:
+    """BEVW_ORACLE_SANITIZE=1 (tests/test_sanitizers.py): `name`.c compiled with AddressSanitizer + UndefinedBehaviorSanitizer into
+    oracle/_san/ (any finding aborts the process).  The process that loads it needs gcc's libasan.so preloaded (LD_PRELOAD)."""
+    out_dir = os.path.join(_HERE, "_san")
+    os.makedirs(out_dir, exist_ok=True)
+    src, out = os.path.join(_HERE, name + ".c"), os.path.join(out_dir, "lib" + name + "_san.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.run(["gcc", "-O1", "-g", "-std=c11", "-fPIC", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+                        "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-shared", "-o", out + ".tmp", src, "-lm"],
+                       check=True)
+        os.replace(out + ".tmp", out)
+    return out
+
+
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    if os.environ.get("BEVW_ORACLE_SANITIZE") == "1":
+        return sanitized_build("bevoracle")
     src = os.path.join(_HERE, "bevoracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
         subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True)

@@ -17,11 +17,17 @@ def hipcc_path():
     return HIPCC if os.path.exists(HIPCC) else shutil.which("hipcc")
 
 
-def build(src: str, exe: str, timeout: int = 900) -> None:
+SANITIZE = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+
+
+def build(src: str, exe: str, timeout: int = 900, sanitize: bool = False) -> None:
+    """sanitize: AddressSanitizer + UndefinedBehaviorSanitizer (clang's runtimes ship with ROCm's llvm); any finding aborts the program."""
     hipcc = hipcc_path()
     obj, stub_c, stub_o = exe + ".o", exe + "_fatbin_stub.c", exe + "_fatbin_stub.o"
+    sanitize = sanitize or os.environ.get("BEVW_NATIVE_SANITIZE") == "1"   # the sanitizer leg re-runs the emulator tests this way
+    san = SANITIZE if sanitize else []
     try:
-        r = subprocess.run([hipcc] + FLAGS + ["--cuda-host-only", "-c", src, "-o", obj], capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run([hipcc] + FLAGS + san + ["--cuda-host-only", "-c", src, "-o", obj], capture_output=True, text=True, timeout=timeout)
         if r.returncode == 0:
             syms = subprocess.run(["nm", obj], capture_output=True, text=True, timeout=60).stdout
             wanted = sorted(set(re.findall(r"^\s+U (__hip_fatbin\w*)$", syms, flags=re.M)))
@@ -30,10 +36,11 @@ def build(src: str, exe: str, timeout: int = 900) -> None:
                     f.write('__attribute__((section(".hip_fatbin"), aligned(4096))) const char %s[8] = {0};\n' % s)
                 f.write("int bevw_native_build_stub;\n")
             ok = subprocess.run(["gcc", "-c", stub_c, "-o", stub_o], capture_output=True, text=True, timeout=60).returncode == 0
-            ok = ok and subprocess.run([hipcc, obj, stub_o, "-o", exe], capture_output=True, text=True, timeout=300).returncode == 0
+            ok = ok and subprocess.run([hipcc] + san + [obj, stub_o, "-o", exe], capture_output=True, text=True, timeout=300).returncode == 0
             if ok and subprocess.run([exe, "--bevw-selfcheck-noop"], capture_output=True, timeout=120).returncode is not None:
                 return
     except (OSError, subprocess.SubprocessError):
         pass
+    assert not sanitize, "sanitized host build failed: " + (r.stderr[-2000:] if "r" in dir() else "")
     r = subprocess.run([hipcc] + FLAGS + [src, "-o", exe], capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]

@@ -15,6 +15,7 @@ CAMS = ("front", "back", "left", "right")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "sanitize: the oracle / host emulators / JPEG marker parser under ASan + UBSan (CPU only)")
 
 
 def decode_bgr(raw: bytes) -> np.ndarray:

@@ -206,6 +206,41 @@ static int run(const Rig &r, const char *out_path)
                 }
         for (int k = 0; k < 3; ++k) CHECK(sums[k] == want[k], "channel sum %d: %u, expected %llu", k, sums[k], want[k]);
     }
+    // the COMPACT scratch of the balance schedule (bevw_unit.h: unit_gsrc_compact): only the sampled 4-texel groups of a frame set, 12 bytes
+    // each in ascending order; the units read it through group lists of ranks.  Emulated here with the group list k_plan_touch produces on the
+    // GPU (every texel of every contributor's 2 x 2 footprint), restated on the host: the image must not change by a byte.
+    if (!r.wide && r.fw % 4 == 0) {
+        const uint32_t gw = (uint32_t)r.fw / 4, row_bytes = (uint32_t)r.fw * 3;
+        std::vector<uint8_t> touched((size_t)r.ncams * r.fh * gw, 0);
+        for (int y = 0; y < r.bh; ++y)
+            for (int x = 0; x < r.bw; ++x) {
+                const size_t o = (size_t)y * r.bw + x;
+                int count = 0;
+                for (int c = 0; c < r.ncams; ++c) {
+                    if (r.mk[c][o] == 0) continue;
+                    const int sx = r.l1[c][o * 2], sy = r.l1[c][o * 2 + 1];
+                    if (sx >= r.fw || sx + 1 < 0 || sy >= r.fh || sy + 1 < 0) continue;
+                    if (count++ >= 2) continue;
+                    for (int dy = 0; dy < 2; ++dy)
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const int tx = sx + dx, ty = sy + dy;
+                            if ((unsigned)tx < (unsigned)r.fw && (unsigned)ty < (unsigned)r.fh) touched[((size_t)c * r.fh + ty) * gw + tx / 4] = 1;
+                        }
+                }
+            }
+        std::vector<uint32_t> groups;
+        for (size_t bit = 0; bit < touched.size(); ++bit)
+            if (touched[bit]) groups.push_back((uint32_t)(bit / gw) * row_bytes + (uint32_t)(bit % gw) * 12u);
+        UnitPlanHost upc = up;
+        CHECK(unit_gsrc_compact(up.gsrc, groups, upc.gsrc), "a unit loads a group the sampled-group list does not hold");
+        const size_t stride = unit_compact_stride(groups.size());
+        std::vector<uint8_t> compact(stride, 0x5a), img2((size_t)pitch * r.bh * 3, 0);
+        for (size_t i = 0; i < groups.size(); ++i) memcpy(compact.data() + i * 12, r.frames.data() + groups[i], 12);
+        for (size_t u = 0; u < up.desc.size(); ++u)
+            unit_emulate(upc, (uint32_t)u, cls_of[u], compact.data(), stride, r.blend != 0, r.car.empty() ? nullptr : car_p.data(), pitch, img2.data());
+        CHECK(memcmp(img2.data(), img.data(), img2.size()) == 0, "the image from the compact scratch differs from the image from the frames");
+        printf("compact scratch ok: %zu groups (%.1f %% of the frame set's bytes)\n", groups.size(), 100.0 * groups.size() * 12 / set_bytes);
+    }
     printf("unit schedule ok: %zu units (classes", up.desc.size());
     for (int c = 0; c < kUnitClasses; ++c)
         printf(" %dx%d%s:%zu[px %zu groups %zu lines %zu sectors %zu]", kUnitClassNQ[c], kUnitClassGR[c], kUnitClassCON[c] == 2 ? "d" : "", up.list[c].size(), up.cls_pixels[c], up.cls_groups[c],

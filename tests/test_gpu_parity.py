@@ -468,7 +468,7 @@ def test_full_size_batch_properties(ffi, SB, oracle, blend, balance):
     d_out.fill(0xA5)
     for b in range(batch):
         d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
-    bev.run_device(d_in.ptr, batch, None, d_out.ptr)
+    bev.run_device(d_in.ptr, batch, None, d_out.ptr, out_bytes=d_out.nbytes)
     bev.sync()
     out = np.ascontiguousarray(d_out.download((batch, 1080, pitch, 3))[:, :, :1080])
     # a frame's BEV does not depend on its position in the batch (XCD / chunk mapping, batch loop)
@@ -501,7 +501,7 @@ def test_bench_configuration_batch_256_all_random(ffi, SB, oracle, blend):
     d_out.fill(0x5A)
     for b in range(batch):
         d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
-    bev.run_device(d_in.ptr, batch, None, d_out.ptr)
+    bev.run_device(d_in.ptr, batch, None, d_out.ptr, out_bytes=d_out.nbytes)
     bev.sync()
     want = [ref(*frames[u]) for u in range(uniq)]
     per = 1080 * pitch * 3
@@ -511,6 +511,67 @@ def test_bench_configuration_batch_256_all_random(ffi, SB, oracle, blend):
             assert np.array_equal(out[k][:, :1080], want[(b0 + k) % uniq]), "frame %d of the batch differs from the oracle" % (b0 + k)
     d_in.free()
     d_out.free()
+
+
+def test_bench_configuration_4_blend_balance_batch_256_all_random(ffi, SB, oracle):
+    """BASELINE config 4 exactly as bench.py --workload blend_balance_b256 times it: BevGenerator(blend=True, balance=True), 256 frame
+    sets resident in HBM, run_device (the engine cuts the batch into 2 slices of 128 over its two streams), the default device layout.
+    Worst-case input: every byte uniform random, 3 distinct frame sets cycled through the batch.  Every one of the 256 BEVs must equal
+    the oracle's luminance_balance -> warp -> blend -> cv2.add -> color_balance result of its frame set -- bit-exact."""
+    cfg, rig = W.CONFIG_S, W.rig_s()
+    batch, uniq = 256, 3
+    frames = W.synthetic_frames(uniq, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=W.SEED + 29, kind="random")
+    bev, ref = make_pair(SB, oracle, rig, cfg, True, True)
+    assert bev.plan_info()["schedule"] == 2
+    d_in = ffi.DeviceBuffer(batch * frames[0].nbytes)
+    pitch = bev.out_pitch
+    d_out = ffi.DeviceBuffer(batch * bev.out_image_bytes)
+    d_out.fill(0x5A)
+    for b in range(batch):
+        d_in.upload(frames[b % uniq], offset=b * frames[0].nbytes)
+    for _ in range(2):   # twice: the second step re-uses every scratch buffer of the first (pre-gain BEV, per-unit sums, shifted groups)
+        bev.run_device(d_in.ptr, batch, None, d_out.ptr, out_bytes=d_out.nbytes)
+    bev.sync()
+    want = [ref(*frames[u]) for u in range(uniq)]
+    per = bev.out_image_bytes
+    for b0 in range(0, batch, 32):
+        out = d_out.download((32, 1080, pitch, 3), offset=b0 * per)
+        for k in range(32):
+            assert np.array_equal(out[k][:, :1080], want[(b0 + k) % uniq]), "frame %d of the batch differs from the oracle" % (b0 + k)
+    d_in.free()
+    d_out.free()
+
+
+def test_bench_configuration_2_undistort_batch_64_all_random(ffi, oracle):
+    """BASELINE config 2 exactly as bench.py --workload undistort_b64 times it: bevw_fisheye_remapper_create + bevw_remap_device on 64
+    images resident in HBM.  Every image uniform random and DISTINCT; every output compared with oracle.remap through the oracle's own
+    fisheye maps (cv2.fisheye.initUndistortRectifyMap + cv2.remap, intrinsicCalib.py:193-195) -- bit-exact."""
+    import ctypes as C
+    ucfg = W.CONFIG_UNDISTORT
+    K, D = W.undistort_calibration()
+    fw, fh = ucfg["FRAME_WIDTH"], ucfg["FRAME_HEIGHT"]
+    L = ffi.lib()
+    r = C.c_void_p()
+    ffi.check(L.bevw_fisheye_remapper_create(0, fw, fh, ffi.ptr(ffi.f64(K, 9)), ffi.ptr(ffi.f64(D, 4)), ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"],
+                                             0.0, 0.0, C.byref(r)))
+    try:
+        batch = 64
+        imgs = np.random.default_rng(W.SEED + 31).integers(0, 256, (batch, fh, fw, 3), dtype=np.uint8)
+        Kd = oracle.camera_mat_dst(K, fw, fh, ucfg["FOCAL_SCALE"], ucfg["SIZE_SCALE"])
+        m1, m2 = oracle.fisheye_init_undistort_rectify_map(K, D, Kd, (int(fw * ucfg["SIZE_SCALE"]), int(fh * ucfg["SIZE_SCALE"])))
+        dh, dw = m1.shape[:2]
+        d_in = ffi.DeviceBuffer(imgs.nbytes).upload(imgs)
+        d_out = ffi.DeviceBuffer(batch * dh * dw * 3)
+        d_out.fill(0x5A)
+        ffi.check(L.bevw_remap_device(r, d_in.ptr, batch, d_out.ptr))
+        ffi.check(L.bevw_remapper_sync(r))
+        out = d_out.download((batch, dh, dw, 3))
+        for b in range(batch):
+            assert np.array_equal(out[b], oracle.remap(imgs[b], m1, m2)), "image %d of the batch differs from the oracle" % b
+        d_in.free()
+        d_out.free()
+    finally:
+        L.bevw_remapper_destroy(r)
 
 
 def test_4k_rig_spot(ffi, SB, oracle):
@@ -609,7 +670,7 @@ def test_output_pitch_aligned_config_s(ffi, SB, oracle, blend, balance):
     d_out.fill(0x5A)
     for b in range(batch):
         d_in.upload(frames[b % 2], offset=b * frames[0].nbytes)
-    bev.run_device(d_in.ptr, batch, d_car.ptr, d_out.ptr)
+    bev.run_device(d_in.ptr, batch, d_car.ptr, d_out.ptr, out_bytes=d_out.nbytes)
     bev.sync()
     out = d_out.download((batch, bh, bev.out_pitch, 3))
     for b in range(batch):

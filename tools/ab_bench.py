@@ -34,7 +34,7 @@ def main():
             e = dict(os.environ)
             e.update(env)
             out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", a.workload, "--steps", str(a.steps), "--warmup", "5",
-                                  "--no-cpu-baseline", "--no-f4"] + a.bench_args.split(), env=e, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
+                                  "--no-cpu-baseline", "--no-f4", "--no-live-traffic"] + a.bench_args.split(), env=e, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()
             try:
                 d = json.loads(out[-1])
                 res[label].append(d["roofline"].get("kernel_ms_median") or d["roofline"]["kernel_ms"])

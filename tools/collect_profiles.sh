@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-end evidence, run on the GPU box from the repo root:  gpurun -- 'bash tools/collect_profiles.sh'
-# Everything lands under gpurun_out/final/; copy what should be judged into profiles/r04_final/.
+# Everything lands under gpurun_out/final/; copy what should be judged into profiles/r05_final/.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
@@ -12,18 +12,18 @@ cd /tmp && export TMPDIR=/tmp
 # row f4: kernel statistics and the VALU instruction counts behind roofline.bound = valu_issue of the JPEG lines
 for w in jpeg_decode_b64 jpeg_encode_b64 jpeg_bev_jpeg_b64; do
   rm -rf /tmp/kt_$w /tmp/pv_$w
-  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_$w.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
-  BEVW_BENCH_NO_HOST_API=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_$w -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_$w.log 2>&1
+  BEVW_BENCH_NO_HOST_API=1 timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_$w -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /tmp/pv_$w.log 2>&1
   cp $(find /tmp/pv_$w -name "*counter_collection.csv" | head -1) $O/pmc_valu_$w.csv
 done
 rm -rf /tmp/kt_rep /tmp/pv_rep
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 6 --warmup 2 --no-cpu-baseline > /tmp/kt_rep.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 6 --warmup 2 --no-cpu-baseline --no-live-traffic > /tmp/kt_rep.log 2>&1
 cp $(find /tmp/kt_rep -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_jpeg_decode_b64_repo_files.csv
-timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 3 --warmup 1 --no-cpu-baseline > /tmp/pv_rep.log 2>&1
+timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_rep -- python $R/bench.py --workload jpeg_decode_b64 --jpeg-source repo --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > /tmp/pv_rep.log 2>&1
 cp $(find /tmp/pv_rep -name "*counter_collection.csv" | head -1) $O/pmc_valu_jpeg_decode_b64_repo.csv
 cd $R
-python tools/r04/jpeg_valu.py $O | grep "wave-level"
+python tools/jpeg_valu.py $O | grep "wave-level"
 python - <<'P'
 import json
 d=json.load(open('gpurun_out/final/jpeg_valu.json'))
@@ -49,11 +49,11 @@ python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'))
 cd /tmp && export TMPDIR=/tmp
 for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k; do
   rm -rf /tmp/kt_$w
-  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline > /tmp/kt_$w.log 2>&1
+  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline --no-live-traffic > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c
-    timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --single-layout --no-cpu-baseline > /tmp/pmc_${w}_$c.log 2>&1
+    timeout 120 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${w}_$c -- python $R/bench.py --workload $w --steps 3 --warmup 1 --placements 1 --single-layout --no-cpu-baseline --no-live-traffic > /tmp/pmc_${w}_$c.log 2>&1
     cp $(find /tmp/pmc_${w}_$c -name "*counter_collection.csv" | head -1) $O/pmc_${w}_$c.csv 2>/dev/null
   done
 done

@@ -1,4 +1,4 @@
-"""Decode the files a soak kept (gpurun_out/soak_jpeg_fail_*.npz) and compare with libjpeg-turbo (Pillow):  python tools/r04/jpeg_repro.py [files.npz ...]"""
+"""Decode the files a soak kept (gpurun_out/soak_jpeg_fail_*.npz) and compare with libjpeg-turbo (Pillow):  python tools/jpeg_repro.py [files.npz ...]"""
 import glob, io, os, sys
 import numpy as np
 from PIL import Image

@@ -1,6 +1,6 @@
-"""profiles/jpeg_valu.json from rocprofv3 --pmc SQ_INSTS_VALU passes of the JPEG workloads (tools/r04/run2.sh):
+"""profiles/jpeg_valu.json from rocprofv3 --pmc SQ_INSTS_VALU passes of the JPEG workloads (tools/collect_profiles.sh):
 
-    python tools/r04/jpeg_valu.py <dir with pmc_valu_<workload>.csv files>  ->  <dir>/jpeg_valu.json (+ a per-kernel table on stdout)
+    python tools/jpeg_valu.py <dir with pmc_valu_<workload>.csv files>  ->  <dir>/jpeg_valu.json (+ a per-kernel table on stdout)
 
 Wave-level VALU instructions per UNIT of every workload: the sum over all dispatches of the step's kernels divided by the number of
 steps the process ran (counted through a kernel that runs once per step) and by the units of a step.  bench.py turns the figure into
@@ -30,7 +30,7 @@ def short(name):
 
 def main(d):
     out = {"_comment": "wave-level VALU instructions per unit (SQ_INSTS_VALU summed over the kernels of one step / units per step) from rocprofv3 --pmc "
-                       "passes of `bench.py --workload W --steps 3 --warmup 1 --no-cpu-baseline` (tools/r04/run2.sh); static figures of the round they "
+                       "passes of `bench.py --workload W --steps 3 --warmup 1 --no-cpu-baseline` (tools/collect_profiles.sh); static figures of the round they "
                        "were collected in; bench.py: roofline.bound = valu_issue"}
     for w, (prefixes, marker, per_step_calls, units) in SPEC.items():
         path = os.path.join(d, "pmc_valu_%s.csv" % w)
@@ -50,7 +50,7 @@ def main(d):
         per_step = {k: v / steps for k, v in sums.items() if k.startswith(prefixes)}
         total = sum(per_step.values())
         out[w] = {"valu_wave_insts_per_unit": total / units, "units_per_step": units, "steps_profiled": steps, "round": 4,
-                  "source": "profiles/r04_final/pmc_valu_%s.csv (rocprofv3 --pmc SQ_INSTS_VALU)" % w,
+                  "source": "profiles/r05_final/pmc_valu_%s.csv (rocprofv3 --pmc SQ_INSTS_VALU)" % w,
                   "per_kernel_per_step": {k: round(v) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])}}
         print("%s: %.0f M wave-level VALU instructions per step (%d steps profiled), %.0f per unit" % (w, total / 1e6, steps, total / units))
         for k, v in sorted(per_step.items(), key=lambda kv: -kv[1]):

@@ -5,7 +5,7 @@
 PAT=${1:-k_plan_}
 cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-pass-failed -Wno-inline-asm \
-  -Rpass-analysis=kernel-resource-usage -c cameracalibration_amd/csrc/${2:-bevwarp_plan.hip} -o /tmp/libbevwarp_res.o 2>&1 |
+  -Rpass-analysis=kernel-resource-usage ${BEVW_CFLAGS:-} -c cameracalibration_amd/csrc/${2:-bevwarp_plan.hip} -o /tmp/libbevwarp_res.o 2>&1 |
 python3 -c '
 import re, sys, subprocess
 pat = re.compile(sys.argv[1])

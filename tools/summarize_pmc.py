@@ -42,6 +42,30 @@ def kernel_sums(path):
     return out
 
 
+def per_launch_traffic(fetch_csv, write_csv, launches):
+    """(corrected FETCH KB, WRITE KB, rows) per launch of the per-step kernels in two counter files: the correction rules of this module
+    (wide-stream readers x stream_read, the staged stitch kernels' group loads x group_loads and tile stores x tile_stores, k_lum_groups
+    x gather_64B).  Shared by main() below and by bench.py's live traffic measurement."""
+    fs, ws = kernel_sums(fetch_csv), kernel_sums(write_csv)
+    tf = tw = 0.0
+    rows = []
+    for k in sorted(set(fs) | set(ws)):
+        if not any(p in k for p in PER_STEP):
+            continue
+        a, b = fs.get(k, 0.0) / launches, ws.get(k, 0.0) / launches
+        if any(p in k for p in WIDE_READERS):
+            a *= CAL["stream_read"] if CAL else 2
+        elif CAL and any(p in k for p in GROUP_LOADERS):
+            a *= CAL["group_loads"]
+            b *= CAL["tile_stores"]
+        elif CAL and "k_lum_groups" in k:
+            a *= CAL["gather_64B"]
+        tf += a
+        tw += b
+        rows.append((k, a, b))
+    return tf, tw, rows
+
+
 def main(d):
     md = ["# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), `python bench.py --workload W --steps 3 --warmup 1 --no-cpu-baseline`", "",
           "KB per launch (= one bench step), per-step kernels only, CORRECTED with the factors measured on known byte counts in the kernels' own",
@@ -51,33 +75,20 @@ def main(d):
           "WRITE_SIZE is exact (x%.2f for the 8 x 96-byte tile stores), so write traffic above the output bytes is real (partial-sector evictions)." %
           (CAL or {}).get("tile_stores", 1.0), ""]
     traffic = {"_comment": "HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes "
-                           "(profiles/r04_final/rocprofv3_pmc_hbm_traffic.md, tools/collect_profiles.sh), corrected with the factors of "
-                           "profiles/pmc_calibration.json (measured on known byte counts); bench.py copies the "
-                           "figure of the workload it runs into roofline.traffic."}
+                           "(tools/collect_profiles.sh -> rocprofv3_pmc_hbm_traffic.md), corrected with the factors of "
+                           "profiles/pmc_calibration.json (measured on known byte counts); bench.py measures the same figure live "
+                           "(roofline.traffic) and falls back to this file when rocprofv3 is not available."}
     for w, units in UNITS.items():
         f, wr = os.path.join(d, "pmc_%s_FETCH_SIZE.csv" % w), os.path.join(d, "pmc_%s_WRITE_SIZE.csv" % w)
         if not (os.path.exists(f) and os.path.exists(wr)):
             continue
-        fs, ws = kernel_sums(f), kernel_sums(wr)
         launches = STEPS + WARMUP
         md += ["## %s (%d units per launch)" % (w, units), "", "| kernel | FETCH_SIZE KB (wide readers x2) | WRITE_SIZE KB |", "|---|---|---|"]
-        tf = tw = 0.0
-        for k in sorted(set(fs) | set(ws)):
-            if not any(p in k for p in PER_STEP):
-                continue
-            a, b = fs.get(k, 0.0) / launches, ws.get(k, 0.0) / launches
-            if any(p in k for p in WIDE_READERS):
-                a *= CAL["stream_read"] if CAL else 2
-            elif CAL and any(p in k for p in GROUP_LOADERS):
-                a *= CAL["group_loads"]
-                b *= CAL["tile_stores"]
-            elif CAL and "k_lum_groups" in k:
-                a *= CAL["gather_64B"]
-            tf += a
-            tw += b
+        tf, tw, rows = per_launch_traffic(f, wr, launches)
+        for k, a, b in rows:
             md.append("| `%s` | %.0f | %.0f |" % (k[:90], a, b))
         md += ["| **sum** | %.0f (%.0f MB) | %.0f (%.0f MB) |" % (tf, tf * 1024 / 1e6, tw, tw * 1024 / 1e6), ""]
-        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 4,
+        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 5,
                       "corrected": bool(CAL)}
     open(os.path.join(d, "rocprofv3_pmc_hbm_traffic.md"), "w").write("\n".join(md) + "\n")
     json.dump(traffic, open(os.path.join(d, "hbm_traffic.json"), "w"), indent=1)

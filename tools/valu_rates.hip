@@ -42,7 +42,22 @@
     X(28, "v_xor_b32 %0, %1, %0", "v_xor_b32") \
     X(29, "v_sad_u8 %0, %1, %2, %0", "v_sad_u8") \
     X(30, "v_mad_u16 %0, %1, %2, %0", "v_mad_u16") \
-    X(31, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp")
+    X(31, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf", "v_mov_b32_dpp") \
+    X(32, "v_mul_f32 %0, %1, %0", "v_mul_f32") \
+    X(33, "v_add_f32 %0, %1, %0", "v_add_f32") \
+    X(34, "v_cvt_f32_u32 %0, %0", "v_cvt_f32_u32") \
+    X(35, "v_cvt_i32_f32 %0, %0", "v_cvt_i32_f32") \
+    X(36, "v_floor_f32 %0, %0", "v_floor_f32") \
+    X(37, "v_max3_u32 %0, %1, %2, %0", "v_max3_u32") \
+    X(38, "v_med3_i32 %0, %1, %2, %0", "v_med3_i32") \
+    X(39, "v_cmp_lt_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc", "v_cmp_lt_u32 + v_cndmask_b32 (vcc), per PAIR") \
+    X(40, "v_cmp_lt_u32 vcc, %1, %0", "v_cmp_lt_u32 (vcc)") \
+    X(41, "v_cvt_pk_u8_f32 %0, %1, 1, %0", "v_cvt_pk_u8_f32") \
+    X(42, "v_mul_f64 %0, %1, %0", "(placeholder, see 43)") \
+    X(44, "v_sub_u32 %0, %1, %0", "v_sub_u32") \
+    X(45, "v_ashrrev_i32 %0, 3, %0", "v_ashrrev_i32") \
+    X(46, "v_rndne_f32 %0, %0", "v_rndne_f32") \
+    X(47, "v_fract_f32 %0, %0", "v_fract_f32")
 
 template <int OP>
 __global__ void __launch_bounds__(1024) k_valu(int iters, uint32_t *__restrict__ sink, unsigned long long *__restrict__ cyc)
@@ -54,11 +69,16 @@ __global__ void __launch_bounds__(1024) k_valu(int iters, uint32_t *__restrict__
     for (int i = 0; i < 8; ++i) r2[i] = u2{r[i], r[i + 8]};
     const uint32_t w = threadIdx.x | 0x01020304u;
     const u2 w2 = u2{w, w};
+    const unsigned long long smask = __builtin_amdgcn_readfirstlane(iters) * 0x9e3779b97f4a7c15ull;   // a wave-uniform 64-bit lane mask in SGPRs
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             if (OP == 17) { asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(r2[i & 7]) : "v"(r2[(i + 1) & 7]), "v"(w2)); continue; }
+            if (OP == 42) continue;
+            if (OP == 43) { asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(r[(i + 1) & 15]), "s"(smask)); continue; }
+            if (OP == 48) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(r2[i & 7]) : "v"(r[(i + 1) & 15]), "v"(w) : "vcc"); continue; }
+            if (OP == 49) { asm volatile("v_mul_f64 %0, %1, %0" : "+v"(r2[i & 7]) : "v"(r2[(i + 1) & 7])); continue; }
 #define X(N, ASM, NAME) if (OP == N) asm volatile(ASM : "+v"(r[i]) : "v"(r[(i + 1) & 15]), "v"(w) : "vcc");
             OPS(X)
 #undef X
@@ -91,6 +111,9 @@ int main()
         printf("\n");                                                                                            \
     }
     OPS(X)
+    X(43, "", "v_cndmask_b32_e64 (SGPR-pair mask)")
+    X(48, "", "v_mad_u64_u32")
+    X(49, "", "v_mul_f64")
 #undef X
     return 0;
 }
