@@ -41,6 +41,7 @@ struct Plan {
     void *hdr = nullptr;         // uint32[ntiles]
     void *psums = nullptr;       // uint32[batch][ntiles][3]  (balance: per-tile channel sums)
     size_t psums_cap = 0;
+    int psums_layout = -1;       // entries per frame the zeros of psums were laid out for (plan_stitch_impl)
     // destination widths that are not a multiple of 4 pixels: the kernels' 12-byte stores need dword-aligned pixel quads,
     // so they write rows of `pitch` = bw rounded up to 4 pixels into pad_out and k_plan_unpad compacts them (one more
     // pass over the output instead of the per-pixel schedule)
@@ -331,6 +332,9 @@ struct PlanArgs {
     const uint32_t *un_gsrc;
     int un_skew;                 // unit_skew constant of the plan
     uint32_t set_stride;         // units: bytes between consecutive frame sets (0: fw * fh * 3 * ncams; else the compact scratch, bevw_unit.h)
+    // channel sums (balance): psums[frame][nsum][3], ONE writer per entry and frame -- unit u writes entry u, the per-tap kernel entry
+    // sum_base + its position in the tile list (sum_base = number of units; 0 when it serves every tile)
+    int nsum, sum_base;
 };
 
 // Block index -> (batch chunk, tile group).  Blocks are dealt to the 8 XCDs round-robin (block id % 8), and each XCD has
@@ -425,13 +429,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))
         }
         if (SUMS) {
             // per-tile channel sums of the pre-gain BEV (color_balance means, surroundBEV.py:44-47); pixels outside
-            // the image have no plan entry and contribute 0.  (The tile is no unit's sum tile: units never own it.)
+            // the image have no plan entry and contribute 0.  One entry per listed tile (PlanArgs::sum_base).
             unsigned s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { s0 += px[j][0]; s1 += px[j][1]; s2 += px[j][2]; }
             s0 = wave_sum_u32(s0); s1 = wave_sum_u32(s1); s2 = wave_sum_u32(s2);
             if (lane == 0) {
-                uint32_t *ps = a.psums + ((size_t)b * a.ntiles + tile) * 3;
+                uint32_t *ps = a.psums + ((size_t)b * a.nsum + a.sum_base + slot) * 3;
                 ps[0] = s0; ps[1] = s1; ps[2] = s2;
             }
         }
@@ -684,19 +688,29 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     a.nchunks = (batch + nb - 1) / nb;
     a.xcd_affine = (a.nchunks >= 8 && tune.xcd_map) ? tune.xcd_map : 0;
     const bool with_sums = balance || sums;
+    // channel-sum entries per frame: one per unit + one per base tile left to the per-tap kernel (or one per tile without units).  Every
+    // entry has exactly one writer per frame (no atomics, round 5: 2.4 M atomic adds per config-4 step cost 58 us of the 600), and every writer
+    // writes every frame of the call -- except units without a contributor, which return early: their entries keep the zeros of the allocation
+    a.nsum = use_units ? p.n_un_all + p.n_slow : p.ntiles;
+    a.sum_base = use_units ? p.n_un_all : 0;
     if (with_sums) {
         if (psums_frames < batch) { psums_frames = batch; psums_first = 0; }
-        const size_t need = (size_t)psums_frames * p.ntiles * 3 * sizeof(uint32_t);
+        const size_t per_frame = (size_t)(p.n_un_all + p.n_slow > p.ntiles ? p.n_un_all + p.n_slow : p.ntiles) * 3;   // either layout fits
+        const size_t need = (size_t)psums_frames * per_frame * sizeof(uint32_t);
         if (need > p.psums_cap) {
             // (never while another stream still uses the buffer: the first half-batch call of a step sizes it for the whole step)
             if (p.psums) (void)hipFree(p.psums);
             p.psums = nullptr; p.psums_cap = 0;
             if ((e = hipMalloc(&p.psums, need)) != hipSuccess) return e;
             p.psums_cap = need;
+            p.psums_layout = -1;
         }
-        a.psums = static_cast<uint32_t *>(p.psums) + (size_t)psums_first * p.ntiles * 3;
-        // the units add their sums atomically: zero first
-        if ((e = hipMemsetAsync(a.psums, 0, (size_t)batch * p.ntiles * 3 * sizeof(uint32_t), st)) != hipSuccess) return e;
+        if (p.psums_layout != a.nsum) {   // a new buffer, or the other layout (units <-> every tile on the per-tap kernel): zero once
+            if ((e = hipMemsetAsync(p.psums, 0, p.psums_cap, st)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // (the other stream's slice may start before this stream reaches the memset)
+            p.psums_layout = a.nsum;
+        }
+        a.psums = static_cast<uint32_t *>(p.psums) + (size_t)psums_first * a.nsum * 3;
     }
     auto grid_blocks = [&]() -> unsigned {
         if (a.xcd_affine >= 1) return (unsigned)(a.ngroups * (((a.nchunks + 7) / 8) * 8));
@@ -734,7 +748,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (with_sums) {
-        hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, p.ntiles, d_chsums);
+        hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, a.nsum, d_chsums);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (scratch) {

@@ -637,6 +637,12 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 #ifndef BEVW_UNIT_EARLY_STORE
 #define BEVW_UNIT_EARLY_STORE 0
 #endif
+#ifndef BEVW_UNIT_NO_BIG
+#define BEVW_UNIT_NO_BIG 0
+#endif
+#ifndef BEVW_UNIT_ABL_SUMS
+#define BEVW_UNIT_ABL_SUMS 0
+#endif
 #ifdef BEVW_UNIT_PRIO_ON
 #define BEVW_UNIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -672,7 +678,7 @@ __device__ __forceinline__ void unit_store_quad(pair_u32x3 v, __amdgpu_buffer_rs
     else __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, kPairStoreAux);
 }
 template <bool BLEND, bool SUMS, int NQ, int GR, int NCON, bool WIDE = false>
-__device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds)
+__device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds, uint4 *wave_sums = nullptr)
 {
     static_assert(NQ >= 1 && NQ <= kUnitMaxNQ && GR >= 1 && GR <= kUnitMaxGR && (NCON == 1 || NCON == 2), "unit class");
     static_assert(!(WIDE && SUMS), "wide plans carry no channel sums");
@@ -842,7 +848,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             uint32_t acc[4][3];
 #pragma unroll
             for (int p = 0; p < 4; ++p) bilinear_pairs(pw[i0[j][0][p]], pw[i1[j][0][p]], wxa[j][0][p], wxa[j][0][p] << 16, wy[j][0][p], acc[p]);
-            if (NCON == 1 && !SUMS && !car_any) {
+            if (NCON == 1 && !car_any) {
                 pack_accs(acc, d[j][0], d[j][1], d[j][2]);
             } else {
                 uint32_t P[4];
@@ -864,19 +870,18 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                         P[p] = px;
                     }
                 }
-                if (SUMS) {   // the lane's own sums over its quad slots; the wave reduction follows the loop
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        tb = __builtin_amdgcn_udot4(P[p], 0x00000001u, tb, false);
-                        tg = __builtin_amdgcn_udot4(P[p], 0x00000100u, tg, false);
-                        tr = __builtin_amdgcn_udot4(P[p], 0x00010000u, tr, false);
-                    }
-                }
                 if (car_any) {     // uniform over the wave; the sprite is not kept in registers across the frame loop
                     const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
                     add_car(P, c.x, c.y, c.z);
                 }
                 pack_pixels(P, d[j][0], d[j][1], d[j][2]);
+            }
+            if (SUMS) {
+                // the lane's own channel sums over its quad slots, from the 12 packed bytes B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3 (no sprite in
+                // this mode: the car is added behind the gains); the wave reduction follows the loop
+                tb = __builtin_amdgcn_udot4(d[j][2], 0x00000100u, __builtin_amdgcn_udot4(d[j][1], 0x00010000u, __builtin_amdgcn_udot4(d[j][0], 0x01000001u, tb, false), false), false);
+                tg = __builtin_amdgcn_udot4(d[j][2], 0x00010000u, __builtin_amdgcn_udot4(d[j][1], 0x01000001u, __builtin_amdgcn_udot4(d[j][0], 0x00000100u, tg, false), false), false);
+                tr = __builtin_amdgcn_udot4(d[j][2], 0x01000001u, __builtin_amdgcn_udot4(d[j][1], 0x00000100u, __builtin_amdgcn_udot4(d[j][0], 0x00010000u, tr, false), false), false);
             }
 #if BEVW_UNIT_EARLY_STORE
             {   // experiment: a quad is stored as soon as it is interpolated (the store stream spread over the frame's arithmetic)
@@ -889,12 +894,14 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         if (SUMS) {
             // One wave reduction per frame, on the VALU (DPP adds): round 3 reduced every quad slot with __shfl_xor = 12 ds_bpermute_b32 per
             // slot, more LDS-pipe instructions than the slot's pixel reads.  A lane's NQ x 4 pixels sum to <= 4080 per channel, a wave to
-            // <= 261120.  Skipped quads and lanes without a quad have zero entries: they add 0.  psums is zeroed per call (plan_stitch_impl)
+            // <= 261120.  Skipped quads and lanes without a quad have zero entries: they add 0.  The four waves' sums meet in LDS behind the
+            // frame's barrier (two slots, alternating with the frame), and ONE lane triple of the block stores the unit's entry: no atomics
+#if BEVW_UNIT_ABL_SUMS == 2   // (timing experiment: no wave reduction -- wrong sums)
+            const uint32_t wb = tb, wg = tg, wr = tr;
+#else
             const uint32_t wb = wave_sum_dpp(tb), wg = wave_sum_dpp(tg), wr = wave_sum_dpp(tr);
-            if (lane == 0 && b < b_end) {
-                uint32_t *ps = a.psums + ((size_t)frame_of(b) * a.ntiles + sum_tile) * 3;
-                atomicAdd(ps + 0, wb); atomicAdd(ps + 1, wg); atomicAdd(ps + 2, wr);
-            }
+#endif
+            if (lane == 0) wave_sums[(ring & 1) * kUnitWaves + wave] = make_uint4(wb, wg, wr, 0u);
         }
         if (DB) land((ring + 1) % D);    // frame b+1 into the other half: nobody reads it before the barrier
 #if !BEVW_UNIT_EARLY_STORE
@@ -909,6 +916,11 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
         }
 #endif
         block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
+        if (SUMS && wave == 0 && lane < 3 && b < b_end) {
+            // (slot ring & 1 is written again in frame b + 2, behind the barrier of frame b + 1, which this wave passes after these reads)
+            const uint32_t *ws = reinterpret_cast<const uint32_t *>(wave_sums + (ring & 1) * kUnitWaves) + lane;
+            a.psums[((size_t)b * a.nsum + unit) * 3 + lane] = ws[0] + ws[4] + ws[8] + ws[12];
+        }
     };
 #endif
 #pragma unroll
@@ -929,20 +941,23 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 // block -> (chunk, unit) of the list of ALL units in the partition's own (spatial) order, class in bits 28..31: neighbouring units run
 // at the same time on the same XCD, whatever their class, so the two halves of a sector that two units share meet in the L2
 template <bool BLEND, bool SUMS>
-__device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_id, uint8_t *lds)
+__device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_id, uint8_t *lds, uint4 *wave_sums)
 {
     uint32_t chunk, group;
     if (!plan_block_map(a, block_id, chunk, group)) return;
     if ((int)group >= a.nlist) return;
     const uint32_t e = __builtin_amdgcn_readfirstlane(a.tile_list[group]), unit = e & 0x0fffffffu;
-#define BEVW_UNIT_CASE(C) case C: plan_unit_run<BLEND, SUMS, kUnitClassNQ[C], kUnitClassGR[C], kUnitClassCON[C]>(a, chunk, unit, lds); break;
+#define BEVW_UNIT_CASE(C) case C: plan_unit_run<BLEND, SUMS, kUnitClassNQ[C], kUnitClassGR[C], kUnitClassCON[C]>(a, chunk, unit, lds, wave_sums); break;
     switch (e >> 28) {
         BEVW_UNIT_CASE(0) BEVW_UNIT_CASE(1) BEVW_UNIT_CASE(2) BEVW_UNIT_CASE(3)
         // class 4 (two quads per lane, two contributors): its blend variant would set the kernel's register budget (177 .. 197 VGPRs);
         // plans of blend handles are compiled without it (UnitTuning::wide_double)
-        case 4: if (!BLEND) plan_unit_run<false, SUMS, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4]>(a, chunk, unit, lds); break;
-        BEVW_UNIT_CASE(5) BEVW_UNIT_CASE(7)
-        default: plan_unit_run<BLEND, SUMS, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6]>(a, chunk, unit, lds); break;
+        case 4: if (!BLEND) plan_unit_run<false, SUMS, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4]>(a, chunk, unit, lds, wave_sums); break;
+        BEVW_UNIT_CASE(5)
+#if !BEVW_UNIT_NO_BIG   // (experiment builds without the (4, 4) class: every other class fits 128 VGPRs = 4 waves per SIMD; plans then need BEVW_UNIT_BIG=0)
+        BEVW_UNIT_CASE(7)
+#endif
+        default: plan_unit_run<BLEND, SUMS, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6]>(a, chunk, unit, lds, wave_sums); break;
     }
 #undef BEVW_UNIT_CASE
 }
@@ -955,7 +970,8 @@ template <bool BLEND, bool SUMS>
 __global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_eu(BEVW_PLAN_ALL_WAVES, BEVW_PLAN_ALL_WAVES))) k_plan_units(PlanArgs a)
 {
     __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
-    plan_unit_any<BLEND, SUMS>(a, blockIdx.x, patch);
+    __shared__ uint4 wave_sums[SUMS ? 2 * kUnitWaves : 1];   // balance: the waves' channel sums of a frame (plan_unit_run)
+    plan_unit_any<BLEND, SUMS>(a, blockIdx.x, patch, wave_sums);
 }
 
 // wide plans (analytic projection): every unit class in one launch, partition order, as plan_unit_any
