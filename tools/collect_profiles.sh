@@ -1,11 +1,14 @@
 #!/bin/bash
-# Round-end evidence, run on the GPU box from the repo root:  gpurun -- 'bash tools/collect_profiles.sh'
-# Everything lands under gpurun_out/final/; copy what should be judged into profiles/r05_final/.
+# Round-end evidence, run on the GPU box from the repo root:
+#   git rev-parse HEAD > tools/scratch/git_head.txt; git status --porcelain | wc -l >> tools/scratch/git_head.txt; gpurun -- 'bash tools/collect_profiles.sh'
+# (.git does not travel to the box: the hash of the tree the collection ran on goes along as a file and is copied beside the results).
+# Everything lands under gpurun_out/final/; copy what should be judged into profiles/rNN_final/ (ONE such directory per round).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
+{ echo "collected $(date -u +%Y-%m-%dT%H:%M:%SZ) on $(python -c 'from cameracalibration_amd import _ffi; print(_ffi.device_name(0))' 2>/dev/null)"; echo "git HEAD + number of uncommitted files:"; cat tools/scratch/git_head.txt 2>/dev/null || echo unknown; echo "libbevwarp.so sha256: $(sha256sum cameracalibration_amd/libbevwarp.so | cut -c1-16)"; } > $O/COLLECTION.txt
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -n "passed\|failed" $O/pytest_gpu.log | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 cd /tmp && export TMPDIR=/tmp
@@ -24,6 +27,7 @@ timeout 200 rocprofv3 --pmc SQ_INSTS_VALU --output-format csv -d /tmp/pv_rep -- 
 cp $(find /tmp/pv_rep -name "*counter_collection.csv" | head -1) $O/pmc_valu_jpeg_decode_b64_repo.csv
 cd $R
 python tools/jpeg_valu.py $O | grep "wave-level"
+python tools/valu_mix.py $O      # the instruction-mix-weighted issue peak of the JPEG lines (peak_ginst, peak_basis)
 python - <<'P'
 import json
 d=json.load(open('gpurun_out/final/jpeg_valu.json'))
@@ -47,9 +51,10 @@ BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 -
   bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 --placements 1 --single-layout 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
 python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
 cd /tmp && export TMPDIR=/tmp
+# kernel statistics: the average over THREE buffer placements (placement variance is +-5 %: one draw can flatter or slander the kernel)
 for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k; do
   rm -rf /tmp/kt_$w
-  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 1 --single-layout --no-cpu-baseline --no-live-traffic > /tmp/kt_$w.log 2>&1
+  timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 3 --single-layout --no-cpu-baseline --no-live-traffic > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_${w}_$c

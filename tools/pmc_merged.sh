@@ -9,7 +9,7 @@ i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1)); rm -rf /tmp/pm_$i
-  env $E timeout 120 rocprofv3 --pmc $set --output-format csv -d /tmp/pm_$i -- python $R/bench.py --workload $W --steps 3 --warmup 1 --placements 1 --single-layout --no-cpu-baseline "$@" > /tmp/pm_$i.log 2>&1
+  env $E timeout 120 rocprofv3 --pmc $set --output-format csv -d /tmp/pm_$i -- python $R/bench.py --workload $W --steps 3 --warmup 1 --placements 1 --single-layout --no-cpu-baseline --no-f4 --no-live-traffic "$@" > /tmp/pm_$i.log 2>&1
   f=$(find /tmp/pm_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp $f $O/pass_$i.csv || { echo "pass $i failed"; tail -3 /tmp/pm_$i.log; }
 done <<'SETS'
 GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES
