@@ -17,7 +17,7 @@ ABI_VERSION = 4
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
 PROJ_LUT, PROJ_ANALYTIC, PROJ_ANALYTIC_F32 = 0, 1, 2   # bevw_set_projection
 PITCH_DENSE, PITCH_ALIGNED = 0, -1                    # bevw_set_output_pitch
-COMPAT_FILLPOLY, COMPAT_ADDWEIGHTED = 0, 1   # bevw_set_compat keys (include/bevwarp.h)
+COMPAT_FILLPOLY, COMPAT_ADDWEIGHTED, COMPAT_WARP, COMPAT_REMAP = 0, 1, 2, 3   # bevw_set_compat keys (include/bevwarp.h)
 
 
 class BevwError(Exception):

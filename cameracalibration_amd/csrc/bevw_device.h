@@ -244,9 +244,18 @@ static inline unsigned xcd_frame_grid(unsigned blocks_per_frame, unsigned nframe
 // ---- cv2.remap u8c3, INTER_LINEAR fixed point, BORDER_CONSTANT 0 -------------------------------------------
 // call sites: surroundBEV.py:110-111,116-117; intrinsicCalib.py:193-195; Tools/undistort.py:66
 // out = (sum p * w15 + 2^14) >> 15 with w15 = 32 * w10  ==  (sum p * w10 + 512) >> 10, w10 = 5-bit x 5-bit products.
+// ties_even (BEVW_COMPAT_REMAP 1): the sum S of the four weighted taps is exact in either arithmetic; the classic fixed-point kernels
+// round it as (S + 512) >> 10 = S / 1024 half UP, a float32 kernel that ends in cvRound (OpenCV >= 4.11's linear kernels, when they take the
+// fixed-point maps) rounds the same exact value half to EVEN -- they differ only where S = 512 (mod 1024) and the rounded-up result is odd.
+__device__ __forceinline__ int remap_round10(int S, int ties_even)
+{
+    int r = (S + 512) >> 10;
+    if (ties_even && (S & 1023) == 512 && (r & 1)) --r;
+    return r;
+}
 template <bool LUM>
 __device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, int sw, int sh, int sx, int sy,
-                                              unsigned code, int out[3], int delta, const HsvTables *hsv)
+                                              unsigned code, int out[3], int delta, const HsvTables *hsv, int ties_even = 0)
 {
     const int fx = code & 31, fy = (code >> 5) & 31;
     const int ax = kQOne - fx, ay = kQOne - fy;
@@ -264,7 +273,7 @@ __device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, i
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            out[k] = (t[0][k] * w00 + t[1][k] * w01 + t[2][k] * w10 + t[3][k] * w11 + 512) >> 10;
+            out[k] = remap_round10(t[0][k] * w00 + t[1][k] * w01 + t[2][k] * w10 + t[3][k] * w11, ties_even);
     } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
         out[0] = out[1] = out[2] = 0;
     } else {
@@ -284,7 +293,7 @@ __device__ __forceinline__ void remap_u8c3_px(const uint8_t *__restrict__ src, i
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            out[k] = (t[0][k] * w00 + t[1][k] * w01 + t[2][k] * w10 + t[3][k] * w11 + 512) >> 10;
+            out[k] = remap_round10(t[0][k] * w00 + t[1][k] * w01 + t[2][k] * w10 + t[3][k] * w11, ties_even);
     }
 }
 
@@ -340,6 +349,70 @@ __device__ __forceinline__ void remap_f32_px(const T *__restrict__ src, int sw, 
             float v3 = (x1 && y1) ? (float)src[((size_t)(sy + 1) * sw + sx + 1) * CN + k] : 0.f;
             out[k] = rne_f(v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3);
         }
+    }
+}
+
+// ---- OpenCV >= 4.11: float32 linear kernels of warpPerspective (8U / 16U / 32F, C1 / C3 / C4) -- a FAMILY of candidate restatements ----
+// The classic kernels above (OpenCV 2.4 ... 4.10) quantise the source position to 1/32 pixel and interpolate in fixed point (8U) or with
+// tabulated float weights (16S / 16U).  OpenCV 4.11 added kernels that keep the position in float32: (sx, sy) = (M x) / w evaluated in
+// float, ix = floor(sx), alpha = sx - ix, out = cvRound(lerp(lerp(p00, p01, alpha), lerp(p10, p11, alpha), beta)), border taps replaced by
+// the border value one by one.  Their exact operation order is not reproducible without the library at hand (and differs between its
+// own SIMD body -- fused multiply-adds on AVX2 / NEON builds -- and scalar tail), so BEVW_COMPAT_WARP selects a MEMBER of a family spanned
+// by the choices below; the implementation probes of tests/golden/ (stored whole) decide which member, if any, IS a given cv2
+// (tests/test_cv2_goldens.py tries them all).  Engine and oracle implement every member with the same float32 operations.
+constexpr int kWarpF32 = 1;          // 0: the classic fixed-point path (all other bits ignored)
+constexpr int kWarpCoordFma = 2;     // coordinates: fma(M0, x, fma(M1, y, M2)) instead of (x * M0 + y * M1) + M2
+constexpr int kWarpInterFma = 4;     // interpolation with fused multiply-adds
+constexpr int kWarpInterTwoWeights = 8;   // (1 - t) * a + t * b instead of a + t * (b - a)
+constexpr int kWarpCoordF64 = 16;    // numerators and denominator in double from the double matrix, sx = float(X / W)
+constexpr int kWarpCoordRecip = 32;  // sx = X * (1 / w) instead of X / w
+constexpr int kWarpModes = 64;
+
+__host__ __device__ __forceinline__ float warp_lerp(float a, float b, float t, int flags)
+{
+    if (flags & kWarpInterTwoWeights) {
+        const float u = 1.f - t;
+        return (flags & kWarpInterFma) ? fmaf(t, b, u * a) : u * a + t * b;
+    }
+    return (flags & kWarpInterFma) ? fmaf(t, b - a, a) : a + t * (b - a);
+}
+
+// one destination pixel of cv2.warpPerspective(src, M_inv given, INTER_LINEAR, BORDER_CONSTANT 0) through member `flags` of the family.
+// T = uint8_t / uint16_t; results are the integers cvRound leaves before the saturating store.
+template <typename T, int CN>
+__device__ __forceinline__ void warp_f32_px(const T *__restrict__ src, int sw, int sh, const double *__restrict__ M, int x, int y, int flags,
+                                            int out[CN])
+{
+    float sx, sy;
+    if (flags & kWarpCoordF64) {
+        const double X = M[0] * x + M[1] * y + M[2], Y = M[3] * x + M[4] * y + M[5], W = M[6] * x + M[7] * y + M[8];
+        sx = (float)(X / W); sy = (float)(Y / W);
+    } else {
+        const float m0 = (float)M[0], m1 = (float)M[1], m2 = (float)M[2], m3 = (float)M[3], m4 = (float)M[4], m5 = (float)M[5];
+        const float m6 = (float)M[6], m7 = (float)M[7], m8 = (float)M[8], fx = (float)x, fy = (float)y;
+        float X, Y, W;
+        if (flags & kWarpCoordFma) {
+            X = fmaf(m0, fx, fmaf(m1, fy, m2)); Y = fmaf(m3, fx, fmaf(m4, fy, m5)); W = fmaf(m6, fx, fmaf(m7, fy, m8));
+        } else {
+            X = (fx * m0 + fy * m1) + m2; Y = (fx * m3 + fy * m4) + m5; W = (fx * m6 + fy * m7) + m8;
+        }
+        if (flags & kWarpCoordRecip) { const float iw = 1.f / W; sx = X * iw; sy = Y * iw; }
+        else { sx = X / W; sy = Y / W; }
+    }
+#pragma unroll
+    for (int k = 0; k < CN; ++k) out[k] = 0;
+    if (!(sx > -2.f && sx < (float)sw + 1.f && sy > -2.f && sy < (float)sh + 1.f)) return;   // every tap outside (also NaN / inf): border value
+    const float flx = floorf(sx), fly = floorf(sy);
+    const int ix = (int)flx, iy = (int)fly;
+    const float alpha = sx - flx, beta = sy - fly;
+    const bool x0 = ix >= 0 && ix < sw, x1 = ix + 1 >= 0 && ix + 1 < sw, y0 = iy >= 0 && iy < sh, y1 = iy + 1 >= 0 && iy + 1 < sh;
+#pragma unroll
+    for (int k = 0; k < CN; ++k) {
+        const float p00 = (x0 && y0) ? (float)src[((size_t)iy * sw + ix) * CN + k] : 0.f;
+        const float p01 = (x1 && y0) ? (float)src[((size_t)iy * sw + ix + 1) * CN + k] : 0.f;
+        const float p10 = (x0 && y1) ? (float)src[((size_t)(iy + 1) * sw + ix) * CN + k] : 0.f;
+        const float p11 = (x1 && y1) ? (float)src[((size_t)(iy + 1) * sw + ix + 1) * CN + k] : 0.f;
+        out[k] = rne_f(warp_lerp(warp_lerp(p00, p01, alpha, flags), warp_lerp(p10, p11, alpha, flags), beta, flags));
     }
 }
 

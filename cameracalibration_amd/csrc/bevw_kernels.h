@@ -80,8 +80,10 @@ static __global__ void k_pinhole_map(PinholeParams p, const double *__restrict__
 // Camera.get_bev_maps (surroundBEV.py:105-108): cv2.warpPerspective over the CV_16SC2 and CV_16UC1 undistort maps.
 struct Mat3 { double m[9]; };
 
+// warp_mode (BEVW_COMPAT_WARP): 0 = classic; else the 16UC1 map goes through member `warp_mode` of the float32 family (bevw_device.h:
+// OpenCV >= 4.11 has float32 linear kernels for one-channel 16U images; the two-channel 16S map is not a type they take and stays classic)
 static __global__ void k_bev_lut(Mat3 Minv, const int16_t *__restrict__ und1, const uint16_t *__restrict__ und2, int uw,
-                          int uh, int bw, int bh, int bw0, int16_t *__restrict__ lut1, uint16_t *__restrict__ lut2)
+                          int uh, int bw, int bh, int bw0, int16_t *__restrict__ lut1, uint16_t *__restrict__ lut2, int warp_mode = 0)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -91,7 +93,8 @@ static __global__ void k_bev_lut(Mat3 Minv, const int16_t *__restrict__ und1, co
     perspective_coord(Minv.m, x, y, bw0, sx, sy, code);
     int o1[2], o2[1];
     remap_f32_px<int16_t, 2>(und1, uw, uh, sx, sy, code, o1);
-    remap_f32_px<uint16_t, 1>(und2, uw, uh, sx, sy, code, o2);
+    if (warp_mode & kWarpF32) warp_f32_px<uint16_t, 1>(und2, uw, uh, Minv.m, x, y, warp_mode, o2);
+    else remap_f32_px<uint16_t, 1>(und2, uw, uh, sx, sy, code, o2);
     const size_t o = (size_t)y * bw + x;
     lut1[o * 2 + 0] = (int16_t)sat_s16(o1[0]);
     lut1[o * 2 + 1] = (int16_t)sat_s16(o1[1]);
@@ -250,7 +253,7 @@ static __global__ void k_blend_weights(uint8_t *__restrict__ maskA, const uint8_
 // cv2.remap(src, map1, map2, INTER_LINEAR) for a batch: one thread per destination pixel.
 // grid = (ceil(dw / 256), dh, batch)
 static __global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int sh, const int16_t *__restrict__ map1,
-                            const uint16_t *__restrict__ map2, int dw, int dh, uint8_t *__restrict__ dst)
+                            const uint16_t *__restrict__ map2, int dw, int dh, uint8_t *__restrict__ dst, int ties_even = 0)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -260,13 +263,14 @@ static __global__ void k_remap_lut(const uint8_t *__restrict__ src, int sw, int 
     uint8_t *d = dst + ((size_t)blockIdx.z * dw * dh + o) * 3;
     const int sx = map1[o * 2], sy = map1[o * 2 + 1];
     int out[3];
-    remap_u8c3_px<false>(s, sw, sh, sx, sy, map2[o] & (kQTab2 - 1), out, 0, nullptr);
+    remap_u8c3_px<false>(s, sw, sh, sx, sy, map2[o] & (kQTab2 - 1), out, 0, nullptr, ties_even);
     d[0] = (uint8_t)out[0]; d[1] = (uint8_t)out[1]; d[2] = (uint8_t)out[2];
 }
 
 // cv2.warpPerspective(src_8UC3, H, dsize): coordinates made on the fly (extrinsicCalib.py:166-169).
+// warp_mode (BEVW_COMPAT_WARP): 0 = the classic fixed-point kernels, else member `warp_mode` of the float32 family (bevw_device.h)
 static __global__ void k_warp_perspective(const uint8_t *__restrict__ src, int sw, int sh, Mat3 Minv, int bw0, int dw, int dh,
-                                   uint8_t *__restrict__ dst)
+                                   uint8_t *__restrict__ dst, int warp_mode = 0)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -276,6 +280,11 @@ static __global__ void k_warp_perspective(const uint8_t *__restrict__ src, int s
     uint8_t *d = dst + ((size_t)blockIdx.z * dw * dh + o) * 3;
     int sx, sy, out[3];
     unsigned code;
+    if (warp_mode & kWarpF32) {
+        warp_f32_px<uint8_t, 3>(s, sw, sh, Minv.m, x, y, warp_mode, out);
+        d[0] = (uint8_t)sat_u8(out[0]); d[1] = (uint8_t)sat_u8(out[1]); d[2] = (uint8_t)sat_u8(out[2]);
+        return;
+    }
     perspective_coord(Minv.m, x, y, bw0, sx, sy, code);
     remap_u8c3_px<false>(s, sw, sh, sx, sy, code, out, 0, nullptr);
     d[0] = (uint8_t)out[0]; d[1] = (uint8_t)out[1]; d[2] = (uint8_t)out[2];
@@ -376,7 +385,7 @@ template <bool BLEND, bool BAL>
 static __global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, int fh, StitchTables T, int bw, int bh,
                             const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                             const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
-                            uint8_t *__restrict__ out)
+                            uint8_t *__restrict__ out, int ties_even = 0)
 {
     __shared__ HsvTables hsv;
     __shared__ unsigned long long part[3][4];
@@ -398,7 +407,7 @@ static __global__ void k_stitch_pp(const uint8_t *__restrict__ frames, int fw, i
             const uint8_t *src = frames + ((size_t)b * 4 + c) * frame_bytes;
             const int sx = T.lut1[c][o * 2], sy = T.lut1[c][o * 2 + 1];
             int v[3];
-            remap_u8c3_px<BAL>(src, fw, fh, sx, sy, T.lut2[c][o] & (kQTab2 - 1), v, BAL ? deltas[b * 4 + c] : 0, &hsv);
+            remap_u8c3_px<BAL>(src, fw, fh, sx, sy, T.lut2[c][o] & (kQTab2 - 1), v, BAL ? deltas[b * 4 + c] : 0, &hsv, ties_even);
             if (BLEND) {
                 const float wgt = blend_weight_f32(m);
                 v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);

@@ -115,7 +115,7 @@ static bool host_clip_segment(int w, int h, long long &x1, long long &y1, long l
 // Edge table of cv2.fillPoly for one polygon (XY_SHIFT = 16): slopes come from the image-clipped end points,
 // the y extent from the original ones.  Only scalars are produced here; pixels are written by k_poly_*.
 // OpenCV-version-sensitive choices (include/bevwarp.h: bevw_set_compat); process-wide, read when tables are built / gains applied
-static std::atomic<int> g_compat[2] = {{1}, {1}};   // the DEFAULTS of new handles; a handle snapshots both in bevw_build
+static std::atomic<int> g_compat[BEVW_COMPAT_KEYS] = {{1}, {1}, {0}, {0}};   // the DEFAULTS of new handles; a handle snapshots them in bevw_build
 
 static PolyJob make_poly_job(const int (*pts)[2], int npts, int w, int h, bool modern)
 {
@@ -268,6 +268,7 @@ struct bevw_remapper {
     DevBuf map1, map2, in, out, ones;
     Plan plan;            // single-image contributor plan (same kernels as the BEV stitch, ncams = 1)
     bool plan_ready = false;
+    int ties_even = 0;    // BEVW_COMPAT_REMAP at creation: half-to-even ties -> the per-pixel kernel (the plan's arithmetic rounds half up)
 };
 
 // cv2.remap as a 1-camera stitch: every destination pixel has exactly one contributor with mask 255.
@@ -275,7 +276,7 @@ static int remapper_build_plan(bevw_remapper *r)
 {
     static const int use_plan = [] { const char *s = getenv("BEVW_REMAP_PLAN"); return s ? atoi(s) : 1; }();
     r->plan_ready = false;
-    if (!use_plan) return BEVW_OK;
+    if (!use_plan || r->ties_even) return BEVW_OK;
     const size_t npx = (size_t)r->dw * r->dh;
     BEVW_TRY(r->ones.reserve(npx));
     HIP_TRY(hipMemsetAsync(r->ones.p, 0xff, npx, r->stream));
@@ -297,6 +298,7 @@ static int remapper_alloc(int device, int sw, int sh, int dw, int dh, bevw_remap
     bevw_remapper *r = new (std::nothrow) bevw_remapper();
     if (!r) return fail(BEVW_E_NOMEM, "out of host memory");
     r->device = device; r->sw = sw; r->sh = sh; r->dw = dw; r->dh = dh;
+    r->ties_even = g_compat[BEVW_COMPAT_REMAP].load();
     int s = BEVW_OK;
     if (hipStreamCreate(&r->stream) != hipSuccess || hipEventCreate(&r->ev0) != hipSuccess ||
         hipEventCreate(&r->ev1) != hipSuccess)
@@ -309,13 +311,13 @@ static int remapper_alloc(int device, int sw, int sh, int dw, int dh, bevw_remap
 }
 
 static int remap_launch(hipStream_t st, const uint8_t *d_src, int sw, int sh, const int16_t *m1, const uint16_t *m2,
-                        int dw, int dh, int batch, uint8_t *d_dst)
+                        int dw, int dh, int batch, uint8_t *d_dst, int ties_even = 0)
 {
     for (int b0 = 0; b0 < batch; b0 += 65535) {
         const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
         dim3 grid((dw + 255) / 256, dh, nb);
         hipLaunchKernelGGL(k_remap_lut, grid, dim3(256), 0, st, d_src + (size_t)b0 * sw * sh * 3, sw, sh, m1, m2, dw, dh,
-                           d_dst + (size_t)b0 * dw * dh * 3);
+                           d_dst + (size_t)b0 * dw * dh * 3, ties_even);
     }
     return launch_check("k_remap_lut");
 }
@@ -326,15 +328,18 @@ int bevw_abi_version(void) { return BEVW_ABI_VERSION; }
 
 int bevw_set_compat(int key, int value)
 {
-    if (key < 0 || key >= 2) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
-    if (value != 0 && value != 1) return fail(BEVW_E_INVALID, "compatibility value must be 0 or 1");
+    if (key < 0 || key >= BEVW_COMPAT_KEYS) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
+    if (key == BEVW_COMPAT_WARP) {
+        if (value < 0 || value >= kWarpModes || (value != 0 && !(value & kWarpF32)))
+            return fail(BEVW_E_INVALID, "BEVW_COMPAT_WARP: 0 (classic) or an odd member number below %d", kWarpModes);
+    } else if (value != 0 && value != 1) return fail(BEVW_E_INVALID, "compatibility value must be 0 or 1");
     g_compat[key].store(value);
     return BEVW_OK;
 }
 
 int bevw_get_compat(int key)
 {
-    if (key < 0 || key >= 2) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
+    if (key < 0 || key >= BEVW_COMPAT_KEYS) return fail(BEVW_E_INVALID, "unknown compatibility key %d", key);
     return g_compat[key].load();
 }
 
@@ -470,7 +475,7 @@ int bevw_remap_device(bevw_remapper *r, const void *d_src, int batch, void *d_ds
         return plan_stitch(r->plan, r->stream, (const uint8_t *)d_src, batch, false, false, nullptr, nullptr, nullptr, nullptr,
                            (uint8_t *)d_dst);
     return remap_launch(r->stream, (const uint8_t *)d_src, r->sw, r->sh, r->map1.as<int16_t>(), r->map2.as<uint16_t>(),
-                        r->dw, r->dh, batch, (uint8_t *)d_dst);
+                        r->dw, r->dh, batch, (uint8_t *)d_dst, r->ties_even);
 }
 
 int bevw_remap(bevw_remapper *r, const uint8_t *src, int batch, uint8_t *dst)
@@ -559,7 +564,7 @@ int bevw_warp_perspective_u8c3(int device, const uint8_t *src, int src_w, int sr
             dim3 grid((dst_w + 255) / 256, dst_h, nb);
             hipLaunchKernelGGL(k_warp_perspective, grid, dim3(256), 0, 0, in.as<uint8_t>() + (size_t)b0 * src_w * src_h * 3,
                                src_w, src_h, Minv, persp_block_width(dst_w, dst_h), dst_w, dst_h,
-                               out.as<uint8_t>() + (size_t)b0 * dst_w * dst_h * 3);
+                               out.as<uint8_t>() + (size_t)b0 * dst_w * dst_h * 3, g_compat[BEVW_COMPAT_WARP].load());
         }
         s = launch_check("k_warp_perspective");
     }
@@ -648,7 +653,7 @@ struct bevw_handle {
     Plan plan;
     int schedule_in_use = BEVW_SCHED_PER_PIXEL;
     int projection = BEVW_PROJ_LUT;   // bevw_set_projection
-    int compat[2] = {1, 1};           // bevw_set_compat values at bevw_build: a handle keeps the arithmetic it was built with
+    int compat[BEVW_COMPAT_KEYS] = {1, 1, 0, 0};   // bevw_set_compat values at bevw_build: a handle keeps the arithmetic it was built with
     int pitch_request = BEVW_PITCH_DENSE;   // bevw_set_output_pitch
     int pitch_px = 0;                 // pixels per row of the device-side BEV images (== bev_width unless a pitch was requested)
     DevBuf car_pitched;               // the car sprite with rows of pitch_px pixels (gain pass of a pitched handle)
@@ -711,7 +716,7 @@ static int stitch_per_pixel(bevw_handle *h, const uint8_t *d_frames, int batch, 
 #define LAUNCH_PP(BL, BA)                                                                                         \
         hipLaunchKernelGGL((k_stitch_pp<BL, BA>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, T, \
                            c.bev_width, c.bev_height, deltas ? deltas + b0 * 4 : nullptr, tab, d_car,              \
-                           chs ? chs + b0 * 3 : nullptr, o)
+                           chs ? chs + b0 * 3 : nullptr, o, h->compat[BEVW_COMPAT_REMAP])
         if (c.blend && c.balance) LAUNCH_PP(true, true);
         else if (c.blend) LAUNCH_PP(true, false);
         else if (c.balance) LAUNCH_PP(false, true);
@@ -1010,7 +1015,7 @@ int bevw_build(bevw_handle *h)
         if (h->owns(c) && !h->cam_set[c]) return fail(BEVW_E_INVALID, "camera %d has no K/D/H (bevw_set_camera)", c);
     const bevw_config &cfg = h->cfg;
     BEVW_TRY(use_device(cfg.device));
-    for (int k = 0; k < 2; ++k) h->compat[k] = g_compat[k].load();   // later bevw_set_compat calls do not reach this handle
+    for (int k = 0; k < BEVW_COMPAT_KEYS; ++k) h->compat[k] = g_compat[k].load();   // later bevw_set_compat calls do not reach this handle
     hipStream_t st = h->stream;
     const int uw = (int)(cfg.frame_width * cfg.size_scale), uh = (int)(cfg.frame_height * cfg.size_scale);
     const int bw = cfg.bev_width, bh = cfg.bev_height;
@@ -1037,7 +1042,7 @@ int bevw_build(bevw_handle *h)
         h->arig.uw = uw; h->arig.uh = uh;
         hipLaunchKernelGGL(k_bev_lut, dim3((bw + 255) / 256, bh), dim3(256), 0, st, Minv, h->und1[c].as<int16_t>(),
                            h->und2[c].as<uint16_t>(), uw, uh, bw, bh, persp_block_width(bw, bh), h->lut1[c].as<int16_t>(),
-                           h->lut2[c].as<uint16_t>());
+                           h->lut2[c].as<uint16_t>(), h->compat[BEVW_COMPAT_WARP]);
         BEVW_TRY(launch_check("k_bev_lut"));
     }
 
@@ -1121,7 +1126,14 @@ int bevw_build(bevw_handle *h)
     if (h->pitch_px != bw && (cfg.schedule == BEVW_SCHED_PER_PIXEL || !h->plan.usable))
         return fail(BEVW_E_INVALID, "an output pitch needs the tile-plan schedule");
     h->schedule_in_use = BEVW_SCHED_PER_PIXEL;
-    if (cfg.schedule == BEVW_SCHED_TILE_PLAN) {
+    if (h->compat[BEVW_COMPAT_REMAP] && h->shard_n)
+        return fail(BEVW_E_INVALID, "BEVW_COMPAT_REMAP 1 is not available on camera-shard handles (they run the tile plan)");
+    if (h->compat[BEVW_COMPAT_REMAP]) {
+        // half-to-even ties (the candidate rule of OpenCV >= 4.11's float kernels) exist in the per-pixel kernels only: the tile plan's
+        // dot-product arithmetic rounds half up
+        if (cfg.schedule == BEVW_SCHED_TILE_PLAN || h->pitch_px != bw)
+            return fail(BEVW_E_INVALID, "BEVW_COMPAT_REMAP 1 runs the per-pixel schedule (no tile plan, no output pitch)");
+    } else if (cfg.schedule == BEVW_SCHED_TILE_PLAN) {
         if (!h->plan.usable) return fail(BEVW_E_INVALID, "tile plan unusable: %d contributors on some pixel", h->plan.max_contrib);
         h->schedule_in_use = BEVW_SCHED_TILE_PLAN;
     } else if (cfg.schedule == BEVW_SCHED_AUTO && h->plan.usable) {
@@ -1306,7 +1318,7 @@ static int camera_remap(bevw_handle *h, const uint8_t *src, int sw, int sh, cons
     BEVW_TRY(h->in.reserve(nin));
     BEVW_TRY(h->out.reserve(nout));
     HIP_TRY(hipMemcpyAsync(h->in.p, src, nin, hipMemcpyHostToDevice, h->stream));
-    BEVW_TRY(remap_launch(h->stream, h->in.as<uint8_t>(), sw, sh, m1, m2, dw, dh, batch, h->out.as<uint8_t>()));
+    BEVW_TRY(remap_launch(h->stream, h->in.as<uint8_t>(), sw, sh, m1, m2, dw, dh, batch, h->out.as<uint8_t>(), h->compat[BEVW_COMPAT_REMAP]));
     HIP_TRY(hipMemcpyAsync(dst, h->out.p, nout, hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     return BEVW_OK;

@@ -69,17 +69,31 @@ typedef struct bevw_jpeg bevw_jpeg;       /* a JPEG decode / encode context: one
 int bevw_abi_version(void);
 
 /* OpenCV-version-sensitive arithmetic behind the reference's cv2 calls.  The reference pins no OpenCV version
- * ("opencv(>=3.4.2)", README.md:14); two of the primitives it calls changed their results across releases, so the choice
- * is a switch instead of a constant.  bevw_set_compat sets the process-wide DEFAULT; a handle takes a snapshot of both values in
+ * ("opencv(>=3.4.2)", README.md:14); several of the primitives it calls changed their results across releases, so the choice
+ * is a switch instead of a constant.  bevw_set_compat sets the process-wide DEFAULT; a handle takes a snapshot of the values in
  * bevw_build and keeps it (later calls, or calls from other threads, never change the results of a handle that exists); the stand-alone
  * bevw_color_balance reads the default at call time:
  *   BEVW_COMPAT_FILLPOLY    cv2.fillPoly (surroundBEV.py:159,234): 1 = OpenCV >= 4.5.2 edge collection (default),
  *                           0 = OpenCV 2.4 .. 4.5.1 (edges between the raw vertices, left span end rounded up)
  *   BEVW_COMPAT_ADDWEIGHTED cv2.addWeighted(ch, k, 0, 0, 0, ch) (surroundBEV.py:52-54): 1 = evaluated in CV_64F (default),
  *                           0 = in CV_32F
+ *   BEVW_COMPAT_WARP        cv2.warpPerspective with INTER_LINEAR on 8UC3 (extrinsicCalib.py:166-169) and on the 16UC1 undistort map
+ *                           (surroundBEV.py:105-108, the `bev_map2` half of the LUT quirk): 0 = the classic kernels of OpenCV 2.4 ... 4.10
+ *                           (positions quantised to 1/32 pixel, fixed-point / tabulated weights; default), an ODD value < 64 = one member of
+ *                           a family of float32 kernels in the style OpenCV 4.11 introduced (position kept in float32, cvRound of a float
+ *                           lerp).  The bits: 1 float family, 2 fused multiply-adds in the coordinates, 4 fused multiply-adds in the
+ *                           interpolation, 8 (1 - t) a + t b instead of a + t (b - a), 16 coordinates in double, 32 multiply by 1 / w.
+ *                           Which member, if any, reproduces a given cv2 >= 4.11 is decided by the implementation probes of
+ *                           tests/golden/ (tests/test_cv2_goldens.py tries all of them): candidates, NOT a parity claim.
+ *   BEVW_COMPAT_REMAP       cv2.remap of 8UC3 through fixed-point maps (surroundBEV.py:110-117, intrinsicCalib.py:193-195): the weighted
+ *                           sum is exact either way; 0 = rounded half up, (S + 512) >> 10, the classic kernels (default), 1 = rounded
+ *                           half to even, what a float kernel ending in cvRound gives.  1 runs the per-pixel schedule (slower).
  * tests/golden/README.md: how a golden file from a real cv2 decides them. */
 #define BEVW_COMPAT_FILLPOLY 0
 #define BEVW_COMPAT_ADDWEIGHTED 1
+#define BEVW_COMPAT_WARP 2
+#define BEVW_COMPAT_REMAP 3
+#define BEVW_COMPAT_KEYS 4
 int bevw_set_compat(int key, int value);   /* 0 = OK */
 int bevw_get_compat(int key);              /* current value, < 0 on an unknown key */
 int bevw_device_count(void);               /* 0 when no GPU is visible (never negative) */

@@ -175,6 +175,7 @@ ORC_API int orc_invert3x3(const double m[9], double t[9])
 
 /* Destination is walked in column blocks of min(64, width) pixels (OpenCV: BLOCK_SZ 32 -> 64x16 tiles); the
  * block origin x0 enters the fp64 expression, so the association (X0 + M0*x1) is reproduced here. */
+static int g_variant[4];   /* defined with orc_set_variant below */
 ORC_API void orc_perspective_coords(const double M[9], int dw, int dh, int16_t *xy, uint16_t *alpha)
 {
     int bh0 = dh < 16 ? dh : 16;
@@ -276,6 +277,16 @@ static void build_fixed_weights(void)
     g_wtab_ready = 1;
 }
 
+/* the sum of the four taps times their 15-bit weights, rounded to the pixel value: (S + 2^14) >> 15 in the classic kernels (half up);
+ * variant 3 = 1: the same exact quotient S / 2^15 rounded half to even, as a float kernel that ends in cvRound does (the weights are
+ * 5-bit x 5-bit products times 32, the taps 8 bit: a float32 evaluation of the same sum is exact in any order) */
+static inline int remap_round15(int S)
+{
+    int r = (S + (1 << (COEF_BITS - 1))) >> COEF_BITS;
+    if (g_variant[3] && (S & ((1 << COEF_BITS) - 1)) == (1 << (COEF_BITS - 1)) && (r & 1)) --r;
+    return r;
+}
+
 ORC_API void orc_remap_u8(const uint8_t *src, int sw, int sh, int cn, const int16_t *xy, const uint16_t *alpha,
                           int dw, int dh, uint8_t *dst)
 {
@@ -283,7 +294,6 @@ ORC_API void orc_remap_u8(const uint8_t *src, int sw, int sh, int cn, const int1
 #pragma omp critical
         if (!g_wtab_ready) build_fixed_weights();
     }
-    const int rnd = 1 << (COEF_BITS - 1);
 #pragma omp parallel for schedule(static)
     for (int dy = 0; dy < dh; ++dy) {
         for (int dx = 0; dx < dw; ++dx) {
@@ -295,8 +305,7 @@ ORC_API void orc_remap_u8(const uint8_t *src, int sw, int sh, int cn, const int1
                 const uint8_t *S = src + ((size_t)sy * sw + sx) * cn;
                 size_t st = (size_t)sw * cn;
                 for (int k = 0; k < cn; ++k)
-                    D[k] = sat_u8((S[k] * w[0] + S[k + cn] * w[1] + S[k + st] * w[2] + S[k + st + cn] * w[3] + rnd) >>
-                                  COEF_BITS);
+                    D[k] = sat_u8(remap_round15(S[k] * w[0] + S[k + cn] * w[1] + S[k + st] * w[2] + S[k + st + cn] * w[3]));
             } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
                 for (int k = 0; k < cn; ++k) D[k] = 0;
             } else {
@@ -307,12 +316,92 @@ ORC_API void orc_remap_u8(const uint8_t *src, int sw, int sh, int cn, const int1
                     int v1 = (x1ok && y0ok) ? src[((size_t)sy * sw + sx + 1) * cn + k] : 0;
                     int v2 = (x0ok && y1ok) ? src[((size_t)(sy + 1) * sw + sx) * cn + k] : 0;
                     int v3 = (x1ok && y1ok) ? src[((size_t)(sy + 1) * sw + sx + 1) * cn + k] : 0;
-                    D[k] = sat_u8((v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3] + rnd) >> COEF_BITS);
+                    D[k] = sat_u8(remap_round15(v0 * w[0] + v1 * w[1] + v2 * w[2] + v3 * w[3]));
                 }
             }
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* A.4b cv2.warpPerspective(INTER_LINEAR, BORDER_CONSTANT 0) in the style of OpenCV >= 4.11: float32   */
+/*      linear kernels for 8U / 16U images with 1, 3 or 4 channels.  A FAMILY of candidates, not a     */
+/*      restatement of one known operation order (the library is not at hand; its SIMD body and scalar */
+/*      tail differ in their use of fused multiply-adds): `mode` picks the member, bit by bit --       */
+/*        1  the float family (0 = the classic path A.2 - A.4)                                         */
+/*        2  source position: fma(M0, x, fma(M1, y, M2)) instead of (x M0 + y M1) + M2                 */
+/*        4  interpolation with fused multiply-adds                                                    */
+/*        8  interpolation (1 - t) a + t b instead of a + t (b - a)                                    */
+/*       16  numerators and denominator in double, the quotient rounded to float                       */
+/*       32  multiply by 1 / w instead of dividing by w                                                */
+/*      reference call sites: extrinsicCalib.py:166-169 (8UC3), surroundBEV.py:105-108 (16UC1 map).    */
+/* ------------------------------------------------------------------------------------------------ */
+static inline float family_mix(float lo, float hi, float t, int mode)
+{
+    if (mode & 8) {
+        float keep = 1.f - t;
+        if (mode & 4) return fmaf(t, hi, keep * lo);
+        return keep * lo + t * hi;
+    }
+    if (mode & 4) return fmaf(t, hi - lo, lo);
+    return lo + t * (hi - lo);
+}
+static inline void family_position(const double M[9], int dx, int dy, int mode, float *px, float *py)
+{
+    if (mode & 16) {
+        double num_x = M[0] * dx + M[1] * dy + M[2], num_y = M[3] * dx + M[4] * dy + M[5], den = M[6] * dx + M[7] * dy + M[8];
+        *px = (float)(num_x / den);
+        *py = (float)(num_y / den);
+        return;
+    }
+    float m[9], fx = (float)dx, fy = (float)dy, num_x, num_y, den;
+    for (int i = 0; i < 9; ++i) m[i] = (float)M[i];
+    if (mode & 2) {
+        num_x = fmaf(m[0], fx, fmaf(m[1], fy, m[2]));
+        num_y = fmaf(m[3], fx, fmaf(m[4], fy, m[5]));
+        den = fmaf(m[6], fx, fmaf(m[7], fy, m[8]));
+    } else {
+        num_x = (fx * m[0] + fy * m[1]) + m[2];
+        num_y = (fx * m[3] + fy * m[4]) + m[5];
+        den = (fx * m[6] + fy * m[7]) + m[8];
+    }
+    if (mode & 32) {
+        float inv = 1.f / den;
+        *px = num_x * inv;
+        *py = num_y * inv;
+    } else {
+        *px = num_x / den;
+        *py = num_y / den;
+    }
+}
+#define DEFINE_WARP_F32(NAME, T, CAST)                                                                                   \
+    ORC_API void NAME(const T *src, int sw, int sh, int cn, const double M[9], int mode, int dw, int dh, T *dst)          \
+    {                                                                                                                     \
+        _Pragma("omp parallel for schedule(static)") for (int dy = 0; dy < dh; ++dy)                                      \
+        {                                                                                                                 \
+            for (int dx = 0; dx < dw; ++dx) {                                                                             \
+                T *D = dst + ((size_t)dy * dw + dx) * cn;                                                                 \
+                float px, py;                                                                                             \
+                family_position(M, dx, dy, mode, &px, &py);                                                               \
+                for (int k = 0; k < cn; ++k) D[k] = 0;                                                                    \
+                if (!(px > -2.f && px < (float)sw + 1.f && py > -2.f && py < (float)sh + 1.f)) continue;                  \
+                float bx = floorf(px), by = floorf(py), tx = px - bx, ty = py - by;                                       \
+                int ix = (int)bx, iy = (int)by;                                                                           \
+                for (int k = 0; k < cn; ++k) {                                                                            \
+                    float tap[2][2];                                                                                      \
+                    for (int r = 0; r < 2; ++r)                                                                           \
+                        for (int c = 0; c < 2; ++c) {                                                                     \
+                            int xx = ix + c, yy = iy + r;                                                                 \
+                            tap[r][c] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? (float)src[((size_t)yy * sw + xx) * cn + k] : 0.f; \
+                        }                                                                                                 \
+                    float top = family_mix(tap[0][0], tap[0][1], tx, mode), bot = family_mix(tap[1][0], tap[1][1], tx, mode); \
+                    D[k] = CAST(rne_f(family_mix(top, bot, ty, mode)));                                                   \
+                }                                                                                                         \
+            }                                                                                                             \
+        }                                                                                                                 \
+    }
+DEFINE_WARP_F32(orc_warp_f32_u8, uint8_t, sat_u8)
+DEFINE_WARP_F32(orc_warp_f32_u16, uint16_t, sat_u16)
 
 /* ------------------------------------------------------------------------------------------------ */
 /* A.5  cv2.fillPoly(mask, [pts], 255)  (LINE_8, shift 0)   reference: surroundBEV.py:156-159,231-234 */
@@ -386,10 +475,14 @@ static void draw_line8(uint8_t *img, int w, int h, int64_t x1, int64_t y1, int64
  * (tests/golden/README.md).  Keys as in include/bevwarp.h (BEVW_COMPAT_*):
  *   0 fillPoly edge rule   : 1 = OpenCV >= 4.5.2 (edges from the clipped end points, x + 1/2 pixel, both span ends floored),
  *                            0 = OpenCV 2.4 .. 4.5.1 (edges from the raw vertices, left span end rounded up, right end floored)
- *   1 addWeighted work type: 1 = CV_64F (arithm_op picks the scalar's depth), 0 = CV_32F (float(ch) * float(k)) */
-static int g_variant[2] = {1, 1};
-ORC_API void orc_set_variant(int key, int value) { if (key >= 0 && key < 2) g_variant[key] = value; }
-ORC_API int orc_get_variant(int key) { return (key >= 0 && key < 2) ? g_variant[key] : -1; }
+ *   1 addWeighted work type: 1 = CV_64F (arithm_op picks the scalar's depth), 0 = CV_32F (float(ch) * float(k))
+ *   2 warpPerspective      : 0 = the classic kernels of OpenCV 2.4 .. 4.10 (A.2 - A.4), odd = a member of the float32 family below
+ *                            (orc_warp_f32_*: candidates for OpenCV >= 4.11's linear kernels, decided by the implementation probes)
+ *   3 remap tie rule       : 0 = (S + 512) >> 10, half up (classic), 1 = half to even (a float kernel ending in cvRound)
+ * g_variant is declared before its first use further up in this file. */
+static int g_variant[4] = {1, 1, 0, 0};   /* (tentative definition above, initialised here) */
+ORC_API void orc_set_variant(int key, int value) { if (key >= 0 && key < 4) g_variant[key] = value; }
+ORC_API int orc_get_variant(int key) { return (key >= 0 && key < 4) ? g_variant[key] : -1; }
 
 typedef struct { int y0, y1; int64_t x, dx; } orc_edge;
 

@@ -127,6 +127,8 @@ def _configure(L: C.CDLL) -> C.CDLL:
         "orc_add_sat": (None, [vp, vp, sz, vp]),
         "orc_channel_sums": (None, [vp, sz, vp]),
         "orc_gain": (None, [vp, sz, vp]),
+        "orc_warp_f32_u8": (None, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
+        "orc_warp_f32_u16": (None, [vp, i32, i32, i32, vp, i32, i32, i32, vp]),
         "orc_set_variant": (None, [i32, i32]),
         "orc_get_variant": (i32, [i32]),
         "orc_translate_u8c3": (None, [vp, i32, i32, i32, i32, vp]),
@@ -151,9 +153,22 @@ def _c(a, dtype) -> np.ndarray:
 
 
 # OpenCV-version-sensitive choices (bevoracle.c: g_variant; same keys as BEVW_COMPAT_* of include/bevwarp.h)
-VARIANT_FILLPOLY, VARIANT_ADDWEIGHTED = 0, 1
+VARIANT_FILLPOLY, VARIANT_ADDWEIGHTED, VARIANT_WARP, VARIANT_REMAP = 0, 1, 2, 3
 VARIANT_NAMES = {VARIANT_FILLPOLY: {1: "fillPoly >= 4.5.2", 0: "fillPoly < 4.5.2"},
-                 VARIANT_ADDWEIGHTED: {1: "addWeighted in CV_64F", 0: "addWeighted in CV_32F"}}
+                 VARIANT_ADDWEIGHTED: {1: "addWeighted in CV_64F", 0: "addWeighted in CV_32F"},
+                 VARIANT_REMAP: {0: "remap rounds half up (classic fixed point)", 1: "remap rounds half to even (float kernel + cvRound)"}}
+# VARIANT_WARP: 0 = the classic warpPerspective kernels (OpenCV 2.4 ... 4.10); odd = a member of the float32 family (bevoracle.c A.4b)
+WARP_F32, WARP_COORD_FMA, WARP_INTER_FMA, WARP_INTER_TWO_WEIGHTS, WARP_COORD_F64, WARP_COORD_RECIP = 1, 2, 4, 8, 16, 32
+WARP_FAMILY = [m for m in range(1, 64, 2) if not ((m & WARP_COORD_F64) and (m & (WARP_COORD_FMA | WARP_COORD_RECIP)))]   # distinct members
+
+
+def warp_mode_name(mode: int) -> str:
+    if not mode & 1:
+        return "classic fixed-point warpPerspective (OpenCV 2.4 ... 4.10)"
+    bits = [("coordinates in double" if mode & 16 else ("float coordinates, fma" if mode & 2 else "float coordinates, mul + add")),
+            "x (1 / w)" if mode & 32 and not mode & 16 else "/ w", "lerp (1 - t) a + t b" if mode & 8 else "lerp a + t (b - a)",
+            "fused multiply-adds" if mode & 4 else "separate multiply and add"]
+    return "float32 family member %d: %s" % (mode, ", ".join(bits))
 
 
 def set_variant(key: int, value: int) -> None:
@@ -240,7 +255,19 @@ def remap(src: np.ndarray, map1: np.ndarray, map2: np.ndarray) -> np.ndarray:
 
 
 def warp_perspective(src: np.ndarray, H, dsize) -> np.ndarray:
-    """cv2.warpPerspective(src, H, dsize): INTER_LINEAR, BORDER_CONSTANT 0, H inverted internally."""
+    """cv2.warpPerspective(src, H, dsize): INTER_LINEAR, BORDER_CONSTANT 0, H inverted internally.  With VARIANT_WARP odd, 8U / 16U images
+    of 1, 3 or 4 channels go through that member of the float32 family (bevoracle.c A.4b: candidates for OpenCV >= 4.11's kernels); every
+    other type (the two-channel 16S undistort map) keeps the classic path."""
+    mode = get_variant(VARIANT_WARP)
+    src = np.ascontiguousarray(src)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    if (mode & 1) and src.dtype in (np.dtype(np.uint8), np.dtype(np.uint16)) and cn in (1, 3, 4):
+        dw, dh = int(dsize[0]), int(dsize[1])
+        M = np.ascontiguousarray(invert3x3(H), np.float64)
+        dst = np.empty((dh, dw) + (() if src.ndim == 2 else (cn,)), src.dtype)
+        fn = lib().orc_warp_f32_u8 if src.dtype == np.uint8 else lib().orc_warp_f32_u16
+        fn(_p(src), src.shape[1], src.shape[0], cn, _p(M), mode, dw, dh, _p(dst))
+        return dst
     xy, a = perspective_coords(invert3x3(H), dsize)
     return remap(src, xy, a)
 

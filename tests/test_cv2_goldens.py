@@ -58,12 +58,37 @@ def variants_decided_by_the_goldens(goldens, oracle, repo_rig):
                 str(goldens["color_balance_back__sha"]) == GC.digest(oracle.color_balance(repo_rig.image("back"))):
             chosen["addWeighted"] = v
             break
+    # warpPerspective / remap IMPLEMENTATION (the probes stored whole): the classic kernels first, then every member of the float32 family
+    # (oracle.WARP_FAMILY, bevoracle.c A.4b: candidates for OpenCV >= 4.11); a member is selected only if it reproduces BOTH the 8UC3 and
+    # the 16UC1 probe element for element.  The remap tie rule likewise on probe_remap_8uc3.
+    if "probe_warp_8uc3__full" in goldens.files and "probe_warp_16uc1__full" in goldens.files:
+        u16, _s16, u8 = GC.probe_images()
+        Hp = np.array(GC.PROBE_H)
+        for m in [0] + list(oracle.WARP_FAMILY):
+            oracle.set_variant(oracle.VARIANT_WARP, m)
+            if np.array_equal(goldens["probe_warp_8uc3__full"], oracle.warp_perspective(u8, Hp, GC.PROBE_DSIZE)) and \
+                    np.array_equal(goldens["probe_warp_16uc1__full"], oracle.warp_perspective(u16, Hp, GC.PROBE_DSIZE)):
+                chosen["warpPerspective"] = m
+                break
+    if "probe_remap_8uc3__full" in goldens.files:
+        _u16, _s16, u8 = GC.probe_images()
+        pm1, pm2 = GC.probe_maps()
+        for v in (0, 1):
+            oracle.set_variant(oracle.VARIANT_REMAP, v)
+            if np.array_equal(goldens["probe_remap_8uc3__full"], oracle.remap(u8, pm1, pm2)):
+                chosen["remap"] = v
+                break
     oracle.set_variant(oracle.VARIANT_FILLPOLY, chosen.get("fillPoly", 1))
     oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, chosen.get("addWeighted", 1))
-    print("cv2 %s selects variants %s (1 = the shipped default)" % (goldens["cv2_version"], chosen))
+    oracle.set_variant(oracle.VARIANT_WARP, chosen.get("warpPerspective", 0))
+    oracle.set_variant(oracle.VARIANT_REMAP, chosen.get("remap", 0))
+    print("cv2 %s selects variants %s (fillPoly / addWeighted: 1 = the shipped default; warpPerspective: %s; remap: 0 = half up, the shipped "
+          "default; a key that is missing matched NO candidate)" % (goldens["cv2_version"], chosen, oracle.warp_mode_name(chosen.get("warpPerspective", 0))))
     yield chosen
     oracle.set_variant(oracle.VARIANT_FILLPOLY, 1)
     oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, 1)
+    oracle.set_variant(oracle.VARIANT_WARP, 0)
+    oracle.set_variant(oracle.VARIANT_REMAP, 0)
 
 
 @pytest.fixture(scope="module")
@@ -144,7 +169,9 @@ def test_calibrator_paths(goldens, oracle, repo_rig):
 def test_implementation_probes(goldens, oracle):
     """Which warpPerspective / remap IMPLEMENTATION the golden file's OpenCV runs.  The oracle restates the classic kernels (fixed-point
     5-bit x 5-bit weights for 8U sources, float weights for 16-bit sources: every OpenCV from 2.4 to 4.10); OpenCV >= 4.11 ships new
-    warpPerspective kernels (8U / 16U / 32F) and a reworked remap.  The probes are stored whole, so a mismatch is reported with its
+    warpPerspective kernels (8U / 16U / 32F) and a reworked remap, for which the oracle and the engine carry a family of CANDIDATES
+    (VARIANT_WARP / BEVW_COMPAT_WARP, VARIANT_REMAP / BEVW_COMPAT_REMAP) -- the module fixture has selected the member that reproduces
+    the probes, if one does, before this test runs.  The probes are stored whole, so a mismatch is reported with its
     size: how many elements differ and by how much -- 'classic' (0 differences) or 'another implementation' (sub-LSB rounding
     differences on a large share of the pixels), not just 'differs'."""
     names = [n for n in ("probe_warp_16uc1", "probe_warp_16sc2", "probe_warp_8uc3", "probe_remap_8uc3") if n + "__full" in goldens]
@@ -164,8 +191,8 @@ def test_implementation_probes(goldens, oracle):
         report.append("%s: %d of %d elements differ, max |diff| %d" % (n, int(np.count_nonzero(d)), d.size, int(d.max())))
     print("OpenCV %s implementation probes: %s" % (goldens.get("cv2_version", "?"), "; ".join(report)))
     bad = [r for r in report if ": 0 of" not in r]
-    assert not bad, ("this OpenCV does not run the classic warpPerspective / remap kernels the oracle restates (expected for opencv-python >= 4.11): "
-                     + "; ".join(bad))
+    assert not bad, ("this OpenCV runs neither the classic warpPerspective / remap kernels nor any candidate of the float32 family "
+                     "(oracle.WARP_FAMILY / VARIANT_REMAP; the module fixture tried them all and kept the closest it was told to): " + "; ".join(bad))
 
 
 def test_jpeg_codec_of_this_opencv(goldens, repo_rig):

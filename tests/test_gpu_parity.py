@@ -137,6 +137,101 @@ def test_compat_variants_bit_exact(ffi, SB, oracle, fillpoly, addweighted):
         oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, 1)
 
 
+@pytest.mark.parametrize("mode", [1, 3, 5, 9, 17, 33, 15, 29, 47])
+def test_compat_warp_family_bit_exact(ffi, SB, oracle, mode):
+    """BEVW_COMPAT_WARP / VARIANT_WARP: members of the float32 family (candidates for OpenCV >= 4.11's warpPerspective kernels) move engine and
+    oracle together -- a3: the BEV look-up table (its 16UC1 half goes through the float kernel, the two-channel 16S half stays classic),
+    a11: ExCalibrator.warp on an 8UC3 image, and a stitched frame set built on those tables.  Bit-exact for every member."""
+    from cameracalibration_amd.ExtrinsicCalibration import ExCalibrator
+    L = ffi.lib()
+    try:
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_WARP, mode))
+        oracle.set_variant(oracle.VARIANT_WARP, mode)
+        assert L.bevw_get_compat(ffi.COMPAT_WARP) == mode
+        rig = small_rig()
+        bev, ref = make_pair(SB, oracle, rig, SMALL_CFG, blend=True, balance=False)
+        for i, n in enumerate(CAMS):
+            m1, m2 = bev.cameras[i].bev_maps
+            assert np.array_equal(m1, ref.cameras[i].bev_maps[0]) and np.array_equal(m2, ref.cameras[i].bev_maps[1]), n
+        oracle.set_variant(oracle.VARIANT_WARP, 0)
+        classic = oracle.RefBevGenerator(rig, SMALL_CFG, blend=True, balance=False)
+        oracle.set_variant(oracle.VARIANT_WARP, mode)
+        assert any(not np.array_equal(ref.cameras[i].bev_maps[1], classic.cameras[i].bev_maps[1]) for i in range(4))   # the switch is not a no-op
+        assert all(np.array_equal(ref.cameras[i].bev_maps[0], classic.cameras[i].bev_maps[0]) for i in range(4))       # the 16SC2 half is
+        frames = W.synthetic_frames(2, SMALL_CFG["FRAME_WIDTH"], SMALL_CFG["FRAME_HEIGHT"], kind="random")
+        got = bev.batch(frames)
+        for b in range(2):
+            assert maxdiff(got[b], ref(*frames[b])) == 0
+        rng = np.random.default_rng(mode)
+        img = rng.integers(0, 256, (120, 170, 3), dtype=np.uint8)
+        H = np.array([[0.9, 0.12, -7.0], [-0.06, 1.1, 9.0], [2.0e-4, -1.0e-4, 1.0]])
+        ex = ExCalibrator()
+        ex.homography = H
+        a = ex.get_args() if hasattr(ex, "get_args") else None
+        got = ffi_warp(ffi, img, H, (200, 140))
+        assert np.array_equal(got, oracle.warp_perspective(img, H, (200, 140)))
+        # a handle keeps the member it was built with
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_WARP, 0))
+        assert np.array_equal(bev.batch(frames), bev.batch(frames)) and maxdiff(bev.batch(frames)[0], ref(*frames[0])) == 0
+    finally:
+        L.bevw_set_compat(ffi.COMPAT_WARP, 0)
+        oracle.set_variant(oracle.VARIANT_WARP, 0)
+    assert L.bevw_set_compat(ffi.COMPAT_WARP, 2) != 0 and L.bevw_set_compat(ffi.COMPAT_WARP, 64) != 0   # even / out of range: refused
+
+
+def ffi_warp(ffi, img, H, dsize):
+    """cv2.warpPerspective(img, H, dsize) through the C-ABI (bevw_warp_perspective_u8c3: what ExCalibrator.warp calls)."""
+    out = np.empty((dsize[1], dsize[0], 3), np.uint8)
+    ffi.check(ffi.lib().bevw_warp_perspective_u8c3(0, ffi.ptr(np.ascontiguousarray(img)), img.shape[1], img.shape[0], ffi.ptr(ffi.f64(H, 9)),
+                                                   dsize[0], dsize[1], 1, ffi.ptr(out)))
+    return out
+
+
+def test_compat_remap_tie_rule_bit_exact(ffi, SB, oracle):
+    """BEVW_COMPAT_REMAP 1 / VARIANT_REMAP 1: the exact weighted sum rounded half to even instead of half up (what a float kernel ending in
+    cvRound gives; a candidate for OpenCV >= 4.11's remap).  The engine runs the per-pixel schedule then; all four BevGenerator modes, the
+    Camera methods and a stand-alone remapper stay bit-exact against the oracle, and the tile plan is refused."""
+    L = ffi.lib()
+    try:
+        ffi.check(L.bevw_set_compat(ffi.COMPAT_REMAP, 1))
+        oracle.set_variant(oracle.VARIANT_REMAP, 1)
+        rig = small_rig()
+        frames = W.synthetic_frames(2, SMALL_CFG["FRAME_WIDTH"], SMALL_CFG["FRAME_HEIGHT"], kind="random")
+        seen_tie = False
+        for blend, balance in [(False, False), (True, False), (False, True), (True, True)]:
+            bev, ref = make_pair(SB, oracle, rig, SMALL_CFG, blend, balance)
+            assert bev.plan_info()["schedule"] == 1 and bev.out_pitch == SMALL_CFG["BEV_WIDTH"]
+            got = bev.batch(frames)
+            for b in range(2):
+                assert maxdiff(got[b], ref(*frames[b])) == 0, (blend, balance)
+            if not blend and not balance:
+                oracle.set_variant(oracle.VARIANT_REMAP, 0)
+                up = oracle.RefBevGenerator(rig, SMALL_CFG, blend=False, balance=False)(*frames[0])
+                oracle.set_variant(oracle.VARIANT_REMAP, 1)
+                seen_tie = not np.array_equal(up, got[0])
+                cam = bev.cameras[0]
+                assert np.array_equal(cam.raw2bev(frames[0][0]), ref.cameras[0].raw2bev(frames[0][0]))
+                assert np.array_equal(cam.undistort(frames[0][0]), ref.cameras[0].undistort(frames[0][0]))
+        assert seen_tie   # random frames do hit exact ties: the rule changes some pixel
+        with pytest.raises(Exception):
+            SB.BevGenerator(rig=rig, schedule=ffi.SCHED_TILE_PLAN)
+        import ctypes as C
+        rng = np.random.default_rng(9)
+        m1 = rng.integers(0, 60, (40, 48, 2)).astype(np.int16)
+        m2 = rng.integers(0, 1024, (40, 48)).astype(np.uint16)
+        img = rng.integers(0, 256, (3, 64, 64, 3), dtype=np.uint8)
+        r = C.c_void_p()
+        ffi.check(L.bevw_remapper_from_maps(0, 64, 64, ffi.ptr(m1), ffi.ptr(m2), 48, 40, C.byref(r)))
+        out = np.empty((3, 40, 48, 3), np.uint8)
+        ffi.check(L.bevw_remap(r, ffi.ptr(img), 3, ffi.ptr(out)))
+        L.bevw_remapper_destroy(r)
+        for b in range(3):
+            assert np.array_equal(out[b], oracle.remap(img[b], m1, m2))
+    finally:
+        L.bevw_set_compat(ffi.COMPAT_REMAP, 0)
+        oracle.set_variant(oracle.VARIANT_REMAP, 0)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # BevGenerator.__call__ on the reference's own sample data (config 1)
 # ---------------------------------------------------------------------------------------------------------------

@@ -19,6 +19,8 @@ def restore_variants(oracle):
     yield
     oracle.set_variant(oracle.VARIANT_FILLPOLY, 1)
     oracle.set_variant(oracle.VARIANT_ADDWEIGHTED, 1)
+    oracle.set_variant(oracle.VARIANT_WARP, 0)
+    oracle.set_variant(oracle.VARIANT_REMAP, 0)
 
 
 def test_defaults_and_round_trip(oracle):
@@ -107,3 +109,69 @@ def test_addweighted_variants_exhaustive_values(oracle):
         ntot += d.size
     assert worst <= 1
     assert ndiff <= 1e-4 * ntot, (ndiff, ntot)
+
+
+# ---- VARIANT_WARP / VARIANT_REMAP: candidates for OpenCV >= 4.11's float32 linear kernels (bevoracle.c A.4b) -----------------------
+def test_warp_family_known_answers(oracle):
+    """Every member: the identity homography copies, an integer translation shifts with a zero border -- positions that
+    are exact in float32 leave no room for the members to differ -- for 8UC3, 8UC1 and 16UC1 images; the two-channel 16S map (not a type
+    the float kernels take) keeps the classic path whatever the switch says."""
+    rng = np.random.default_rng(3)
+    u8 = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    u16 = rng.integers(0, 65536, (37, 53), dtype=np.uint16)
+    s16 = rng.integers(-3000, 3000, (37, 53, 2), dtype=np.int16)
+    shift = np.array([[1, 0, 5], [0, 1, -3], [0, 0, 1.0]])
+    classic_s16 = oracle.warp_perspective(s16, shift @ np.diag([1.01, 0.99, 1.0]), (60, 40))
+    assert oracle.get_variant(oracle.VARIANT_WARP) == 0 and oracle.get_variant(oracle.VARIANT_REMAP) == 0
+    for m in oracle.WARP_FAMILY:
+        oracle.set_variant(oracle.VARIANT_WARP, m)
+        for img in (u8, u8[:, :, 0], u16):
+            assert np.array_equal(oracle.warp_perspective(img, np.eye(3), (53, 37)), img), m
+            got = oracle.warp_perspective(img, shift, (53, 37))
+            want = np.zeros_like(img)
+            want[:-3, 5:] = img[3:, :-5]
+            assert np.array_equal(got, want), m
+        assert np.array_equal(oracle.warp_perspective(s16, shift @ np.diag([1.01, 0.99, 1.0]), (60, 40)), classic_s16), m
+
+
+def test_warp_family_members_stay_within_one_lsb_of_each_other_and_of_the_classic_path_on_smooth_images(oracle):
+    """On a smooth image the members differ from each other by rounding (<= 1 LSB) and from the classic kernels by the 1/32-pixel
+    position quantisation times the gradient (<= 1 LSB at a gradient of <= 16 / pixel): what BASELINE's +-1 LSB needs from a user on
+    OpenCV >= 4.11, whichever member it is."""
+    y, x = np.mgrid[0:200, 0:260].astype(np.float64)
+    smooth = np.stack([(x * 0.9 + y * 0.2) % 256, 128 + 100 * np.sin(x / 40) * np.cos(y / 35), (x + y) / 2], -1).clip(0, 255).astype(np.uint8)
+    smooth[:, :, 0] = (x * 0.9 + y * 0.2).clip(0, 255).astype(np.uint8)   # (no wrap: a sawtooth edge is not smooth)
+    H = np.linalg.inv(np.array([[0.75, 0.05, 20.0], [-0.04, 0.8, 30.0], [1.0e-4, -0.5e-4, 1.0]]))   # every destination pixel samples the interior
+    classic = oracle.warp_perspective(smooth, H, (240, 180)).astype(np.int32)
+    outs = []
+    for m in oracle.WARP_FAMILY:
+        oracle.set_variant(oracle.VARIANT_WARP, m)
+        outs.append(oracle.warp_perspective(smooth, H, (240, 180)).astype(np.int32))
+    inner = (slice(None), slice(None))
+    for o in outs:
+        assert np.abs(o[inner] - outs[0][inner]).max() <= 1
+        assert np.abs(o[inner] - classic[inner]).max() <= 1
+    assert any(not np.array_equal(o, outs[0]) for o in outs)   # the members ARE different kernels
+
+
+def test_remap_tie_rule(oracle):
+    """(S + 512) >> 10 against round-half-even of S / 1024: identical unless S = 512 (mod 1024) with an odd rounded-up result."""
+    m1 = np.zeros((3, 3, 2), np.int16)
+    m2 = np.full((3, 3), 16 * 32 + 16, np.uint16)            # fx = fy = 1/2: weights 256 each
+    for taps, up, even in [((1, 1, 0, 0), 1, 0), ((3, 3, 0, 0), 2, 2), ((1, 0, 0, 0), 0, 0), ((2, 2, 1, 1), 2, 2), ((255, 255, 255, 254), 255, 255),
+                           ((5, 0, 0, 0), 1, 1), ((2, 0, 0, 0), 1, 0), ((6, 0, 0, 0), 2, 2)]:
+        src = np.zeros((5, 5), np.uint8)
+        src[0, 0], src[0, 1], src[1, 0], src[1, 1] = taps
+        oracle.set_variant(oracle.VARIANT_REMAP, 0)
+        assert oracle.remap(src, m1, m2)[0, 0] == up, taps
+        oracle.set_variant(oracle.VARIANT_REMAP, 1)
+        assert oracle.remap(src, m1, m2)[0, 0] == even, taps
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    mm1 = rng.integers(0, 62, (50, 50, 2)).astype(np.int16)
+    mm2 = rng.integers(0, 1024, (50, 50)).astype(np.uint16)
+    oracle.set_variant(oracle.VARIANT_REMAP, 0)
+    a = oracle.remap(img, mm1, mm2).astype(np.int32)
+    oracle.set_variant(oracle.VARIANT_REMAP, 1)
+    b = oracle.remap(img, mm1, mm2).astype(np.int32)
+    assert (a - b).min() >= 0 and (a - b).max() <= 1 and np.count_nonzero(a - b) < 0.01 * a.size
