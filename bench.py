@@ -810,7 +810,10 @@ def main():
                      "traffic_over_algorithmic": (traffic / (alg_bytes * batch)) if traffic else None,
                      "kernel_ms": launch_ms, "kernel_ms_median": lap_median, "kernel_ms_min": laps[0], "kernel_ms_max": laps[-1],
                      "frac_median": alg_bytes * batch / (lap_median * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch},
+                     "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch,
+                     # the same step priced at 64-byte sector granularity (workloads.SECTOR_GRANULAR_BYTES): what a minifying map must move at least
+                     "sector_floor_bytes_per_unit": W.SECTOR_GRANULAR_BYTES.get(a.workload),
+                     "frac_sector_floor": (W.SECTOR_GRANULAR_BYTES[a.workload] * batch / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if a.workload in W.SECTOR_GRANULAR_BYTES else None},
         "placements": {"n": placements, "reported": "median placement (by wall time of its K steps)",
                        "ms_per_step": [round(x["wall"] / a.steps * 1e3, 4) for x in draws],
                        "kernel_ms_median": [round(x["lap_median"], 4) for x in draws]},

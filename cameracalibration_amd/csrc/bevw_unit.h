@@ -643,6 +643,9 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 #ifndef BEVW_UNIT_ABL_SUMS
 #define BEVW_UNIT_ABL_SUMS 0
 #endif
+#ifndef BEVW_UNIT_ABL_LDS
+#define BEVW_UNIT_ABL_LDS 0
+#endif
 #ifdef BEVW_UNIT_PRIO_ON
 #define BEVW_UNIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -730,6 +733,10 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][con][p], i1[j][con][p], wxa[j][con][p], wy[j][con][p]);
+#if BEVW_UNIT_ABL_LDS   // (timing experiment, wrong pixels: every lane reads its own consecutive qword -- the pixel reads without bank conflicts)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { i0[j][con][p] = (uint32_t)lane + 64u * (uint32_t)p; i1[j][con][p] = (uint32_t)lane + 64u * (uint32_t)p + 256u; }
+#endif
             }
         }
         if (kWeights) {

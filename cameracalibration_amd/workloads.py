@@ -131,3 +131,16 @@ ALGORITHMIC_BYTES = {
     "direct_stitch_analytic_f32_b64": 5_532_357,   # config 3's bytes: the analytic modes touch (nearly) the same texels
     "direct_stitch_analytic_f64_b64": 5_532_357,
 }
+
+# The same workloads at 64-byte SECTOR granularity: the unique 64-byte segments of the frames the sampled texels touch (SURVEY.md B.2,
+# "sector-granular B") + the output bytes -- the least a memory system that moves whole sectors can move, whatever the kernel.  A strongly
+# minifying map (the 4K rig: 3.5 x) uses 44 % of every sector it has to fetch, so its roofline fraction on ALGORITHMIC bytes (0.23) reads
+# worse than the kernel is; bench.py reports both (roofline.frac_sector_floor) so that the figure is interpretable.
+SECTOR_GRANULAR_BYTES = {
+    "direct_stitch_b256": 2_635_392 + 3_499_200,
+    "blend_b256": 2_774_400 + 3_499_200,
+    "blend_4k": 18_937_216 + 3_499_200,
+    "blend_4k_camera_shard": 18_937_216 + 3_499_200,
+    "direct_stitch_analytic_f32_b64": 2_635_392 + 3_499_200,
+    "direct_stitch_analytic_f64_b64": 2_635_392 + 3_499_200,
+}
