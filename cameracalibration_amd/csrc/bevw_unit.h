@@ -21,7 +21,7 @@
 // barrier per frame, as the block tiles of round 2; mid and near field (2, 4) and (1, 4) -- the patch takes the whole 32 KB,
 // two barriers per frame.  (A (4, 4) class needs 163 VGPRs = 3 waves per SIMD for every class of the merged launch; without
 // it the partition pays 1.5 % more requests and every class stays below 128.)  Units are classes of the merged launch
-// (k_plan_all: 256 threads, 32 KB).
+// (k_plan_units: 256 threads, 32 KB).
 // Base tiles with a two-contributor pixel (seams, blend overlaps), a blend weight below 255 or a frame-border footprint keep
 // their round-2 classes: a unit never stores a quad of such a base tile (kUnitSkip).  Every unit pixel therefore has weight
 // 255 = 1.0f exactly, and the kernel needs no blend variant: trunc(f32(v) * 1.0f) == v.  Base tiles without any contributor
@@ -69,7 +69,7 @@ struct UnitDesc {
                          // classes three (first entries, second entries, the two u8 blend weights of every pixel as w0 | w1 << 8)
     uint32_t gs_off;     // group offsets of the unit start at un_gsrc[gs_off * kUnitThreads]
     uint32_t lq;         // log2 of the lanes per row (quads per row rounded up to a power of two, >= 4)
-    uint32_t sum_tile;   // balance: psums slot (a base tile owned by this unit)
+    uint32_t sum_tile;   // a base tile owned by this unit (diagnostics; the channel sums of the balance path are indexed by the unit itself)
     uint32_t groups;     // distinct groups; 0 = the unit only writes (no contributor anywhere)
     uint32_t pixels;     // contributing pixels (diagnostics)
 };
@@ -691,7 +691,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     const uint32_t *dp = reinterpret_cast<const uint32_t *>(a.un_desc + unit);
     const uint32_t pos = __builtin_amdgcn_readfirstlane(dp[0]), shape = __builtin_amdgcn_readfirstlane(dp[1]);
     const uint32_t ent_off = __builtin_amdgcn_readfirstlane(dp[2]), gs_off = __builtin_amdgcn_readfirstlane(dp[3]);
-    const uint32_t lq = __builtin_amdgcn_readfirstlane(dp[4]), sum_tile = __builtin_amdgcn_readfirstlane(dp[5]);
+    const uint32_t lq = __builtin_amdgcn_readfirstlane(dp[4]);
     const uint32_t ngroups = __builtin_amdgcn_readfirstlane(dp[6]);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

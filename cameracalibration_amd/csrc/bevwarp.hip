@@ -855,7 +855,7 @@ static int gain_pass(bevw_handle *h, hipStream_t st, const uint8_t *gain_in, con
 
 // blend + balance on the tile plan (BASELINE config 4), `parts` slices of the batch alternating over the handle's two streams.
 // Per slice: V sums of the raw frames (k_vsum: HBM-bound, reads every byte of the four frames) -> deltas -> luminance round trip of the
-// sampled texel groups into the scratch frame set (k_lum_groups: VALU-bound) -> the unit stitch with per-unit channel sums (HBM-bound)
+// sampled texel groups into the compact scratch (k_lum_groups: balanced between its 1.3 GB and its arithmetic) -> the unit stitch with per-unit channel sums
 // -> the gain pass (copy rate).  In one stream these run strictly one after the other, a memory-bound kernel while the VALUs idle and a
 // VALU-bound one while the memory idles; every quantity is per frame set, so slices are independent, and a slice's kernels overlap
 // the neighbouring slice's kernels of the OTHER kind (round 4: profiles/r04/ab_config4_slices.log; same idea as the two slices of a JPEG
