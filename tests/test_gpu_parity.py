@@ -770,6 +770,35 @@ def test_output_pitch_aligned_config_s(ffi, SB, oracle, blend, balance):
         buf.free()
 
 
+def test_run_device_on_a_pitched_handle_wants_the_buffer_size(ffi, SB, oracle):
+    """the default device layout has rows of whole sectors (1088 pixels for a 1080-pixel BEV); the library sees raw pointers, so a
+    caller that sized its buffer for dense images must fail loudly instead of being overrun: run_device refuses a pitched handle without
+    out_bytes and any buffer that is too small; dense handles keep the reference-shaped call."""
+    cfg, rig = SMALL_CFG, small_rig()
+    set_args(SB, cfg)
+    bw, bh = cfg["BEV_WIDTH"], cfg["BEV_HEIGHT"]
+    frames = W.synthetic_frames(1, cfg["FRAME_WIDTH"], cfg["FRAME_HEIGHT"], seed=5, kind="random")
+    d_in = ffi.DeviceBuffer(frames.nbytes).upload(frames)
+    bev = SB.BevGenerator(rig=rig)                               # 'auto' -> aligned: 248 -> 256 pixels per row
+    assert bev.out_pitch == 256 and bev.out_image_bytes == 256 * bh * 3
+    d_dense = ffi.DeviceBuffer(bw * bh * 3)
+    with pytest.raises(Exception, match="out_bytes"):
+        bev.run_device(d_in.ptr, 1, None, d_dense.ptr)
+    with pytest.raises(Exception, match="need"):
+        bev.run_device(d_in.ptr, 1, None, d_dense.ptr, out_bytes=d_dense.nbytes)
+    d_ok = ffi.DeviceBuffer(bev.out_image_bytes)
+    bev.run_device(d_in.ptr, 1, None, d_ok.ptr, out_bytes=d_ok.nbytes)
+    bev.sync()
+    want = oracle.RefBevGenerator(rig, cfg, blend=False, balance=False)(*frames[0])
+    assert np.array_equal(d_ok.download((bh, 256, 3))[:, :bw], want)
+    dense = SB.BevGenerator(rig=rig, output_pitch='dense')
+    dense.run_device(d_in.ptr, 1, None, d_dense.ptr)            # the reference-shaped call: no size needed
+    dense.sync()
+    assert np.array_equal(d_dense.download((bh, bw, 3)), want)
+    for b in (d_in, d_dense, d_ok):
+        b.free()
+
+
 def test_output_pitch_small_rig_and_errors(ffi, SB, oracle):
     """An explicit pitch on the small rig (248 -> 272 pixels), the dense default, and the refusals: a pitch below the width, not a
     multiple of 4, or together with the per-pixel schedule."""

@@ -321,6 +321,36 @@ def test_jpeg_pipeline_refuses_truncated_files_and_streams_identically(IC, JO, r
     assert want[0][0] == JO.imencode(ref(*[JO.imdecode(f) for f in files], car))
 
 
+def test_jpeg_stream_delivers_the_batch_in_flight_before_an_error_and_leaves_clean_slots(IC, JO, repo_rig, oracle):
+    """when the staging of batch k + 1 fails (a file that is not a JPEG), batch k is on the GPU already and is good work -- the
+    stream yields it, THEN raises; when the collect of batch k fails (a truncated file shows only after decoding), the generator raises and
+    drains whatever is in flight.  Either way the next call on the same generator object starts from clean slots and is bit-exact."""
+    from cameracalibration_amd._ffi import BevwError
+    from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
+
+    cams = JC.repo_camera_jpegs()
+    files = [cams[n] for n in W.CAMERA_NAMES]
+    cfg = dict(W.CONFIG_R, CAR_WIDTH=200, CAR_HEIGHT=350)
+    ns = SB.BevGenerator.get_args()
+    for k, v in cfg.items():
+        setattr(ns, k, v)
+    bev = SB.BevGenerator(blend=False, balance=False, rig=repo_rig.rig)
+    good = bev.jpeg([files])
+    not_a_jpeg = [files[0], b"definitely not a JPEG file", files[2], files[3]]
+    got = []
+    with pytest.raises(Exception):
+        for out in bev.jpeg_stream([[files], [files[::-1]], [not_a_jpeg], [files]]):
+            got.append(out)
+    assert len(got) == 2 and got[0] == good and got[1] == bev.jpeg([files[::-1]])   # both batches before the bad one were delivered
+    cut = files[2][: len(files[2]) * 3 // 5] + b"\xff\xd9"
+    got = []
+    with pytest.raises(BevwError, match="before their image is complete"):
+        for out in bev.jpeg_stream([[files], [[files[0], files[1], cut, files[3]]], [files], [files]]):
+            got.append(out)
+    assert got == [good]
+    assert list(bev.jpeg_stream([[files], [files]])) == [good, good] and bev.jpeg([files]) == good   # the slots are clean
+
+
 def test_exif_orientations_are_applied_like_cv2_imread(IC, codec):
     """cv2.imread turns an image by its EXIF orientation tag (OpenCV's ExifTransform); so does the decoder, on the GPU.  Reference: the same
     file decoded by libjpeg-turbo (Pillow) and turned by Pillow's exif_transpose -- the EXIF specification's eight cases, odd sizes included."""
