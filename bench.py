@@ -788,6 +788,14 @@ def main():
                  "frac": alg_bytes * batch * a.steps / (o_mid["ev_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
                  "placements_ms_per_step": [round(x["wall"] / a.steps * 1e3, 4) for x in o_draws]}
 
+    # the measured yardstick beside the specification peak: what a plain copy kernel moves (bytes read + written per second)
+    # between two fresh 1 GiB buffers on THIS box, default-policy and streaming accesses, the better of the two
+    copy_gbs = None
+    if d.rank == 0 and d.world == 1 and not os.environ.get("BEVW_BENCH_CHILD"):
+        try:
+            copy_gbs = max(_ffi.device_copy_rate(1 << 30, 10, False, dev), _ffi.device_copy_rate(1 << 30, 10, True, dev))
+        except Exception:
+            copy_gbs = None
     lt = live_traffic(a, batch) if (d.rank == 0 and d.world == 1 and w["kind"] != "camera") else None
     traffic, traffic_fetch, traffic_write, traffic_source = lt if lt else static_traffic(a.workload, batch)
     agg = aggregate(units_world, batch, a.steps, wall, ev_ms, alg_bytes)
@@ -808,6 +816,10 @@ def main():
                      "frac_worst_placement": alg_bytes * batch * a.steps / (max(x["ev_ms"] for x in draws) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_fetch": traffic_fetch, "traffic_write": traffic_write, "traffic_source": traffic_source,
                      "traffic_over_algorithmic": (traffic / (alg_bytes * batch)) if traffic else None,
+                     # bytes the step really moves per second, against what a plain copy kernel moves on this box (read + write)
+                     "moved_gbs": (traffic / (launch_ms * 1e-3) / 1e9) if traffic else None, "device_copy_gbs": copy_gbs,
+                     "moved_over_device_copy": (traffic / (launch_ms * 1e-3) / 1e9 / copy_gbs) if (traffic and copy_gbs) else None,
+                     "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                      "kernel_ms": launch_ms, "kernel_ms_median": lap_median, "kernel_ms_min": laps[0], "kernel_ms_max": laps[-1],
                      "frac_median": alg_bytes * batch / (lap_median * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "algorithmic_bytes_per_unit": alg_bytes, "units_per_launch": batch,

@@ -46,6 +46,7 @@ SIGNATURES = {
     "bevw_memcpy_h2d": (_i, [_i, _vp, _vp, _sz]),
     "bevw_memcpy_d2h": (_i, [_i, _vp, _vp, _sz]),
     "bevw_memset": (_i, [_i, _vp, _i, _sz]),
+    "bevw_device_copy_rate": (_i, [_i, _sz, _i, _i, C.POINTER(C.c_double)]),
     "bevw_create": (_i, [C.POINTER(bevw_config), _pvp]),
     "bevw_set_camera": (_i, [_vp, _i, _vp, _vp, _vp]),
     "bevw_build": (_i, [_vp]),
@@ -171,6 +172,14 @@ def device_count() -> int:
 def require_device() -> None:
     if device_count() <= 0:
         raise BevwError("no HIP device is visible: cameracalibration_amd has no CPU path")
+
+
+def device_copy_rate(nbytes: int = 1 << 30, reps: int = 10, streaming: bool = False, device: int = 0) -> float:
+    """GB/s a plain copy kernel MOVES (bytes read + bytes written) between two fresh buffers of `nbytes`: a measured yardstick beside the
+    8 TB/s specification peak (bevw_device_copy_rate)."""
+    g = C.c_double()
+    check(lib().bevw_device_copy_rate(int(device), int(nbytes), int(reps), int(bool(streaming)), C.byref(g)))
+    return float(g.value)
 
 
 def device_name(device: int = 0) -> str:

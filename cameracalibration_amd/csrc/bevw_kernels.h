@@ -910,4 +910,17 @@ static __global__ void k_resize_linear(const uint8_t *__restrict__ src, int w, i
     }
 }
 
+// a plain copy: the measured yardstick of bevw_device_copy_rate (csrc/bevwarp.hip)
+template <int NT>
+static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + i);
+        uint32_t *d4 = reinterpret_cast<uint32_t *>(dst + i);
+        const uint4 v = make_uint4(once_load<NT>(s4), once_load<NT>(s4 + 1), once_load<NT>(s4 + 2), once_load<NT>(s4 + 3));
+        once_store<NT>(d4, v.x); once_store<NT>(d4 + 1, v.y); once_store<NT>(d4 + 2, v.z); once_store<NT>(d4 + 3, v.w);
+    }
+}
+
 }  // namespace bevw

@@ -398,6 +398,41 @@ int bevw_memset(int device, void *dst, int value, size_t nbytes)
     return BEVW_OK;
 }
 
+// A plain device-to-device copy kernel and its rate: the yardstick SURVEY.md 8(d) asks for beside the 8 TB/s specification figure ("also
+// report fraction of a measured device-copy kernel").  16 bytes per lane and trip, grid-stride; streaming == 1: non-temporal loads and stores.
+int bevw_device_copy_rate(int device, size_t nbytes, int reps, int streaming, double *gb_per_s_moved)
+{
+    if (!gb_per_s_moved || reps <= 0 || nbytes < 16) return fail(BEVW_E_INVALID, "bad argument");
+    BEVW_TRY(use_device(device));
+    DevBuf a, b;
+    int s = a.reserve(nbytes);
+    if (s == BEVW_OK) s = b.reserve(nbytes);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (s == BEVW_OK && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) s = fail(BEVW_E_HIP, "event creation failed");
+    if (s == BEVW_OK && hipMemset(a.p, 0x5a, nbytes) != hipSuccess) s = fail(BEVW_E_HIP, "memset failed");
+    if (s == BEVW_OK) {
+        const size_t n = nbytes / 16;
+        const dim3 grid(256 * 16), block(256);
+        auto launch = [&] {
+            if (streaming) hipLaunchKernelGGL(k_copy16<1>, grid, block, 0, nullptr, a.as<uint4>(), b.as<uint4>(), n);
+            else hipLaunchKernelGGL(k_copy16<0>, grid, block, 0, nullptr, a.as<uint4>(), b.as<uint4>(), n);
+        };
+        launch();   // warm-up
+        (void)hipEventRecord(e0, nullptr);
+        for (int r = 0; r < reps; ++r) launch();
+        (void)hipEventRecord(e1, nullptr);
+        s = launch_check("k_copy16");
+        float ms = 0.f;
+        if (s == BEVW_OK && (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess || !(ms > 0.f)))
+            s = fail(BEVW_E_HIP, "timing the copy failed");
+        if (s == BEVW_OK) *gb_per_s_moved = 2.0 * (double)(n * 16) * reps / ((double)ms * 1e-3) / 1e9;   // bytes read + bytes written
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    a.release(); b.release();
+    return s;
+}
+
 // ---- remapper -------------------------------------------------------------------------------------------------
 int bevw_fisheye_remapper_create(int device, int frame_width, int frame_height, const double K[9], const double D[4],
                                  double focal_scale, double size_scale, double offset_h, double offset_v,

@@ -106,6 +106,10 @@ int bevw_free(int device, void *dptr);
 int bevw_memcpy_h2d(int device, void *dst, const void *src, size_t nbytes);
 int bevw_memcpy_d2h(int device, void *dst, const void *src, size_t nbytes);
 int bevw_memset(int device, void *dst, int value, size_t nbytes);
+/* Rate of a plain device-to-device copy kernel over two fresh buffers of nbytes (GB/s of bytes READ + WRITTEN; streaming != 0: non-temporal
+ * loads and stores): the measured yardstick bench.py reports beside the 8 TB/s specification peak.  Additive: no reference
+ * counterpart. */
+int bevw_device_copy_rate(int device, size_t nbytes, int reps, int streaming, double *gb_per_s_moved);
 
 /* ---- BevGenerator: construction = table build (surroundBEV.py:283-294) ----------------------------------- */
 int bevw_create(const bevw_config *cfg, bevw_handle **out);

@@ -770,6 +770,15 @@ def test_output_pitch_aligned_config_s(ffi, SB, oracle, blend, balance):
         buf.free()
 
 
+def test_device_copy_yardstick(ffi):
+    """bevw_device_copy_rate: what a plain copy kernel moves (read + write) on this box -- the measured figure bench.py prints beside the 8 TB/s
+    specification peak.  Sanity only: above 1 TB/s, below the specification."""
+    for streaming in (False, True):
+        g = ffi.device_copy_rate(256 << 20, 5, streaming)
+        assert 1000.0 < g < 8000.0, (streaming, g)
+    assert ffi.lib().bevw_device_copy_rate(0, 8, 1, 0, None) != 0
+
+
 def test_run_device_on_a_pitched_handle_wants_the_buffer_size(ffi, SB, oracle):
     """the default device layout has rows of whole sectors (1088 pixels for a 1080-pixel BEV); the library sees raw pointers, so a
     caller that sized its buffer for dense images must fail loudly instead of being overrun: run_device refuses a pitched handle without
