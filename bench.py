@@ -793,7 +793,7 @@ def main():
     copy_gbs = None
     if d.rank == 0 and d.world == 1 and not os.environ.get("BEVW_BENCH_CHILD"):
         try:
-            copy_gbs = max(_ffi.device_copy_rate(1 << 30, 10, False, dev), _ffi.device_copy_rate(1 << 30, 10, True, dev))
+            copy_gbs = max(_ffi.device_copy_rate(1 << 30, 10, st, dev) for st in (False, True) for _ in range(3))   # (fresh buffers per trial: placements differ)
         except Exception:
             copy_gbs = None
     lt = live_traffic(a, batch) if (d.rank == 0 and d.world == 1 and w["kind"] != "camera") else None
