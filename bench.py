@@ -791,7 +791,8 @@ def main():
     # the measured yardstick beside the specification peak: what a plain copy kernel moves (bytes read + written per second)
     # between two fresh 1 GiB buffers on THIS box, default-policy and streaming accesses, the better of the two
     copy_gbs = None
-    if d.rank == 0 and d.world == 1 and not os.environ.get("BEVW_BENCH_CHILD"):
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or bool(os.environ.get("ROCP_TOOL_LIBRARIES"))   # (keep profiles of the step clean)
+    if d.rank == 0 and d.world == 1 and not os.environ.get("BEVW_BENCH_CHILD") and not under_profiler and not a.no_live_traffic:
         try:
             copy_gbs = max(_ffi.device_copy_rate(1 << 30, 10, st, dev) for st in (False, True) for _ in range(3))   # (fresh buffers per trial: placements differ)
         except Exception:
