@@ -302,8 +302,10 @@ __device__ __forceinline__ unsigned vsum_piece(const VsumPiece &p)
     auto v = [](unsigned t) { return max(t & 255u, max((t >> 8) & 255u, (t >> 16) & 255u)); };
     return v(p.x) + v(t1) + v(t2) + v(t3);
 }
+// part_stride 0: the blocks of a frame add their sums atomically into sums[frame] (zeroed by the caller); > 0: block x of frame y stores
+// its sum at sums[y * part_stride + x] -- no atomics, no zeroing pass in front of the kernel; k_lum_delta adds the parts.
 static __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_bytes, int vec_ok,
-                       unsigned long long *__restrict__ sums)
+                       unsigned long long *__restrict__ sums, int part_stride = 0)
 {
     const uint8_t *f = frames + (size_t)blockIdx.y * frame_bytes;
     const size_t npieces = vec_ok ? frame_bytes / 12 : 0;
@@ -335,18 +337,25 @@ static __global__ void k_vsum(const uint8_t *__restrict__ frames, size_t frame_b
     if (threadIdx.x == 0) {
         unsigned long long t = 0;
         for (int i2 = 0; i2 < (int)(blockDim.x >> 6); ++i2) t += part[i2];
-        atomicAdd(&sums[blockIdx.y], t);
+        if (part_stride > 0) sums[(size_t)blockIdx.y * part_stride + blockIdx.x] = t;
+        else atomicAdd(&sums[blockIdx.y], t);
     }
 }
 
 // luminance_balance scalars (surroundBEV.py:64-72): delta_c = cvRound(V_mean - V_c), V_mean = (Vf+Vb+Vl+Vr)/4.
 // one thread per 4-camera frame set.
-static __global__ void k_lum_delta(const unsigned long long *__restrict__ vsums, double npx, int nsets, int *__restrict__ deltas)
+// nparts / part_stride: every frame's V sum arrives as `nparts` partial sums, part_stride entries apart per frame (k_vsum); 1 / 1: whole sums.
+static __global__ void k_lum_delta(const unsigned long long *__restrict__ vsums, double npx, int nsets, int *__restrict__ deltas, int nparts = 1,
+                                   int part_stride = 1)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nsets) return;
     double m[4];
-    for (int c = 0; c < 4; ++c) m[c] = (double)vsums[b * 4 + c] / npx;
+    for (int c = 0; c < 4; ++c) {
+        unsigned long long t = 0;   // exact: integer sums, whatever the number of parts
+        for (int p = 0; p < nparts; ++p) t += vsums[(size_t)(b * 4 + c) * part_stride + p];
+        m[c] = (double)t / npx;
+    }
     const double vmean = (m[0] + m[1] + m[2] + m[3]) / 4;
     for (int c = 0; c < 4; ++c) deltas[b * 4 + c] = rne_d(vmean - m[c]);
 }
@@ -725,18 +734,40 @@ static __global__ void k_apply_mask(const uint8_t *__restrict__ img, const uint8
 // k_gain with a per-frame 3 x 256 look-up table (the gain is one fp64 multiply + cvRound per byte VALUE, so 768
 // table entries per frame replace 3.5 M fp64 operations) and 12-byte vector accesses (4 pixels per lane).
 // Needs npx % 4 == 0 and 4-byte aligned images.  grid = (blocks, batch), block = 256; in place when in == out.
+// psums != nullptr: the channel sums of a frame arrive as `nsum` partial sums (one per unit / border tile of the tile plan:
+// psums[frame][nsum][3], bevw_plan.h) and every block adds them up itself -- integer sums, the same value k_reduce_psums would have left in
+// chsums, without that kernel between the stitch and this pass.
 static __global__ void __launch_bounds__(256) k_gain_lut(const uint8_t *in, size_t npx, const unsigned long long *__restrict__ chsums,
                                                    const uint8_t *__restrict__ car, uint8_t *out, uint32_t blocks_per_frame,
-                                                   uint32_t nframes, int f32 = 0, size_t npx_mean = 0)
+                                                   uint32_t nframes, int f32 = 0, size_t npx_mean = 0, const uint32_t *__restrict__ psums = nullptr,
+                                                   int nsum = 0)
 {
     __shared__ uint8_t lut[3][256];
+    __shared__ unsigned long long part[3][4];
     uint32_t frame, blk;
     if (!xcd_frame_map(blockIdx.x, blocks_per_frame, nframes, frame, blk)) return;   // grid: xcd_frame_grid()
+    unsigned long long total[3];
+    if (psums != nullptr) {
+        const uint32_t *p = psums + (size_t)frame * nsum * 3;
+        unsigned long long acc[3] = {0, 0, 0};
+        for (int t = threadIdx.x; t < nsum; t += blockDim.x) { acc[0] += p[t * 3]; acc[1] += p[t * 3 + 1]; acc[2] += p[t * 3 + 2]; }
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long w = wave_sum_u64(acc[k]);
+            if (lane == 0) part[k][wv] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) total[k] = part[k][0] + part[k][1] + part[k][2] + part[k][3];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) total[k] = chsums[frame * 3 + k];
+    }
     {
         // npx_mean: pixels the channel means are taken over when the images carry padding columns (bevw_set_output_pitch); 0 = npx
         const double n = (double)(npx_mean ? npx_mean : npx);
-        const double B = (double)chsums[frame * 3 + 0] / n, G = (double)chsums[frame * 3 + 1] / n,
-                     R = (double)chsums[frame * 3 + 2] / n;
+        const double B = (double)total[0] / n, G = (double)total[1] / n, R = (double)total[2] / n;
         const double K = (R + G + B) / 3;
         const double gain[3] = {K / B, K / G, K / R};
         for (int i = threadIdx.x; i < 768; i += blockDim.x) {

@@ -747,7 +747,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         else hipLaunchKernelGGL((k_stitch_plan<false, false>), grid, block, 0, st, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    if (with_sums) {
+    if (with_sums && d_chsums != nullptr) {   // (nullptr: the caller's gain pass adds the partial sums itself: plan_sum_entries)
         hipLaunchKernelGGL(k_reduce_psums, dim3(batch), dim3(256), 0, st, a.psums, a.nsum, d_chsums);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
@@ -761,6 +761,13 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     return hipSuccess;
+}
+
+// the partial channel sums the last plan_stitch_impl call with sums left for frame `first` of the psums buffer, and their number per frame
+static inline const uint32_t *plan_sum_entries(const Plan &p, int first, int &nsum)
+{
+    nsum = p.psums_layout;
+    return static_cast<const uint32_t *>(p.psums) + (size_t)first * (size_t)(nsum > 0 ? nsum : 0) * 3;
 }
 
 // a plan that holds only a WIDE unit schedule (analytic projection mode: plan_analytic_units) -> one launch of k_plan_unit_wide

@@ -723,9 +723,11 @@ static int fill_poly_device(hipStream_t st, const MaskGeometry &g, int cam, bool
     return launch_check("k_poly_fill");
 }
 
+constexpr int kVsumParts = 256;   // blocks per frame of k_vsum at most (luminance_stats): partial sums per frame in bevw_handle::vsums
+
 static int ensure_stats(bevw_handle *h, int batch)
 {
-    BEVW_TRY(h->vsums.reserve(sizeof(unsigned long long) * 4 * (size_t)batch));
+    BEVW_TRY(h->vsums.reserve(sizeof(unsigned long long) * 4 * (size_t)batch * kVsumParts));   // per frame: the partial V sums of k_vsum's blocks
     BEVW_TRY(h->deltas.reserve(sizeof(int) * 4 * (size_t)batch));
     BEVW_TRY(h->chsums.reserve(sizeof(unsigned long long) * 3 * (size_t)batch));
     return BEVW_OK;
@@ -847,12 +849,13 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
     return launch_check("k_stitch_analytic");
 }
 
-// luminance statistics of a batch of 4-camera sets -> deltas[batch][4]
+// luminance statistics of a batch of 4-camera sets -> deltas[batch][4].  d_vsums: kVsumParts entries per frame (ensure_stats): every block
+// of k_vsum stores its partial sum, k_lum_delta adds them -- no atomics and no zeroing pass per step (round 5: the 4 KB hipMemsetAsync in
+// front of every slice's k_vsum cost 20 us of stream time, twice per config-4 step).
 static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, int fw, int fh, unsigned long long *d_vsums,
                            int *d_deltas)
 {
     const size_t frame_bytes = (size_t)fw * fh * 3;
-    HIP_TRY(hipMemsetAsync(d_vsums, 0, sizeof(unsigned long long) * 4 * (size_t)nsets, st));
     const int nframes = nsets * 4;
     const int vec_ok = (frame_bytes % 4 == 0 && ((uintptr_t)d_frames & 3u) == 0) ? 1 : 0;   // k_vsum's 12-byte loads
     int bpf = 2048 / (nframes > 0 ? nframes : 1);
@@ -861,25 +864,28 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
     for (int f0 = 0; f0 < nframes; f0 += 65535) {
         const int nf = nframes - f0 < 65535 ? nframes - f0 : 65535;
         hipLaunchKernelGGL(k_vsum, dim3(bpf, nf), dim3(256), 0, st, d_frames + (size_t)f0 * frame_bytes, frame_bytes, vec_ok,
-                           d_vsums + f0);
+                           d_vsums + (size_t)f0 * kVsumParts, kVsumParts);
     }
     hipLaunchKernelGGL(k_lum_delta, dim3((nsets + 63) / 64), dim3(64), 0, st, d_vsums, (double)fw * (double)fh, nsets,
-                       d_deltas);
+                       d_deltas, bpf, kVsumParts);
     return launch_check("k_vsum/k_lum_delta");
 }
 
 // The gain pass of frame sets [b0, b0 + n) (color_balance + car, surroundBEV.py:43-55, 323-324) on `st`
+// from_plan: the channel sums are the partial sums the tile plan's stitch of these frames left behind (k_gain_lut adds them itself)
 static int gain_pass(bevw_handle *h, hipStream_t st, const uint8_t *gain_in, const uint8_t *gain_car, const uint8_t *d_car, uint8_t *d_out, int b0, int n,
-                     bool lut_ok)
+                     bool lut_ok, bool from_plan = false)
 {
     const bevw_config &c = h->cfg;
     const size_t npx_true = (size_t)c.bev_width * c.bev_height, npx = (size_t)h->pitch_px * c.bev_height;
     for (int k0 = b0; k0 < b0 + n; k0 += 65535) {
         const int nb = b0 + n - k0 < 65535 ? b0 + n - k0 : 65535;
+        int nsum = 0;
+        const uint32_t *ps = (from_plan && lut_ok) ? plan_sum_entries(h->plan, k0, nsum) : nullptr;
         if (lut_ok)
             hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, st, gain_in + (size_t)k0 * npx * 3, npx,
                                h->chsums.as<unsigned long long>() + (size_t)k0 * 3, gain_car, d_out + (size_t)k0 * npx * 3, 32u,
-                               (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1, npx_true);
+                               (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1, npx_true, ps, nsum);
         else
             hipLaunchKernelGGL(k_gain, dim3(64, nb), dim3(256), 0, st, d_out + (size_t)k0 * npx * 3, npx,
                                h->chsums.as<unsigned long long>() + (size_t)k0 * 3, d_car, d_out + (size_t)k0 * npx * 3,
@@ -938,16 +944,17 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
         if (!n) continue;
         hipStream_t st = (part & 1) ? h->stream2 : h->stream;
         const uint8_t *fr = d_frames + (size_t)b0 * set_bytes;
-        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, h->vsums.as<unsigned long long>() + (size_t)b0 * 4, h->deltas.as<int>() + (size_t)b0 * 4));
+        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, h->vsums.as<unsigned long long>() + (size_t)b0 * 4 * kVsumParts, h->deltas.as<int>() + (size_t)b0 * 4));
         if (part == 0 && parts > 1 && skew_env) {   // the other stream's first slice starts when this one's V sums are done
             HIP_TRY(hipEventRecord(h->ev_skew, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_skew, 0));
         }
         uint8_t *scratch = h->tmp.as<uint8_t>() + (size_t)b0 * cstride;
         BEVW_TRY(plan_lum_groups(h->plan, st, fr, scratch, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>()));
+        const bool lut_ok = npx % 4 == 0;   // (odd image sizes: the byte-wise gain kernel, in place, from k_reduce_psums' sums)
         BEVW_TRY(plan_stitch(h->plan, st, fr, n, c.blend != 0, false, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>(), nullptr,
-                             h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0, scratch));
-        BEVW_TRY(gain_pass(h, st, gain_in, gain_car, d_car, d_out, b0, n, npx % 4 == 0));   // (odd image sizes: the byte-wise gain kernel, in place)
+                             lut_ok ? nullptr : h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0, scratch));
+        BEVW_TRY(gain_pass(h, st, gain_in, gain_car, d_car, d_out, b0, n, lut_ok, true));
     }
     if (parts > 1) {   // everything the caller enqueues on the handle's stream afterwards sees the whole batch
         HIP_TRY(hipEventRecord(h->ev_join, h->stream2));
@@ -1690,7 +1697,7 @@ int bevw_luminance_balance(int device, const uint8_t *frames, int batch, int wid
     DevBuf in, o, vs, dl, tb;
     int s = in.reserve(n);
     if (s == BEVW_OK) s = o.reserve(n);
-    if (s == BEVW_OK) s = vs.reserve(sizeof(unsigned long long) * 4 * (size_t)batch);
+    if (s == BEVW_OK) s = vs.reserve(sizeof(unsigned long long) * 4 * (size_t)batch * kVsumParts);
     if (s == BEVW_OK) s = dl.reserve(sizeof(int) * 4 * (size_t)batch);
     if (s == BEVW_OK) s = tb.reserve(sizeof(HsvTables));
     HsvTables tab = make_hsv_tables();
