@@ -852,8 +852,9 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
 // luminance statistics of a batch of 4-camera sets -> deltas[batch][4].  d_vsums: kVsumParts entries per frame (ensure_stats): every block
 // of k_vsum stores its partial sum, k_lum_delta adds them -- no atomics and no zeroing pass per step (round 5: the 4 KB hipMemsetAsync in
 // front of every slice's k_vsum cost 20 us of stream time, twice per config-4 step).
+// parts_out != nullptr: only the V sums; the caller's next kernel derives the deltas from the *parts_out partial sums per frame (plan_lum_groups)
 static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, int fw, int fh, unsigned long long *d_vsums,
-                           int *d_deltas)
+                           int *d_deltas, int *parts_out = nullptr)
 {
     const size_t frame_bytes = (size_t)fw * fh * 3;
     const int nframes = nsets * 4;
@@ -866,6 +867,7 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
         hipLaunchKernelGGL(k_vsum, dim3(bpf, nf), dim3(256), 0, st, d_frames + (size_t)f0 * frame_bytes, frame_bytes, vec_ok,
                            d_vsums + (size_t)f0 * kVsumParts, kVsumParts);
     }
+    if (parts_out) { *parts_out = bpf; return launch_check("k_vsum"); }
     hipLaunchKernelGGL(k_lum_delta, dim3((nsets + 63) / 64), dim3(64), 0, st, d_vsums, (double)fw * (double)fh, nsets,
                        d_deltas, bpf, kVsumParts);
     return launch_check("k_vsum/k_lum_delta");
@@ -944,13 +946,19 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
         if (!n) continue;
         hipStream_t st = (part & 1) ? h->stream2 : h->stream;
         const uint8_t *fr = d_frames + (size_t)b0 * set_bytes;
-        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, h->vsums.as<unsigned long long>() + (size_t)b0 * 4 * kVsumParts, h->deltas.as<int>() + (size_t)b0 * 4));
+        // BEVW_BAL_DELTA_KERNEL=0 (A/B): the deltas derived inside k_lum_groups from the partial V sums instead of by k_lum_delta, a kernel of
+        // its own in between -- measured SLOWER (1.669 against 1.660 ms, profiles/r05/ab_call17...: 22 k blocks repeat four fp64 divisions)
+        static const int delta_kernel = [] { const char *s = getenv("BEVW_BAL_DELTA_KERNEL"); return s ? atoi(s) : 1; }();
+        int vparts = 0;
+        unsigned long long *vs = h->vsums.as<unsigned long long>() + (size_t)b0 * 4 * kVsumParts;
+        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, vs, h->deltas.as<int>() + (size_t)b0 * 4, delta_kernel ? nullptr : &vparts));
+        if (delta_kernel) vs = nullptr;
         if (part == 0 && parts > 1 && skew_env) {   // the other stream's first slice starts when this one's V sums are done
             HIP_TRY(hipEventRecord(h->ev_skew, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_skew, 0));
         }
         uint8_t *scratch = h->tmp.as<uint8_t>() + (size_t)b0 * cstride;
-        BEVW_TRY(plan_lum_groups(h->plan, st, fr, scratch, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>()));
+        BEVW_TRY(plan_lum_groups(h->plan, st, fr, scratch, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>(), vs, vparts, kVsumParts));
         const bool lut_ok = npx % 4 == 0;   // (odd image sizes: the byte-wise gain kernel, in place, from k_reduce_psums' sums)
         BEVW_TRY(plan_stitch(h->plan, st, fr, n, c.blend != 0, false, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>(), nullptr,
                              lut_ok ? nullptr : h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0, scratch));

@@ -770,6 +770,32 @@ def test_output_pitch_aligned_config_s(ffi, SB, oracle, blend, balance):
         buf.free()
 
 
+def test_balance_with_the_deltas_derived_inside_the_round_trip_kernel(ffi):
+    """BEVW_BAL_DELTA_KERNEL=0 (an A/B switch read once per process, hence the child): k_lum_groups derives luminance_balance's shifts from
+    k_vsum's partial sums itself instead of k_lum_delta in between.  Same bytes as the oracle."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from cameracalibration_amd import workloads as W\n"
+        "from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB\n"
+        "from oracle import oracle as O\n"
+        "import test_gpu_parity as T\n"
+        "rig = T.small_rig(); T.set_args(SB, T.SMALL_CFG)\n"
+        "frames = W.synthetic_frames(40, T.SMALL_CFG['FRAME_WIDTH'], T.SMALL_CFG['FRAME_HEIGHT'], kind='random')\n"
+        "bev = SB.BevGenerator(blend=True, balance=True, rig=rig)\n"
+        "ref = O.RefBevGenerator(rig, T.SMALL_CFG, blend=True, balance=True)\n"
+        "got = bev.batch(frames)\n"
+        "assert bev.plan_info()['schedule'] == 2\n"
+        "assert all(np.array_equal(got[b], ref(*frames[b])) for b in range(40))\n"
+        "print('deltas inside k_lum_groups ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEVW_BAL_DELTA_KERNEL="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "deltas inside k_lum_groups ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_device_copy_yardstick(ffi):
     """bevw_device_copy_rate: what a plain copy kernel moves (read + write) on this box -- the measured figure bench.py prints beside the 8 TB/s
     specification peak.  Sanity only: above 1 TB/s, below the specification."""
