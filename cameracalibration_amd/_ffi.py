@@ -12,7 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BEVW_LIB_PATH") or os.path.join(_HERE, "libbevwarp.so")   # override: A/B of two builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 SCHED_AUTO, SCHED_PER_PIXEL, SCHED_TILE_PLAN = 0, 1, 2
 PROJ_LUT, PROJ_ANALYTIC, PROJ_ANALYTIC_F32 = 0, 1, 2   # bevw_set_projection

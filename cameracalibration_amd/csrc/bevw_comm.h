@@ -12,6 +12,7 @@
 // still run) on machines without RCCL; the types come from <rccl/rccl.h>, nothing is linked.
 #pragma once
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <rccl/rccl.h>
 
 namespace bevw {
@@ -35,10 +36,17 @@ static inline const RcclApi &rccl()
 {
     static const RcclApi api = [] {
         RcclApi a;
+        // BEVW_RCCL_LIB (read once per process): the library to use instead -- another RCCL build, or the stand-in of tests/native/rccl_standin.cpp
+        // with which the test-suite runs the rank > 0 branches below on a box with fewer GPUs than ranks (real RCCL refuses two ranks on one device)
+        const char *over = getenv("BEVW_RCCL_LIB");
+        if (over && over[0]) {
+            a.so = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!a.so) { a.why = "the library BEVW_RCCL_LIB names could not be dlopen'ed"; return a; }
+        }
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) {
-            a.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (a.so) break;
+            a.so = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         }
         if (!a.so) { a.why = "librccl.so could not be dlopen'ed"; return a; }
 #define BEVW_SYM(field, name)                                                           \

@@ -122,7 +122,7 @@ __device__ __forceinline__ int sat_u16(int v) { return v < 0 ? 0 : (v > 65535 ? 
 
 // ---- cvtColor BGR<->HSV 8-bit + V shift: luminance_balance (SurroundBirdEyeView/surroundBEV.py:57-79) ------
 // Tables of the round trip, built once on the host (make_hsv_tables, csrc/bevwarp.hip), copied into LDS by every kernel that shifts texels.
-struct HsvTables {
+struct alignas(16) HsvTables {   // (16: hsv_tables_to_lds copies it with 16-byte LDS stores)
     int sdiv[256];    // cvRound((255 << 12) / (1.0 * i))                                          (BGR2HSV, 8 bit)
     int hdiv[256];    // cvRound((180 << 12) / (6.0 * i))
     // HSV2BGR's hue arithmetic, per 8-bit H value, indexed by the LOW BYTE of the signed hue quotient q = (num * hdiv[diff] + 2048) >> 12
@@ -133,7 +133,7 @@ struct HsvTables {
     //        {{1,3,0},{1,0,2},{3,0,1},{0,2,1},{0,1,3},{2,1,0}} with candidates 2 / 3 (only one of them is ever selected) as "middle".
     uint2 hue[256];
 };
-static_assert(sizeof(HsvTables) == 4096, "HsvTables is copied as 1024 dwords");
+static_assert(sizeof(HsvTables) == 4096 && alignof(HsvTables) >= 16, "HsvTables is copied as 256 x 16 bytes");
 
 // host side: the table entry of hue byte i (see HsvTables::hue); plain float32 arithmetic, no contraction
 static inline void hsv_hue_entry(int i, uint32_t &gbits, uint32_t &sel)
@@ -419,6 +419,20 @@ __device__ __forceinline__ void warp_f32_px(const T *__restrict__ src, int sw, i
 // ---- BlendMask weight: (img * float32(mask / 255.0)).astype(uint8)  (surroundBEV.py:187-188, 279-280) -------
 __host__ __device__ __forceinline__ float blend_weight_f32(int mask_u8) { return (float)((double)mask_u8 / 255.0); }
 __device__ __forceinline__ int blend_mul(int v, float w) { return (int)((float)v * w); }  // truncation
+// The same truncation without floats, for the unit kernels (round 6): for every v, m in 0 .. 255
+//     trunc(f32(v) * f32(m / 255.0)) == (v * m) / 255 == (v * (m * 32897)) >> 23
+// (the float product is within 2^-17 relative of v m / 255 and never crosses an integer it should not: all 65,536 pairs are checked by
+// tests/native/blend_exhaustive.cpp, which compiles these two functions and blend_weight_f32 for the host).  m * 32897 <= 8,388,735 fits
+// 24 bits and v * that fits 32: v_mul_u32_u24 + v_lshrrev_b32.
+__host__ __device__ __forceinline__ uint32_t blend_weight_q23(uint32_t mask_u8) { return mask_u8 * 32897u; }
+__host__ __device__ __forceinline__ uint32_t blend_apply_q23(uint32_t v, uint32_t wq)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(v, wq) >> 23;
+#else
+    return (v * wq) >> 23;
+#endif
+}
 
 // ---- wave64 / block reductions for the balance statistics --------------------------------------------------
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)

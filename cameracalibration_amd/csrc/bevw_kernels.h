@@ -941,16 +941,33 @@ static __global__ void k_resize_linear(const uint8_t *__restrict__ src, int w, i
     }
 }
 
-// a plain copy: the measured yardstick of bevw_device_copy_rate (csrc/bevwarp.hip)
+// a plain copy: the measured yardstick of bevw_device_copy_rate (csrc/bevwarp.hip).  Round 6: kCopyDepth independent 16-byte loads in flight per
+// lane before the first store (round 5's one-load-per-trip loop with dword-wise non-temporal accesses gave 4.8 - 5.1 TB/s where
+// tools/hbm_stream.hip's unrolled copy gives 5.35); every block-trip moves kCopyDepth consecutive 4 KB pieces, blocks interleaved.
+constexpr int kCopyDepth = 8;
+typedef uint32_t copy_u32x4 __attribute__((ext_vector_type(4)));
 template <int NT>
-static __global__ void __launch_bounds__(256) k_copy16(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
+static __global__ void __launch_bounds__(256) k_copy16(const copy_u32x4 *__restrict__ src, copy_u32x4 *__restrict__ dst, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t *s4 = reinterpret_cast<const uint32_t *>(src + i);
-        uint32_t *d4 = reinterpret_cast<uint32_t *>(dst + i);
-        const uint4 v = make_uint4(once_load<NT>(s4), once_load<NT>(s4 + 1), once_load<NT>(s4 + 2), once_load<NT>(s4 + 3));
-        once_store<NT>(d4, v.x); once_store<NT>(d4 + 1, v.y); once_store<NT>(d4 + 2, v.z); once_store<NT>(d4 + 3, v.w);
+    const size_t span = (size_t)kCopyDepth * 256;
+    size_t base = (size_t)blockIdx.x * span;
+    for (; base + span <= n; base += (size_t)gridDim.x * span) {
+        copy_u32x4 v[kCopyDepth];
+#pragma unroll
+        for (int u = 0; u < kCopyDepth; ++u) {
+            const copy_u32x4 *p = src + base + (size_t)u * 256 + threadIdx.x;
+            v[u] = NT ? __builtin_nontemporal_load(p) : *p;
+        }
+#pragma unroll
+        for (int u = 0; u < kCopyDepth; ++u) {
+            copy_u32x4 *q = dst + base + (size_t)u * 256 + threadIdx.x;
+            if (NT) __builtin_nontemporal_store(v[u], q);
+            else *q = v[u];
+        }
+    }
+    for (size_t i = base + threadIdx.x; i < n && base < n; i += 256) {   // the last, partial span (at most one block gets here with work)
+        if (i >= base + span) break;
+        dst[i] = src[i];
     }
 }
 

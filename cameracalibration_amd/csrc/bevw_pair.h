@@ -11,9 +11,6 @@
 // (Rounds 2 - 3 also ran per-wave and per-block schedules on this format -- "pair classes", "block tiles", "seam tiles"; round 4
 // retired them: every staged pixel is a unit pixel now.  Their measurements stay in profiles/r02/, profiles/r03/.)
 #pragma once
-#ifndef BEVW_UNIT_ABL_BARRIER
-#define BEVW_UNIT_ABL_BARRIER 0
-#endif
 
 namespace bevw {
 
@@ -74,10 +71,6 @@ __host__ __device__ __forceinline__ void pack_accs(const uint32_t acc[4][3], uin
 }
 
 // LDS writes of this wave done, then the block's barrier (vector-memory operations stay in flight across it)
-#if BEVW_UNIT_ABL_BARRIER   // (timing experiment, wrong pixels: the waves of a block never wait for each other)
-__device__ __forceinline__ void block_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-#else
 __device__ __forceinline__ void block_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-#endif
 
 }  // namespace bevw

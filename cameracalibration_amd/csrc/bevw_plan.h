@@ -199,32 +199,15 @@ static __global__ void k_plan_touch(const uint2 *__restrict__ plan, int ntiles, 
 constexpr int kLumTrips = 8;
 static __global__ void __launch_bounds__(256) k_lum_groups(const uint8_t *__restrict__ frames, uint8_t *__restrict__ scratch, size_t set_bytes,
                                                             size_t scratch_stride, uint32_t frame_bytes, const uint32_t *__restrict__ groups, int ngroups,
-                                                            int *__restrict__ deltas, const HsvTables *__restrict__ tab,
-                                                            uint32_t blocks_per_frame, uint32_t nframes, const unsigned long long *__restrict__ vsums = nullptr,
-                                                            int nparts = 0, int part_stride = 0, double npx = 0.0)
+                                                            const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
+                                                            uint32_t blocks_per_frame, uint32_t nframes)
 {
     __shared__ HsvTables hsv;
     __shared__ int cam_delta[4];
     uint32_t frame, blk;
     if (!xcd_frame_map(blockIdx.x, blocks_per_frame, nframes, frame, blk)) return;   // grid: xcd_frame_grid()
     hsv_tables_to_lds(hsv, tab);
-    if (vsums != nullptr) {
-        // luminance_balance's scalars (surroundBEV.py:64-72) straight from k_vsum's partial sums: delta_c = cvRound(V_mean - V_c),
-        // V_mean = (Vf + Vb + Vl + Vr) / 4 -- k_lum_delta's arithmetic, done by every block for its own frame set (the kernel in
-        // between is gone); block 0 of the frame set leaves the deltas for the per-tap kernel of the border tiles
-        if (threadIdx.x < 4) {
-            double m[4];
-            for (int c = 0; c < 4; ++c) {
-                unsigned long long t = 0;
-                for (int p = 0; p < nparts; ++p) t += vsums[((size_t)frame * 4 + c) * part_stride + p];
-                m[c] = (double)t / npx;
-            }
-            const double vmean = (m[0] + m[1] + m[2] + m[3]) / 4;
-            const int dl = rne_d(vmean - m[threadIdx.x]);
-            cam_delta[threadIdx.x] = dl;
-            if (blk == 0) deltas[frame * 4 + threadIdx.x] = dl;
-        }
-    } else if (threadIdx.x < 4) cam_delta[threadIdx.x] = deltas[frame * 4 + threadIdx.x];
+    if (threadIdx.x < 4) cam_delta[threadIdx.x] = deltas[frame * 4 + threadIdx.x];   // k_lum_delta's (a kernel of its own: bevwarp.hip luminance_stats)
     const uint8_t *fin = frames + (size_t)frame * set_bytes;
     uint8_t *fout = scratch + (size_t)frame * scratch_stride;
     const int g0 = (int)blk * (kLumTrips * 256) + (int)threadIdx.x;
@@ -386,7 +369,7 @@ template <bool BLEND, bool LUM, bool SUMS = LUM>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) k_stitch_plan(PlanArgs a)
 {
     constexpr bool BAL = LUM;
-    __shared__ uint32_t hsv_words[BAL ? sizeof(HsvTables) / 4 : 1];   // (no LDS for the variants without the luminance round trip)
+    __shared__ __attribute__((aligned(16))) uint32_t hsv_words[BAL ? sizeof(HsvTables) / 4 : 1];   // (no LDS for the variants without the luminance round trip)
     const HsvTables &hsv = *reinterpret_cast<const HsvTables *>(hsv_words);
     if (BAL) {
         hsv_tables_to_lds(*reinterpret_cast<HsvTables *>(hsv_words), a.tab);
@@ -707,7 +690,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
     const bool with_sums = balance || sums;
     // channel-sum entries per frame: one per unit + one per base tile left to the per-tap kernel (or one per tile without units).  Every
     // entry has exactly one writer per frame (no atomics, round 5: 2.4 M atomic adds per config-4 step cost 58 us of the 600), and every writer
-    // writes every frame of the call -- except units without a contributor, which return early: their entries keep the zeros of the allocation
+    // writes every frame of the call (units without a contributor write zeros): no entry depends on what the buffer held before
     a.nsum = use_units ? p.n_un_all + p.n_slow : p.ntiles;
     a.sum_base = use_units ? p.n_un_all : 0;
     if (with_sums) {
@@ -722,11 +705,7 @@ static inline hipError_t plan_stitch_impl(Plan &p, hipStream_t st, const uint8_t
             p.psums_cap = need;
             p.psums_layout = -1;
         }
-        if (p.psums_layout != a.nsum) {   // a new buffer, or the other layout (units <-> every tile on the per-tap kernel): zero once
-            if ((e = hipMemsetAsync(p.psums, 0, p.psums_cap, st)) != hipSuccess) return e;
-            if ((e = hipStreamSynchronize(st)) != hipSuccess) return e;   // (the other stream's slice may start before this stream reaches the memset)
-            p.psums_layout = a.nsum;
-        }
+        p.psums_layout = a.nsum;   // (entries per frame of the layout in use: plan_sum_entries)
         a.psums = static_cast<uint32_t *>(p.psums) + (size_t)psums_first * a.nsum * 3;
     }
     auto grid_blocks = [&]() -> unsigned {
@@ -814,10 +793,8 @@ static inline hipError_t plan_unit_wide_launch(const Plan &p, hipStream_t st, co
 }
 
 // luminance-shift the sampled texel groups of every raw frame of the batch into the compact scratch (p.compact_stride bytes per frame set)
-// d_vsums != nullptr: the deltas are computed here from k_vsum's partial sums (nparts per frame, part_stride apart) and WRITTEN to d_deltas
 static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch,
-                                       int *d_deltas, const HsvTables *d_tab, const unsigned long long *d_vsums = nullptr, int nparts = 0,
-                                       int part_stride = 0)
+                                       const int *d_deltas, const HsvTables *d_tab)
 {
     if (p.n_groups == 0 || p.compact_stride == 0) return hipSuccess;
     const size_t set_bytes = (size_t)p.fw * p.fh * 3 * p.ncams;
@@ -826,8 +803,7 @@ static inline hipError_t plan_lum_band(const Plan &p, hipStream_t st, const uint
         const unsigned bpf = (unsigned)(p.n_groups + 256 * kLumTrips - 1) / (256 * kLumTrips);
         hipLaunchKernelGGL(k_lum_groups, dim3(xcd_frame_grid(bpf, (unsigned)nb)), dim3(256), 0, st, d_frames + (size_t)b0 * set_bytes,
                            d_scratch + (size_t)b0 * p.compact_stride, set_bytes, p.compact_stride, (uint32_t)p.fw * p.fh * 3,
-                           static_cast<const uint32_t *>(p.groups), p.n_groups, d_deltas + (size_t)b0 * 4, d_tab, bpf, (uint32_t)nb,
-                           d_vsums ? d_vsums + (size_t)b0 * 4 * part_stride : nullptr, nparts, part_stride, (double)p.fw * (double)p.fh);
+                           static_cast<const uint32_t *>(p.groups), p.n_groups, d_deltas + (size_t)b0 * 4, d_tab, bpf, (uint32_t)nb);
     }
     return hipGetLastError();
 }

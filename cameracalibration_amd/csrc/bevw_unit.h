@@ -46,6 +46,14 @@
 #include <cstring>
 #include <vector>
 
+// format of the wave-store (unit_store_quad16 below): 0 = 12 bytes per lane; 1 = lane quads repacked into 3 x 16 bytes where the output rows
+// are whole 64-byte sectors (the streaming layout); 2 = in every layout.  Round 6's A/B (profiles/r06/README.md section 1): the format is NOT
+// what limits the store stream -- the vector L1 merges either form into one write request per 64-byte sector (TCP_TCC_WRITE_REQ is the same),
+// the microbenchmark's rates agree to +-2 %, and the repack's 11 VALU instructions per quad slot cost config 3 4 % -> 0 stays the default.
+#ifndef BEVW_UNIT_STORE16
+#define BEVW_UNIT_STORE16 0
+#endif
+
 namespace bevw {
 
 constexpr int kUnitWaves = 4;
@@ -111,6 +119,14 @@ __host__ __device__ __forceinline__ void unit_decode_wide(uint32_t e, uint32_t f
     i1 = ((e >> 10) & 0xffcu) | (e & 3u);
     fx = (float)((((e >> 22) & 31u) << 16) | (f & 0xffffu)) * (1.0f / (float)(1u << kUnitFracBits));
     fy = (float)(((e >> 27) << 16) | (f >> 16)) * (1.0f / (float)(1u << kUnitFracBits));
+}
+// 16-byte store format: dwords q .. q + 3 of S = {d0, d1, d2, n0, n1, n2} -- lane q (0 .. 2) of a lane quad holds d, its right neighbour n
+__host__ __device__ __forceinline__ void unit_repack16(int q, const uint32_t d[3], const uint32_t n[3], uint32_t o[4])
+{
+    o[0] = q == 0 ? d[0] : (q == 1 ? d[1] : d[2]);
+    o[1] = q == 0 ? d[1] : (q == 1 ? d[2] : n[0]);
+    o[2] = q == 0 ? d[2] : (q == 1 ? n[0] : n[1]);
+    o[3] = q == 0 ? n[0] : (q == 1 ? n[1] : n[2]);
 }
 __host__ __device__ __forceinline__ bool unit_no_contributor(uint32_t e) { return ((e >> 2) & 1023u) == ((e >> 12) & 1023u); }
 // one pixel from its two pair entries in fp32: b0 b1 g0 g1 | r0 r1 of both footprint rows -> B | G << 8 | R << 16, round half to even.
@@ -548,9 +564,11 @@ static inline std::vector<uint32_t> unit_host_headers(const std::vector<int16_t>
 // ---------------------------------------------------------------------------------------------------------------------------------
 static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, const uint8_t *frame_set, size_t set_bytes, bool blend,
                                 const uint8_t *car, int pitch, uint8_t *out_img, uint32_t sums[3] = nullptr, std::vector<uint8_t> *written = nullptr)
+    // written: per PIXEL, the number of its BYTES stored (3 = every byte exactly once)
 {
     const UnitDesc &d = up.desc[unit];
     const int NQ = kUnitClassNQ[cls], GR = kUnitClassGR[cls], NCON = kUnitClassCON[cls], fpart = NCON == 2 ? 3 : 1, parts = fpart + (up.wide ? NCON : 0);
+    const bool store16 = BEVW_UNIT_STORE16 == 2 || (BEVW_UNIT_STORE16 == 1 && ((uint32_t)pitch * 3u) % 64u == 0u);   // as plan_unit_run
     std::vector<uint8_t> patch((size_t)kUnitMaxGroups * 32, 0xcd);
     if (d.groups != 0)
         for (int r = 0; r < GR; ++r)
@@ -566,7 +584,10 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
             }
     const int ux = (int)(int16_t)(d.pos & 0xffffu), uy = (int)(d.pos >> 16), uw = (int)(d.shape & 0xffffu), uh = (int)(d.shape >> 16);
     for (int wave = 0; wave < kUnitWaves; ++wave)
-        for (int j = 0; j < NQ; ++j)
+        for (int j = 0; j < NQ; ++j) {
+            uint32_t od[64][3];     // the wave's packed quads of this slot, the lanes' store masks and offsets: the store format needs the neighbours
+            bool st[64];
+            size_t so[64];
             for (int lane = 0; lane < 64; ++lane) {
                 const int sidx = unit_slot(wave, j);
                 int qx, row;
@@ -592,9 +613,9 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                                 memcpy(&q1, patch.data() + (size_t)i1 * 8, 8);
                                 bilinear_pairs(q0, q1, wxa, wxa << 16, wy, acc);
                             }
-                            const float wf = NCON == 2 ? blend_weight_f32((int)((e[2 * 256 + p] >> (8 * con)) & 255u)) : 1.f;
+                            const uint32_t wm = NCON == 2 ? blend_weight_q23((e[2 * 256 + p] >> (8 * con)) & 255u) : 0u;
                             for (int k = 0; k < 3; ++k) {
-                                const int v = (int)((acc[k] >> 16) & 255u), c = (blend && NCON == 2) ? (int)((float)v * wf) : v;
+                                const int v = (int)((acc[k] >> 16) & 255u), c = (blend && NCON == 2) ? (int)blend_apply_q23((uint32_t)v, wm) : v;
                                 px[k] = con == 0 ? c : (px[k] + c < 255 ? px[k] + c : 255);
                             }
                         }
@@ -603,18 +624,31 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
                             for (int k = 0; k < 3; ++k) sums[k] += (uint32_t)px[k];
                     }
                 const int x = ux + 4 * qx + unit_skew(up.skew, uy + row);
-                if (4 * qx >= uw || row >= uh || x < 0 || x >= pitch || (unit_no_contributor(e[0]) && (e[0] & kUnitSkip))) continue;   // the lane's store is masked
-                uint32_t o[3];
-                const size_t ooff = ((size_t)(uy + row) * pitch + x) * 3;
-                if (car) {
+                st[lane] = !(4 * qx >= uw || row >= uh || x < 0 || x >= pitch || (unit_no_contributor(e[0]) && (e[0] & kUnitSkip)));   // else: the lane's store is masked
+                so[lane] = ((size_t)(uy + row) * pitch + x) * 3;
+                if (st[lane] && car) {
                     uint32_t c[3];
-                    memcpy(c, car + ooff, 12);
+                    memcpy(c, car + so[lane], 12);
                     add_car(P, c[0], c[1], c[2]);
                 }
-                pack_pixels(P, o[0], o[1], o[2]);
-                memcpy(out_img + ooff, o, 12);
-                if (written) for (int k = 0; k < 4; ++k) ++(*written)[(size_t)(uy + row) * pitch + x + k];
+                pack_pixels(P, od[lane][0], od[lane][1], od[lane][2]);
             }
+            // the wave-store (unit_store_quad16 / unit_store_quad): whole lane quads write 3 x 16 bytes, the other lanes 12 bytes
+            for (int lane = 0; lane < 64; ++lane) {
+                const int q = lane & 3, l0 = lane & ~3;
+                const bool whole = store16 && st[l0] && st[l0 + 1] && st[l0 + 2] && st[l0 + 3];
+                if (whole) {
+                    if (q == 3) continue;
+                    uint32_t o[4];
+                    unit_repack16(q, od[lane], od[lane + 1], o);   // (lane + 1 <= l0 + 3: the next lane of the quad)
+                    memcpy(out_img + so[lane] + 4 * q, o, 16);
+                    if (written) for (int k = 0; k < 16; ++k) ++(*written)[(so[lane] + 4 * q + k) / 3];
+                } else if (st[lane]) {
+                    memcpy(out_img + so[lane], od[lane], 12);
+                    if (written) for (int k = 0; k < 12; ++k) ++(*written)[(so[lane] + k) / 3];
+                }
+            }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -627,29 +661,20 @@ static inline void unit_emulate(const UnitPlanHost &up, uint32_t unit, int cls, 
 // (LDS indices and weights of 4 pixels) + 8 per round of groups in flight; nothing else lives across the frame loop -- the car
 // sprite is re-read per frame by the few units that lie under it.
 // NCON == 2: two plan entries and two blend weights per pixel (seams, blend overlaps): second contribution added with saturation
-// (cv2.add, surroundBEV.py:318-320), weights applied as trunc(f32(v) * w) when BLEND (surroundBEV.py:279-280).
+// (cv2.add, surroundBEV.py:318-320), weights applied as trunc(f32(v) * f32(m / 255.0)) when BLEND (surroundBEV.py:279-280) -- in its exact
+// integer form (v * (m * 32897)) >> 23 (blend_apply_q23, bevw_device.h: one 24-bit multiply and a shift instead of cvt / mul / cvt).
 // WIDE: the plan carries 21-bit fractions and the pixels are interpolated in fp32 (the analytic projection mode); wxa / wy then hold the
 // bit patterns of fx / fy.
-// (experiment: -DBEVW_UNIT_PRIO_ON raises the wave priority around the memory instructions of a frame; profiles/r03/sweeps.log)
 #ifndef BEVW_UNIT_DEPTH
 #define BEVW_UNIT_DEPTH 2
-#endif
-#ifndef BEVW_UNIT_EARLY_STORE
-#define BEVW_UNIT_EARLY_STORE 0
 #endif
 #ifndef BEVW_UNIT_NO_BIG
 #define BEVW_UNIT_NO_BIG 0
 #endif
-#ifndef BEVW_UNIT_ABL_SUMS
-#define BEVW_UNIT_ABL_SUMS 0
-#endif
-#ifndef BEVW_UNIT_ABL_LDS
-#define BEVW_UNIT_ABL_LDS 0
-#endif
-#ifdef BEVW_UNIT_PRIO_ON
-#define BEVW_UNIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define BEVW_UNIT_PRIO(x) ((void)0)
+// Timing experiments that produce wrong pixels (the memory-only replay of the request stream) live in bevw_unit_experiments.h and are compiled
+// only into tagged variant builds (-DBEVW_EXPERIMENT=<n>, cameracalibration_amd/build.py refuses flags without a tag).
+#ifdef BEVW_EXPERIMENT
+#include "bevw_unit_experiments.h"
 #endif
 // sum of v over the 64 lanes of the wave, uniform result: four DPP adds inside the rows of 16 lanes (quad swaps, half-row and row mirrors),
 // two row broadcasts (gfx9 wave64: lane 15 of every row into the next row, lane 31 into rows 2 and 3), then lane 63 holds the total
@@ -680,6 +705,25 @@ __device__ __forceinline__ void unit_store_quad(pair_u32x3 v, __amdgpu_buffer_rs
     if (streaming) __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, kPairStreamAux);
     else __builtin_amdgcn_raw_buffer_store_b96(v, ro, off, 0, kPairStoreAux);
 }
+// Round 6: the FORMAT of the wave-store.  64 lanes x 12 bytes put a lane across every 64-byte sector boundary of the row run (64 / 12 = 5.33 lanes
+// per sector); the 4 x 12 bytes of a LANE QUAD (16 pixels of one row: lanes 4k .. 4k+3 always lie in one row, lq >= 2) repacked into 3 x 16 bytes
+// and stored as buffer_store_dwordx4 from 3 of the 4 lanes cover the same 48 bytes with every 16-byte piece inside one sector.  The repack is
+// the funnel S[q .. q + 3] of S = {d0, d1, d2, n0, n1, n2}, n = the next lane's dwords (3 v_mov_b32 quad_perm [1, 2, 3, 3], 8 v_cndmask).
+// Lane quads in which some lane does not store (a skipped base tile never cuts a lane quad, but a unit's last columns or the image's right edge
+// may) keep the 12-byte store: `off12` is in range only for their lanes, and the second store is skipped wave-uniformly (`part_any`).
+// tools/store_pattern.hip "format" is the microbenchmark of exactly this pair; profiles/r06/README.md has the A/B.
+__device__ __forceinline__ void unit_store_quad16(uint32_t d0, uint32_t d1, uint32_t d2, __amdgpu_buffer_rsrc_t ro, int off16, int q, bool streaming)
+{
+    const uint32_t d[3] = {d0, d1, d2};
+    const uint32_t n[3] = {(uint32_t)__builtin_amdgcn_update_dpp(0, (int)d0, 0xF9, 0xf, 0xf, false),    // quad_perm [1, 2, 3, 3]
+                           (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d1, 0xF9, 0xf, 0xf, false),
+                           (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d2, 0xF9, 0xf, 0xf, false)};
+    uint32_t o[4];
+    unit_repack16(q, d, n, o);
+    const pair_u32x4 v = {o[0], o[1], o[2], o[3]};
+    if (streaming) __builtin_amdgcn_raw_buffer_store_b128(v, ro, off16, 0, kPairStreamAux);
+    else __builtin_amdgcn_raw_buffer_store_b128(v, ro, off16, 0, kPairStoreAux);
+}
 template <bool BLEND, bool SUMS, int NQ, int GR, int NCON, bool WIDE = false>
 __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk, uint32_t unit, uint8_t *lds, uint4 *wave_sums = nullptr)
 {
@@ -703,7 +747,12 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     constexpr bool DB = 2 * kPatch <= kUnitMaxGroups * 32;      // both halves fit the block's 32 KB
 
     uint32_t i0[NQ][NCON][4], i1[NQ][NCON][4], wxa[NQ][NCON][4], wy[NQ][NCON][4], gs[GR], ooff_masked[NQ];
-    float wf[NQ][NCON][4];
+    // 16-byte store format (unit_store_quad16): the lane's offset of its 16-byte piece (lanes q < 3 of whole lane quads; out of range otherwise);
+    // bit j of part_bits = slot j of this lane stores 12 bytes after all (its lane quad is not whole); part_any: some lane of the wave does
+    const bool store16 = BEVW_UNIT_STORE16 == 2 || (BEVW_UNIT_STORE16 == 1 && streaming);
+    uint32_t ooff16[NQ], part_bits = 0;
+    bool part_any[NQ];
+    uint32_t wq[NQ][NCON][4];    // blend weights as 24-bit integer factors (blend_weight_q23)
     const bool with_car = !SUMS && a.car != nullptr;
     const __amdgpu_buffer_rsrc_t rcar = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(with_car ? a.car : a.out), 0,
                                                                           with_car ? (uint32_t)img_bytes : 0u, kBufferWord3);
@@ -733,24 +782,36 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             } else {
 #pragma unroll
                 for (int p = 0; p < 4; ++p) unit_decode(e[p], i0[j][con][p], i1[j][con][p], wxa[j][con][p], wy[j][con][p]);
-#if BEVW_UNIT_ABL_LDS   // (timing experiment, wrong pixels: every lane reads its own consecutive qword -- the pixel reads without bank conflicts)
-#pragma unroll
-                for (int p = 0; p < 4; ++p) { i0[j][con][p] = (uint32_t)lane + 64u * (uint32_t)p; i1[j][con][p] = (uint32_t)lane + 64u * (uint32_t)p + 256u; }
-#endif
             }
         }
         if (kWeights) {
             const uint4 w4 = unit_plan_load(a.un_entries + ((size_t)ent_off + sidx * kParts + 2) * 64 + lane);
             const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-            for (int p = 0; p < 4; ++p) { wf[j][0][p] = blend_weight_f32((int)(w[p] & 255u)); wf[j][NCON - 1][p] = blend_weight_f32((int)((w[p] >> 8) & 255u)); }
+            for (int p = 0; p < 4; ++p) { wq[j][0][p] = blend_weight_q23(w[p] & 255u); wq[j][NCON - 1][p] = blend_weight_q23((w[p] >> 8) & 255u); }
         }
         const bool store = 4 * qx < uw && row < uh && x >= 0 && x < a.pitch && !(unit_no_contributor(e0) && (e0 & kUnitSkip));
         ooff_masked[j] = store ? ooff : kPairNoGroup;   // out of range of the image's buffer descriptor: neither read (car) nor written
+        {
+            const bool whole = ((__builtin_amdgcn_ballot_w64(store) >> (lane & ~3)) & 0xfull) == 0xfull;
+            ooff16[j] = (store16 && whole && (lane & 3) < 3) ? ooff + 4u * (uint32_t)(lane & 3) : kPairNoGroup;
+            const bool part = store && !(store16 && whole);
+            part_bits |= (part ? 1u : 0u) << j;
+            part_any[j] = __builtin_amdgcn_ballot_w64(part) != 0;
+        }
         const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);
         car_or |= c.x | c.y | c.z;
     }
     const bool car_any = __builtin_amdgcn_ballot_w64(car_or != 0) != 0;
+    // the 12 output bytes of quad slot j to image `ro` (unit_store_quad16 / unit_store_quad)
+    auto store_slot = [&](int j, uint32_t d0, uint32_t d1, uint32_t d2, const __amdgpu_buffer_rsrc_t ro) {
+        if (BEVW_UNIT_STORE16 == 0) {
+            unit_store_quad(pair_u32x3{d0, d1, d2}, ro, (int)ooff_masked[j], streaming);
+            return;
+        }
+        if (store16) unit_store_quad16(d0, d1, d2, ro, (int)ooff16[j], lane & 3, streaming);
+        if (part_any[j]) unit_store_quad(pair_u32x3{d0, d1, d2}, ro, ((part_bits >> j) & 1u) ? (int)ooff_masked[j] : (int)kPairNoGroup, streaming);
+    };
     const int b_begin = (int)chunk * a.nb, b_end = min(a.batch, b_begin + a.nb);
 
     if (ngroups == 0) {
@@ -762,8 +823,10 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #pragma unroll
             for (int j = 0; j < NQ; ++j) {
                 const pair_u32x3 c = __builtin_amdgcn_raw_buffer_load_b96(rcar, (int)ooff_masked[j], 0, 0);   // zeros without a sprite
-                unit_store_quad(c, ro, (int)ooff_masked[j], streaming);
+                store_slot(j, c.x, c.y, c.z, ro);
             }
+            // its channel sums are zero, and it says so for every frame: no entry depends on what the buffer held before (another layout's sums)
+            if (SUMS && wave == 0 && lane < 3) a.psums[((size_t)b * a.nsum + unit) * 3 + lane] = 0u;
         }
         return;
     }
@@ -796,22 +859,8 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     auto acc_to_px = [](const uint32_t acc[3]) {
         return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
     };
-#ifdef BEVW_UNIT_ABLATE_MEMORY_ONLY
-    // timing experiment (wrong pixels): the same loads and stores per frame, no conversion, no LDS, no interpolation, no barrier
-    auto frame = [&](int b, int ring) {
-        uint32_t keep = 0;
-#pragma unroll
-        for (int r = 0; r < GR; ++r) keep ^= pf[ring][r].x ^ pf[ring][r].y ^ pf[ring][r].z ^ pf[ring][r].w;
-        // BEVW_UNIT_ABLATE_MEMORY_ONLY: 1 = loads and stores, 2 = loads only (a store that never fires keeps them alive), 3 = stores only
-        if (BEVW_UNIT_ABLATE_MEMORY_ONLY != 3) issue(b + D, ring);
-        uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;
-        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            if (BEVW_UNIT_ABLATE_MEMORY_ONLY == 2 && keep != 0x12345679u) continue;
-            unit_store_quad(pair_u32x3{keep, keep + i0[j][0][0], keep}, ro, (int)ooff_masked[j], streaming);
-        }
-    };
+#ifdef BEVW_EXPERIMENT
+    auto frame = [&](int b, int ring) { BEVW_EXPERIMENT_FRAME(b, ring) };
 #else
     auto frame = [&](int b, int ring) {
         if (!DB) {
@@ -819,9 +868,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
             block_lds_barrier();
         }
         const uint2 *const pw = reinterpret_cast<const uint2 *>(lds + (DB ? (ring & 1) * kPatch : 0));
-        BEVW_UNIT_PRIO(3);
         issue(b + D, ring);        // the ring slot of frame b has been converted
-        BEVW_UNIT_PRIO(0);
         uint32_t d[NQ][3];
         uint32_t tb = 0, tg = 0, tr = 0;
 #pragma unroll
@@ -838,8 +885,8 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             const uint32_t a0 = (v >> (8 * k)) & 255u, a1 = (v1 >> (8 * k)) & 255u;
-                            const int c0 = kWeights ? (int)((float)a0 * wf[j][0][p]) : (int)a0, c1 = kWeights ? (int)((float)a1 * wf[j][NCON - 1][p]) : (int)a1;
-                            px |= (uint32_t)min(255, c0 + c1) << (8 * k);
+                            const uint32_t c0 = kWeights ? blend_apply_q23(a0, wq[j][0][p]) : a0, c1 = kWeights ? blend_apply_q23(a1, wq[j][NCON - 1][p]) : a1;
+                            px |= min(255u, c0 + c1) << (8 * k);
                         }
                         v = px;
                     }
@@ -871,8 +918,8 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
                             const uint32_t v0 = (acc[p][k] >> 16) & 255u, v1 = (acc1[k] >> 16) & 255u;
-                            const int c0 = kWeights ? (int)((float)v0 * wf[j][0][p]) : (int)v0, c1 = kWeights ? (int)((float)v1 * wf[j][NCON - 1][p]) : (int)v1;
-                            px |= (uint32_t)min(255, c0 + c1) << (8 * k);
+                            const uint32_t c0 = kWeights ? blend_apply_q23(v0, wq[j][0][p]) : v0, c1 = kWeights ? blend_apply_q23(v1, wq[j][NCON - 1][p]) : v1;
+                            px |= min(255u, c0 + c1) << (8 * k);
                         }
                         P[p] = px;
                     }
@@ -890,38 +937,22 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
                 tg = __builtin_amdgcn_udot4(d[j][2], 0x00010000u, __builtin_amdgcn_udot4(d[j][1], 0x01000001u, __builtin_amdgcn_udot4(d[j][0], 0x00000100u, tg, false), false), false);
                 tr = __builtin_amdgcn_udot4(d[j][2], 0x01000001u, __builtin_amdgcn_udot4(d[j][1], 0x00000100u, __builtin_amdgcn_udot4(d[j][0], 0x00010000u, tr, false), false), false);
             }
-#if BEVW_UNIT_EARLY_STORE
-            {   // experiment: a quad is stored as soon as it is interpolated (the store stream spread over the frame's arithmetic)
-                uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;
-                const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-                unit_store_quad(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], streaming);
-            }
-#endif
         }
         if (SUMS) {
             // One wave reduction per frame, on the VALU (DPP adds): round 3 reduced every quad slot with __shfl_xor = 12 ds_bpermute_b32 per
             // slot, more LDS-pipe instructions than the slot's pixel reads.  A lane's NQ x 4 pixels sum to <= 4080 per channel, a wave to
             // <= 261120.  Skipped quads and lanes without a quad have zero entries: they add 0.  The four waves' sums meet in LDS behind the
             // frame's barrier (two slots, alternating with the frame), and ONE lane triple of the block stores the unit's entry: no atomics
-#if BEVW_UNIT_ABL_SUMS == 2   // (timing experiment: no wave reduction -- wrong sums)
-            const uint32_t wb = tb, wg = tg, wr = tr;
-#else
             const uint32_t wb = wave_sum_dpp(tb), wg = wave_sum_dpp(tg), wr = wave_sum_dpp(tr);
-#endif
             if (lane == 0) wave_sums[(ring & 1) * kUnitWaves + wave] = make_uint4(wb, wg, wr, 0u);
         }
         if (DB) land((ring + 1) % D);    // frame b+1 into the other half: nobody reads it before the barrier
-#if !BEVW_UNIT_EARLY_STORE
         {
             uint8_t *img = a.out + (size_t)frame_of(b) * img_bytes;   // past the chunk: re-writes the last frame with the same bytes
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(img, 0, (uint32_t)img_bytes, kBufferWord3);
-            BEVW_UNIT_PRIO(3);
 #pragma unroll
-            for (int j = 0; j < NQ; ++j)
-                unit_store_quad(pair_u32x3{d[j][0], d[j][1], d[j][2]}, ro, (int)ooff_masked[j], streaming);
-            BEVW_UNIT_PRIO(0);
+            for (int j = 0; j < NQ; ++j) store_slot(j, d[j][0], d[j][1], d[j][2], ro);
         }
-#endif
         block_lds_barrier();       // DB: half[ring ^ 1] complete for everybody, half[ring] free for frame b+2; else: the patch is free
         if (SUMS && wave == 0 && lane < 3 && b < b_end) {
             // (slot ring & 1 is written again in frame b + 2, behind the barrier of frame b + 1, which this wave passes after these reads)
@@ -932,7 +963,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #endif
 #pragma unroll
     for (int u = 0; u < D; ++u) issue(b_begin + u, u);
-#ifndef BEVW_UNIT_ABLATE_MEMORY_ONLY
+#ifndef BEVW_EXPERIMENT
     if (DB) {
         land(0);
         block_lds_barrier();

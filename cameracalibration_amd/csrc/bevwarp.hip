@@ -399,7 +399,8 @@ int bevw_memset(int device, void *dst, int value, size_t nbytes)
 }
 
 // A plain device-to-device copy kernel and its rate: the yardstick SURVEY.md 8(d) asks for beside the 8 TB/s specification figure ("also
-// report fraction of a measured device-copy kernel").  16 bytes per lane and trip, grid-stride; streaming == 1: non-temporal loads and stores.
+// report fraction of a measured device-copy kernel").  Eight 16-byte loads in flight per lane, blocks interleaved; streaming == 1: non-temporal
+// loads and stores.
 int bevw_device_copy_rate(int device, size_t nbytes, int reps, int streaming, double *gb_per_s_moved)
 {
     if (!gb_per_s_moved || reps <= 0 || nbytes < 16) return fail(BEVW_E_INVALID, "bad argument");
@@ -412,10 +413,10 @@ int bevw_device_copy_rate(int device, size_t nbytes, int reps, int streaming, do
     if (s == BEVW_OK && hipMemset(a.p, 0x5a, nbytes) != hipSuccess) s = fail(BEVW_E_HIP, "memset failed");
     if (s == BEVW_OK) {
         const size_t n = nbytes / 16;
-        const dim3 grid(256 * 16), block(256);
+        const dim3 grid(256 * 32), block(256);
         auto launch = [&] {
-            if (streaming) hipLaunchKernelGGL(k_copy16<1>, grid, block, 0, nullptr, a.as<uint4>(), b.as<uint4>(), n);
-            else hipLaunchKernelGGL(k_copy16<0>, grid, block, 0, nullptr, a.as<uint4>(), b.as<uint4>(), n);
+            if (streaming) hipLaunchKernelGGL(k_copy16<1>, grid, block, 0, nullptr, a.as<copy_u32x4>(), b.as<copy_u32x4>(), n);
+            else hipLaunchKernelGGL(k_copy16<0>, grid, block, 0, nullptr, a.as<copy_u32x4>(), b.as<copy_u32x4>(), n);
         };
         launch();   // warm-up
         (void)hipEventRecord(e0, nullptr);
@@ -852,9 +853,7 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
 // luminance statistics of a batch of 4-camera sets -> deltas[batch][4].  d_vsums: kVsumParts entries per frame (ensure_stats): every block
 // of k_vsum stores its partial sum, k_lum_delta adds them -- no atomics and no zeroing pass per step (round 5: the 4 KB hipMemsetAsync in
 // front of every slice's k_vsum cost 20 us of stream time, twice per config-4 step).
-// parts_out != nullptr: only the V sums; the caller's next kernel derives the deltas from the *parts_out partial sums per frame (plan_lum_groups)
-static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, int fw, int fh, unsigned long long *d_vsums,
-                           int *d_deltas, int *parts_out = nullptr)
+static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, int fw, int fh, unsigned long long *d_vsums, int *d_deltas)
 {
     const size_t frame_bytes = (size_t)fw * fh * 3;
     const int nframes = nsets * 4;
@@ -867,13 +866,13 @@ static int luminance_stats(hipStream_t st, const uint8_t *d_frames, int nsets, i
         hipLaunchKernelGGL(k_vsum, dim3(bpf, nf), dim3(256), 0, st, d_frames + (size_t)f0 * frame_bytes, frame_bytes, vec_ok,
                            d_vsums + (size_t)f0 * kVsumParts, kVsumParts);
     }
-    if (parts_out) { *parts_out = bpf; return launch_check("k_vsum"); }
     hipLaunchKernelGGL(k_lum_delta, dim3((nsets + 63) / 64), dim3(64), 0, st, d_vsums, (double)fw * (double)fh, nsets,
                        d_deltas, bpf, kVsumParts);
     return launch_check("k_vsum/k_lum_delta");
 }
 
-// The gain pass of frame sets [b0, b0 + n) (color_balance + car, surroundBEV.py:43-55, 323-324) on `st`
+// The gain pass of frame sets [b0, b0 + n) (color_balance + car, surroundBEV.py:43-55, 323-324) on `st`; gain_in = the pre-gain image of
+// frame set b0 (the slice's own buffer, or frame b0's place in a whole-batch one: the caller decides).
 // from_plan: the channel sums are the partial sums the tile plan's stitch of these frames left behind (k_gain_lut adds them itself)
 static int gain_pass(bevw_handle *h, hipStream_t st, const uint8_t *gain_in, const uint8_t *gain_car, const uint8_t *d_car, uint8_t *d_out, int b0, int n,
                      bool lut_ok, bool from_plan = false)
@@ -885,7 +884,7 @@ static int gain_pass(bevw_handle *h, hipStream_t st, const uint8_t *gain_in, con
         int nsum = 0;
         const uint32_t *ps = (from_plan && lut_ok) ? plan_sum_entries(h->plan, k0, nsum) : nullptr;
         if (lut_ok)
-            hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, st, gain_in + (size_t)k0 * npx * 3, npx,
+            hipLaunchKernelGGL(k_gain_lut, dim3(xcd_frame_grid(32, (unsigned)nb)), dim3(256), 0, st, gain_in + (size_t)(k0 - b0) * npx * 3, npx,
                                h->chsums.as<unsigned long long>() + (size_t)k0 * 3, gain_car, d_out + (size_t)k0 * npx * 3, 32u,
                                (uint32_t)nb, h->compat[BEVW_COMPAT_ADDWEIGHTED] ? 0 : 1, npx_true, ps, nsum);
         else
@@ -913,19 +912,6 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
     const size_t set_bytes = (size_t)c.frame_width * c.frame_height * 12;
     BEVW_TRY(ensure_stats(h, batch));
     const size_t cstride = h->plan.compact_stride;   // the compact scratch: only the sampled texel groups of a frame set (bevw_unit.h: unit_gsrc_compact)
-    BEVW_TRY(h->tmp.reserve(cstride * (size_t)batch));
-    // the gain pass reads the pre-gain BEV from a buffer of its own instead of rewriting the output in place: a read stream
-    // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
-    // one more BEV batch of HBM (0.9 GB at batch 256).  No room for it: the gain pass runs in place -- never an error
-    static const int oop = [] { const char *s = getenv("BEVW_GAIN_OOP"); return s ? atoi(s) : 1; }();
-    uint8_t *gain_in = d_out;
-    if (oop && npx % 4 == 0 && h->pre.reserve(npx * 3 * (size_t)batch) == BEVW_OK) gain_in = h->pre.as<uint8_t>();
-    const uint8_t *gain_car = d_car;
-    if (pitched && d_car) {   // the gain pass walks the image as a flat array: the sprite needs the same row pitch
-        BEVW_TRY(h->car_pitched.reserve(npx * 3));
-        BEVW_TRY(plan_pad_image(h->stream, d_car, c.bev_width, h->pitch_px, c.bev_height, h->car_pitched.as<uint8_t>()));
-        gain_car = h->car_pitched.as<uint8_t>();
-    }
     static const int parts_env = [] { const char *s = getenv("BEVW_BAL_PARTS"); return s ? atoi(s) : 0; }();
     static const int skew_env = [] { const char *s = getenv("BEVW_BAL_SKEW"); return s ? atoi(s) : 0; }();
     // slices share the plan's padded scratch image when the BEV width is not a multiple of 4 pixels: one slice then
@@ -937,6 +923,27 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
     if (scratch) parts = 1;
     if (parts > batch) parts = batch;
     if (parts > 1 && !h->stream2 && hipStreamCreate(&h->stream2) != hipSuccess) { (void)hipGetLastError(); h->stream2 = nullptr; parts = 1; }
+    // BEVW_BAL_RING=1 (A/B of round 6, profiles/r06/README.md): the two intermediate buffers of a slice -- the compact scratch of shifted texel
+    // groups and the pre-gain BEV -- belong to the STREAM, not to the frame sets: slice k reuses the addresses of slice k - 2, so that with
+    // slices small enough both stay in the 256 MB Infinity Cache between their writer and their reader and are overwritten there
+    static const int ring_env = [] { const char *s = getenv("BEVW_BAL_RING"); return s ? atoi(s) : 0; }();
+    const bool ring = ring_env != 0 && parts > 2;
+    const int slice_max = (batch + parts - 1) / parts;
+    const size_t slots = ring ? (size_t)2 * slice_max : (size_t)batch;
+    BEVW_TRY(h->tmp.reserve(cstride * slots));
+    // the gain pass reads the pre-gain BEV from a buffer of its own instead of rewriting the output in place: a read stream
+    // and a write stream instead of one read-modify-write stream (config 4 2.108 -> 2.052 ms, profiles/r02/sweeps.log); costs
+    // one more BEV batch of HBM (0.9 GB at batch 256).  No room for it: the gain pass runs in place -- never an error
+    static const int oop = [] { const char *s = getenv("BEVW_GAIN_OOP"); return s ? atoi(s) : 1; }();
+    uint8_t *gain_in = d_out;
+    if (oop && npx % 4 == 0 && h->pre.reserve(npx * 3 * slots) == BEVW_OK) gain_in = h->pre.as<uint8_t>();
+    const bool pre_ring = ring && gain_in != d_out;
+    const uint8_t *gain_car = d_car;
+    if (pitched && d_car) {   // the gain pass walks the image as a flat array: the sprite needs the same row pitch
+        BEVW_TRY(h->car_pitched.reserve(npx * 3));
+        BEVW_TRY(plan_pad_image(h->stream, d_car, c.bev_width, h->pitch_px, c.bev_height, h->car_pitched.as<uint8_t>()));
+        gain_car = h->car_pitched.as<uint8_t>();
+    }
     if (parts > 1) {
         HIP_TRY(hipEventRecord(h->ev_fork, h->stream));          // the caller's uploads (and the padded sprite) were enqueued on stream
         HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_fork, 0));
@@ -946,23 +953,22 @@ static int balance_plan_run(bevw_handle *h, const uint8_t *d_frames, int batch, 
         if (!n) continue;
         hipStream_t st = (part & 1) ? h->stream2 : h->stream;
         const uint8_t *fr = d_frames + (size_t)b0 * set_bytes;
-        // BEVW_BAL_DELTA_KERNEL=0 (A/B): the deltas derived inside k_lum_groups from the partial V sums instead of by k_lum_delta, a kernel of
-        // its own in between -- measured SLOWER (1.669 against 1.660 ms, profiles/r05/ab_call17...: 22 k blocks repeat four fp64 divisions)
-        static const int delta_kernel = [] { const char *s = getenv("BEVW_BAL_DELTA_KERNEL"); return s ? atoi(s) : 1; }();
-        int vparts = 0;
-        unsigned long long *vs = h->vsums.as<unsigned long long>() + (size_t)b0 * 4 * kVsumParts;
-        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, vs, h->deltas.as<int>() + (size_t)b0 * 4, delta_kernel ? nullptr : &vparts));
-        if (delta_kernel) vs = nullptr;
+        // (Deriving the deltas inside k_lum_groups instead of by k_lum_delta, a kernel of its own in between, measured SLOWER: 1.669 against
+        // 1.660 ms, profiles/r05/ab_call17...: 22 k blocks repeat four fp64 divisions.  The switch is gone.)
+        BEVW_TRY(luminance_stats(st, fr, n, c.frame_width, c.frame_height, h->vsums.as<unsigned long long>() + (size_t)b0 * 4 * kVsumParts,
+                                 h->deltas.as<int>() + (size_t)b0 * 4));
         if (part == 0 && parts > 1 && skew_env) {   // the other stream's first slice starts when this one's V sums are done
             HIP_TRY(hipEventRecord(h->ev_skew, h->stream));
             HIP_TRY(hipStreamWaitEvent(h->stream2, h->ev_skew, 0));
         }
-        uint8_t *scratch = h->tmp.as<uint8_t>() + (size_t)b0 * cstride;
-        BEVW_TRY(plan_lum_groups(h->plan, st, fr, scratch, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>(), vs, vparts, kVsumParts));
+        const size_t slot0 = ring ? (size_t)(part & 1) * slice_max : (size_t)b0;   // the slice's first frame-set slot in the intermediate buffers
+        uint8_t *shifted = h->tmp.as<uint8_t>() + slot0 * cstride;
+        uint8_t *pre = gain_in + (pre_ring ? slot0 : (size_t)b0) * npx * 3;
+        BEVW_TRY(plan_lum_groups(h->plan, st, fr, shifted, n, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>()));
         const bool lut_ok = npx % 4 == 0;   // (odd image sizes: the byte-wise gain kernel, in place, from k_reduce_psums' sums)
         BEVW_TRY(plan_stitch(h->plan, st, fr, n, c.blend != 0, false, h->deltas.as<int>() + (size_t)b0 * 4, h->hsv.as<HsvTables>(), nullptr,
-                             lut_ok ? nullptr : h->chsums.as<unsigned long long>() + (size_t)b0 * 3, gain_in + (size_t)b0 * npx * 3, true, batch, b0, scratch));
-        BEVW_TRY(gain_pass(h, st, gain_in, gain_car, d_car, d_out, b0, n, lut_ok, true));
+                             lut_ok ? nullptr : h->chsums.as<unsigned long long>() + (size_t)b0 * 3, pre, true, batch, b0, shifted));
+        BEVW_TRY(gain_pass(h, st, pre, gain_car, d_car, d_out, b0, n, lut_ok, true));
     }
     if (parts > 1) {   // everything the caller enqueues on the handle's stream afterwards sees the whole batch
         HIP_TRY(hipEventRecord(h->ev_join, h->stream2));

@@ -62,10 +62,9 @@ int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, boo
     return BEVW_OK;
 }
 
-int plan_lum_groups(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch, int *d_deltas, const HsvTables *d_tab,
-                    const unsigned long long *d_vsums, int nparts, int part_stride)
+int plan_lum_groups(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch, const int *d_deltas, const HsvTables *d_tab)
 {
-    hipError_t e = plan_lum_band(p, st, d_frames, d_scratch, batch, d_deltas, d_tab, d_vsums, nparts, part_stride);
+    hipError_t e = plan_lum_band(p, st, d_frames, d_scratch, batch, d_deltas, d_tab);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "k_lum_groups launch failed: %s", hipGetErrorString(e));
     return BEVW_OK;
 }

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define BEVW_ABI_VERSION 4
+#define BEVW_ABI_VERSION 5
 
 typedef enum bevw_status {
     BEVW_OK = 0,
@@ -72,7 +72,8 @@ int bevw_abi_version(void);
  * ("opencv(>=3.4.2)", README.md:14); several of the primitives it calls changed their results across releases, so the choice
  * is a switch instead of a constant.  bevw_set_compat sets the process-wide DEFAULT; a handle takes a snapshot of the values in
  * bevw_build and keeps it (later calls, or calls from other threads, never change the results of a handle that exists); the stand-alone
- * bevw_color_balance reads the default at call time:
+ * entry points without a handle read the default at CALL time: bevw_color_balance (BEVW_COMPAT_ADDWEIGHTED) and
+ * bevw_warp_perspective_u8c3 (BEVW_COMPAT_WARP):
  *   BEVW_COMPAT_FILLPOLY    cv2.fillPoly (surroundBEV.py:159,234): 1 = OpenCV >= 4.5.2 edge collection (default),
  *                           0 = OpenCV 2.4 .. 4.5.1 (edges between the raw vertices, left span end rounded up)
  *   BEVW_COMPAT_ADDWEIGHTED cv2.addWeighted(ch, k, 0, 0, 0, ch) (surroundBEV.py:52-54): 1 = evaluated in CV_64F (default),
@@ -203,7 +204,9 @@ int bevw_combine_device(bevw_handle *h, const void *const *d_parts, const int32_
 
 /* ---- the exchange step of the camera-per-GPU mode over RCCL / xGMI (no reference code: the reference is single
  * process; BASELINE.json north_star "sharded one-camera-per-GPU ... with an RCCL gather over xGMI for the final stitch").
- * librccl.so is dlopen'ed on first use, so the library loads and every single-GPU entry point works without it.
+ * librccl.so is dlopen'ed on first use, so the library loads and every single-GPU entry point works without it; the environment
+ * variable BEVW_RCCL_LIB (read once per process) names the library to load instead -- another RCCL build, or the stand-in with which the
+ * test-suite runs the multi-rank branches on a box with fewer GPUs than ranks (tests/native/rccl_standin.cpp).
  * A communicator spans ONE camera group (1, 2 or 4 ranks; rank order = ascending camera order).  Every call below is
  * enqueued on the handle's own HIP stream: rank-local stitch, exchange and combine need no host synchronisation.
  *   bevw_comm_unique_id  group rank 0 creates the 128-byte id; the caller carries it to the other ranks (any out-of-band

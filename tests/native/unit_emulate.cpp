@@ -163,12 +163,13 @@ static int run(const Rig &r, const char *out_path)
         for (size_t u = 0; u < up.desc.size(); ++u)
             unit_emulate(up, (uint32_t)u, cls_of[u], r.frames.data() + (size_t)b * set_bytes, set_bytes, r.blend != 0, r.car.empty() ? nullptr : car_p.data(), pitch,
                          img.data() + (size_t)b * pitch * r.bh * 3, nullptr, &wr);
-        if (b == 0) written = wr;
+        if (b == 0)
+            for (size_t i = 0; i < wr.size(); ++i) written[i] = (uint8_t)(wr[i] / 3);
         size_t bad = 0, off_by_one = 0, total = 0;
         for (int y = 0; y < r.bh; ++y)
             for (int x = 0; x < pitch; ++x) {
                 const bool cl = x < bw_own && (hdr[(size_t)(y / 8) * tiles_x + x / 32] & kHdrBlock) != 0;
-                CHECK(wr[(size_t)y * pitch + x] == (cl ? 1 : 0), "pixel (%d, %d) stored %d times (claimed %d)", x, y, wr[(size_t)y * pitch + x], (int)cl);
+                CHECK(wr[(size_t)y * pitch + x] == (cl ? 3 : 0), "pixel (%d, %d): %d bytes stored (claimed %d; 3 = each byte once)", x, y, wr[(size_t)y * pitch + x], (int)cl);
                 if (x >= r.bw) {   // padding: zeros
                     for (int k = 0; k < 3; ++k) CHECK(img[(((size_t)b * r.bh + y) * pitch + x) * 3 + k] == 0, "padding pixel (%d, %d) not zero", x, y);
                     continue;

@@ -243,7 +243,7 @@ def test_rccl_transport_world_1_self_test():
         gen.close()
 
 
-def rccl_world_n_parity(out_dir, world):
+def rccl_world_n_parity(out_dir, world, extra_env=None):
     """Spawns one worker per GPU (tests/_rccl_worker.py, the product's native RCCL transport, no torch) and compares what the stitch ranks
     wrote with BevGenerator(blend=True, balance=True) on the same 4K frame sets -- bit-exact.  Also used by bench.py before it times the
     camera-shard workload on more than one GPU."""
@@ -254,7 +254,7 @@ def rccl_world_n_parity(out_dir, world):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), str(out_dir)], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -279,19 +279,70 @@ def rccl_world_n_parity(out_dir, world):
     return logs
 
 
+def build_rccl_standin(out_dir):
+    """tests/native/rccl_standin.cpp -> <out_dir>/librccl_standin.so (host code only: seconds)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    lib = os.path.join(str(out_dir), "librccl_standin.so")
+    r = subprocess.run([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", os.path.join(ROOT, "tests", "native", "rccl_standin.cpp"), "-o", lib, "-lpthread"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return lib
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [1, 2, 4])
 def test_rccl_world_n_parity(tmp_path, world):
-    """the rank > 0 branches of the native RCCL exchange (bevw_shard_gather_parts, bevw_shard_allgather_vsums,
-    k_vsums_interleave) run the moment two GPUs are visible: one process per GPU on the 4K rig with blend + balance, bit-exact against
-    BevGenerator.  World 1 runs everywhere (same worker, no exchange) so that the harness itself stays tested on 1-GPU boxes."""
+    """The rank > 0 branches of the native RCCL exchange (bevw_shard_gather_parts, bevw_shard_allgather_vsums, k_vsums_interleave): one
+    process per rank on the 4K rig with blend + balance, bit-exact against BevGenerator.  With one GPU per rank the library is the real
+    librccl; on a box with FEWER GPUs than ranks (real RCCL refuses two ranks on one device) the ranks share device 0 and the nine
+    entry points the product dlsym()s come from tests/native/rccl_standin.cpp through BEVW_RCCL_LIB -- every line of the product's
+    exchange code above the nccl* calls is the one an 8-GPU node runs.  World 1 runs the same worker without an exchange."""
     from cameracalibration_amd import _ffi
 
+    env = {}
     if _ffi.device_count() < world:
-        pytest.skip("needs %d GPUs, %d visible" % (world, _ffi.device_count()))
-    if world > 1:
+        if _ffi.device_count() < 1:
+            pytest.skip("no GPU")
+        env["BEVW_RCCL_LIB"] = build_rccl_standin(tmp_path)
+        print("world %d on %d GPU(s): the RCCL stand-in carries the exchange" % (world, _ffi.device_count()))
+    elif world > 1:
         assert _ffi.lib().bevw_comm_available() == 1
-    rccl_world_n_parity(tmp_path, world)
+    rccl_world_n_parity(tmp_path, world, env)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_rccl_standin_mesh_on_host_buffers(tmp_path, world):
+    """The stand-in itself, without a GPU: its socket mesh, grouped send / receive (boxes far beyond a socket buffer, every rank once the
+    root, a ring with sends and receives on every rank, a pair to itself), the all-gather and the size check, on host buffers
+    (BEVW_RCCL_STANDIN_HOST=1), one process per rank through ctypes."""
+    import ctypes as C
+
+    if not os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    lib = build_rccl_standin(tmp_path)
+    os.environ["BEVW_RCCL_STANDIN_HOST"] = "1"
+    try:
+        L = C.CDLL(lib)
+        ident = (C.c_char * 128)()
+        assert L.ncclGetUniqueId(ident) == 0
+    finally:
+        del os.environ["BEVW_RCCL_STANDIN_HOST"]
+    raw = bytes(ident)
+    assert b"bevw-rccl-standin" in raw
+    env = dict(os.environ, BEVW_RCCL_STANDIN_HOST="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rccl_standin_worker.py"), lib, raw.hex(), str(r), str(world)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=120)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise AssertionError("the stand-in workers did not finish: " + "\n".join(logs))
+    assert all(p.returncode == 0 for p in procs), "\n".join(logs)[-4000:]
+    for r in range(world):
+        assert "standin rank %d of %d ok" % (r, world) in logs[r]
 
 
 def test_control_channel_over_sockets():

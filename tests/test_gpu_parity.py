@@ -770,9 +770,11 @@ def test_output_pitch_aligned_config_s(ffi, SB, oracle, blend, balance):
         buf.free()
 
 
-def test_balance_with_the_deltas_derived_inside_the_round_trip_kernel(ffi):
-    """BEVW_BAL_DELTA_KERNEL=0 (an A/B switch read once per process, hence the child): k_lum_groups derives luminance_balance's shifts from
-    k_vsum's partial sums itself instead of k_lum_delta in between.  Same bytes as the oracle."""
+@pytest.mark.parametrize("parts,ring", [(8, 1), (5, 1), (7, 0)])
+def test_balance_slices_with_ring_buffers(ffi, parts, ring):
+    """BEVW_BAL_PARTS / BEVW_BAL_RING (switches read once per process, hence the child): config 4's chain in many small slices over the handle's
+    two streams, the compact scratch and the pre-gain BEV as per-stream ring buffers that every second slice overwrites (round 6's
+    Infinity-Cache A/B).  Uneven slices (40 frame sets in 7 or 8 parts), a sprite, the device-resident entry: same bytes as the oracle."""
     import os
     import subprocess
     import sys
@@ -786,14 +788,16 @@ def test_balance_with_the_deltas_derived_inside_the_round_trip_kernel(ffi):
         "import test_gpu_parity as T\n"
         "rig = T.small_rig(); T.set_args(SB, T.SMALL_CFG)\n"
         "frames = W.synthetic_frames(40, T.SMALL_CFG['FRAME_WIDTH'], T.SMALL_CFG['FRAME_HEIGHT'], kind='random')\n"
+        "car = np.random.default_rng(5).integers(0, 200, (T.SMALL_CFG['BEV_HEIGHT'], T.SMALL_CFG['BEV_WIDTH'], 3), dtype=np.uint8)\n"
         "bev = SB.BevGenerator(blend=True, balance=True, rig=rig)\n"
         "ref = O.RefBevGenerator(rig, T.SMALL_CFG, blend=True, balance=True)\n"
-        "got = bev.batch(frames)\n"
-        "assert bev.plan_info()['schedule'] == 2\n"
-        "assert all(np.array_equal(got[b], ref(*frames[b])) for b in range(40))\n"
-        "print('deltas inside k_lum_groups ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEVW_BAL_DELTA_KERNEL="0"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "deltas inside k_lum_groups ok" in r.stdout, r.stdout + r.stderr
+        "for rnd in range(2):\n"
+        "    got = bev.batch(frames, car if rnd else None)\n"
+        "    assert bev.plan_info()['schedule'] == 2\n"
+        "    assert all(np.array_equal(got[b], ref(*frames[b], car if rnd else None)) for b in range(40)), rnd\n"
+        "print('balance slices ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEVW_BAL_PARTS=str(parts), BEVW_BAL_RING=str(ring)), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "balance slices ok" in r.stdout, r.stdout + r.stderr
 
 
 def test_device_copy_yardstick(ffi):

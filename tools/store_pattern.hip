@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
 constexpr int BW = 1080, BH = 1080, BATCH = 256;
@@ -136,6 +138,121 @@ template <typename F> static float timeit(F launch)
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / 5;
 }
 
+// round 6: the FORMAT of a unit's wave-store, separated from its shape.  Same rectangles, rows dealt round-robin, buffer stores with the
+// product's cache policy (AUX: 0 default, 3 = nt | sc0 streaming):
+//   FMT 0  one buffer_store_dwordx3 per lane (12 B: lanes straddle every 64-byte sector boundary, 64 / 12 = 5.33)          [product, rounds 3 - 5]
+//   FMT 1  the 4 x 12 B of a lane quad repacked with quad_perm DPP moves into 3 x 16 B; buffer_store_dwordx4 from 48 lanes: the same row run,
+//          every 64-byte sector written by exactly 4 lanes; lane quads with a masked lane fall back to dwordx3 (second, wave-uniformly skipped store)
+//   FMT 2  the same repack through LDS (3 ds_write_b32 at stride 12 B, one ds_read_b128)
+//   FMT 3  global_store_dwordx3 (what rounds 3 - 5 measured in this tool)
+// Every dword written = its own dword index inside the image + the frame: main() checks the images byte for byte after each variant.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+template <int LQ, int NQ, int FMT, int AUX>
+__global__ void __launch_bounds__(256) k_units_fmt(uint8_t *__restrict__ out, int pitch, int units_x, int nunits, int nb, int nchunks, int bw_eff)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t xch[4][64 * 3];
+    const uint32_t ng = (uint32_t)nunits, id = blockIdx.x;
+    const uint32_t x8 = id & 7u, k = id >> 3, chunk = x8 + 8u * (k / ng), unit = k % ng;
+    if ((int)chunk >= nchunks) return;
+    constexpr int W = 4 << LQ, RPS = 64 >> LQ, H = NQ * 4 * RPS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, q = lane & 3;
+    const int ux = (int)(unit % units_x) * W, uy = (int)(unit / units_x) * H;
+    const uint32_t img = (uint32_t)pitch * BH * 3;
+    constexpr uint32_t NONE = 0x80000000u;
+    uint32_t off12[NQ], off16[NQ], base[NQ];
+    bool anyp[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+        const int sidx = j * 4 + wave;
+        const int x = ux + 4 * (lane & ((1 << LQ) - 1)), y = uy + sidx * RPS + (lane >> LQ);
+        const bool ok = x < bw_eff && y < BH;
+        const uint32_t off = ((uint32_t)y * pitch + x) * 3;
+        base[j] = off / 4;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(ok);
+        const bool full = ((m >> (lane & ~3)) & 0xfull) == 0xfull;
+        if (FMT == 1 || FMT == 2) {
+            off16[j] = (full && q < 3) ? off - 12u * q + 16u * q : NONE;
+            off12[j] = (!full && ok) ? off : NONE;
+            anyp[j] = __builtin_amdgcn_ballot_w64(!full && ok) != 0;
+        } else {
+            off12[j] = ok ? off : NONE;
+        }
+    }
+    for (int b = 0; b < nb; ++b) {
+        uint8_t *ob = out + (size_t)(chunk * nb + b) * img;
+        const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, img, 0x00020000u);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t v0 = base[j] + b, v1 = base[j] + 1 + b, v2 = base[j] + 2 + b;
+            if (FMT == 0) {
+                __builtin_amdgcn_raw_buffer_store_b96(u32x3{v0, v1, v2}, ro, (int)off12[j], 0, AUX);
+            } else if (FMT == 3) {
+                if (off12[j] != NONE) { uint32_t *op = reinterpret_cast<uint32_t *>(ob + off12[j]); op[0] = v0; op[1] = v1; op[2] = v2; }
+            } else {
+                u32x4 o;
+                if (FMT == 1) {
+                    // the next lane's three dwords (quad_perm [1, 2, 3, 3]), then the funnel S[q .. q + 3] of S = {v0, v1, v2, n0, n1, n2}
+                    const uint32_t n0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v0, 0xF9, 0xf, 0xf, false);
+                    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v1, 0xF9, 0xf, 0xf, false);
+                    const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v2, 0xF9, 0xf, 0xf, false);
+                    o.x = q == 0 ? v0 : (q == 1 ? v1 : v2);
+                    o.y = q == 0 ? v1 : (q == 1 ? v2 : n0);
+                    o.z = q == 0 ? v2 : (q == 1 ? n0 : n1);
+                    o.w = q == 0 ? n0 : (q == 1 ? n1 : n2);
+                } else {
+                    uint32_t *xw = xch[wave];
+                    xw[lane * 3] = v0; xw[lane * 3 + 1] = v1; xw[lane * 3 + 2] = v2;
+                    __builtin_amdgcn_wave_barrier();
+                    o = *reinterpret_cast<const u32x4 *>(xw + (lane & ~3) * 3 + q * 4 - (q == 3 ? 4 : 0));
+                    __builtin_amdgcn_wave_barrier();
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, ro, (int)off16[j], 0, AUX);
+                if (anyp[j]) __builtin_amdgcn_raw_buffer_store_b96(u32x3{v0, v1, v2}, ro, (int)off12[j], 0, AUX);
+            }
+        }
+    }
+}
+static bool check_units_image(const uint8_t *d_out, int pitch, int bw_eff, int nb)
+{
+    // frames 0 and nb + 1 (chunk 1, frame 1) of the batch: dword i of frame f holds i + (f % nb)
+    const size_t img = (size_t)pitch * BH * 3;
+    static uint32_t *h = nullptr;
+    if (!h) h = (uint32_t *)malloc((size_t)1088 * BH * 3);
+    for (int f : {0, nb + 1}) {
+        CK(hipMemcpy(h, d_out + (size_t)f * img, img, hipMemcpyDeviceToHost));
+        for (int y = 0; y < BH; ++y)
+            for (int i = 0; i < bw_eff * 3 / 4; ++i) {
+                const size_t d = ((size_t)y * pitch * 3) / 4 + i;
+                if (h[d] != (uint32_t)d + (uint32_t)(f % nb)) { printf("    MISMATCH frame %d row %d dword %d: %08x != %08x\n", f, y, i, h[d], (uint32_t)d + f % nb); return false; }
+            }
+    }
+    return true;
+}
+template <int LQ, int NQ, int FMT, int AUX> static void run_fmt(uint8_t *out, int pitch, int nb, const char *name, int bw_eff = BW)
+{
+    constexpr int W = 4 << LQ, H = NQ * 4 * (64 >> LQ);
+    const int units_x = (std::max(BW, bw_eff) + W - 1) / W, units_y = (BH + H - 1) / H, nunits = units_x * units_y, nchunks = BATCH / nb;
+    const unsigned grid = nunits * ((nchunks + 7) / 8 * 8);
+    const double bytes = (double)BATCH * BW * BH * 3;
+    CK(hipMemset(out, 0xee, (size_t)BATCH * 1088 * BH * 3));
+    auto launch = [&] { hipLaunchKernelGGL((k_units_fmt<LQ, NQ, FMT, AUX>), dim3(grid), dim3(256), 0, 0, out, pitch, units_x, nunits, nb, nchunks, bw_eff); };
+    float best = 1e9f, sum = 0;
+    for (int rep = 0; rep < 3; ++rep) { const float ms = timeit(launch); best = std::min(best, ms); sum += ms; }
+    const bool ok = check_units_image(out, pitch, bw_eff, nb);
+    static const char *fn[] = {"buffer dwordx3 x 64 lanes", "DPP repack, dwordx4 x 48", "LDS repack, dwordx4 x 48", "global dwordx3 x 64"};
+    printf("%-44s %-26s aux %d  %7.3f ms (mean %7.3f)  %7.1f GB/s  %s\n", name, fn[FMT], AUX, best, sum / 3, bytes / best * 1e-6, ok ? "bytes ok" : "WRONG BYTES");
+}
+template <int LQ, int NQ> static void run_fmt_all(uint8_t *out, int pitch, int nb, const char *name, int bw_eff = BW)
+{
+    run_fmt<LQ, NQ, 0, 3>(out, pitch, nb, name, bw_eff);
+    run_fmt<LQ, NQ, 1, 3>(out, pitch, nb, name, bw_eff);
+    run_fmt<LQ, NQ, 2, 3>(out, pitch, nb, name, bw_eff);
+    run_fmt<LQ, NQ, 0, 0>(out, pitch, nb, name, bw_eff);
+    run_fmt<LQ, NQ, 1, 0>(out, pitch, nb, name, bw_eff);
+    run_fmt<LQ, NQ, 3, 0>(out, pitch, nb, name, bw_eff);
+}
+
 template <int LX> static void run_tiles(uint8_t *out, int nb, int xcd, const char *name, int nmath = 0, bool store = true)
 {
     const int tiles_x = (BW + 4 * LX - 1) / (4 * LX), tiles_y = (BH + 64 / LX - 1) / (64 / LX), ntiles = tiles_x * tiles_y;
@@ -148,6 +265,22 @@ template <int LX> static void run_tiles(uint8_t *out, int nb, int xcd, const cha
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "format")) {   // round 6: store format A/B on the unit shapes (profiles/r06/store_format.log)
+        const size_t alloc = (size_t)BATCH * 1088 * BH * 3;
+        uint8_t *out;
+        CK(hipMalloc(&out, alloc));
+        for (int pass = 0; pass < 2; ++pass) {
+            run_fmt_all<6, 4>(out, 1088, 16, "units 256x16, 16 fr/blk, pitch 1088, pad written", 1088);
+            run_fmt_all<6, 4>(out, 1080, 16, "units 256x16, 16 fr/blk, dense");
+            run_fmt_all<5, 4>(out, 1088, 16, "units 128x32, 16 fr/blk, pitch 1088, pad written", 1088);
+            run_fmt_all<4, 4>(out, 1088, 16, "units 64x64, 16 fr/blk, pitch 1088, pad written", 1088);
+            run_fmt_all<6, 1>(out, 1088, 16, "units 256x4, 16 fr/blk, pitch 1088, pad written", 1088);
+            run_fmt_all<3, 4>(out, 1088, 16, "units 32x128, 16 fr/blk, pitch 1088, pad written", 1088);
+        }
+        float ms = timeit([&] { hipLaunchKernelGGL(k_linear, dim3(2048), dim3(256), 0, 0, (uint4 *)out, (size_t)BATCH * BW * BH * 3 / 16); });
+        printf("%-44s %7.3f ms  %7.1f GB/s\n", "linear stream, 16 B per lane", ms, (double)BATCH * BW * BH * 3 / ms * 1e-6);
+        return 0;
+    }
     if (argc > 1) {   // "strips": only the strip assignments, dense, 8 frames per block (counter runs: 6 dispatches per mode, modes 0 1 3 4 in this order)
         const size_t alloc = (size_t)BATCH * 1088 * BH * 3;
         uint8_t *out;
