@@ -563,8 +563,9 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
     }
 }
 
-// grid = (ceil(bw / 256), bh, ceil(batch / kAnalyticFrames)): a thread evaluates the projection of its pixel once per call and samples
-// kAnalyticFrames frames with it (the calibration of a handle is the same for every frame of a call; no table ever reaches memory).
+// grid = (ceil(bw / 256), bh, ceil(batch / fpt)): a thread evaluates the projection of its pixel and samples `fpt` frames with it (the
+// calibration of a handle is the same for every frame of a call; no table ever reaches memory).  fpt = kAnalyticFrames by default;
+// fpt = 1 (BEVW_ANALYTIC_FRAMES=1) is north_star's wording taken literally: inverse homography + fisheye model per output pixel PER FRAME.
 // tiles != nullptr: grid = (number of listed tiles, 1, chunks) -- a block takes one 32 x 8 base tile of the list (the tiles the unit
 // schedule of the analytic mode leaves over: frame-border footprints)
 constexpr int kAnalyticFrames = 32;   // (8: the projection was a third of a 64-frame call; profiles/r03/sweeps.log)
@@ -572,7 +573,7 @@ template <bool BLEND, bool BAL, typename F>
 static __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh, int batch,
                                   const int *__restrict__ deltas, const HsvTables *__restrict__ tab,
                                   const uint8_t *__restrict__ car, unsigned long long *__restrict__ chsums,
-                                  uint8_t *__restrict__ out, const uint32_t *__restrict__ tiles = nullptr, int tiles_x = 0)
+                                  uint8_t *__restrict__ out, const uint32_t *__restrict__ tiles = nullptr, int tiles_x = 0, int fpt = kAnalyticFrames)
 {
     __shared__ HsvTables hsv;
     __shared__ unsigned long long part[3][4];
@@ -588,7 +589,7 @@ static __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int
         y = (t / tiles_x) * 8 + (int)(threadIdx.x >> 5);
         if (y >= bh) { x = bw; y = 0; }     // below the image: an idle lane
     }
-    const int b_begin = blockIdx.z * kAnalyticFrames, b_end = min(batch, b_begin + kAnalyticFrames);
+    const int b_begin = blockIdx.z * fpt, b_end = min(batch, b_begin + fpt);
     const size_t frame_bytes = (size_t)fw * fh * 3;
     const size_t o = (size_t)y * bw + (x < bw ? x : 0);
     // dword accesses: frames on 4-byte boundaries (window loads) / rows of whole pixel quads on 4-byte boundaries (12-byte stores)

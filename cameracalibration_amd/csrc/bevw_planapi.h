@@ -17,7 +17,6 @@ int plan_stitch(Plan &p, hipStream_t st, const uint8_t *d_frames, int batch, boo
                 const uint8_t *d_scratch = nullptr);
 
 // balance: luminance round trip of the sampled texel groups of the raw frames into the compact scratch (p.compact_stride bytes per frame set)
-// d_vsums != nullptr: k_vsum's partial V sums (nparts per frame, part_stride entries apart) -- the deltas are derived from them inside the kernel and written to d_deltas
 int plan_lum_groups(const Plan &p, hipStream_t st, const uint8_t *d_frames, uint8_t *d_scratch, int batch, const int *d_deltas, const HsvTables *d_tab);
 
 // rows of bw pixels -> rows of pitch pixels (the car sprite of a pitched handle)

@@ -859,7 +859,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
     auto acc_to_px = [](const uint32_t acc[3]) {
         return __builtin_amdgcn_perm(acc[2], __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u), 0x0c060100u);
     };
-#ifdef BEVW_EXPERIMENT
+#ifdef BEVW_EXPERIMENT_FRAME
     auto frame = [&](int b, int ring) { BEVW_EXPERIMENT_FRAME(b, ring) };
 #else
     auto frame = [&](int b, int ring) {
@@ -963,7 +963,7 @@ __device__ __forceinline__ void plan_unit_run(const PlanArgs &a, uint32_t chunk,
 #endif
 #pragma unroll
     for (int u = 0; u < D; ++u) issue(b_begin + u, u);
-#ifndef BEVW_EXPERIMENT
+#ifndef BEVW_EXPERIMENT_FRAME
     if (DB) {
         land(0);
         block_lds_barrier();
@@ -1009,7 +1009,13 @@ __global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_
 {
     __shared__ __attribute__((aligned(16))) uint8_t patch[kUnitMaxGroups * 32];
     __shared__ uint4 wave_sums[SUMS ? 2 * kUnitWaves : 1];   // balance: the waves' channel sums of a frame (plan_unit_run)
+#ifdef BEVW_EXPERIMENT_TRACE_BEGIN
+    BEVW_EXPERIMENT_TRACE_BEGIN();
+#endif
     plan_unit_any<BLEND, SUMS>(a, blockIdx.x, patch, wave_sums);
+#ifdef BEVW_EXPERIMENT_TRACE_END
+    BEVW_EXPERIMENT_TRACE_END(a)
+#endif
 }
 
 // wide plans (analytic projection): every unit class in one launch, partition order, as plan_unit_any

@@ -824,11 +824,15 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
     const int *deltas = h->deltas.as<int>();
     const HsvTables *tab = h->hsv.as<HsvTables>();
     unsigned long long *chs = h->chsums.as<unsigned long long>();
-    const int per_launch = 65535 * kAnalyticFrames;
+    // frames a thread samples with one evaluation of the projection (BEVW_ANALYTIC_FRAMES, read once per process; 1 = the projection per
+    // output pixel AND frame: bench.py's direct_stitch_analytic_perpixel_b64)
+    static const int fpt_env = [] { const char *s = getenv("BEVW_ANALYTIC_FRAMES"); return s ? atoi(s) : 0; }();
+    const int fpt = fpt_env >= 1 && fpt_env <= 1024 ? fpt_env : kAnalyticFrames;
+    const int per_launch = 65535 * fpt;
     for (int b0 = 0; b0 < batch; b0 += per_launch) {
         const int nb = batch - b0 < per_launch ? batch - b0 : per_launch;
-        dim3 grid((c.bev_width + 255) / 256, c.bev_height, (nb + kAnalyticFrames - 1) / kAnalyticFrames), block(256);
-        if (left_tiles) grid = dim3((unsigned)n_left, 1, (nb + kAnalyticFrames - 1) / kAnalyticFrames);
+        dim3 grid((c.bev_width + 255) / 256, c.bev_height, (nb + fpt - 1) / fpt), block(256);
+        if (left_tiles) grid = dim3((unsigned)n_left, 1, (nb + fpt - 1) / fpt);
         const int tiles_x = h->aplan.tiles_x;
         const uint8_t *fr = d_frames + (size_t)b0 * 4 * c.frame_width * c.frame_height * 3;
         uint8_t *o = d_out + (size_t)b0 * c.bev_width * c.bev_height * 3;
@@ -836,10 +840,10 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
         do {                                                                                                                 \
             if (h->projection == BEVW_PROJ_ANALYTIC_F32)                                                                     \
                 hipLaunchKernelGGL((k_stitch_analytic<BL, BA, float>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o, left_tiles, tiles_x); \
+                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o, left_tiles, tiles_x, fpt); \
             else                                                                                                             \
                 hipLaunchKernelGGL((k_stitch_analytic<BL, BA, double>), grid, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, \
-                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o, left_tiles, tiles_x); \
+                                   c.bev_width, c.bev_height, nb, deltas ? deltas + b0 * 4 : nullptr, tab, d_car, chs ? chs + b0 * 3 : nullptr, o, left_tiles, tiles_x, fpt); \
         } while (0)
         if (c.blend && c.balance) LAUNCH_AN(true, true);
         else if (c.blend) LAUNCH_AN(true, false);

@@ -112,3 +112,13 @@ int plan_stitch_wide(const Plan &p, hipStream_t st, const uint8_t *d_frames, int
 }
 
 }  // namespace bevw
+
+#ifdef BEVW_EXPERIMENT_TRACE_END
+// experiment builds only (bevw_unit_experiments.h, BEVW_EXPERIMENT=4): the block records of the last k_plan_units launch
+extern "C" int bevw_experiment_trace(void *out, size_t nbytes)
+{
+    if (nbytes > sizeof(bevw::UnitTraceRec) * bevw::kUnitTraceCap) nbytes = sizeof(bevw::UnitTraceRec) * bevw::kUnitTraceCap;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(bevw::g_unit_trace), nbytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -130,6 +130,7 @@ ALGORITHMIC_BYTES = {
     "blend_4k_camera_shard": 11_810_991,  # same frames, camera per GPU (exchange bytes are overhead, not counted)
     "direct_stitch_analytic_f32_b64": 5_532_357,   # config 3's bytes: the analytic modes touch (nearly) the same texels
     "direct_stitch_analytic_f64_b64": 5_532_357,
+    "direct_stitch_analytic_perpixel_b64": 5_532_357,
 }
 
 # The same workloads at 64-byte SECTOR granularity: the unique 64-byte segments of the frames the sampled texels touch (SURVEY.md B.2,
@@ -143,4 +144,5 @@ SECTOR_GRANULAR_BYTES = {
     "blend_4k_camera_shard": 18_937_216 + 3_499_200,
     "direct_stitch_analytic_f32_b64": 2_635_392 + 3_499_200,
     "direct_stitch_analytic_f64_b64": 2_635_392 + 3_499_200,
+    "direct_stitch_analytic_perpixel_b64": 2_635_392 + 3_499_200,
 }
