@@ -462,6 +462,9 @@ struct AnalyticRig {
     double d[4][4];             // D
     double nfx[4], nfy[4], ncx[4], ncy[4]; // K' of the undistorted image (get_camera_mat_dst)
     int uw, uh;                 // undistorted image size
+    // the same calibration rounded to float32 ONCE on the host (bevw_build), with 1 / nfx, 1 / nfy: what the fp32 mode computes with
+    // (round 6: it used to convert every fp64 field per pixel)
+    float fMinv[4][9], ffx[4], ffy[4], fcx[4], fcy[4], fd[4][4], finv_nfx[4], finv_nfy[4], fncx[4], fncy[4];
 };
 
 // F = double: the specification's arithmetic (oracle/np_analytic.py).  F = float: the same formulas in fp32 (atanf, sqrtf; positions good
@@ -470,9 +473,35 @@ template <typename F>
 struct AnalyticTap { int sx, sy; F ax, ay; };   // raw-frame footprint of one (pixel, camera): top-left texel and the fractions
 
 // BEV pixel (x, y) of camera c -> footprint; false when the pixel samples nothing (outside the undistorted image or the frame)
+// fp32 mode: the formulas below with float32 parameters, fused multiply-adds and reciprocals (v_rcp_f32, 1 ulp) instead of IEEE divisions --
+// an arithmetic of its own, held against the fp64 specification by PSNR and by the share of identical bytes (tests/test_analytic.py), not
+// bit for bit.  The same function serves the once-per-handle map (k_analytic_map<float>) and the per-pixel kernel (k_stitch_analytic<.., float>).
+__device__ __forceinline__ bool analytic_project_f32(const AnalyticRig &R, int c, int x, int y, int fw, int fh, AnalyticTap<float> &t)
+{
+    const float *M = R.fMinv[c];
+    const float xf = (float)x, yf = (float)y;
+    const float X = fmaf(M[0], xf, fmaf(M[1], yf, M[2])), Y = fmaf(M[3], xf, fmaf(M[4], yf, M[5])), Wd = fmaf(M[6], xf, fmaf(M[7], yf, M[8]));
+    if (Wd == 0.f) return false;
+    const float iw = __builtin_amdgcn_rcpf(Wd);
+    const float u = X * iw, v = Y * iw;
+    if (!(u >= 0.f && u <= (float)(R.uw - 1) && v >= 0.f && v <= (float)(R.uh - 1))) return false;
+    const float xn = (u - R.fncx[c]) * R.finv_nfx[c], yn = (v - R.fncy[c]) * R.finv_nfy[c];
+    const float r = __builtin_amdgcn_sqrtf(fmaf(xn, xn, yn * yn));
+    const float theta = atanf(r);
+    const float t2 = theta * theta;
+    const float poly = fmaf(t2, fmaf(t2, fmaf(t2, fmaf(t2, R.fd[c][3], R.fd[c][2]), R.fd[c][1]), R.fd[c][0]), 1.f);   // 1 + k1 t^2 + k2 t^4 + k3 t^6 + k4 t^8
+    const float scale = (r == 0.f) ? 1.f : theta * poly * __builtin_amdgcn_rcpf(r);
+    const float px = fmaf(R.ffx[c] * xn, scale, R.fcx[c]), py = fmaf(R.ffy[c] * yn, scale, R.fcy[c]);
+    if (!(px > -1.f && px < (float)fw && py > -1.f && py < (float)fh)) return false;   // the whole footprint is outside
+    const float fpx = floorf(px), fpy = floorf(py);
+    t.sx = (int)fpx; t.sy = (int)fpy;
+    t.ax = px - fpx; t.ay = py - fpy;
+    return true;
+}
 template <typename F>
 __device__ __forceinline__ bool analytic_project(const AnalyticRig &R, int c, int x, int y, int fw, int fh, AnalyticTap<F> &t)
 {
+    if constexpr (sizeof(F) == 4) return analytic_project_f32(R, c, x, y, fw, fh, t);
     const double *M = R.Minv[c];
     const F X = (F)M[0] * x + (F)M[1] * y + (F)M[2], Y = (F)M[3] * x + (F)M[4] * y + (F)M[5], Wd = (F)M[6] * x + (F)M[7] * y + (F)M[8];
     if (Wd == (F)0) return false;
@@ -559,7 +588,8 @@ __device__ __forceinline__ void analytic_sample(const uint8_t *__restrict__ src,
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const F top = ((F)1 - tp.ax) * t[0][k] + tp.ax * t[1][k], bot = ((F)1 - tp.ax) * t[2][k] + tp.ax * t[3][k];
-        out[k] = sat_u8(rne_d((double)(((F)1 - tp.ay) * top + tp.ay * bot)));
+        if constexpr (sizeof(F) == 4) out[k] = sat_u8(__float2int_rn(((F)1 - tp.ay) * top + tp.ay * bot));   // (a convex combination of bytes: no range check needed)
+        else out[k] = sat_u8(rne_d((double)(((F)1 - tp.ay) * top + tp.ay * bot)));
     }
 }
 

@@ -173,7 +173,7 @@ struct UnitTuning {
     int align_lines = 1;             // group slots: the groups of one source line stay inside one 64-lane load instruction
     int own_empty = 1;               // base tiles without a contributor are unit tiles
     int own_double = 1;              // base tiles with a second contributor or a blend weight are unit tiles (classes with two entries per pixel)
-    int wide_double = 1;             // the two-quad class of those units (its blend variant needs 177+ VGPRs: off for blend handles)
+    int wide_double = 1;             // the two-quad class of those units (BEVW_UNIT_WIDE_DOUBLE=0: as rounds 3 - 5 compiled blend handles)
     int skew = 0;                    // unit boundaries aligned to this many bytes in every row (unit_skew): 0 (off), 32 or 64
     int row_order = 0;               // launch order of the rows of root cells (see the end of unit_compile)
     int own_padding = 1;             // the padding columns of a pitched output are written (zeros) by the units at the right edge
@@ -988,9 +988,9 @@ __device__ __forceinline__ void plan_unit_any(const PlanArgs &a, uint32_t block_
 #define BEVW_UNIT_CASE(C) case C: plan_unit_run<BLEND, SUMS, kUnitClassNQ[C], kUnitClassGR[C], kUnitClassCON[C]>(a, chunk, unit, lds, wave_sums); break;
     switch (e >> 28) {
         BEVW_UNIT_CASE(0) BEVW_UNIT_CASE(1) BEVW_UNIT_CASE(2) BEVW_UNIT_CASE(3)
-        // class 4 (two quads per lane, two contributors): its blend variant would set the kernel's register budget (177 .. 197 VGPRs);
-        // plans of blend handles are compiled without it (UnitTuning::wide_double)
-        case 4: if (!BLEND) plan_unit_run<false, SUMS, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4]>(a, chunk, unit, lds, wave_sums); break;
+        // class 4 (two quads per lane, two contributors): with float blend weights (rounds 3 - 5) its blend variant needed 177 .. 197 VGPRs and
+        // blend handles went without it; with the integer weights of round 6 (blend_apply_q23) every variant stays below 168
+        BEVW_UNIT_CASE(4)
         BEVW_UNIT_CASE(5)
 #if !BEVW_UNIT_NO_BIG   // (experiment builds without the (4, 4) class: every other class fits 128 VGPRs = 4 waves per SIMD; plans then need BEVW_UNIT_BIG=0)
         BEVW_UNIT_CASE(7)
@@ -1030,8 +1030,7 @@ __global__ void __launch_bounds__(kUnitThreads) __attribute__((amdgpu_waves_per_
 #define BEVW_UNIT_CASE(C) case C: plan_unit_run<BLEND, false, kUnitClassNQ[C], kUnitClassGR[C], kUnitClassCON[C], true>(a, chunk, unit, patch); break;
     switch (e >> 28) {
         BEVW_UNIT_CASE(0) BEVW_UNIT_CASE(1) BEVW_UNIT_CASE(2) BEVW_UNIT_CASE(3)
-        case 4: if (!BLEND) plan_unit_run<false, false, kUnitClassNQ[4], kUnitClassGR[4], kUnitClassCON[4], true>(a, chunk, unit, patch); break;
-        BEVW_UNIT_CASE(5) BEVW_UNIT_CASE(7)
+        BEVW_UNIT_CASE(4) BEVW_UNIT_CASE(5) BEVW_UNIT_CASE(7)
         default: plan_unit_run<BLEND, false, kUnitClassNQ[6], kUnitClassGR[6], kUnitClassCON[6], true>(a, chunk, unit, patch); break;
     }
 #undef BEVW_UNIT_CASE

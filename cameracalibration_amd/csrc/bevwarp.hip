@@ -1100,6 +1100,10 @@ int bevw_build(bevw_handle *h)
         for (int k = 0; k < 4; ++k) h->arig.d[c][k] = h->D[c][k];
         h->arig.nfx[c] = Kd[0]; h->arig.nfy[c] = Kd[4]; h->arig.ncx[c] = Kd[2]; h->arig.ncy[c] = Kd[5];
         h->arig.uw = uw; h->arig.uh = uh;
+        for (int k = 0; k < 9; ++k) h->arig.fMinv[c][k] = (float)Minv.m[k];
+        h->arig.ffx[c] = (float)h->K[c][0]; h->arig.ffy[c] = (float)h->K[c][4]; h->arig.fcx[c] = (float)h->K[c][2]; h->arig.fcy[c] = (float)h->K[c][5];
+        for (int k = 0; k < 4; ++k) h->arig.fd[c][k] = (float)h->D[c][k];
+        h->arig.finv_nfx[c] = (float)(1.0 / Kd[0]); h->arig.finv_nfy[c] = (float)(1.0 / Kd[4]); h->arig.fncx[c] = (float)Kd[2]; h->arig.fncy[c] = (float)Kd[5];
         hipLaunchKernelGGL(k_bev_lut, dim3((bw + 255) / 256, bh), dim3(256), 0, st, Minv, h->und1[c].as<int16_t>(),
                            h->und2[c].as<uint16_t>(), uw, uh, bw, bh, persp_block_width(bw, bh), h->lut1[c].as<int16_t>(),
                            h->lut2[c].as<uint16_t>(), h->compat[BEVW_COMPAT_WARP]);

@@ -21,6 +21,7 @@ static UnitTuning unit_tuning_env()
     if (const char *s = getenv("BEVW_UNIT_STAGGER")) t.stagger = atoi(s);
     if (const char *s = getenv("BEVW_UNIT_RUN_COST")) t.run_cost = atoi(s);
     if (const char *s = getenv("BEVW_UNIT_BIG")) t.big_class = atoi(s);
+    if (const char *s = getenv("BEVW_UNIT_WIDE_DOUBLE")) t.wide_double = atoi(s);
     return t;
 }
 
@@ -43,7 +44,8 @@ int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, i
 {
     static const UnitTuning unit_tune = unit_tuning_env();
     UnitTuning tune = unit_tune;
-    if (blend) tune.wide_double = 0;   // the blend kernels carry no two-quad two-contributor class (bevw_unit.h: plan_unit_any)
+    (void)blend;   // (rounds 3 - 5 compiled blend handles without the two-quad two-contributor class: its float blend variant needed 177+ VGPRs;
+                   // with round 6's integer weights it fits the kernel's budget, bevw_unit.h: plan_unit_any)
     // rows of whole sectors (an output pitch): column cuts on sector boundaries are free, all others split a sector for good -> a higher
     // price per write sector (3 -> 8: -0.4 ... -2 % on config 3, -2 % on the 4K rig, nothing slower; profiles/r03/sweeps.log).  The dense
     // layout keeps 3: there every cut shares sectors and the price only drives the source lines up (40 k -> 50 k per frame)
@@ -87,7 +89,7 @@ int plan_build_wide(Plan &p, const std::vector<int16_t> sxy[4], const std::vecto
     UnitTuning tune = unit_tuning_env();
     if (tune.max_groups > kUnitMaxGroups - 1) tune.max_groups = kUnitMaxGroups - 1;   // one group slot stays free: the zeros of pixels without a contributor
     tune.skew = 0;
-    if (blend) tune.wide_double = 0;
+    (void)blend;
     std::vector<uint16_t> no_codes[4];
     UnitPlanHost up;
     unit_compile(sxy, no_codes, mask, 4, fw, fh, bw, bh, bw, p.tiles_x, p.tiles_y, hdr, up, tune, frac);

@@ -93,7 +93,7 @@ static int run(const Rig &r, const char *out_path)
     if (const char *e = getenv("BEVW_UNIT_ALIGN_LINES")) tune.align_lines = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_OWN_EMPTY")) tune.own_empty = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_OWN_DOUBLE")) tune.own_double = atoi(e);
-    tune.wide_double = r.blend ? 0 : 1;   // as plan_build does for blend handles
+    tune.wide_double = 1;                 // as plan_build (rounds 3 - 5: 0 for blend handles)
     if (const char *e = getenv("BEVW_UNIT_WIDE_DOUBLE")) tune.wide_double = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_SKEW")) tune.skew = atoi(e);
     if (const char *e = getenv("BEVW_UNIT_STAGGER")) tune.stagger = atoi(e);

@@ -106,6 +106,43 @@ def test_hip_analytic_with_balance_runs_and_stays_close_to_the_table_path(ffi, S
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frames_per_thread", [1, 32])
+def test_hip_analytic_per_pixel_kernel_f32_against_the_specification(ffi, frames_per_thread):
+    """north_star's wording taken literally (bench.py: direct_stitch_analytic_perpixel_b64): k_stitch_analytic on every pixel -- no unit plan
+    (BEVW_ANALYTIC_UNITS=0), the inverse homography + fisheye model in fp32 evaluated per output pixel and per frame (BEVW_ANALYTIC_FRAMES=1; 32 =
+    the kernel's default amortisation) -- against the fp64 specification oracle/np_analytic.py on the reference's own frames, batch of 3 with a
+    sprite: PSNR, share of identical bytes and the maximum difference (an fp32 arithmetic of its own: not bit for bit).  The switches are read
+    once per process, hence the child."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O, np_analytic as NA\n"
+        "from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB\n"
+        "import test_analytic as T, conftest as CT\n"
+        "rr = CT.RepoRig()\n"
+        "a = SB.BevGenerator.get_args()\n"
+        "for k, v in dict(O.DEFAULT_CFG).items(): setattr(a, k, v)\n"
+        "frames = [rr.image(n) for n in O.CAMERAS]\n"
+        "for blend in (False, True):\n"
+        "    spec = NA.AnalyticBevGenerator(rr.rig, dict(O.DEFAULT_CFG), blend=blend)(*frames)\n"
+        "    bev = SB.BevGenerator(blend=blend, rig=rr.rig, projection='analytic_f32')\n"
+        "    got = bev.batch(np.stack([np.stack(frames)] * 3))\n"
+        "    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])\n"
+        "    d = np.abs(got[0].astype(np.int32) - spec.astype(np.int32))\n"
+        "    print('per-pixel fp32 kernel vs fp64 specification, blend=%%s: PSNR %%.1f dB, %%.2f %%%% identical, max %%d LSB' %% (blend, T.psnr(spec, got[0]), 100 * (d == 0).mean(), int(d.max())))\n"
+        "    assert T.psnr(spec, got[0]) > 55.0 and (d == 0).mean() > 0.97 and d.max() <= 2, (T.psnr(spec, got[0]), (d == 0).mean(), d.max())\n"
+        "print('per-pixel analytic ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BEVW_ANALYTIC_UNITS="0", BEVW_ANALYTIC_FRAMES=str(frames_per_thread)),
+                       capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0 and "per-pixel analytic ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("blend", [False, True])
 def test_hip_analytic_f32_against_fp64(ffi, SB, oracle, repo_rig, blend):
     """fp32 projection (positions good to ~1e-4 pixel) against the fp64 mode: judged by PSNR and max difference, not byte for byte"""

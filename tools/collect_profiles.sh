@@ -11,6 +11,8 @@ cd $R
 { echo "collected $(date -u +%Y-%m-%dT%H:%M:%SZ) on $(python -c 'from cameracalibration_amd import _ffi; print(_ffi.device_name(0))' 2>/dev/null)"; echo "git HEAD + number of uncommitted files:"; cat tools/scratch/git_head.txt 2>/dev/null || echo unknown; echo "libbevwarp.so sha256: $(sha256sum cameracalibration_amd/libbevwarp.so | cut -c1-16)"; } > $O/COLLECTION.txt
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; grep -n "passed\|failed" $O/pytest_gpu.log | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
+# the multi-rank branches of the native RCCL exchange (real librccl with one GPU per rank; the stand-in of tests/native/rccl_standin.cpp on a 1-GPU box)
+timeout 600 python -m pytest tests/test_camera_shard.py -m gpu -q -s -k "rccl_world_n_parity" > $O/pytest_rccl_world_n.log 2>&1; grep -E "stand-in|passed|failed|skipped" $O/pytest_rccl_world_n.log | tail -4
 cd /tmp && export TMPDIR=/tmp
 # row f4: kernel statistics and the VALU instruction counts behind roofline.bound = valu_issue of the JPEG lines
 for w in jpeg_decode_b64 jpeg_encode_b64 jpeg_bev_jpeg_b64; do
@@ -37,7 +39,7 @@ json.dump(d,open('profiles/jpeg_valu.json','w'),indent=1)   # (on the box: the J
 P
 # the driver's own command: the default line with its f4 summary
 ( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.time; tail -3 $O/bench_default.time | head -1
-for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k direct_stitch_analytic_f32_b64 direct_stitch_analytic_f64_b64; do
+for w in direct_stitch_b256 blend_b256 blend_balance_b256 undistort_b64 blend_4k direct_stitch_analytic_f32_b64 direct_stitch_analytic_f64_b64 direct_stitch_analytic_perpixel_b64; do
   timeout 600 python bench.py --workload $w --no-f4 2>/dev/null | tail -1 > $O/bench_$w.json
   python -c "import json;d=json.load(open('$O/bench_$w.json'));o=d.get('other_output_layout');print('$w',round(d['value']),d['unit'],'ms',round(d['ms_per_step'],4),'frac',round(d['roofline']['frac'],3),'placements',d['placements']['ms_per_step'],'| other layout',o and (o['output_layout'],round(o['ms_per_step'],4)),'| cpu',d['cpu_baseline'] and round(d['cpu_baseline']['value'],1))"
 done
@@ -52,7 +54,7 @@ BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 -
 python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
 cd /tmp && export TMPDIR=/tmp
 # kernel statistics: the average over THREE buffer placements (placement variance is +-5 %: one draw can flatter or slander the kernel)
-for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k; do
+for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k direct_stitch_analytic_perpixel_b64; do
   rm -rf /tmp/kt_$w
   timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$w -- python $R/bench.py --workload $w --steps 10 --warmup 2 --placements 3 --single-layout --no-cpu-baseline --no-live-traffic > /tmp/kt_$w.log 2>&1
   cp $(find /tmp/kt_$w -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_$w.csv
@@ -70,3 +72,7 @@ bash tools/pmc_merged.sh final/pmc_direct_stitch_dense direct_stitch_b256 "" --o
 bash tools/pmc_merged.sh final/pmc_blend_balance blend_balance_b256 "" > /dev/null 2>&1
 for t in pmc_direct_stitch_aligned pmc_direct_stitch_dense pmc_blend_balance; do cp $O/$t/summary.txt $O/$t.txt; rm -rf $O/$t; done
 tail -30 $O/pmc_direct_stitch_aligned.txt
+# block timeline of the config-3 and blend steps (tools/block_timeline.py; needs build_var/libbevwarp_x4.so = -DBEVW_EXPERIMENT=4 of the same tree)
+if [ -f build_var/libbevwarp_x4.so ]; then
+  for v in "" "--blend"; do echo "=== block_timeline $v"; BEVW_LIB_PATH=build_var/libbevwarp_x4.so timeout 300 python tools/block_timeline.py $v; done > $O/block_timeline.log 2>&1
+fi
