@@ -479,7 +479,11 @@ class BevGenerator:
         encode chained by events on their streams), a host thread parses and stages batch i + 1 (its upload overlaps the kernels) and this
         thread fetches the files of batch i - 1.  Three codec contexts rotate, so the three stages never share a buffer.  Yields one list of
         files per batch, in order; results are identical to ``jpeg(batch)``.  ``copy=False`` yields ``memoryview`` slices of one host buffer
-        per batch instead of ``bytes``."""
+        per batch instead of ``bytes``.
+
+        Throughput note: the pipeline keeps seven HIP streams busy and the runtime multiplexes them onto 4 hardware queues by default; the
+        published figure is with 8 -- call ``cameracalibration_amd._ffi.prefer_hw_queues()`` before the first use of
+        the package in the process (importing the package does not change the environment)."""
         from concurrent.futures import ThreadPoolExecutor
 
         imgcodecs = self._imgcodecs()

@@ -50,6 +50,11 @@ int plan_build(Plan &p, hipStream_t st, const StitchTables &T, int fw, int fh, i
     // price per write sector (3 -> 8: -0.4 ... -2 % on config 3, -2 % on the 4K rig, nothing slower; profiles/r03/sweeps.log).  The dense
     // layout keeps 3: there every cut shares sectors and the price only drives the source lines up (40 k -> 50 k per frame)
     if (out_pitch > 0 && !getenv("BEVW_UNIT_SECTOR_COST")) tune.sector_cost = 8;
+    // One-camera plans (the fisheye remapper, BASELINE config 2: 378 units x 8 chunks = 3.9 rounds of blocks over the chip's 768 slots) are
+    // launched longest unit first: with so few rounds the tail of the spatial order costs more than the neighbours' shared lines return --
+    // batch 16 / 32 / 64 / 128: -4 ... -5.5 % (0.0804 -> 0.0765 ms at 64), batch 256 +1.8 %.  The 4-camera plans keep the spatial order
+    // (config 3 +4 % with it, the 4K rig +5.6 %).  profiles/r06/call9..11
+    if (ncams == 1 && !getenv("BEVW_UNIT_ROW_ORDER")) tune.row_order = 4;
     hipError_t e = plan_build_impl(p, st, T, fw, fh, bw, bh, ncams, plan_tuning().units != 0, tune, out_pitch);
     if (e != hipSuccess) return fail(BEVW_E_HIP, "tile-plan build failed: %s", hipGetErrorString(e));
     return BEVW_OK;

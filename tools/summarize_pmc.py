@@ -88,11 +88,14 @@ def main(d):
         for k, a, b in rows:
             md.append("| `%s` | %.0f | %.0f |" % (k[:90], a, b))
         md += ["| **sum** | %.0f (%.0f MB) | %.0f (%.0f MB) |" % (tf, tf * 1024 / 1e6, tw, tw * 1024 / 1e6), ""]
-        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": 5,
+        traffic[w] = {"fetch_bytes": int(tf * 1024), "write_bytes": int(tw * 1024), "units_per_launch": units, "round": ROUND,
                       "corrected": bool(CAL)}
     open(os.path.join(d, "rocprofv3_pmc_hbm_traffic.md"), "w").write("\n".join(md) + "\n")
     json.dump(traffic, open(os.path.join(d, "hbm_traffic.json"), "w"), indent=1)
     print("\n".join(md[-12:]))
+
+
+ROUND = int(os.environ.get("BEVW_ROUND", "6"))   # the round the collection belongs to (a label in hbm_traffic.json)
 
 
 def dispatches(path):
