@@ -695,6 +695,84 @@ static __global__ void k_stitch_analytic(const uint8_t *__restrict__ frames, int
     }
 }
 
+// north_star's wording taken literally -- "a fused per-output-pixel kernel that inverts the 3x3 homography, applies the K/D fisheye forward
+// projection and bilinear-samples the source image" -- as a kernel of its own (round 6): ONE thread = one BEV pixel of ONE frame; per
+// contributing camera the inverse homography + fisheye model (analytic_project) and at once the fp32 / fp64 bilinear sample of the 2 x 2
+// footprint; blend weight, saturating sum, car sprite; the 4 lanes of a pixel quad hand their pixels to one 12-byte store.  Nothing is kept
+// across cameras or frames (k_stitch_analytic above amortises the projection over `fpt` frames and carries up to four taps in registers: 546
+// wave-level VALU instructions per wave and pixel at fpt = 1, a third of them register moves and 64-bit address arithmetic).  Interior
+// footprints of 4-byte aligned frame sets are two buffer_load_dwordx3 with 32-bit offsets inside the frame set of frame b; the others take
+// analytic_sample's per-byte path.  No balance variant (the luminance statistics need the kernel above).
+// grid = (ceil(bw / 256), bh, batch); bench.py: direct_stitch_analytic_perpixel_b64 (BEVW_ANALYTIC_UNITS=0, BEVW_ANALYTIC_FRAMES=1).
+typedef uint32_t an_u32x3 __attribute__((ext_vector_type(3)));
+template <bool BLEND, typename F>
+static __global__ void __launch_bounds__(256) k_stitch_perpixel(const uint8_t *__restrict__ frames, int fw, int fh, AnalyticRig R, StitchTables T, int bw, int bh,
+                                                               const uint8_t *__restrict__ car, uint8_t *__restrict__ out)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
+    const uint32_t fb32 = (uint32_t)fw * (uint32_t)fh * 3u, row32 = (uint32_t)fw * 3u;
+    const size_t set_bytes = (size_t)fb32 * 4;
+    const uint8_t *set_base = frames + (size_t)b * set_bytes;
+    const bool set32 = (fb32 & 3u) == 0 && (((uintptr_t)frames) & 3u) == 0 && set_bytes < ((size_t)1 << 31);
+    const __amdgpu_buffer_rsrc_t set = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(set_base), 0, set32 ? (uint32_t)set_bytes : 0u, 0x00020000u);
+    const uint32_t o = (uint32_t)y * (uint32_t)bw + (uint32_t)(x < bw ? x : 0);
+    int acc[3] = {0, 0, 0};
+    if (x < bw) {
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {   // (camera order: the reference adds front, back, left, right)
+            const int m = T.mask[c][o];
+            if (m == 0) continue;
+            AnalyticTap<F> t;
+            if (!analytic_project<F>(R, c, x, y, fw, fh, t)) continue;   // contributes 0
+            int v[3];
+            const uint32_t toff = ((uint32_t)t.sy * (uint32_t)fw + (uint32_t)t.sx) * 3u;
+            if (set32 && (unsigned)t.sx < (unsigned)(fw - 1) && (unsigned)t.sy < (unsigned)(fh - 1) && (toff & ~3u) + row32 + 12u <= fb32) {
+                const uint32_t w0 = (uint32_t)c * fb32 + toff, w1 = w0 + row32;
+                const an_u32x3 a = __builtin_amdgcn_raw_buffer_load_b96(set, (int)(w0 & ~3u), 0, 0), bb = __builtin_amdgcn_raw_buffer_load_b96(set, (int)(w1 & ~3u), 0, 0);
+                // 8 footprint bytes of a row (B0 G0 R0 B1 G1 R1 x x) from the 12-byte window around them
+                const uint32_t r0x = __builtin_amdgcn_alignbyte(a.y, a.x, w0 & 3u), r0y = __builtin_amdgcn_alignbyte(a.z, a.y, w0 & 3u);
+                const uint32_t r1x = __builtin_amdgcn_alignbyte(bb.y, bb.x, w1 & 3u), r1y = __builtin_amdgcn_alignbyte(bb.z, bb.y, w1 & 3u);
+                const uint32_t t00[3] = {r0x & 255u, (r0x >> 8) & 255u, (r0x >> 16) & 255u}, t01[3] = {r0x >> 24, r0y & 255u, (r0y >> 8) & 255u};
+                const uint32_t t10[3] = {r1x & 255u, (r1x >> 8) & 255u, (r1x >> 16) & 255u}, t11[3] = {r1x >> 24, r1y & 255u, (r1y >> 8) & 255u};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const F top = ((F)1 - t.ax) * (F)t00[k] + t.ax * (F)t01[k], bot = ((F)1 - t.ax) * (F)t10[k] + t.ax * (F)t11[k];
+                    if constexpr (sizeof(F) == 4) v[k] = sat_u8(__float2int_rn(((F)1 - t.ay) * top + t.ay * bot));
+                    else v[k] = sat_u8(rne_d((double)(((F)1 - t.ay) * top + t.ay * bot)));
+                }
+            } else {
+                // (frame border; BAL = false: the table argument is never read -- any valid object will do)
+                analytic_sample<false, F>(set_base + (size_t)c * fb32, fw, fh, t, v, 0, *reinterpret_cast<const HsvTables *>(&R), false);
+            }
+            if (BLEND) {
+                const float wgt = blend_weight_f32(m);
+                v[0] = blend_mul(v[0], wgt); v[1] = blend_mul(v[1], wgt); v[2] = blend_mul(v[2], wgt);
+            }
+            acc[0] = min(255, acc[0] + v[0]); acc[1] = min(255, acc[1] + v[1]); acc[2] = min(255, acc[2] + v[2]);
+        }
+        if (car != nullptr) {
+            acc[0] = min(255, acc[0] + car[(size_t)o * 3]); acc[1] = min(255, acc[1] + car[(size_t)o * 3 + 1]);
+            acc[2] = min(255, acc[2] + car[(size_t)o * 3 + 2]);
+        }
+    }
+    uint8_t *img = out + (size_t)b * bw * bh * 3;
+    if ((bw & 3) == 0 && (((uintptr_t)out) & 3) == 0) {
+        // the 4 lanes of a pixel quad hand their pixels to the first one, which stores 12 bytes (bw % 4 == 0: a quad is inside the image or
+        // outside as a whole; blockDim.x is a multiple of 4).  quad_perm DPP moves: no LDS traffic
+        const uint32_t P = (uint32_t)acc[0] | ((uint32_t)acc[1] << 8) | ((uint32_t)acc[2] << 16);
+        const uint32_t P1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0x55, 0xf, 0xf, false);   // quad_perm [1, 1, 1, 1]
+        const uint32_t P2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0xAA, 0xf, 0xf, false);   // [2, 2, 2, 2]
+        const uint32_t P3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)P, 0xFF, 0xf, 0xf, false);   // [3, 3, 3, 3]
+        if ((threadIdx.x & 3u) == 0 && x < bw) {
+            uint32_t *d = reinterpret_cast<uint32_t *>(img + (size_t)o * 3);
+            d[0] = P | (P1 << 24); d[1] = (P1 >> 8) | (P2 << 16); d[2] = (P2 >> 16) | (P3 << 8);
+        }
+    } else if (x < bw) {
+        uint8_t *d = img + (size_t)o * 3;
+        d[0] = (uint8_t)acc[0]; d[1] = (uint8_t)acc[1]; d[2] = (uint8_t)acc[2];
+    }
+}
+
 // per-channel sums of a batch of images (color_balance as an exported helper). grid = (blocks, batch)
 static __global__ void k_channel_sums(const uint8_t *__restrict__ img, size_t npx, unsigned long long *__restrict__ chsums)
 {

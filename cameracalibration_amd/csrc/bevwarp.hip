@@ -836,6 +836,18 @@ static int stitch_analytic(bevw_handle *h, const uint8_t *d_frames, int batch, c
         const int tiles_x = h->aplan.tiles_x;
         const uint8_t *fr = d_frames + (size_t)b0 * 4 * c.frame_width * c.frame_height * 3;
         uint8_t *o = d_out + (size_t)b0 * c.bev_width * c.bev_height * 3;
+        if (fpt == 1 && !c.balance && left_tiles == nullptr) {
+            // one thread per pixel AND frame: the fused per-output-pixel kernel of its own (bevw_kernels.h: k_stitch_perpixel)
+            const dim3 g1((c.bev_width + 255) / 256, c.bev_height, nb);
+            if (h->projection == BEVW_PROJ_ANALYTIC_F32) {
+                if (c.blend) hipLaunchKernelGGL((k_stitch_perpixel<true, float>), g1, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, c.bev_width, c.bev_height, d_car, o);
+                else hipLaunchKernelGGL((k_stitch_perpixel<false, float>), g1, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, c.bev_width, c.bev_height, d_car, o);
+            } else {
+                if (c.blend) hipLaunchKernelGGL((k_stitch_perpixel<true, double>), g1, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, c.bev_width, c.bev_height, d_car, o);
+                else hipLaunchKernelGGL((k_stitch_perpixel<false, double>), g1, block, 0, h->stream, fr, c.frame_width, c.frame_height, h->arig, T, c.bev_width, c.bev_height, d_car, o);
+            }
+            continue;
+        }
 #define LAUNCH_AN(BL, BA)                                                                                                   \
         do {                                                                                                                 \
             if (h->projection == BEVW_PROJ_ANALYTIC_F32)                                                                     \

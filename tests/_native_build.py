@@ -20,14 +20,15 @@ def hipcc_path():
 SANITIZE = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
 
 
-def build(src: str, exe: str, timeout: int = 900, sanitize: bool = False) -> None:
-    """sanitize: AddressSanitizer + UndefinedBehaviorSanitizer (clang's runtimes ship with ROCm's llvm); any finding aborts the program."""
+def build(src: str, exe: str, timeout: int = 900, sanitize: bool = False, extra=()) -> None:
+    """sanitize: AddressSanitizer + UndefinedBehaviorSanitizer (clang's runtimes ship with ROCm's llvm); any finding aborts the program.
+    extra: more compiler flags (e.g. -DBEVW_UNIT_STORE16=2 for the emulator of a variant build)."""
     hipcc = hipcc_path()
     obj, stub_c, stub_o = exe + ".o", exe + "_fatbin_stub.c", exe + "_fatbin_stub.o"
     sanitize = sanitize or os.environ.get("BEVW_NATIVE_SANITIZE") == "1"   # the sanitizer leg re-runs the emulator tests this way
     san = SANITIZE if sanitize else []
     try:
-        r = subprocess.run([hipcc] + FLAGS + san + ["--cuda-host-only", "-c", src, "-o", obj], capture_output=True, text=True, timeout=timeout)
+        r = subprocess.run([hipcc] + FLAGS + list(extra) + san + ["--cuda-host-only", "-c", src, "-o", obj], capture_output=True, text=True, timeout=timeout)
         if r.returncode == 0:
             syms = subprocess.run(["nm", obj], capture_output=True, text=True, timeout=60).stdout
             wanted = sorted(set(re.findall(r"^\s+U (__hip_fatbin\w*)$", syms, flags=re.M)))
@@ -42,5 +43,5 @@ def build(src: str, exe: str, timeout: int = 900, sanitize: bool = False) -> Non
     except (OSError, subprocess.SubprocessError):
         pass
     assert not sanitize, "sanitized host build failed: " + (r.stderr[-2000:] if "r" in dir() else "")
-    r = subprocess.run([hipcc] + FLAGS + [src, "-o", exe], capture_output=True, text=True, timeout=timeout)
+    r = subprocess.run([hipcc] + FLAGS + list(extra) + [src, "-o", exe], capture_output=True, text=True, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]

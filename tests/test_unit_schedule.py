@@ -40,6 +40,25 @@ def test_units_on_synthetic_tables(exe):
     assert r.stdout.count("unit schedule ok") == 5
 
 
+@pytest.mark.parametrize("pitch", [None, "aligned"])
+def test_units_with_the_16_byte_store_format(tmp_path, pitch):
+    """-DBEVW_UNIT_STORE16=2 (round 6's store-format A/B, off by default): the wave-store of whole lane quads as 3 x 16 bytes -- the funnel
+    unit_repack16 the kernel executes with DPP moves -- in the host emulator: every claimed byte stored exactly once, every pixel right, on the
+    synthetic tables and 25 random rigs, dense rows and rows of whole sectors (odd widths leave lane quads with a masked lane: the 12-byte path)."""
+    from tests import _native_build
+
+    exe = str(tmp_path / "unit_emulate_store16")
+    _native_build.build(os.path.join(ROOT, "tests", "native", "unit_emulate.cpp"), exe, extra=["-DBEVW_UNIT_STORE16=2"])
+    env = dict(os.environ)
+    if pitch:
+        env["BEVW_EMU_PITCH"] = pitch
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and r.stdout.count("unit schedule ok") == 5, r.stdout + r.stderr
+    env["BEVW_EMU_FUZZ"] = "900 25"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _run(exe, tmp_path, luts, masks, frames, car, fw, fh, bw, bh, blend=False, fracs=None):
     """luts: [(int16 [bh,bw,2], uint16 [bh,bw])], masks: [uint8 [bh,bw]], frames: uint8 [n, ncams, fh, fw, 3];
     fracs: [uint32 [bh,bw,2]] 21-bit fractions -> a wide plan (the analytic projection mode)"""

@@ -9,7 +9,7 @@ from cameracalibration_amd.SurroundBirdEyeView import surroundBEV as SB
 from oracle import oracle as O, np_analytic
 O.build()
 import os, time
-bad, done, t_end = 0, 0, time.time() + float(os.environ.get("BEVW_SOAK_SECONDS", "1e9"))   # BEVW_SOAK_SECONDS: stop there and report what was done
+bad, done, edge, t_end = 0, 0, 0, time.time() + float(os.environ.get("BEVW_SOAK_SECONDS", "1e9"))   # BEVW_SOAK_SECONDS: stop there and report what was done
 for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if time.time() > t_end: break
     rng = np.random.default_rng(70000 + seed)
@@ -36,5 +36,18 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         if d.max() > 1 or (d == 0).mean() < 0.999:
             bad += 1; print("MISMATCH seed", seed, cfg, blend, b, int(d.max()), float((d == 0).mean())); break
     del bev
+    # the fp32 mode (an arithmetic of its own: float32 parameters, fused multiply-adds, reciprocals) against the same specification: positions
+    # good to ~1e-4 pixel -> a rounding flip here and there on all-random frames, never more than 1 LSB
+    bev32 = SB.BevGenerator(blend=blend, balance=False, rig=rig, projection='analytic_f32')
+    got32 = bev32.batch(frames, car)
+    for b in sorted(set([0, batch - 1])):
+        d = np.abs(got32[b].astype(np.int32) - spec(*frames[b], car).astype(np.int32))
+        # two contributors of a blend pixel may each flip -> 2 LSB; a pixel ON the edge of the undistorted image or of the frame (where the fp64
+        # test "inside" holds with equality) may be decided the other way in fp32 -> an isolated large difference: counted, bounded, not 0
+        lim = 2 if blend else 1
+        if (d == 0).mean() < 0.985 or (d > lim).mean() > 0.005:
+            bad += 1; print("MISMATCH (fp32 mode) seed", seed, cfg, blend, b, int(d.max()), float((d == 0).mean()), float((d > lim).mean())); break
+        edge += int((d > lim).sum())
+    del bev32
     done += 1
-print("analytic soak", sys.argv[1], sys.argv[2], "cases run", done, "mismatches", bad)
+print("analytic soak", sys.argv[1], sys.argv[2], "cases run", done, "mismatches", bad, "| fp32 mode: bytes decided the other way on an edge:", edge)
