@@ -50,8 +50,8 @@ WORKLOADS = {
                      metric="stitched BEV frames/sec (4-cam 3840x2160->1080x1080, blend)"),
     # The table-free projection mode.  The first two evaluate the camera model ONCE PER HANDLE on the GPU (k_analytic_map, fp32 / fp64)
     # into a wide unit plan with 21-bit fractions and then run the unit schedule with fp32 interpolation (k_plan_unit_wide): per frame they cost what a
-    # table with finer fractions costs, NOT a projection.  The third is north_star's wording taken literally: k_stitch_analytic with one frame per
-    # thread -- inverse homography + K / D fisheye model + fp32 bilinear sample evaluated per output pixel AND per frame, no table anywhere.
+    # table with finer fractions costs, NOT a projection.  The third is north_star's wording taken literally: k_stitch_perpixel, one thread per
+    # pixel and frame -- inverse homography + K / D fisheye model + fp32 bilinear sample evaluated per output pixel AND per frame, no table anywhere.
     "direct_stitch_analytic_f32_b64": dict(kind="bev", cfg="S", blend=False, balance=False, batch=64, unit="frames/s", projection="analytic_f32",
                                            metric="stitched BEV frames/sec (4-cam 1280x960->1080x1080, analytic fp32 projection evaluated once per handle, 21-bit fractions, fp32 interpolation)"),
     "direct_stitch_analytic_f64_b64": dict(kind="bev", cfg="S", blend=False, balance=False, batch=64, unit="frames/s", projection="analytic",
