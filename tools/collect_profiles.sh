@@ -52,6 +52,16 @@ python -c "import json;d=json.load(open('$O/bench_jpeg_decode_b64_repo_files.jso
 BEVW_BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
   bench.py --gpus 2 --steps 5 --warmup 2 --batch 64 --placements 1 --single-layout 2>/dev/null | tail -1 > $O/bench_two_ranks_one_gpu_gloo.json
 python -c "import json;d=json.load(open('$O/bench_two_ranks_one_gpu_gloo.json'));print('2 ranks sharing one GPU (plumbing check):',d['n_gpus'],round(d['value']))"
+# the camera-per-GPU bench workload with 2 and 4 ranks on ONE GPU: the bench's pre-timing parity check and its timed pipeline over the library's own
+# RCCL layer, the nccl* entry points from the stand-in (rates are those of unix sockets: a plumbing check, never a figure)
+if [ "$(python -c 'from cameracalibration_amd import _ffi; print(_ffi.device_count())')" = "1" ]; then
+  /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared tests/native/rccl_standin.cpp -o /tmp/librccl_standin.so -lpthread
+  for n in 2 4; do
+    BEVW_RCCL_LIB=/tmp/librccl_standin.so BEVW_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2956$n \
+      bench.py --gpus $n --workload blend_4k_camera_shard --steps 5 --warmup 2 --batch 8 2>/dev/null | tail -1 > $O/bench_camera_shard_${n}_ranks_one_gpu_standin.json
+    python -c "import json;d=json.load(open('$O/bench_camera_shard_${n}_ranks_one_gpu_standin.json'));print('camera shard, $n ranks on one GPU over the RCCL stand-in: parity', d['config'].get('parity_check','')[:6], '| transport', d['config'].get('transport','')[:12])"
+  done
+fi
 cd /tmp && export TMPDIR=/tmp
 # kernel statistics: the average over THREE buffer placements (placement variance is +-5 %: one draw can flatter or slander the kernel)
 for w in direct_stitch_b256 blend_balance_b256 undistort_b64 blend_b256 blend_4k direct_stitch_analytic_perpixel_b64; do
