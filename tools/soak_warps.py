@@ -1,13 +1,18 @@
 """Parity soak (GPU box): random fisheye / pinhole remappers (scales, axis offsets), random homography warps, resize, translate.
-Usage: python tools/soak_warps.py N_CASES   (prints every mismatch; round 1: 400 cases, none)"""
-import sys, ctypes as C, numpy as np
+Usage: python tools/soak_warps.py FIRST_SEED LAST_SEED   (prints every mismatch; BEVW_SOAK_SECONDS: stop there and report what was done.
+Round 6: the script used to take N_CASES only and printed its result at the very end -- two calls that gave it a seed RANGE were cut off by
+their time-out without a line; it now takes the range, honours the time budget and always reports.)"""
+import os, sys, time, ctypes as C, numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from cameracalibration_amd import _ffi, workloads as W
 from oracle import oracle as O
 O.build()
-L = _ffi.lib(); bad = 0
+L = _ffi.lib(); bad = 0; done = 0
 K0, D0, _ = W.repo_rig()["front"]
-for seed in range(int(sys.argv[1])):
+first, last = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, int(sys.argv[1]))
+t_end = time.time() + float(os.environ.get("BEVW_SOAK_SECONDS", "1e9"))
+for seed in range(first, last):
+    if time.time() > t_end: break
     rng = np.random.default_rng(90000 + seed)
     fw = int(rng.choice([64, 97, 160, 200, 322, 400, 640])); fh = int(rng.choice([48, 65, 128, 150, 258, 480]))
     A = np.diag([fw / 1280.0, fh / 1024.0, 1.0]); K = A @ K0
@@ -42,5 +47,6 @@ for seed in range(int(sys.argv[1])):
     sx, sy = int(rng.integers(-fw, fw)), int(rng.integers(-fh, fh)); tout = np.empty_like(imgs)
     _ffi.check(L.bevw_translate_u8c3(0, _ffi.ptr(imgs), fw, fh, sx, sy, batch, _ffi.ptr(tout)))
     ok = ok and all(np.array_equal(tout[b], O.translate(imgs[b], sx, sy)) for b in range(batch))
-    if not ok: bad += 1; print("MISMATCH seed", seed, fw, fh, fs, ss, pin)
-print("soak2", sys.argv[1], "mismatches", bad)
+    done += 1
+    if not ok: bad += 1; print("MISMATCH seed", seed, fw, fh, fs, ss, pin, flush=True)
+print("soak of remappers / warps / resize / translate, seeds", first, "..", "cases run", done, "mismatches", bad)
